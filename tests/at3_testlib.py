@@ -1,0 +1,269 @@
+"""Shared helpers for the tests, bench.py's cpu_baseline leg and tools/: ctypes bindings of the
+CPU oracle (oracle/libat3oracle.so), the optional real-reference build (oracle/_ref/libat3ref.so,
+only buildable where /root/reference exists) and seeded synthetic PCM generators.
+
+TEST INFRASTRUCTURE: nothing under atracdenc_amd/ imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libat3oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libat3ref.so")
+
+LP2 = 132300
+LP4 = 66150
+
+
+class Tap(ctypes.Structure):
+    _fields_ = [
+        ("n_points", ctypes.c_int32 * 4),
+        ("level", (ctypes.c_int32 * 8) * 4),
+        ("loc", (ctypes.c_int32 * 8) * 4),
+        ("ges_frame", ctypes.c_float * 4),
+        ("loudness_ch", ctypes.c_float),
+        ("loudness_track", ctypes.c_float),
+        ("sfi", ctypes.c_int32 * 32),
+        ("energy", ctypes.c_float * 32),
+        ("values", ctypes.c_float * 1024),
+        ("n_tonal", ctypes.c_int32),
+        ("tonal_pos", ctypes.c_int32 * 64),
+        ("tonal_len", ctypes.c_int32 * 64),
+        ("tonal_sfi", ctypes.c_int32 * 64),
+        ("tonal_values", (ctypes.c_float * 8) * 64),
+    ]
+
+
+TAP_DTYPE = np.dtype([
+    ("n_points", "<i4", (4,)), ("level", "<i4", (4, 8)), ("loc", "<i4", (4, 8)), ("ges_frame", "<f4", (4,)),
+    ("loudness_ch", "<f4"), ("loudness_track", "<f4"), ("sfi", "<i4", (32,)), ("energy", "<f4", (32,)),
+    ("values", "<f4", (1024,)), ("n_tonal", "<i4"), ("tonal_pos", "<i4", (64,)), ("tonal_len", "<i4", (64,)),
+    ("tonal_sfi", "<i4", (64,)), ("tonal_values", "<f4", (64, 8)),
+])
+assert TAP_DTYPE.itemsize == ctypes.sizeof(Tap)
+
+
+def build_oracle():
+    """Compile oracle/libat3oracle.so (and oracle/_ref when the reference sources exist)."""
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "oracle"])
+    if os.path.isdir("/root/reference/src") and not os.path.exists(REF_SO):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class CpuCodec:
+    """ctypes view of one of the two CPU implementations (prefix 'at3o' or 'ref')."""
+
+    def __init__(self, path, prefix):
+        self.lib = ctypes.CDLL(path)
+        self.prefix = prefix
+        f = self._f
+        f("encode").restype = ctypes.c_int
+        f("quant_mantisas").restype = ctypes.c_float
+        f("quant_mantisas").argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+        f("log2f").restype = ctypes.c_float
+        f("log2f").argtypes = [ctypes.c_float]
+        f("calc_curve").restype = ctypes.c_int
+        f("calc_curve").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p]
+        f("relation_to_idx_hdr").restype = ctypes.c_int
+        f("relation_to_idx_hdr").argtypes = [ctypes.c_float]
+        f("gain_energy_scale").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
+
+    def _f(self, name):
+        return getattr(self.lib, f"{self.prefix}_{name}")
+
+    def encode(self, pcm, bitrate=LP2, no_gain=False, no_tonal=False, bfu_idx_const=0, taps=False):
+        """pcm: float32 [nblocks, 1024, nch] -> (frames uint8 [nblocks-1, frame_sz], taps or None)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        nb, _, nch = pcm.shape
+        out = np.zeros(max(nb - 1, 1) * 1024, dtype=np.uint8)
+        fsz = ctypes.c_int()
+        tap = np.zeros((max(nb - 1, 1), nch), dtype=TAP_DTYPE) if taps else None
+        n = self._f("encode")(int(bitrate), nch, int(no_gain), int(no_tonal), int(bfu_idx_const), _vp(pcm), nb,
+                              _vp(out), ctypes.byref(fsz), _vp(tap) if taps else None)
+        frames = out[: n * fsz.value].reshape(n, fsz.value).copy()
+        return frames, (tap[:n] if taps else None)
+
+    def qmf(self, pcm_mono):
+        pcm_mono = np.ascontiguousarray(pcm_mono, dtype=np.float32)
+        nb = pcm_mono.size // 1024
+        sub = np.zeros((4, nb * 256), dtype=np.float32)
+        self._f("qmf")(_vp(pcm_mono), nb, _vp(sub))
+        return sub
+
+    def mdct(self, bands, n_points=None, level=None, loc=None):
+        """bands float32 [4,512] ([overlap|new]); returns (specs[1024], mutated bands)."""
+        bands = np.ascontiguousarray(bands, dtype=np.float32).copy()
+        specs = np.zeros(1024, dtype=np.float32)
+        if n_points is None:
+            self._f("mdct")(_vp(specs), _vp(bands), None, None, None)
+        else:
+            n_points = np.ascontiguousarray(n_points, dtype=np.int32)
+            level = np.ascontiguousarray(level, dtype=np.int32)
+            loc = np.ascontiguousarray(loc, dtype=np.int32)
+            self._f("mdct")(_vp(specs), _vp(bands), _vp(n_points), _vp(level), _vp(loc))
+        return specs, bands
+
+    def mdct512(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(256, dtype=np.float32)
+        self._f("mdct512")(_vp(x), _vp(out))
+        return out
+
+    def gain_energy_scale(self, prev, cur, level, loc, prev_scale):
+        prev = np.ascontiguousarray(prev, dtype=np.float32)
+        cur = np.ascontiguousarray(cur, dtype=np.float32)
+        level = np.ascontiguousarray(level, dtype=np.int32)
+        loc = np.ascontiguousarray(loc, dtype=np.int32)
+        out = np.zeros(4, dtype=np.float32)
+        self._f("gain_energy_scale")(_vp(prev), _vp(cur), len(level), _vp(level), _vp(loc), prev_scale, _vp(out))
+        return out
+
+    def upsample(self, x512):
+        x512 = np.ascontiguousarray(x512, dtype=np.float32)
+        out = np.zeros(4096, dtype=np.float32)
+        hfr = ctypes.c_float()
+        self._f("upsample")(_vp(x512), _vp(out), ctypes.byref(hfr))
+        return out, np.float32(hfr.value)
+
+    def analyze_gain(self, x, n_points=32):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        g = np.zeros(n_points, dtype=np.float32)
+        lo = np.zeros(n_points, dtype=np.float32)
+        hi = np.zeros(n_points, dtype=np.float32)
+        self._f("analyze_gain")(_vp(x), x.size, n_points, _vp(g), _vp(lo), _vp(hi))
+        return g, lo, hi
+
+    def calc_curve(self, gain, ctx, min_score, lo, hi):
+        gain = np.ascontiguousarray(gain, dtype=np.float32)
+        lo = np.ascontiguousarray(lo, dtype=np.float32)
+        hi = np.ascontiguousarray(hi, dtype=np.float32)
+        ctx = np.ascontiguousarray(ctx, dtype=np.float32).copy()
+        level = np.zeros(8, dtype=np.int32)
+        loc = np.zeros(8, dtype=np.int32)
+        n = self._f("calc_curve")(_vp(gain), _vp(ctx), float(min_score), _vp(lo), _vp(hi), _vp(level), _vp(loc))
+        return level[:n].copy(), loc[:n].copy(), ctx
+
+    def relation_to_idx_hdr(self, x):
+        return self._f("relation_to_idx_hdr")(float(x))
+
+    def quant_mantisas(self, values, mul, ea):
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        mant = np.zeros(values.size, dtype=np.int32)
+        e = self._f("quant_mantisas")(_vp(values), values.size, float(mul), int(ea), _vp(mant))
+        return mant, np.float32(e)
+
+    def scale_frame(self, specs):
+        specs = np.ascontiguousarray(specs, dtype=np.float32)
+        sfi = np.zeros(32, dtype=np.int32)
+        en = np.zeros(32, dtype=np.float32)
+        vals = np.zeros(1024, dtype=np.float32)
+        self._f("scale_frame")(_vp(specs), _vp(sfi), _vp(en), _vp(vals))
+        return sfi, en, vals
+
+    def flatness(self, energy):
+        energy = np.ascontiguousarray(energy, dtype=np.float32)
+        out = np.zeros(32, dtype=np.float32)
+        self._f("flatness")(_vp(energy), _vp(out))
+        return out
+
+    def log2f(self, x):
+        return np.float32(self._f("log2f")(float(x)))
+
+    def tables(self):
+        names = [("scale", 64), ("encwin", 256), ("gainlevel", 16), ("gaininterp", 31), ("qmfwin", 48),
+                 ("loud", 1024), ("ath", 1024)]
+        arrs = [np.zeros(n, dtype=np.float32) for _, n in names]
+        self._f("tables")(*[_vp(a) for a in arrs])
+        return {k: a for (k, _), a in zip(names, arrs)}
+
+
+_oracle = None
+_ref = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        _oracle = CpuCodec(ORACLE_SO, "at3o")
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = CpuCodec(REF_SO, "ref")
+    return _ref
+
+
+# ----------------------------------------------------------------------------------------------
+# Seeded synthetic PCM: float32 = s16 / 32768, shape [nblocks, 1024, 2]
+# ----------------------------------------------------------------------------------------------
+def _quant16(x):
+    return (np.round(np.clip(x, -1.0, 32767.0 / 32768.0) * 32768.0) / 32768.0).astype(np.float32)
+
+
+def pcm_noise(nblocks, seed=1, amp=8192):
+    rng = np.random.RandomState(seed)
+    return (rng.randint(-amp, amp, size=(nblocks, 1024, 2)).astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+
+
+def pcm_burst(nblocks, period=3000, lo=0.02, hi=0.6, freq=3000.0, right=0.5, phase=0):
+    n = nblocks * 1024
+    t = np.arange(n, dtype=np.float64)
+    amp = np.where(((t + phase) // period) % 2 == 0, lo, hi)
+    left = amp * np.sin(2 * np.pi * freq * t / 44100.0)
+    x = np.stack([left, right * left], axis=-1)
+    return _quant16(x).reshape(nblocks, 1024, 2)
+
+
+def pcm_tones(nblocks, freqs=(440.0, 1000.0, 3000.0, 7000.0, 11000.0), amp=0.1):
+    n = nblocks * 1024
+    t = np.arange(n, dtype=np.float64)
+    left = sum(amp * np.sin(2 * np.pi * f * t / 44100.0) for f in freqs)
+    rightv = sum(amp * np.sin(2 * np.pi * f * t / 44100.0 + 0.3 * i) for i, f in enumerate(freqs))
+    return _quant16(np.stack([left, rightv], axis=-1)).reshape(nblocks, 1024, 2)
+
+
+def pcm_silence(nblocks):
+    return np.zeros((nblocks, 1024, 2), dtype=np.float32)
+
+
+def pcm_mix(nblocks, seed=7):
+    """Noise bed + tones + percussive bursts: exercises gain curves, tonal extraction and allocation."""
+    rng = np.random.RandomState(seed)
+    n = nblocks * 1024
+    t = np.arange(n, dtype=np.float64)
+    bed = rng.randn(n, 2) * 0.01
+    tone = 0.15 * np.sin(2 * np.pi * 2500.0 * t / 44100.0)[:, None] * np.array([1.0, 0.7])
+    env = np.zeros(n)
+    for start in rng.randint(0, n, size=max(1, nblocks // 2)):
+        ln = rng.randint(200, 3000)
+        seg = np.arange(min(ln, n - start))
+        env[start:start + seg.size] += rng.uniform(0.2, 0.8) * np.exp(-seg / (0.3 * ln))
+    hit = env[:, None] * rng.randn(n, 2) * 0.5
+    return _quant16(bed + tone + hit).reshape(nblocks, 1024, 2)
+
+
+SIGNALS = {
+    "noise": pcm_noise,
+    "burst": pcm_burst,
+    "tones": pcm_tones,
+    "silence": pcm_silence,
+    "mix": pcm_mix,
+}
