@@ -1,0 +1,156 @@
+"""ctypes binding of include/at3hip.h (the same stub a maintainer would write for any FFI)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libat3hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+AT3HIP_PCM_ON_DEVICE = 1
+AT3HIP_OUT_ON_DEVICE = 2
+LP2 = 132300
+LP4 = 66150
+
+
+class At3HipError(RuntimeError):
+    pass
+
+
+class Config(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("bitrate", "channels", "no_gain_control", "no_tonal", "bfu_idx_const",
+                                               "n_streams", "max_blocks", "device_id")]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "qmf_ms", "gain_ms", "curve_ms", "qmf_mdct_ms", "psy_ms",
+                                               "alloc_ms")] + [("qmf_mdct_launches", ctypes.c_int32)]
+
+
+SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint_stereo", "at3hip_last_error",
+           "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
+           "at3hip_set_stream", "at3hip_version"]
+
+
+def build_library(verbose=False):
+    """Compile libat3hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-o", LIB_PATH, os.path.join(CSRC, "at3hip.hip"), os.path.join(CSRC, "at3_tables.cpp")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib_cache = {}
+
+
+def load_library(path=None):
+    path = path or os.environ.get("AT3HIP_LIB") or LIB_PATH
+    if path in _lib_cache:
+        return _lib_cache[path]
+    if not os.path.exists(path):
+        raise At3HipError(f"{path} not found: build it with atracdenc_amd.build_library() / __graft_entry__.build(); "
+                          "there is no CPU fallback")
+    lib = ctypes.CDLL(path)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    lib.at3hip_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
+    lib.at3hip_create.restype = ctypes.c_int
+    lib.at3hip_destroy.argtypes = [vp]
+    lib.at3hip_destroy.restype = None
+    lib.at3hip_frame_size.argtypes = [vp]
+    lib.at3hip_joint_stereo.argtypes = [vp]
+    lib.at3hip_last_error.argtypes = [vp]
+    lib.at3hip_last_error.restype = ctypes.c_char_p
+    lib.at3hip_encode.argtypes = [vp, vp, i32, vp, ctypes.POINTER(i32), ctypes.c_uint32]
+    lib.at3hip_reset.argtypes = [vp]
+    lib.at3hip_mdct.argtypes = [vp, vp, vp, vp, vp, vp, i32, ctypes.c_uint32]
+    lib.at3hip_qmf_mdct.argtypes = [vp, vp, i32, vp, ctypes.c_uint32]
+    lib.at3hip_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
+    lib.at3hip_set_stream.argtypes = [vp, vp]
+    lib.at3hip_version.restype = ctypes.c_uint32
+    _lib_cache[path] = lib
+    return lib
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class At3Hip:
+    """n_streams TAtrac3Encoder objects encoded side by side on one GPU."""
+
+    def __init__(self, n_streams=1, max_blocks=64, bitrate=LP2, no_gain=False, no_tonal=False, bfu_idx_const=0,
+                 device_id=0, lib_path=None):
+        self.lib = load_library(lib_path)
+        self.cfg = Config(int(bitrate), 2, int(no_gain), int(no_tonal), int(bfu_idx_const), int(n_streams),
+                          int(max_blocks), int(device_id))
+        self.ctx = ctypes.c_void_p()
+        rc = self.lib.at3hip_create(ctypes.byref(self.cfg), ctypes.byref(self.ctx))
+        if rc != 0:
+            self.ctx = None
+            raise At3HipError(f"at3hip_create failed with {rc} (no usable MI355X / HIP runtime?)")
+        self.n_streams = n_streams
+        self.frame_size = self.lib.at3hip_frame_size(self.ctx)
+        self.joint_stereo = bool(self.lib.at3hip_joint_stereo(self.ctx))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.at3hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise At3HipError(f"{what} failed ({rc}): {self.lib.at3hip_last_error(self.ctx).decode()}")
+
+    def reset(self):
+        self._check(self.lib.at3hip_reset(self.ctx), "at3hip_reset")
+
+    def encode(self, pcm):
+        """pcm float32 [n_streams, n_blocks, 1024, 2] (host) -> uint8 [n_streams, n_frames, frame_size]."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        assert pcm.ndim == 4 and pcm.shape[0] == self.n_streams and pcm.shape[2:] == (1024, 2), pcm.shape
+        nb = pcm.shape[1]
+        out = np.zeros((self.n_streams, nb, self.frame_size), dtype=np.uint8)
+        nf = ctypes.c_int32()
+        self._check(self.lib.at3hip_encode(self.ctx, _vp(pcm), nb, _vp(out), ctypes.byref(nf), 0), "at3hip_encode")
+        n = nf.value
+        return np.ascontiguousarray(out.reshape(-1)[: self.n_streams * n * self.frame_size].reshape(
+            self.n_streams, n, self.frame_size))
+
+    def encode_device(self, pcm_ptr, n_blocks, out_ptr):
+        """Device-resident PCM/out (raw pointers, e.g. torch tensor .data_ptr()). Returns frames per stream."""
+        nf = ctypes.c_int32()
+        self._check(self.lib.at3hip_encode(self.ctx, ctypes.c_void_p(pcm_ptr), n_blocks, ctypes.c_void_p(out_ptr),
+                                           ctypes.byref(nf), AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE),
+                    "at3hip_encode")
+        return nf.value
+
+    def qmf_mdct_device(self, pcm_ptr, n_blocks, specs_ptr):
+        self._check(self.lib.at3hip_qmf_mdct(self.ctx, ctypes.c_void_p(pcm_ptr), n_blocks, ctypes.c_void_p(specs_ptr),
+                                             AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE), "at3hip_qmf_mdct")
+
+    def mdct(self, bands, n_points=None, level=None, loc=None):
+        """Batched TAtrac3MDCT::Mdct. bands float32 [n,4,512] -> (specs [n,1024], mutated bands)."""
+        bands = np.ascontiguousarray(bands, dtype=np.float32).copy()
+        n = bands.shape[0]
+        specs = np.zeros((n, 1024), dtype=np.float32)
+        if n_points is None:
+            rc = self.lib.at3hip_mdct(self.ctx, _vp(bands), _vp(specs), None, None, None, n, 0)
+        else:
+            n_points = np.ascontiguousarray(n_points, dtype=np.int32)
+            level = np.ascontiguousarray(level, dtype=np.int32)
+            loc = np.ascontiguousarray(loc, dtype=np.int32)
+            rc = self.lib.at3hip_mdct(self.ctx, _vp(bands), _vp(specs), _vp(n_points), _vp(level), _vp(loc), n, 0)
+        self._check(rc, "at3hip_mdct")
+        return specs, bands
+
+    def timings(self):
+        t = Timings()
+        self._check(self.lib.at3hip_get_timings(self.ctx, ctypes.byref(t)), "at3hip_get_timings")
+        return {n: getattr(t, n) for n, _ in Timings._fields_}

@@ -1,0 +1,235 @@
+// Shared device-side definitions of the ATRAC3 encode kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "at3_tables.hpp"
+
+namespace at3 {
+
+// PCM history kept per stream between calls: two full blocks (MDCT overlap source + look-behind of the
+// gain analysis) plus the 138-sample reach of the two-stage 48-tap QMF, rounded up.
+constexpr int kHist = 2304;
+constexpr int kMaxTonal = 24;
+
+struct Curve {          // one band's gain curve (TAtrac3Data::SubbandInfo::TGainPoint list)
+    uint8_t n;
+    uint8_t level[7];
+    uint8_t loc[7];
+    uint8_t pad;
+};
+static_assert(sizeof(Curve) == 16, "Curve layout");
+
+struct GainRec {        // per (stream, frame, channel, band<3): gain-analysis results
+    float hfr;
+    float target;       // CalcCurve's target for this frame (context independent)
+    float cur_hpf;      // mean(gain)
+    float ctx_level;    // context *before* this frame (resolved by the scan kernel)
+    float ctx_target;
+    float ctx_hpf;
+    float pad[2];
+    float gain[32];
+    float lo[32];
+    float hi[32];
+};
+static_assert(sizeof(GainRec) == 104 * 4, "GainRec layout");
+
+struct BandState {      // carried per (stream, channel, band) between calls
+    float last_level, last_target, last_hpf;
+    float pad;
+    Curve prev_curve;
+};
+
+struct TonalBlock {
+    uint16_t pos;
+    uint8_t bfu, len, sfi, pad[3];
+    float values[7];
+    uint8_t pad2[4];
+};
+static_assert(sizeof(TonalBlock) == 40, "TonalBlock layout");
+
+struct PsyRec {         // per (stream, frame, channel)
+    float loud_ch;
+    int32_t n_tonal;
+    uint8_t sfi[32];
+    float energy[32];
+    TonalBlock tonal[kMaxTonal];
+};
+
+// ---- integer constant tables (atrac/at3/atrac3.h:79-176, atrac3_bitstream.cpp:44-49) ----
+__device__ static const uint16_t c_bfu_start[33] = {
+    0,   8,   16,  24,  32,  40,  48,  56,  64,  80,  96,  112, 128, 144, 160, 176, 192,
+    224, 256, 288, 320, 352, 384, 416, 448, 480, 512, 576, 640, 704, 768, 896, 1024};
+__device__ static const uint8_t c_clc_len[8] = {0, 4, 3, 3, 4, 4, 5, 6};
+__device__ static const float c_max_quant[8] = {0.0f, 1.5f, 2.5f, 3.5f, 4.5f, 7.5f, 15.5f, 31.5f};
+__device__ static const uint8_t c_fixed_alloc[32] = {6, 6, 5, 4, 4, 4, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3,
+                                                     3, 3, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 0, 0, 0};
+// Huffman tables flattened: entry = code | bits << 8; table of selector s (1..7) starts at c_huff_off[s-1].
+__device__ static const uint16_t c_huff_off[7] = {0, 9, 14, 0, 21, 36, 67};
+#define HE(code, bits) (uint16_t)((code) | ((bits) << 8))
+__device__ static const uint16_t c_huff[130] = {
+    // table 1 (selectors 1 and 4): 9 entries
+    HE(0x0, 1), HE(0x4, 3), HE(0x5, 3), HE(0xC, 4), HE(0xD, 4), HE(0x1C, 5), HE(0x1D, 5), HE(0x1E, 5), HE(0x1F, 5),
+    // table 2: 5
+    HE(0x0, 1), HE(0x4, 3), HE(0x5, 3), HE(0x6, 3), HE(0x7, 3),
+    // table 3: 7
+    HE(0x0, 1), HE(0x4, 3), HE(0x5, 3), HE(0xC, 4), HE(0xD, 4), HE(0xE, 4), HE(0xF, 4),
+    // table 5: 15
+    HE(0x0, 2), HE(0x2, 3), HE(0x3, 3), HE(0x8, 4), HE(0x9, 4), HE(0xA, 4), HE(0xB, 4), HE(0x1C, 5), HE(0x1D, 5),
+    HE(0x3C, 6), HE(0x3D, 6), HE(0x3E, 6), HE(0x3F, 6), HE(0xC, 4), HE(0xD, 4),
+    // table 6: 31
+    HE(0x0, 3), HE(0x2, 4), HE(0x3, 4), HE(0x4, 4), HE(0x5, 4), HE(0x6, 4), HE(0x7, 4), HE(0x14, 5), HE(0x15, 5),
+    HE(0x16, 5), HE(0x17, 5), HE(0x18, 5), HE(0x19, 5), HE(0x34, 6), HE(0x35, 6), HE(0x36, 6), HE(0x37, 6),
+    HE(0x38, 6), HE(0x39, 6), HE(0x3A, 6), HE(0x3B, 6), HE(0x78, 7), HE(0x79, 7), HE(0x7A, 7), HE(0x7B, 7),
+    HE(0x7C, 7), HE(0x7D, 7), HE(0x7E, 7), HE(0x7F, 7), HE(0x8, 4), HE(0x9, 4),
+    // table 7: 63
+    HE(0x0, 3), HE(0x8, 5), HE(0x9, 5), HE(0xA, 5), HE(0xB, 5), HE(0xC, 5), HE(0xD, 5), HE(0xE, 5), HE(0xF, 5),
+    HE(0x10, 5), HE(0x11, 5), HE(0x24, 6), HE(0x25, 6), HE(0x26, 6), HE(0x27, 6), HE(0x28, 6), HE(0x29, 6),
+    HE(0x2A, 6), HE(0x2B, 6), HE(0x2C, 6), HE(0x2D, 6), HE(0x2E, 6), HE(0x2F, 6), HE(0x30, 6), HE(0x31, 6),
+    HE(0x32, 6), HE(0x33, 6), HE(0x68, 7), HE(0x69, 7), HE(0x6A, 7), HE(0x6B, 7), HE(0x6C, 7), HE(0x6D, 7),
+    HE(0x6E, 7), HE(0x6F, 7), HE(0x70, 7), HE(0x71, 7), HE(0x72, 7), HE(0x73, 7), HE(0x74, 7), HE(0x75, 7),
+    HE(0xEC, 8), HE(0xED, 8), HE(0xEE, 8), HE(0xEF, 8), HE(0xF0, 8), HE(0xF1, 8), HE(0xF2, 8), HE(0xF3, 8),
+    HE(0xF4, 8), HE(0xF5, 8), HE(0xF6, 8), HE(0xF7, 8), HE(0xF8, 8), HE(0xF9, 8), HE(0xFA, 8), HE(0xFB, 8),
+    HE(0xFC, 8), HE(0xFD, 8), HE(0xFE, 8), HE(0xFF, 8), HE(0x2, 4), HE(0x3, 4)};
+#undef HE
+
+__device__ __forceinline__ cpx cmul(cpx a, cpx b)
+{
+    cpx m;
+    m.r = a.r * b.r - a.i * b.i;
+    m.i = a.r * b.i + a.i * b.r;
+    return m;
+}
+
+// log2f with the exact operation sequence of glibc 2.35's FMA build (see at3_tables.cpp); x > 0, finite.
+__device__ __forceinline__ float at3_log2f(const Tables* T, float x)
+{
+    uint32_t ix = __float_as_uint(x);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {  // subnormal (other specials never reach here)
+        ix = __float_as_uint(x * 0x1p23f);
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) % 16;
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)tmp >> 23;
+    const double z = (double)__uint_as_float(iz);
+    const double r = fma(z, T->log2f_tab[i][0], -1.0);
+    const double y0 = T->log2f_tab[i][1] + (double)k;
+    const double r2 = r * r;
+    double y = fma(T->log2f_poly[1], r, T->log2f_poly[2]);
+    y = fma(T->log2f_poly[0], r2, y);
+    const double p = fma(T->log2f_poly[3], r, y0);
+    y = fma(y, r2, p);
+    return (float)y;
+}
+
+// ---- kissfft-order in-LDS FFT -------------------------------------------------------------------
+// F holds `nfft` arrays of N complex points (stride NS) whose inputs were already stored in the
+// decimation-in-time leaf order (see fft_leaf_pos). Recombination runs from the leaves up with the
+// butterfly arithmetic of kf_bfly2 / kf_bfly4 (kiss_fft.c:21-90). Uniform call: every thread of the
+// workgroup must enter; ends with a barrier.
+template <int N>
+__device__ __forceinline__ int fft_leaf_pos(int i)
+{
+    // input index i = q1 + 4 q2 + 16 q3 + ... (radix-4 digits, optional final radix-2 digit)
+    // -> output slot o = q1*N/4 + q2*N/16 + ...
+    int o = 0;
+    int m = N;
+    int rem = i;
+    while (m >= 4 && (m % 4) == 0) {
+        m >>= 2;
+        o += (rem & 3) * m;
+        rem >>= 2;
+    }
+    if (m == 2) o += (rem & 1);
+    return o;
+}
+
+template <int N, bool INVERSE>
+__device__ __forceinline__ void fft_lds(cpx* F, int NS, int nfft, const cpx* tw, int tid, int nthr)
+{
+    // number of radix-4 stages and whether a radix-2 leaf stage exists
+    int lg = 0;
+    for (int t = N; t > 1; t >>= 1) ++lg;
+    int m = 1;
+    if (lg & 1) {
+        // radix-2 leaves: m = 1, fstride = N/2, twiddle index 0
+        const cpx w = tw[0];
+        for (int j = tid; j < nfft * (N / 2); j += nthr) {
+            const int f = j / (N / 2), p = j % (N / 2);
+            cpx* a = F + f * NS + 2 * p;
+            const cpx t = cmul(a[1], w);
+            a[1].r = a[0].r - t.r;
+            a[1].i = a[0].i - t.i;
+            a[0].r += t.r;
+            a[0].i += t.i;
+        }
+        __syncthreads();
+        m = 2;
+    }
+    for (; m < N; m <<= 2) {
+        const int fstride = N / (4 * m);
+        for (int j = tid; j < nfft * (N / 4); j += nthr) {
+            const int f = j / (N / 4), r = j % (N / 4);
+            const int g = r / m, k = r % m;
+            cpx* B = F + f * NS + g * 4 * m + k;
+            const cpx s0 = cmul(B[m], tw[k * fstride]);
+            const cpx s1 = cmul(B[2 * m], tw[2 * k * fstride]);
+            const cpx s2 = cmul(B[3 * m], tw[3 * k * fstride]);
+            cpx s5, s3, s4, f0 = B[0];
+            s5.r = f0.r - s1.r; s5.i = f0.i - s1.i;
+            f0.r += s1.r; f0.i += s1.i;
+            s3.r = s0.r + s2.r; s3.i = s0.i + s2.i;
+            s4.r = s0.r - s2.r; s4.i = s0.i - s2.i;
+            B[2 * m].r = f0.r - s3.r; B[2 * m].i = f0.i - s3.i;
+            f0.r += s3.r; f0.i += s3.i;
+            B[0] = f0;
+            if (INVERSE) {
+                B[m].r = s5.r - s4.i; B[m].i = s5.i + s4.r;
+                B[3 * m].r = s5.r + s4.i; B[3 * m].i = s5.i - s4.r;
+            } else {
+                B[m].r = s5.r + s4.i; B[m].i = s5.i - s4.r;
+                B[3 * m].r = s5.r - s4.i; B[3 * m].i = s5.i + s4.r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Divisor applied to sample i of the "new" half for a gain curve: the running-product ramp of
+// TGainProcessor::Modulate (gain_processor.h:93-112) / BuildSampleDivisors (atrac3denc.cpp:154-173).
+// Returns 1.0f for samples the curve does not touch (x / 1.0f == x, so dividing is a no-op there).
+__device__ __forceinline__ float curve_divisor(const Tables* T, const Curve& c, int i)
+{
+    int pos = 0;
+    for (int p = 0; p < c.n; ++p) {
+        const int lastPos = (int)c.loc[p] << 3;
+        float level = T->gain_level[c.level[p]];
+        if (i >= pos && i < lastPos) return level;
+        if (lastPos > pos) pos = lastPos;
+        if (pos < lastPos + 8) {
+            if (i >= pos && i < lastPos + 8) {
+                const int incPos = ((p + 1) < c.n ? (int)c.level[p + 1] : 4) - (int)c.level[p] + 15;
+                const float inc = T->gain_interp[incPos];
+                for (int q = pos; q < i; ++q) level *= inc;
+                return level;
+            }
+            pos = lastPos + 8;
+        }
+    }
+    return 1.0f;
+}
+
+// atrac3denc.cpp:143-152
+__device__ __forceinline__ float safe_energy_scale(float orig, float mod)
+{
+    const float eps = 1.0e-20f;
+    if (orig <= eps || mod <= eps || !isfinite(orig) || !isfinite(mod)) return 1.0f;
+    const float scale = orig / mod;
+    return (isfinite(scale) && scale > 0.0f) ? scale : 1.0f;
+}
+
+}  // namespace at3

@@ -1,0 +1,948 @@
+// Back-end kernels: loudness / flatness / tonal extraction / scale factors, loudness tracking,
+// bit allocation + mantissa quantisation + sound-unit packing.
+//
+// Reference path replaced (paths relative to the reference's src/):
+//   atrac3denc.cpp:811-830                  loudness sum, flatness, ExtractTonalComponents, MapTonalComponents, ScaleFrame
+//   atrac/atrac_psy_common.cpp:158-199      CalcSpectralFlatnessPerBfu
+//   atrac/atrac_scale.cpp:40-188            QuantMantisas, TScaler::Scale / ScaleFrame
+//   atrac/atrac_psy_common.h:46-54          TrackLoudness
+//   atrac/at3/atrac3_bitstream.cpp:92-847   CLC/VLC cost + emission, CalcBitsAllocation, ConsiderEnergyErr,
+//                                           tonal component grouping/coding, TConfigure/TAlloc, WriteSoundUnit
+//   lib/bs_encode/encode.cpp:57-129         bisection driver (Start / Continue / Submit / Repeat)
+//   lib/bitstream/bitstream.cpp:40-63       MSB-first bit writer
+#pragma once
+#include "at3_common.hpp"
+
+namespace at3 {
+
+struct BackParams {
+    float* specs;            // [S][n_out][2][1024]; tonal lines are zeroed in place
+    const float* ges;        // [S][n_blocks][2][4] by frame index, or null (all 1.0)
+    const Curve* curves;     // [S][n_blocks][2][4] by frame index (zeros when gain control is off)
+    PsyRec* psy;             // [S][n_out][2]
+    float* loud;             // [S][n_out] tracked loudness per frame
+    float* loud_state;       // [S]
+    uint8_t* out;            // [S][n_out][frame_sz]
+    int n_blocks;
+    int f0;
+    int n_streams;
+    int no_tonal;
+    int js;
+    int frame_sz;
+    int bfu_idx_const;
+};
+
+// atrac_scale.cpp:141-172. Returns sfi; values/energy optional.
+__device__ inline int scale_block(const Tables* T, const float* in, int len, float* values, float* energy)
+{
+    float maxAbs = 0.0f;
+    for (int i = 0; i < len; ++i) {
+        const float a = fabsf(in[i]);
+        if (a > maxAbs) maxAbs = a;
+    }
+    if (maxAbs > 1.0f) maxAbs = 1.0f;
+    int sfi = 0;
+    while (sfi < 63 && T->scale[sfi] < maxAbs) ++sfi;   // map::lower_bound on the increasing table
+    const float sf = T->scale[sfi];
+    float e = 0.0f;
+    for (int i = 0; i < len; ++i) {
+        const float x = in[i];
+        e += x * x;
+        if (values) {
+            float v = x / sf;
+            if (fabsf(v) >= 1.0f) v = (v > 0) ? 0.99999f : -0.99999f;
+            values[i] = v;
+        }
+    }
+    if (energy) *energy = e;
+    return sfi;
+}
+
+// One workgroup per (stream, output frame, channel).
+__global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
+{
+    __shared__ float s_spec[1024];
+    __shared__ float s_e[1024];
+    __shared__ double s_log[768];
+    __shared__ int s_run_start[32];
+    __shared__ int s_run_len[32];
+    __shared__ uint16_t s_tv_pos[112];
+    __shared__ float s_tv_val[112];
+    __shared__ uint8_t s_tv_bfu[112];
+    const int tid = threadIdx.x;
+    const int n_out = p.n_blocks - p.f0;
+    const int ch = blockIdx.x & 1;
+    const int fo = (blockIdx.x >> 1) % n_out;
+    const int s = (blockIdx.x >> 1) / n_out;
+    const int f = fo + p.f0;
+    float* specs = p.specs + (((size_t)s * n_out + fo) * 2 + ch) * 1024;
+    PsyRec* rec = p.psy + ((size_t)s * n_out + fo) * 2 + ch;
+
+    for (int i = tid; i < 1024; i += 256) {
+        const float x = specs[i];
+        s_spec[i] = x;
+        s_e[i] = x * x;
+    }
+    if (tid < 32) s_run_len[tid] = 0;
+    __syncthreads();
+
+    if (tid == 255) {
+        // loudness: strictly sequential 1024-term sum (atrac3denc.cpp:811-820)
+        float g[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (p.ges)
+            for (int b = 0; b < 4; ++b) g[b] = p.ges[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + b];
+        float l = 0.0f;
+        for (int i = 0; i < 1024; ++i) l += s_e[i] * g[i >> 8] * T->loud_curve[i];
+        rec->loud_ch = l;
+    } else if (!p.no_tonal) {
+        const double floor_ = (double)1e-12f;
+        for (int i = 64 + tid; i < 768; i += 255) {
+            const double e = (double)fmaxf(0.0f, s_e[i]);
+            s_log[i] = log(e > floor_ ? e : floor_);
+        }
+    }
+    __syncthreads();
+
+    if (!p.no_tonal && tid >= 8 && tid < 29) {
+        const int b = tid;
+        const int start = c_bfu_start[b], end = c_bfu_start[b + 1], len = end - start;
+        double arith = 0.0, meanLog = 0.0;
+        for (int i = start; i < end; ++i) {
+            arith += (double)fmaxf(0.0f, s_e[i]);
+            meanLog += s_log[i];
+        }
+        arith /= (double)len;
+        meanLog /= (double)len;
+        float flat = 1.0f;
+        if (!(arith <= (double)1e-12f)) {
+            const double ratio = exp(meanLog) / arith;
+            flat = (float)fmin(1.0, fmax(0.0, ratio));
+        }
+        if (flat < 0.01f) {  // ExtractTonalComponents search, atrac3denc.cpp:606-625
+            const int maxLen = 5 < len ? 5 : len;
+            float bestScore = -1.0f;
+            int bestStart = start, bestLen = 1;
+            for (int st = start; st < end; ++st) {
+                const int ml = maxLen < end - st ? maxLen : end - st;
+                float score = 0.0f;
+                for (int l = 1; l <= ml; ++l) {
+                    score += fabsf(s_spec[st + l - 1]);
+                    if (score > bestScore) {
+                        bestScore = score;
+                        bestStart = st;
+                        bestLen = l;
+                    }
+                }
+            }
+            if (bestScore > 0.0f) {
+                s_run_start[b] = bestStart;
+                s_run_len[b] = bestLen;
+            }
+        }
+    }
+    __syncthreads();
+
+    if (tid == 0) {
+        int nv = 0;
+        for (int b = 8; b < 29; ++b) {
+            for (int k = 0; k < s_run_len[b]; ++k) {
+                const int pos = s_run_start[b] + k;
+                s_tv_pos[nv] = (uint16_t)pos;
+                s_tv_val[nv] = s_spec[pos];
+                s_tv_bfu[nv] = (uint8_t)b;
+                ++nv;
+                s_spec[pos] = 0.0f;
+                specs[pos] = 0.0f;
+            }
+        }
+        // MapTonalComponents (atrac3denc.cpp:646-662): runs of consecutive positions, at most 7 long
+        int nb = 0;
+        for (int i = 0; i < nv;) {
+            const int startPos = i;
+            int curPos;
+            do {
+                curPos = s_tv_pos[i];
+                ++i;
+            } while (i < nv && s_tv_pos[i] == curPos + 1 && i - startPos < 7);
+            const int len = i - startPos;
+            TonalBlock tb;
+            tb.pos = s_tv_pos[startPos];
+            tb.bfu = s_tv_bfu[startPos];
+            tb.len = (uint8_t)len;
+            for (int j = 0; j < 7; ++j) tb.values[j] = 0.0f;
+            for (int j = 0; j < 3; ++j) tb.pad[j] = 0;
+            for (int j = 0; j < 4; ++j) tb.pad2[j] = 0;
+            tb.sfi = (uint8_t)scale_block(T, s_tv_val + startPos, len, tb.values, nullptr);
+            if (nb < kMaxTonal) rec->tonal[nb] = tb;
+            ++nb;
+        }
+        rec->n_tonal = nb < kMaxTonal ? nb : kMaxTonal;
+    }
+    __syncthreads();
+
+    if (tid < 32) {
+        const int start = c_bfu_start[tid], len = c_bfu_start[tid + 1] - start;
+        float e;
+        const int sfi = scale_block(T, s_spec + start, len, nullptr, &e);
+        rec->sfi[tid] = (uint8_t)sfi;
+        rec->energy[tid] = e;
+    }
+}
+
+// TrackLoudness chain: one thread per stream, sequential over frames (atrac3denc.cpp:833-841).
+__global__ void k_loudness(BackParams p)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.n_streams) return;
+    const int n_out = p.n_blocks - p.f0;
+    float L = p.loud_state[s];
+    for (int fo = 0; fo < n_out; ++fo) {
+        const PsyRec* r = p.psy + ((size_t)s * n_out + fo) * 2;
+        const float l0 = r[0].loud_ch, l1 = r[1].loud_ch;
+        if (p.js) L = (float)(0.98 * (double)L + 0.02 * (double)l0);
+        else L = (float)(0.98 * (double)L + 0.01 * (double)(l0 + l1));
+        p.loud[(size_t)s * n_out + fo] = L;
+    }
+    p.loud_state[s] = L;
+}
+
+// ---- bit writer on an LDS word buffer (MSB first) -------------------------------------------------
+constexpr int kBitWords = 320;  // 10240 bits: upper bound of one channel's sound unit before truncation
+
+__device__ inline void put_bits(uint32_t* words, int pos, uint32_t val, int n)
+{
+    // n in 1..23. Bits beyond the buffer are dropped (they are truncated away by the frame size anyway).
+    if (n <= 0 || pos + n > kBitWords * 32) return;
+    val &= (n >= 32) ? 0xffffffffu : ((1u << n) - 1u);
+    const int w = pos >> 5, off = pos & 31;
+    const int room = 32 - off;
+    if (n <= room) {
+        atomicOr(&words[w], val << (room - n));
+    } else {
+        atomicOr(&words[w], val >> (n - room));
+        atomicOr(&words[w + 1], val << (32 - (n - room)));
+    }
+}
+
+__device__ inline uint32_t huff_entry(int sel, uint32_t idx) { return c_huff[c_huff_off[sel - 1] + idx]; }
+
+__device__ inline uint32_t vlc_index(int m)
+{
+    uint32_t h = (m < 0) ? (((uint32_t)(-m)) << 1) | 1u : ((uint32_t)m) << 1;
+    if (h) h -= 1;
+    return h;
+}
+
+// (code | len << 16) for element i of a BFU quantised with selector wl. Pair-coded selectors (wl == 1)
+// put the pair on the even element.
+__device__ inline uint32_t spec_code(int wl, bool clc, const int8_t* m, int i)
+{
+    if (wl > 1) {
+        if (clc) {
+            const int nb = c_clc_len[wl];
+            return ((uint32_t)m[i] & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
+        }
+        const uint32_t e = huff_entry(wl, vlc_index(m[i]));
+        return (e & 0xffu) | ((e >> 8) << 16);
+    }
+    if (i & 1) return 0;
+    if (clc) {
+        const uint32_t rt[4] = {2, 3, 0, 1};
+        const uint32_t code = (rt[m[i] + 2] << 2) | rt[m[i + 1] + 2];
+        return code | (4u << 16);
+    }
+    const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
+    const uint32_t e = huff_entry(1, rt9[3 * (m[i] + 1) + (m[i + 1] + 1)]);
+    return (e & 0xffu) | ((e >> 8) << 16);
+}
+
+// libstdc++ std::sort order for (key, idx) pairs compared by |key| (see oracle/at3_oracle.c std_sort_abs
+// for the derivation; QuantMantisas at atrac_scale.cpp:79-83 depends on this order for equal keys).
+struct SortItem {
+    float key;
+    int idx;
+};
+__device__ inline bool sless(const SortItem& a, const SortItem& b) { return fabsf(a.key) < fabsf(b.key); }
+
+__device__ inline void s_push_heap(SortItem* first, int hole, int top, SortItem value)
+{
+    int parent = (hole - 1) / 2;
+    while (hole > top && sless(first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+
+__device__ inline void s_adjust_heap(SortItem* first, int hole, int len, SortItem value)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (sless(first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    s_push_heap(first, hole, top, value);
+}
+
+__device__ inline void s_heap_sort(SortItem* first, int len)
+{
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        for (;;) {
+            const SortItem v = first[parent];
+            s_adjust_heap(first, parent, len, v);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    while (len > 1) {
+        --len;
+        const SortItem v = first[len];
+        first[len] = first[0];
+        s_adjust_heap(first, 0, len, v);
+    }
+}
+
+__device__ inline void s_unguarded_linear_insert(SortItem* a, int last)
+{
+    const SortItem v = a[last];
+    int next = last - 1;
+    while (sless(v, a[next])) {
+        a[last] = a[next];
+        last = next;
+        --next;
+    }
+    a[last] = v;
+}
+
+__device__ inline void s_insertion_sort(SortItem* a, int first, int last)
+{
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (sless(a[i], a[first])) {
+            const SortItem v = a[i];
+            for (int j = i; j > first; --j) a[j] = a[j - 1];
+            a[first] = v;
+        } else {
+            s_unguarded_linear_insert(a, i);
+        }
+    }
+}
+
+__device__ inline void std_sort_abs(SortItem* a, int n)
+{
+    if (n <= 0) return;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) ++lg;
+    // introsort loop with an explicit stack instead of recursion on the right partition
+    int stk_first[24], stk_last[24], stk_depth[24];
+    int sp = 0;
+    stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * lg; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+        // The reference recursion handles [cut,last) first (recursively, completely) and then loops on
+        // [first,cut). Partitions are disjoint, so the processing order does not affect the result.
+        while (last - first > 16) {
+            if (depth == 0) {
+                s_heap_sort(a + first, last - first);
+                break;
+            }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            const int ia = first + 1, ib = mid, ic = last - 1;
+            int pick;
+            if (sless(a[ia], a[ib])) {
+                if (sless(a[ib], a[ic])) pick = ib;
+                else if (sless(a[ia], a[ic])) pick = ic;
+                else pick = ia;
+            } else if (sless(a[ia], a[ic])) pick = ia;
+            else if (sless(a[ib], a[ic])) pick = ic;
+            else pick = ib;
+            {
+                const SortItem t = a[first];
+                a[first] = a[pick];
+                a[pick] = t;
+            }
+            int lo = first + 1, hi = last;
+            for (;;) {
+                while (sless(a[lo], a[first])) ++lo;
+                --hi;
+                while (sless(a[first], a[hi])) --hi;
+                if (!(lo < hi)) break;
+                const SortItem t = a[lo];
+                a[lo] = a[hi];
+                a[hi] = t;
+                ++lo;
+            }
+            if (sp < 24) {
+                stk_first[sp] = lo; stk_last[sp] = last; stk_depth[sp] = depth;
+                ++sp;
+            }
+            last = lo;
+        }
+    }
+    if (n > 16) {
+        s_insertion_sort(a, 0, 16);
+        for (int i = 16; i < n; ++i) s_unguarded_linear_insert(a, i);
+    } else {
+        s_insertion_sort(a, 0, n);
+    }
+}
+
+// QuantMantisas for one (bfu, wordlen) unit (atrac_scale.cpp:40-130). Writes int8 mantissas.
+__device__ inline float quant_unit(const float* in, int n, float mul, bool ea, int8_t* mant)
+{
+    float e1 = 0.0f, e2 = 0.0f;
+    const float inv2 = (float)(1.0 / (double)(mul * mul));
+    SortItem cand[128];
+    int nc = 0;
+    for (int j = 0; j < n; ++j) {
+        const float t = in[j] * mul;
+        e1 += in[j] * in[j];
+        const int m = __float2int_rn(t);
+        mant[j] = (int8_t)m;
+        e2 += (float)(m * m) * inv2;
+        if (ea) {
+            const float delta = t - (truncf(t) + 0.5f);
+            if (fabsf(delta) < 0.25f) {
+                cand[nc].key = delta;
+                cand[nc].idx = j;
+                ++nc;
+            }
+        }
+    }
+    if (!ea || nc == 0) return e1 / e2;
+    std_sort_abs(cand, nc);
+    if (e2 < e1) {
+        for (int c = 0; c < nc; ++c) {
+            const int j = cand[c].idx;
+            const float t = in[j] * mul;
+            const int m0 = mant[j];
+            const float am = (float)(m0 < 0 ? -m0 : m0);
+            if (am < fabsf(t) && am < (mul - 1)) {
+                int m = m0;
+                if (m > 0) m++;
+                if (m < 0) m--;
+                if (m == 0) m = t > 0 ? 1 : -1;
+                float ex = e2;
+                ex -= (float)(m0 * m0) * inv2;
+                ex += (float)(m * m) * inv2;
+                if (fabsf(ex - e1) < fabsf(e2 - e1)) {
+                    mant[j] = (int8_t)m;
+                    e2 = ex;
+                }
+            }
+        }
+    } else if (e2 > e1) {
+        for (int c = 0; c < nc; ++c) {
+            const int j = cand[c].idx;
+            const float t = in[j] * mul;
+            const int m0 = mant[j];
+            const float am = (float)(m0 < 0 ? -m0 : m0);
+            if (am > fabsf(t)) {
+                int m = m0;
+                if (m > 0) m--;
+                if (m < 0) m++;
+                float ex = e2;
+                ex -= (float)(m0 * m0) * inv2;
+                ex += (float)(m * m) * inv2;
+                if (fabsf(ex - e1) < fabsf(e2 - e1)) {
+                    mant[j] = (int8_t)m;
+                    e2 = ex;
+                }
+            }
+        }
+    }
+    return e1 / e2;
+}
+
+// Tonal component side information: grouping (GroupTonalComponents, atrac3_bitstream.cpp:338-380) and
+// cost / emission (EncodeTonalComponents :382-524). Serial (one lane). With EMIT the bits go to `words`
+// starting at bit `pos`; returns the number of bits.
+template <bool EMIT>
+__device__ inline int tonal_encode(const PsyRec* rec, const uint8_t* tbits /* [kMaxTonal][8] */, const int* alloc,
+                                   int n_alloc, uint32_t* words, int pos)
+{
+    const int nt = rec->n_tonal;
+    uint8_t grp_of[kMaxTonal];
+    int tcsgn = 0;
+    for (int t = 0; t < nt; ++t) {
+        const int bfu = rec->tonal[t].bfu;
+        if (bfu >= n_alloc) {
+            grp_of[t] = 0xff;
+            continue;
+        }
+        int quant = alloc[bfu] + 4;
+        if (quant > 7) quant = 7;
+        if (quant < 2) quant = 2;
+        grp_of[t] = (uint8_t)(quant * 8 + rec->tonal[t].len);
+    }
+    // first pass: count sub-groups (needed up front for the 5-bit header)
+    for (int g = 16; g < 64; ++g) {
+        int mem[kMaxTonal];
+        int nm = 0;
+        for (int t = 0; t < nt; ++t)
+            if (grp_of[t] == g) mem[nm++] = t;
+        int cur = 0;
+        while (cur < nm) {
+            int start = cur;
+            ++tcsgn;
+            int limiter = 0;
+            do {
+                ++cur;
+                if (cur == nm) break;
+                if ((int)rec->tonal[mem[cur]].pos - (int)(rec->tonal[mem[start]].pos & ~63) < 64) {
+                    ++limiter;
+                } else {
+                    limiter = 0;
+                    start = cur;
+                }
+            } while (limiter < 7);
+        }
+    }
+    int used = 5;
+    if (EMIT) put_bits(words, pos, (uint32_t)tcsgn, 5);
+    if (tcsgn == 0) return used;
+    if (EMIT) put_bits(words, pos + used, 0, 2);
+    used += 2;
+    for (int g = 16; g < 64; ++g) {
+        int mem[kMaxTonal];
+        int nm = 0;
+        for (int t = 0; t < nt; ++t)
+            if (grp_of[t] == g) mem[nm++] = t;
+        if (nm == 0) continue;
+        // sub-group boundaries
+        int sg_start[kMaxTonal];
+        int nsg = 0;
+        {
+            int cur = 0;
+            while (cur < nm) {
+                int start = cur;
+                sg_start[nsg++] = cur;
+                int limiter = 0;
+                do {
+                    ++cur;
+                    if (cur == nm) break;
+                    if ((int)rec->tonal[mem[cur]].pos - (int)(rec->tonal[mem[start]].pos & ~63) < 64) {
+                        ++limiter;
+                    } else {
+                        limiter = 0;
+                        start = cur;
+                    }
+                } while (limiter < 7);
+            }
+        }
+        const int q = g >> 3;
+        const int codedValues = rec->tonal[mem[0]].len;
+        for (int sg = 0; sg < nsg; ++sg) {
+            const int sgStart = sg_start[sg];
+            const int sgEnd = (sg < nsg - 1) ? sg_start[sg + 1] : nm;
+            uint8_t cnt[16];
+            for (int j = 0; j < 16; ++j) cnt[j] = 0;
+            for (int j = sgStart; j < sgEnd; ++j) cnt[rec->tonal[mem[j]].pos >> 6]++;
+            int bandFlag[4];
+            for (int b = 0; b < 4; ++b) bandFlag[b] = cnt[4 * b] | cnt[4 * b + 1] | cnt[4 * b + 2] | cnt[4 * b + 3];
+            if (EMIT)
+                for (int b = 0; b < 4; ++b) put_bits(words, pos + used + b, bandFlag[b] != 0, 1);
+            used += 4;
+            if (EMIT) put_bits(words, pos + used, (uint32_t)codedValues - 1, 3);
+            used += 3;
+            if (EMIT) put_bits(words, pos + used, (uint32_t)q, 3);
+            used += 3;
+            int lastPos = sgStart;
+            for (int j = 0; j < 16; ++j) {
+                if (!bandFlag[j >> 2]) continue;
+                const int coded = cnt[j];
+                if (EMIT) put_bits(words, pos + used, (uint32_t)coded, 3);
+                used += 3;
+                int k = lastPos;
+                for (; k < lastPos + coded; ++k) {
+                    const TonalBlock& tb = rec->tonal[mem[k]];
+                    if (EMIT) {
+                        put_bits(words, pos + used, tb.sfi, 6);
+                        put_bits(words, pos + used + 6, (uint32_t)tb.pos - (uint32_t)j * 64, 6);
+                        int bp = pos + used + 12;
+                        const float mul = c_max_quant[q < 7 ? q : 7];
+                        for (int z = 0; z < tb.len; ++z) {
+                            const int m = __float2int_rn(tb.values[z] * mul);
+                            const uint32_t e = huff_entry(q, vlc_index(m));
+                            put_bits(words, bp, e & 0xffu, (int)(e >> 8));
+                            bp += (int)(e >> 8);
+                        }
+                    }
+                    used += 12 + tbits[mem[k] * 8 + q];
+                }
+                lastPos = k;
+            }
+        }
+    }
+    return used;
+}
+
+// One 64-lane workgroup per (stream, output frame, channel).
+__global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T)
+{
+    __shared__ float s_val[1024];           // scaled values; later aliased by the per-element (code,len) arrays
+    __shared__ int8_t s_mant[7 * 1024];
+    __shared__ float s_err[8 * 32];
+    __shared__ uint16_t s_clc[8 * 32];
+    __shared__ uint16_t s_vlc[8 * 32];
+    __shared__ float s_csfi[32];
+    __shared__ uint8_t s_gate[32];
+    __shared__ int s_alloc[32];
+    __shared__ uint8_t s_tbits[kMaxTonal * 8];
+    __shared__ uint32_t s_words[kBitWords];
+    __shared__ int s_lsum[64];
+    __shared__ int s_misc[8];
+    __shared__ float s_spread;
+
+    const int lane = threadIdx.x;
+    const int n_out = p.n_blocks - p.f0;
+    const int ch = blockIdx.x & 1;
+    const int fo = (blockIdx.x >> 1) % n_out;
+    const int s = (blockIdx.x >> 1) / n_out;
+    const int f = fo + p.f0;
+    const float* specs = p.specs + (((size_t)s * n_out + fo) * 2 + ch) * 1024;
+    const PsyRec* recs = p.psy + ((size_t)s * n_out + fo) * 2;
+    const PsyRec* rec = recs + ch;
+    const Curve* curves = p.curves + ((size_t)s * p.n_blocks + f) * 8;
+    const int half = p.frame_sz >> 1;
+
+    for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
+
+    // ---- scaled values (TScaler::Scale) ----
+    for (int b = 0; b < 32; ++b) {
+        const int start = c_bfu_start[b], len = c_bfu_start[b + 1] - start;
+        const float sf = T->scale[rec->sfi[b]];
+        for (int i = lane; i < len; i += 64) {
+            float v = specs[start + i] / sf;
+            if (fabsf(v) >= 1.0f) v = (v > 0) ? 0.99999f : -0.99999f;
+            s_val[start + i] = v;
+        }
+    }
+
+    // ---- header + gain info bits, joint-stereo byte shift, target bits (WriteSoundUnit :759-810) ----
+    int hdr[2];
+    for (int c2 = 0; c2 < 2; ++c2) {
+        int bits = (p.js && c2 == 1) ? 14 : 6;
+        bits += 2;
+        for (int b = 0; b < 4; ++b) bits += 3 + 9 * curves[c2 * 4 + b].n;
+        hdr[c2] = bits;
+    }
+    int shift = 0;
+    if (p.js) {
+        const int b0 = -6 - hdr[0], b1 = -6 - hdr[1];
+        const int totalUsed = 0 - b0 - b1;
+        const int maxShift = (int)((uint32_t)p.frame_sz / 2 - (1 + ((uint32_t)totalUsed - 1) / 8));
+        const float m = recs[0].loud_ch, sd = recs[1].loud_ch;
+        const float total = sd + m;
+        float ratio = 0.0f;
+        if (total > 0) ratio = (float)((double)(m / total) - 0.5);
+        int v = __float2int_rn((float)p.frame_sz * ratio);
+        if (v > maxShift) v = maxShift;
+        if (v < -maxShift) v = -maxShift;
+        shift = v;
+    }
+    const int nbytes = (ch == 0) ? half + shift : half - shift;
+    int target = -6 - hdr[ch] + 8 * nbytes;
+    if (target < 1) target = 1;
+    target &= 0xffff;
+    const float loudness = p.loud[(size_t)s * n_out + fo] / 0.006f;
+
+    // ---- TConfigure: spread, initial NumBfu ----
+    if (lane == 0) {
+        float sum = 0.0f;
+        for (int i = 0; i < 32; ++i) sum += (float)rec->sfi[i];
+        sum /= 32;
+        float sigma = 0.0f;
+        for (int i = 0; i < 32; ++i) {
+            float t = ((float)rec->sfi[i] - sum);
+            t *= t;
+            sigma += t;
+        }
+        sigma /= 32;
+        sigma = sqrtf(sigma);
+        if (sigma > 14.0f) sigma = 14.0f;
+        s_spread = sigma / 14.0f;
+    }
+    if (lane < 32) {
+        const int i = lane;
+        int band = 0;
+        if (i >= 18) band = 1;
+        if (i >= 26) band = 2;
+        if (i >= 30) band = 3;
+        float g = 1.0f;
+        if (p.ges) g = p.ges[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + band];
+        if (!(isfinite(g) && g > 0.0f)) g = 1.0f;
+        const float corrected = rec->energy[i] * g;
+        const float ath = T->ath_bfu[i] * loudness;
+        s_gate[i] = corrected < ath;
+        s_csfi[i] = fmaxf(0.0f, fminf(63.0f, (float)rec->sfi[i] + 1.5f * at3_log2f(T, g)));
+    }
+    // tonal blocks: VLC bit cost for every quantiser 2..7
+    for (int idx = lane; idx < rec->n_tonal * 6; idx += 64) {
+        const int t = idx / 6, q = 2 + idx % 6;
+        const TonalBlock& tb = rec->tonal[t];
+        const float mul = c_max_quant[q];
+        int bits = 0;
+        for (int z = 0; z < tb.len; ++z) bits += (int)(huff_entry(q, vlc_index(__float2int_rn(tb.values[z] * mul))) >> 8);
+        s_tbits[t * 8 + q] = (uint8_t)bits;
+    }
+    __syncthreads();
+
+    // ---- all 32 x 7 quantised units (what TEncCache computes lazily), largest BFUs first ----
+    for (int u = lane; u < 224; u += 64) {
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+        const float e = quant_unit(s_val + start, n, c_max_quant[wl], bfu > 18, mant);
+        uint32_t clc, vlc = 0;
+        if (wl > 1) {
+            clc = (uint32_t)c_clc_len[wl] * n;
+            for (int j = 0; j < n; ++j) vlc += huff_entry(wl, vlc_index(mant[j])) >> 8;
+        } else {
+            clc = 4u * n / 2;
+            const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
+            for (int j = 0; j < n / 2; ++j)
+                vlc += huff_entry(1, rt9[3 * (mant[2 * j] + 1) + (mant[2 * j + 1] + 1)]) >> 8;
+        }
+        s_err[wl * 32 + bfu] = e;
+        s_clc[wl * 32 + bfu] = (uint16_t)clc;
+        s_vlc[wl * 32 + bfu] = (uint16_t)vlc;
+    }
+    __syncthreads();
+
+    // ---- rate loop: TConfigure / TAlloc under the bisection driver ----
+    const float spread = s_spread;
+    int num_bfu = p.bfu_idx_const ? p.bfu_idx_const : 32;
+    if (target < 101) {
+        int lim = 1;
+        if (target > 5) lim = (target - 5) / 3;
+        if (lim < 1) lim = 1;
+        if (num_bfu > lim) num_bfu = lim;
+    }
+    if (num_bfu < 1) num_bfu = 1;
+    int mode = 1;
+    for (;;) {
+        float minL = -8.0f, maxL = 20.0f, curL = 0.0f, lastL = 20.0f;
+        bool restart = false;
+        for (;;) {
+            const bool exhausted = (maxL <= minL);
+            float lam;
+            if (exhausted) {
+                lam = lastL;
+            } else {
+                curL = (maxL + minL) * 0.5f;
+                lam = curL;
+            }
+            if (lane < 32) {
+                int bits = 0;
+                const int i = lane;
+                if (i < num_bfu && !s_gate[i]) {
+                    float x = 6.0f;
+                    if (i < 3) x = 2.8f;
+                    else if (i < 10) x = 2.6f;
+                    else if (i < 15) x = 3.3f;
+                    else if (i <= 20) x = 3.6f;
+                    else if (i <= 28) x = 4.2f;
+                    const int tmp = (int)(spread * (s_csfi[i] / x) + (1.0f - spread) * (float)c_fixed_alloc[i] - lam);
+                    if (tmp > 7) bits = 7;
+                    else if (tmp < 0) bits = 0;
+                    else if (tmp == 0) bits = 1;
+                    else bits = tmp;
+                }
+                if (i < num_bfu) {
+                    for (int t = 0; t < rec->n_tonal; ++t)
+                        if (rec->tonal[t].bfu == i && bits > 2) bits -= 1;
+                }
+                s_alloc[i] = bits;
+            }
+            __syncthreads();
+            uint32_t used, clc, vlc;
+            for (;;) {
+                used = (uint32_t)num_bfu * 3;
+                clc = 0;
+                vlc = 0;
+                for (int i = 0; i < num_bfu; ++i) {
+                    const int wl = s_alloc[i];
+                    if (wl == 0) continue;
+                    used += 6;
+                    clc += s_clc[wl * 32 + i];
+                    vlc += s_vlc[wl * 32 + i];
+                }
+                // ConsiderEnergyErr: first 10 BFUs (atrac3_bitstream.cpp:241-257)
+                bool adjust = false;
+                const int lim = num_bfu < 10 ? num_bfu : 10;
+                for (int i = 0; i < lim; ++i) {
+                    const int wl = s_alloc[i];
+                    const float e = wl ? s_err[wl * 32 + i] : 0.0f;
+                    if (((e > 0 && e < 0.7f) || e > 1.2f) && (wl < 7)) adjust = true;
+                }
+                __syncthreads();
+                if (!adjust) break;
+                if (lane < lim) {
+                    const int wl = s_alloc[lane];
+                    const float e = wl ? s_err[wl * 32 + lane] : 0.0f;
+                    if (((e > 0 && e < 0.7f) || e > 1.2f) && (wl < 7)) s_alloc[lane] = wl + 1;
+                }
+                __syncthreads();
+            }
+            mode = clc <= vlc ? 1 : 0;
+            const uint32_t spec_bits = used + (mode ? clc : vlc);
+            if (lane == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
+            __syncthreads();
+            const uint32_t total = spec_bits + (uint32_t)(s_misc[0] & 0xffff);
+            __syncthreads();
+            bool done;
+            if (exhausted) {
+                done = true;
+            } else if (total < (uint32_t)target) {
+                lastL = curL;
+                maxL = curL - 0.01f;
+                done = false;
+            } else if (total > (uint32_t)target) {
+                minL = curL + 0.01f;
+                done = false;
+            } else {
+                done = true;
+            }
+            if (!done) continue;
+            if (!p.bfu_idx_const && num_bfu > 1 && s_alloc[num_bfu - 1] == 0) {
+                num_bfu--;
+                restart = true;
+            }
+            break;
+        }
+        __syncthreads();
+        if (!restart) break;
+    }
+
+    // ---- emission (WriteSoundUnit header, EncodeSpecs) ----
+    int pos = 0;
+    if (lane == 0) {
+        if (p.js && ch == 1) {
+            put_bits(s_words, 0, 0, 1);
+            put_bits(s_words, 1, 7, 3);
+            for (int i = 0; i < 4; ++i) put_bits(s_words, 4 + 2 * i, 3, 2);
+            put_bits(s_words, 12, 3, 2);
+            pos = 14;
+        } else {
+            put_bits(s_words, 0, 0x28, 6);
+            pos = 6;
+        }
+        put_bits(s_words, pos, 3, 2);
+        pos += 2;
+        for (int b = 0; b < 4; ++b) {
+            const Curve& c = curves[ch * 4 + b];
+            put_bits(s_words, pos, c.n, 3);
+            pos += 3;
+            for (int i = 0; i < c.n; ++i) {
+                put_bits(s_words, pos, c.level[i], 4);
+                put_bits(s_words, pos + 4, c.loc[i], 5);
+                pos += 9;
+            }
+        }
+        pos += tonal_encode<true>(rec, s_tbits, s_alloc, num_bfu, s_words, pos);
+        put_bits(s_words, pos, (uint32_t)num_bfu - 1, 5);
+        put_bits(s_words, pos + 5, (uint32_t)mode, 1);
+        pos += 6;
+        s_misc[1] = pos;
+    }
+    __syncthreads();
+    pos = s_misc[1];
+    if (lane < num_bfu) put_bits(s_words, pos + 3 * lane, (uint32_t)s_alloc[lane], 3);
+    pos += 3 * num_bfu;
+    if (lane < num_bfu && s_alloc[lane]) {
+        int before = 0;
+        for (int i = 0; i < lane; ++i) before += (s_alloc[i] != 0);
+        put_bits(s_words, pos + 6 * before, rec->sfi[lane], 6);
+    }
+    {
+        int nz = 0;
+        for (int i = 0; i < num_bfu; ++i) nz += (s_alloc[i] != 0);
+        pos += 6 * nz;
+    }
+    __syncthreads();
+    // mantissas: per-element (code,len), two-level prefix sum over 64 lanes x 16 elements
+    uint32_t* s_code = reinterpret_cast<uint32_t*>(s_val);  // 1024 x (code | len << 16), aliases s_val
+    {
+        const int base = lane * 16;
+        int sum = 0;
+        // which BFU does element `base` belong to (BFU sizes are multiples of 8, lanes cover 16 lines)
+        for (int k = 0; k < 16; ++k) {
+            const int i = base + k;
+            int b = 0;
+            while (c_bfu_start[b + 1] <= i) ++b;
+            uint32_t cl = 0;
+            if (b < num_bfu && s_alloc[b]) {
+                const int wl = s_alloc[b];
+                cl = spec_code(wl, mode == 1, s_mant + (wl - 1) * 1024 + c_bfu_start[b], i - c_bfu_start[b]);
+            }
+            // s_val is dead: every lane finished reading it before the quantisation barrier
+            s_code[i] = cl;
+            sum += (int)(cl >> 16);
+        }
+        s_lsum[lane] = sum;
+    }
+    __syncthreads();
+    {
+        int off = pos;
+        for (int l = 0; l < lane; ++l) off += s_lsum[l];
+        const int base = lane * 16;
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t cl = s_code[base + k];
+            const int n = (int)(cl >> 16);
+            if (n) {
+                put_bits(s_words, off, cl & 0xffffu, n);
+                off += n;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- frame assembly (atrac3_bitstream.cpp:826-834): ch0 bytes, then ch1 (byte-reversed when JS) ----
+    uint8_t* frame = p.out + ((size_t)s * n_out + fo) * p.frame_sz;
+    const int dst0 = (ch == 0) ? 0 : half + shift;
+    for (int j = lane; j < nbytes; j += 64) {
+        const int src = (p.js && ch == 1) ? (nbytes - 1 - j) : j;
+        const uint8_t byte = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
+        frame[dst0 + j] = byte;
+    }
+}
+
+// End-of-call state hand-over: PCM history and the last frame's gain curves.
+struct StateParams {
+    const float* pcm;       // [S][n_blocks][1024][2]
+    const float* hist_in;   // [S][kHist][2]
+    float* hist_out;        // [S][kHist][2]
+    const Curve* curves;    // [S][n_blocks][2][4]
+    BandState* state;
+    int n_blocks;
+    int n_streams;
+};
+
+__global__ void k_state_update(StateParams p)
+{
+    const int s = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < kHist) {
+        const float2* pcm2 = reinterpret_cast<const float2*>(p.pcm) + (size_t)s * p.n_blocks * 1024;
+        const float2* hin = reinterpret_cast<const float2*>(p.hist_in) + (size_t)s * kHist;
+        float2* hout = reinterpret_cast<float2*>(p.hist_out) + (size_t)s * kHist;
+        const int g = p.n_blocks * 1024 - kHist + k;
+        hout[k] = (g >= 0) ? pcm2[g] : hin[kHist + g];
+    }
+    if (k < 8) p.state[(size_t)s * 8 + k].prev_curve = p.curves[((size_t)s * p.n_blocks + (p.n_blocks - 1)) * 8 + k];
+}
+
+}  // namespace at3

@@ -1,0 +1,584 @@
+// Gain-control kernels: spectral upsampler + AnalyzeGain, context scan, CalcCurve + point-0 logic.
+//
+// Reference path replaced (paths relative to the reference's src/):
+//   transient_spectral_upsampler.cpp:77-180  TSpectralUpsampler::Process (Planck window, rFFT-512,
+//                                            high-frequency ratio, raised-cosine HPF, x8 zero-padding, irFFT-4096)
+//   tools/kiss_fftr.c:61-153                 kiss_fftr / kiss_fftri packing around the complex FFTs
+//   transient_detector.cpp:33-40, 95-136     calculateRMS, AnalyzeGain (+ micro-chunk quartiles)
+//   transient_detector.cpp:141-482           RelationToIdx, MedianFilter, FindPlateau, BoundaryTransientScore, CalcCurve
+//   atrac3denc.cpp:259-297, 299-579          CalcCurveEarlyMismatchScore, CreateSubbandInfo
+//
+// Band 3 never yields a curve (atrac3denc.cpp:444-450) and its context feeds nothing else, so only
+// bands 0..2 are analysed. The look-ahead "nextLevel" is computed by the reference but never read inside
+// CalcCurve, so it is not computed here.
+#pragma once
+#include "at3_common.hpp"
+
+namespace at3 {
+
+struct GainParams {
+    const float* sub;     // [S][2][4][(n_blocks+2)*256] raw L/R subbands, block b at (b+2)*256
+    GainRec* rec;         // [S][n_blocks][2][3] by frame index
+    BandState* state;     // [S][2][4]
+    Curve* curves;        // [S][n_blocks][2][4]
+    int n_blocks;
+    int f0;
+    int js;
+};
+
+constexpr int kLowCutBin = 38;  // ceil(800 * 512 / 11025)
+
+// FindPlateau + target selection of CalcCurve (transient_detector.cpp:178-238, 284-297), in[32].
+__device__ inline void median3_32(const float* in, float* out)
+{
+    for (int i = 0; i < 32; ++i) {
+        const int lo = i > 0 ? i - 1 : 0;
+        const int hi = i < 31 ? i + 1 : 31;
+        if (hi - lo == 1) {
+            // two elements: sorted ascending, element [1] is the larger
+            out[i] = fmaxf(in[lo], in[hi]);
+        } else {
+            const float a = in[lo], b = in[lo + 1], c = in[hi];
+            out[i] = fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+        }
+    }
+}
+
+__device__ inline float curve_target(const float* in, const float* filtered)
+{
+    float maxRaw = 0.0f;
+    for (int i = 0; i < 32; ++i) maxRaw = fmaxf(maxRaw, in[i]);
+    float bestLevel = 0.0f;
+    int bestEnd = -1;
+    for (int j = 0; j + 3 <= 32; ++j) {
+        const float minVal = fminf(fminf(filtered[j], filtered[j + 1]), filtered[j + 2]);
+        if (minVal > bestLevel) {
+            bestLevel = minVal;
+            bestEnd = j + 2;
+        }
+    }
+    float plateau = 0.0f;
+    bool release = false;
+    if (!(bestLevel < 1e-6f)) {
+        plateau = bestLevel;
+        while (bestEnd + 1 < 32 && filtered[bestEnd + 1] >= bestLevel) ++bestEnd;
+        if (bestEnd < 31) {
+            if (in[31] < bestLevel * 0.1f) {
+                release = true;
+            } else {
+                bool anyHigh = false;
+                for (int i = bestEnd + 1; i < 32; ++i)
+                    if (in[i] >= bestLevel * 0.7f) {
+                        anyHigh = true;
+                        break;
+                    }
+                release = !anyHigh && (in[31] < bestLevel * 0.5f);
+            }
+        }
+    }
+    const bool usePlateau = plateau > 1e-6f && !release && plateau >= maxRaw * 0.4f;
+    return usePlateau ? plateau : in[31];
+}
+
+// One workgroup per (stream, frame, channel, band<3).
+__global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Tables* T)
+{
+    __shared__ cpx s_f[2048];        // rfft-512 core (first 256 entries) then irfft-4096 core
+    __shared__ cpx s_freq[257];
+    __shared__ float s_micro[256];
+    __shared__ float s_gain[32];
+    __shared__ float s_filt[32];
+    const int tid = threadIdx.x;
+    const int nfr = p.n_blocks - p.f0;
+    int wg = blockIdx.x;
+    const int band = wg % 3; wg /= 3;
+    const int ch = wg % 2; wg /= 2;
+    const int f = p.f0 + wg % nfr;
+    const int s = wg / nfr;
+    const int cb = f - 1;  // current block
+    const size_t sublen = (size_t)(p.n_blocks + 2) * 256;
+    const float* sb0 = p.sub + ((size_t)s * 8 + 0 * 4 + band) * sublen + (size_t)(cb + 2) * 256 - 128;
+    const float* sb1 = p.sub + ((size_t)s * 8 + 1 * 4 + band) * sublen + (size_t)(cb + 2) * 256 - 128;
+
+    // 1. window and pack as 256 complex points in FFT leaf order
+    {
+        float v[2];
+        for (int q = 0; q < 2; ++q) {
+            const int i = 2 * tid + q;
+            float x;
+            if (p.js) {
+                const float l = sb0[i], r = sb1[i];
+                x = ch == 0 ? (l + r) * 0.5f : (l - r) * 0.5f;
+            } else {
+                x = (ch == 0 ? sb0 : sb1)[i];
+            }
+            v[q] = x * T->planck[i];
+        }
+        cpx z;
+        z.r = v[0];
+        z.i = v[1];
+        s_f[fft_leaf_pos<256>(tid)] = z;
+    }
+    __syncthreads();
+    fft_lds<256, false>(s_f, 256, 1, T->tw256, tid, 256);
+
+    // 2. kiss_fftr post-processing -> 257 bins
+    if (tid == 0) {
+        const float tr = s_f[0].r, ti = s_f[0].i;
+        s_freq[0].r = tr + ti;
+        s_freq[0].i = 0.0f;
+        s_freq[256].r = tr - ti;
+        s_freq[256].i = 0.0f;
+    }
+    if (tid >= 1 && tid <= 128) {
+        const int k = tid;
+        const cpx fpk = s_f[k];
+        cpx fpnk;
+        fpnk.r = s_f[256 - k].r;
+        fpnk.i = -s_f[256 - k].i;
+        cpx f1k, f2k;
+        f1k.r = fpk.r + fpnk.r; f1k.i = fpk.i + fpnk.i;
+        f2k.r = fpk.r - fpnk.r; f2k.i = fpk.i - fpnk.i;
+        const cpx tw = cmul(f2k, T->stw256[k - 1]);
+        cpx a, b;
+        a.r = (f1k.r + tw.r) * 0.5f; a.i = (f1k.i + tw.i) * 0.5f;
+        b.r = (f1k.r - tw.r) * 0.5f; b.i = (tw.i - f1k.i) * 0.5f;
+        if (k != 128) s_freq[k] = a;   // k == 128: the second store wins in the reference
+        s_freq[256 - k] = b;
+    }
+    __syncthreads();
+
+    // 3. high-frequency ratio: sequential double sums (one lane), meanwhile the others build the
+    //    kiss_fftri input. Only bins 38..256 are non-zero, so tmpbuf is non-zero at k in [38,256] and
+    //    [1792,2010]; everything else is an exact zero.
+    float hfr = 0.0f;
+    if (tid == 255) {
+        double totalE = 0.0, filtE = 0.0;
+        for (int k = 0; k <= 256; ++k) {
+            const double e = (double)s_freq[k].r * s_freq[k].r + (double)s_freq[k].i * s_freq[k].i;
+            totalE += e;
+            float H = 0.0f;
+            if (k >= kLowCutBin + 2) H = 1.0f;
+            else if (k >= kLowCutBin) H = T->hpf_w[k - kLowCutBin + 1];
+            filtE += e * H * H;
+        }
+        hfr = (totalE > 0.0) ? (float)(filtE / totalE) : 0.0f;
+        s_micro[0] = hfr;
+    }
+    {
+        cpx zero;
+        zero.r = 0.0f;
+        zero.i = 0.0f;
+        for (int k = tid; k < 2048; k += 256) s_f[k] = zero;
+    }
+    __syncthreads();
+    hfr = s_micro[0];
+    for (int k = kLowCutBin + tid; k <= 256; k += 256) {
+        cpx fk;
+        const float scale = 8.0f;
+        if (k == 256) {
+            fk.r = s_freq[256].r * scale * 0.5f;
+            fk.i = 0.0f;
+        } else if (k >= kLowCutBin + 2) {
+            fk.r = s_freq[k].r * scale;
+            fk.i = s_freq[k].i * scale;
+        } else {
+            const float w = T->hpf_w[k - kLowCutBin + 1];
+            fk.r = s_freq[k].r * scale * w;
+            fk.i = s_freq[k].i * scale * w;
+        }
+        // fnkc = conj(freq[2048 - k]) = (0, -0): fek = fk, tmp = fk
+        const cpx fok = cmul(fk, T->stw2048[k - 1]);
+        cpx a, b;
+        a.r = fk.r + fok.r; a.i = fk.i + fok.i;
+        b.r = fk.r - fok.r; b.i = -(fk.i - fok.i);
+        s_f[fft_leaf_pos<2048>(k)] = a;
+        s_f[fft_leaf_pos<2048>(2048 - k)] = b;
+    }
+    __syncthreads();
+    fft_lds<2048, true>(s_f, 2048, 1, T->tw2048, tid, 256);
+
+    // 4. AnalyzeGain over upsampled samples [1024, 3072): 32 sub-frames of 64, 8 micro-chunks each
+    const float* sig = reinterpret_cast<const float*>(s_f);
+    const float norm = 1.0f / 4096.0f;
+    {
+        const float* x = sig + 1024 + tid * 8;
+        float acc = 0.0f;
+        for (int i = 0; i < 8; ++i) {
+            const float v = x[i] * norm;
+            acc += v * v;
+        }
+        acc /= 8;
+        s_micro[tid] = sqrtf(acc);
+    }
+    if (tid < 32) {
+        const float* x = sig + 1024 + tid * 64;
+        float acc = 0.0f;
+        for (int i = 0; i < 64; ++i) {
+            const float v = x[i] * norm;
+            acc += v * v;
+        }
+        acc /= 64;
+        s_gain[tid] = sqrtf(acc);
+    }
+    __syncthreads();
+    GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
+    if (tid < 32) {
+        float m[8];
+        for (int i = 0; i < 8; ++i) m[i] = s_micro[tid * 8 + i];
+        for (int i = 1; i < 8; ++i) {  // insertion sort, ascending
+            const float v = m[i];
+            int j = i - 1;
+            while (j >= 0 && m[j] > v) {
+                m[j + 1] = m[j];
+                --j;
+            }
+            m[j + 1] = v;
+        }
+        rec->gain[tid] = s_gain[tid];
+        rec->lo[tid] = m[2];
+        rec->hi[tid] = m[6];
+    }
+    if (tid == 0) {
+        float sum = 0.0f;
+        for (int i = 0; i < 32; ++i) sum += s_gain[i];
+        median3_32(s_gain, s_filt);
+        rec->hfr = hfr;
+        rec->cur_hpf = sum / 32.0f;
+        rec->target = curve_target(s_gain, s_filt);
+    }
+}
+
+// Context chain (TCurveBuilderCtx): one thread per (stream, channel, band<3), sequential over frames.
+// Frames with hfr < 0.05 reset LastLevel and leave LastTarget / LastHpfEnergy untouched
+// (atrac3denc.cpp:319-327); otherwise LastHpfEnergy = mean(gain) (:342-346), LastLevel = gain[31],
+// LastTarget = target (transient_detector.cpp:307-310).
+__global__ void k_gain_scan(GainParams p, int n_streams)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_streams * 6) return;
+    const int band = idx % 3, ch = (idx / 3) % 2, s = idx / 6;
+    BandState* st = p.state + (size_t)s * 8 + ch * 4 + band;
+    float lvl = st->last_level, tgt = st->last_target, hpf = st->last_hpf;
+    for (int f = p.f0; f < p.n_blocks; ++f) {
+        GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
+        rec->ctx_level = lvl;
+        rec->ctx_target = tgt;
+        rec->ctx_hpf = hpf;
+        if (rec->hfr < 0.05f) {
+            lvl = 0.0f;
+        } else {
+            lvl = rec->gain[31];
+            tgt = rec->target;
+            hpf = rec->cur_hpf;
+        }
+    }
+    st->last_level = lvl;
+    st->last_target = tgt;
+    st->last_hpf = hpf;
+}
+
+__device__ inline uint32_t first_set_bit(uint32_t x)
+{
+    uint32_t r = 0;
+    while (x >>= 1) ++r;
+    return r;
+}
+
+// transient_detector.cpp:141-149
+__device__ inline int relation_to_idx(float x)
+{
+    if (x <= 0.5f) {
+        x = 1.0f / fmaxf(x, 0.00048828125f);
+        return 4 + (int)first_set_bit((uint32_t)x);
+    }
+    x = fminf(x, 16.0f);
+    return 4 - (int)first_set_bit((uint32_t)x);
+}
+
+// atrac3denc.h:44-52 (1.0 / x in double then narrowed == correctly rounded float quotient)
+__device__ inline int relation_to_idx_hdr(float x)
+{
+    if (x <= 0.5f) {
+        x = 1.0f / fmaxf(x, 0.00048828125f);
+        return 4 + (int)first_set_bit((uint32_t)(int32_t)truncf(x));
+    }
+    x = fminf(x, 16.0f);
+    return 4 - (int)first_set_bit((uint32_t)(int32_t)truncf(x));
+}
+
+// transient_detector.cpp:255-274
+__device__ inline float boundary_score(const float* env, int loc)
+{
+    const int leftStart = loc - 3 > 0 ? loc - 3 : 0;
+    const int rightEnd = loc + 3 < 32 ? loc + 3 : 32;
+    float leftMax = 0.0f, rightMax = 0.0f;
+    for (int i = leftStart; i < loc; ++i) leftMax = fmaxf(leftMax, env[i]);
+    for (int i = loc; i < rightEnd; ++i) rightMax = fmaxf(rightMax, env[i]);
+    const float eps = 1e-9f;
+    const float attack = (rightMax + eps) / (leftMax + eps);
+    const float release = (leftMax + eps) / (rightMax + eps);
+    return fmaxf(attack, release);
+}
+
+// atrac3denc.cpp:228-297
+__device__ inline float early_mismatch_score(const Tables* T, const float* gain, float target, const Curve& c)
+{
+    if (target <= 1e-9f) return 0.0f;
+    float div[32];
+    for (int sf = 0; sf < 32; ++sf) {
+        float sum = 0.0f;
+        for (int k = 0; k < 8; ++k) sum += curve_divisor(T, c, sf * 8 + k);
+        div[sf] = sum / 8.0f;
+    }
+    uint32_t maxLoc = 0;
+    for (int i = 0; i < c.n; ++i) maxLoc = c.loc[i] > maxLoc ? c.loc[i] : maxLoc;
+    uint32_t evalSf = maxLoc + 3 > 3 ? maxLoc + 3 : 3;
+    if (evalSf > 32) evalSf = 32;
+    const float eps = 1e-9f;
+    float fit = 0.0f;
+    for (uint32_t sf = 0; sf < evalSf; ++sf) {
+        const float mod = gain[sf] / fmaxf(div[sf], eps);
+        const float e = at3_log2f(T, fmaxf(mod, eps) / fmaxf(target, eps));
+        fit += e * e;
+    }
+    fit /= evalSf;
+    float leak = 0.0f, wsum = 0.0f;
+    for (uint32_t sf = 0; sf + 1 < evalSf; ++sf) {
+        const float a = at3_log2f(T, fmaxf(div[sf], eps));
+        const float b = at3_log2f(T, fmaxf(div[sf + 1], eps));
+        const float d = b - a;
+        const float w = 0.5f * (gain[sf] + gain[sf + 1]);
+        leak += d * d * w;
+        wsum += w;
+    }
+    if (wsum > eps) leak /= wsum;
+    return fit + 0.25f * leak;
+}
+
+// One thread per (stream, frame, channel, band<3): CalcCurve + CreateSubbandInfo tail.
+__global__ void k_gain_curve(GainParams p, const Tables* T, int n_streams)
+{
+    const int nfr = p.n_blocks - p.f0;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_streams * nfr * 6) return;
+    const int band = idx % 3; idx /= 3;
+    const int ch = idx % 2; idx /= 2;
+    const int f = p.f0 + idx % nfr;
+    const int s = idx / nfr;
+    const GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
+    Curve out;
+    out.n = 0;
+    out.pad = 0;
+    for (int i = 0; i < 7; ++i) {
+        out.level[i] = 0;
+        out.loc[i] = 0;
+    }
+    Curve* dst = p.curves + ((size_t)s * p.n_blocks + f) * 8 + ch * 4 + band;
+    const float hfr = rec->hfr;
+    if (hfr < 0.05f) {
+        *dst = out;
+        return;
+    }
+    float in[32], lo[32], hi[32], filtered[32];
+    for (int i = 0; i < 32; ++i) {
+        in[i] = rec->gain[i];
+        lo[i] = rec->lo[i];
+        hi[i] = rec->hi[i];
+    }
+    const float curHpf = rec->cur_hpf;
+    const float prevHpf = rec->ctx_hpf;
+    const float hpfRatio = (curHpf > 1e-9f && prevHpf > 1e-9f) ? (prevHpf / curHpf) : 1.0f;
+    const float minScore = 1.9f * fminf(1.5f, fmaxf(1.0f, hpfRatio));
+    const float prevTarget = rec->ctx_target;
+    const float savedLastLevel = rec->ctx_level;
+    const float target = rec->target;   // == ctx.LastTarget after CalcCurve
+    median3_32(in, filtered);
+
+    // ---- CalcCurve (transient_detector.cpp:299-482) ----
+    Curve pts = out;
+    bool have = false;
+    if (!(target < 1e-6f) && !(savedLastLevel < 1e-6f)) {
+        float maxGainC = 0.0f;
+        for (int i = 0; i < 32; ++i) maxGainC = fmaxf(maxGainC, in[i]);
+        const float intraRatio = maxGainC / fmaxf(target, 1e-9f);
+        float interRatio = 1.0f;
+        if (prevTarget > 1e-6f) {
+            const float h = fmaxf(prevTarget, target);
+            const float l = fminf(prevTarget, target);
+            interRatio = h / fmaxf(l, 1e-9f);
+        }
+        const bool sticky = intraRatio <= 7.0f && interRatio <= 10.0f;
+        uint8_t sfLevel[32];
+        for (int i = 0; i < 32; ++i) {
+            int level = relation_to_idx(filtered[i] / target);
+            if (i > 0 && sticky) {
+                float ratioLo = lo[i] / target;
+                float ratioHi = hi[i] / target;
+                if (ratioLo > ratioHi) {
+                    const float t = ratioLo;
+                    ratioLo = ratioHi;
+                    ratioHi = t;
+                }
+                const int idxLo = relation_to_idx(ratioLo);
+                const int idxHi = relation_to_idx(ratioHi);
+                const int minIdx = idxLo < idxHi ? idxLo : idxHi;
+                const int maxIdx = idxLo < idxHi ? idxHi : idxLo;
+                const int prev = sfLevel[i - 1];
+                const int d = level - prev;
+                if (maxIdx - minIdx <= 1 && (d == 1 || d == -1) && prev >= minIdx && prev <= maxIdx) level = prev;
+            }
+            sfLevel[i] = (uint8_t)level;
+        }
+        int targetSf = 0;
+        for (int sf = 30; sf >= 0; --sf)
+            if (sfLevel[sf] != 4) {
+                targetSf = sf + 1;
+                break;
+            }
+        if (targetSf > 0) {
+            int tloc[32], tdelta[32];
+            uint8_t tlev[32];
+            int nt = 0;
+            int prev = 4;
+            for (int sf = targetSf - 1; sf >= 0; --sf) {
+                const int lev = sfLevel[sf];
+                if (lev != prev) {
+                    const int loc = sf + 1;
+                    const int delta = lev > prev ? lev - prev : prev - lev;
+                    bool keep = (loc == targetSf) || (delta >= 2);
+                    if (!keep) keep = boundary_score(filtered, loc) >= minScore;
+                    if (keep) {
+                        tloc[nt] = loc;
+                        tlev[nt] = (uint8_t)lev;
+                        tdelta[nt] = delta;
+                        ++nt;
+                        prev = lev;
+                    }
+                }
+            }
+            // entries are in descending loc order; the reference reverses to ascending
+            for (int i = 0, j = nt - 1; i < j; ++i, --j) {
+                const int a = tloc[i]; tloc[i] = tloc[j]; tloc[j] = a;
+                const int b = tdelta[i]; tdelta[i] = tdelta[j]; tdelta[j] = b;
+                const uint8_t cc = tlev[i]; tlev[i] = tlev[j]; tlev[j] = cc;
+            }
+            if (nt > 6) {
+                // stable sort by (delta desc, loc desc), keep 6, re-sort by loc
+                for (int i = 1; i < nt; ++i) {
+                    const int l0 = tloc[i], d0 = tdelta[i];
+                    const uint8_t v0 = tlev[i];
+                    int j = i - 1;
+                    while (j >= 0 && ((d0 != tdelta[j]) ? (d0 > tdelta[j]) : (l0 > tloc[j]))) {
+                        tloc[j + 1] = tloc[j]; tdelta[j + 1] = tdelta[j]; tlev[j + 1] = tlev[j];
+                        --j;
+                    }
+                    tloc[j + 1] = l0; tdelta[j + 1] = d0; tlev[j + 1] = v0;
+                }
+                nt = 6;
+                for (int i = 1; i < nt; ++i) {
+                    const int l0 = tloc[i], d0 = tdelta[i];
+                    const uint8_t v0 = tlev[i];
+                    int j = i - 1;
+                    while (j >= 0 && l0 < tloc[j]) {
+                        tloc[j + 1] = tloc[j]; tdelta[j + 1] = tdelta[j]; tlev[j + 1] = tlev[j];
+                        --j;
+                    }
+                    tloc[j + 1] = l0; tdelta[j + 1] = d0; tlev[j + 1] = v0;
+                }
+            }
+            if (nt > 0) {
+                have = true;
+                pts.n = (uint8_t)nt;
+                for (int i = 0; i < nt; ++i) {
+                    pts.level[i] = tlev[i];
+                    pts.loc[i] = (uint8_t)tloc[i];
+                }
+            }
+        }
+    }
+    if (!have) {  // "skip: no_curve" (atrac3denc.cpp:395-400)
+        *dst = out;
+        return;
+    }
+
+    // ---- CreateSubbandInfo tail (atrac3denc.cpp:410-577), band < 3 ----
+    float maxGain = 0.0f;
+    for (int i = 0; i < 32; ++i) maxGain = fmaxf(maxGain, in[i]);
+    if (maxGain < 1e-4f) pts.n = 0;
+    if (hfr < 0.3f) pts.n = 0;
+    {
+        const Curve before = pts;
+        bool changed = false;
+        float hpfRmsNextMod = 0.0f;
+        bool valid = false;
+        if (pts.n > 0 && pts.loc[0] > 0) {
+            const uint32_t nBefore = pts.loc[0];
+            const float divisor = T->gain_level[pts.level[0]];
+            float sum = 0.0f;
+            for (uint32_t sf = 0; sf < nBefore; ++sf) sum += in[sf];
+            hpfRmsNextMod = (sum / nBefore) / divisor;
+            valid = true;
+        } else if (pts.n == 0) {
+            float sum = 0.0f;
+            for (int i = 0; i < 32; ++i) sum += in[i];
+            hpfRmsNextMod = sum / 32;
+            valid = true;
+        }
+        const bool p0ok = valid && prevTarget > 1e-6f && hpfRmsNextMod > 1e-6f;
+        if (p0ok) {
+            const int p0 = relation_to_idx_hdr(prevTarget / hpfRmsNextMod);
+            int it = -1;
+            for (int i = 0; i < pts.n; ++i)
+                if (pts.loc[i] == 0) {
+                    it = i;
+                    break;
+                }
+            if (it >= 0) {
+                if (pts.level[it] != p0) {
+                    pts.level[it] = (uint8_t)p0;
+                    changed = true;
+                }
+            } else if (p0 != 4 || pts.n > 0) {
+                for (int i = pts.n; i > 0; --i) {
+                    pts.level[i] = pts.level[i - 1];
+                    pts.loc[i] = pts.loc[i - 1];
+                }
+                pts.level[0] = (uint8_t)p0;
+                pts.loc[0] = 0;
+                pts.n++;
+                changed = true;
+            }
+        }
+        if (changed) {
+            const float scoreBefore = early_mismatch_score(T, in, target, before);
+            const float scoreAfter = early_mismatch_score(T, in, target, pts);
+            bool keepByBoundary = false;
+            if (p0ok) {
+                const float x = prevTarget / hpfRmsNextMod;
+                const float desired = fminf(fmaxf(x, T->gain_level[15]), T->gain_level[0]);
+                const float scaleBefore = T->gain_level[before.n == 0 ? 4 : before.level[0]];
+                const float scaleAfter = T->gain_level[pts.n == 0 ? 4 : pts.level[0]];
+                const float eps = 1e-9f;
+                const float errBefore = fabsf(at3_log2f(T, fmaxf(scaleBefore, eps) / fmaxf(desired, eps)));
+                const float errAfter = fabsf(at3_log2f(T, fmaxf(scaleAfter, eps) / fmaxf(desired, eps)));
+                keepByBoundary = (errAfter + 0.20f < errBefore);
+            }
+            if (!keepByBoundary && scoreAfter > scoreBefore * (1.0f + 0.02f)) pts = before;
+        }
+    }
+    if (pts.n >= 2 && pts.loc[0] == 0 && pts.level[0] == pts.level[1]) {
+        for (int i = 1; i < pts.n; ++i) {
+            pts.level[i - 1] = pts.level[i];
+            pts.loc[i - 1] = pts.loc[i];
+        }
+        pts.n--;
+    }
+    for (int i = pts.n; i < 7; ++i) {
+        pts.level[i] = 0;
+        pts.loc[i] = 0;
+    }
+    *dst = pts;
+}
+
+}  // namespace at3

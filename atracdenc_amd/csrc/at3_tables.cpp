@@ -1,0 +1,150 @@
+// Host-side constant tables (see at3_tables.hpp). Plain C++; compiled with contraction off so the
+// float expressions round exactly like the reference's x86-64 baseline build.
+#include "at3_tables.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace at3 {
+
+namespace {
+
+// QMF prototype, first half (qmf/qmf.cpp:25-32).
+const float kTapHalf[24] = {
+    -0.00001461907,  -0.00009205479, -0.000056157569, 0.00030117269, 0.0002422519,  -0.00085293897,
+    -0.0005205574,   0.0020340169,   0.00078333891,   -0.0042153862, -0.00075614988, 0.0078402944,
+    -0.000061169922, -0.01344162,    0.0024626821,    0.021736089,   -0.007801671,   -0.034090221,
+    0.01880949,      0.054326009,    -0.043596379,    -0.099384367,  0.13207909,     0.46424159};
+
+// Threshold in quiet, millibel re 20 uPa, 4 steps per third starting at 10 Hz (Musepack table used by
+// atrac/atrac_psy_common.cpp:43-83).
+const short kAthMilliBel[] = {
+    9669, 9669, 9626, 9512, 9353, 9113, 8882, 8676, 8469, 8243, 7997, 7748, 7492, 7239, 7000, 6762, 6529, 6302, 6084, 5900,
+    5717, 5534, 5351, 5167, 5004, 4812, 4638, 4466, 4310, 4173, 4050, 3922, 3723, 3577, 3451, 3281, 3132, 3036, 2902, 2760,
+    2658, 2591, 2441, 2301, 2212, 2125, 2018, 1900, 1770, 1682, 1594, 1512, 1430, 1341, 1260, 1198, 1136, 1057, 998,  943,
+    887,  846,  744,  712,  693,  668,  637,  606,  580,  555,  529,  502,  475,  448,  422,  398,  375,  351,  327,  322,
+    312,  301,  291,  268,  246,  215,  182,  146,  107,  61,   13,   -35,  -96,  -156, -179, -235, -295, -350, -401, -421,
+    -446, -499, -532, -535, -513, -476, -431, -313, -179, 8,    203,  403,  580,  736,  881,  1022, 1154, 1251, 1348, 1421,
+    1479, 1399, 1285, 1193, 1287, 1519, 1914, 2369, 3352, 4352, 5352, 6352, 7352, 8352, 9352, 9999, 9999, 9999, 9999, 9999};
+
+const uint16_t kBfuStart[33] = {0,   8,   16,  24,  32,  40,  48,  56,  64,  80,  96,  112, 128, 144, 160, 176, 192,
+                                224, 256, 288, 320, 352, 384, 416, 448, 480, 512, 576, 640, 704, 768, 896, 1024};
+
+float ath_db(float freq)
+{
+    if (freq < 10.) freq = 10.;
+    if (freq > 29853.) freq = 29853.;
+    const double fl = 40. * log10(0.1 * freq);
+    const unsigned idx = (unsigned)fl;
+    return 0.01 * (kAthMilliBel[idx] * (1 + idx - fl) + kAthMilliBel[idx + 1] * (fl - idx));
+}
+
+void fill_twiddles(cpx* tw, int n, bool inverse)
+{
+    const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+    for (int i = 0; i < n; ++i) {
+        double phase = -2 * pi * i / n;
+        if (inverse) phase *= -1;
+        tw[i].r = (float)cos(phase);
+        tw[i].i = (float)sin(phase);
+    }
+}
+
+void fill_super_twiddles(cpx* tw, int ncfft, bool inverse)
+{
+    for (int i = 0; i < ncfft / 2; ++i) {
+        double phase = -3.14159265358979323846264338327 * ((double)(i + 1) / ncfft + .5);
+        if (inverse) phase *= -1;
+        tw[i].r = (float)cos(phase);
+        tw[i].i = (float)sin(phase);
+    }
+}
+
+}  // namespace
+
+void build_tables(Tables* t)
+{
+    memset(t, 0, sizeof(*t));
+    for (int i = 0; i < 24; ++i) t->qmf_win[i] = t->qmf_win[47 - i] = kTapHalf[i] * 2.0;
+    for (uint32_t i = 0; i < 64; ++i) t->scale[i] = pow(2.0, (double)(i / 3.0 - 21.0));
+    for (int i = 0; i < 256; ++i) t->enc_win[i] = (sin(((i + 0.5) / 256.0 - 0.5) * M_PI) + 1.0);
+    for (int i = 0; i < 16; ++i) t->gain_level[i] = pow(2.0, 4 - i);
+    for (int i = 0; i < 31; ++i) t->gain_interp[i] = pow(2.0, -1.0 / 8 * (i - 15));
+
+    {   // MDCT-512 pre/post rotation, scale 1 -> sqrt(1/512) folded in
+        const size_t n = 512;
+        const float alpha = 2.0 * M_PI / (8.0 * n);
+        const float omiga = 2.0 * M_PI / n;
+        float scale = 1.0f;
+        scale = sqrtf(scale / n);
+        for (size_t i = 0; i < (n >> 2); ++i) {
+            t->mdct_sincos[2 * i + 0] = scale * cosf(omiga * i + alpha);
+            t->mdct_sincos[2 * i + 1] = scale * sinf(omiga * i + alpha);
+        }
+    }
+    fill_twiddles(t->tw128, 128, false);
+    fill_twiddles(t->tw256, 256, false);
+    fill_twiddles(t->tw2048, 2048, true);
+    fill_super_twiddles(t->stw256, 256, false);
+    fill_super_twiddles(t->stw2048, 2048, true);
+
+    {   // Planck taper, epsilon 0.15, N = 512
+        const float eN = 0.15f * 512.0f;
+        const float fN = 512.0f;
+        for (int n = 0; n < 512; ++n) {
+            const float fn = (float)n;
+            if (n == 0) {
+                t->planck[n] = 0.0f;
+            } else if (fn < eN) {
+                const float z = eN * (1.0f / fn + 1.0f / (fn - eN));
+                t->planck[n] = 1.0f / (1.0f + expf(z));
+            } else if (fn <= fN - eN) {
+                t->planck[n] = 1.0f;
+            } else {
+                const float m = fN - fn;
+                const float z = eN * (1.0f / m + 1.0f / (m - eN));
+                t->planck[n] = 1.0f / (1.0f + expf(z));
+            }
+        }
+        for (int i = 0; i < 3; ++i) t->hpf_w[i] = 0.5f * (1.0f - cosf((float)M_PI * i / 2.0f));
+    }
+    for (size_t i = 0; i < 1024; ++i) {
+        float f = (float)(i + 3) * 0.5 * 44100 / (float)1024;
+        float v = log10f(f) - 3.5;
+        v = -10 * v * v + 3 - f / 3000;
+        v = pow(10, (0.1 * v));
+        t->loud_curve[i] = v;
+    }
+    {
+        float ath_line[1024];
+        const float mf = (float)44100 / 2000.0;
+        for (size_t i = 0; i < 1024; ++i) {
+            const float f = (float)(i + 1) * mf / 1024;
+            float trh = ath_db(1.e3 * f) - 100;
+            trh -= f * f * 0.015;
+            ath_line[i] = trh;
+        }
+        for (int b = 0; b < 32; ++b) {
+            float x = 999;
+            for (int line = kBfuStart[b]; line < kBfuStart[b + 1]; ++line) x = fminf(x, ath_line[line]);
+            x = pow(10, 0.1f * x);
+            t->ath_bfu[b] = x;
+        }
+    }
+    // log2f of glibc 2.35 (ARM optimized-routines): 16-entry {1/c, log2 c} table + degree-4 polynomial.
+    static const double tab[16][2] = {
+        {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+        {0x1.49539f0f010b0p+0, -0x1.7418b0a1fb77bp-2}, {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+        {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8ea0p+0, -0x1.97c1d1b3b7af0p-3},
+        {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+        {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1.0000000000000p+0, 0x0.0p+0},
+        {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aa0p-1, 0x1.476a9543891bap-3},
+        {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+        {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+    static const double poly[4] = {-0x1.712b6f70a7e4dp-2, 0x1.ecabf496832e0p-2, -0x1.715479ffae3dep-1,
+                                   0x1.715475f35c8b8p+0};
+    memcpy(t->log2f_tab, tab, sizeof(tab));
+    memcpy(t->log2f_poly, poly, sizeof(poly));
+}
+
+}  // namespace at3

@@ -1,0 +1,40 @@
+// Host-built constant tables of the ATRAC3 encode path, uploaded once per context.
+//
+// The reference builds these with libm at start-up (atrac/at3/atrac3.h:178-198, qmf/qmf.cpp:36-45,
+// lib/mdct/mdct.cpp:25-36, kiss_fft.c:357-363, tools/kiss_fftr.c:51-57,
+// transient_spectral_upsampler.cpp:52-68, atrac_psy_common.cpp:126-156, atrac3_bitstream.cpp:694-718).
+// Bit-exact parity needs the same table values, so they are generated on the host with the same
+// libm expressions and never recomputed with device transcendentals.
+#pragma once
+#include <stdint.h>
+
+namespace at3 {
+
+struct cpx {
+    float r, i;
+};
+
+struct Tables {
+    float qmf_win[48];
+    float scale[64];        // ScaleTable
+    float enc_win[256];     // EncodeWindow
+    float gain_level[16];
+    float gain_interp[32];  // 31 used
+    float mdct_sincos[256];
+    float planck[512];
+    float hpf_w[4];         // raised-cosine transition weights, index i = 0..2
+    float loud_curve[1024];
+    float ath_bfu[32];
+    cpx tw128[128];         // forward, MDCT core
+    cpx tw256[256];         // forward, rfft-512 core
+    cpx stw256[128];        // rfft-512 super twiddles
+    cpx tw2048[2048];       // inverse, irfft-4096 core
+    cpx stw2048[1024];      // irfft-4096 super twiddles
+    double log2f_tab[16][2];
+    double log2f_poly[4];
+};
+
+// Fills *t on the host. Pure function of libm.
+void build_tables(Tables* t);
+
+}  // namespace at3

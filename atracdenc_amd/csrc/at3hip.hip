@@ -1,0 +1,441 @@
+// libat3hip: C-ABI host layer (include/at3hip.h) over the gfx950 kernels. No CPU fallback: every
+// compute entry point launches HIP kernels; failures are reported as error codes.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/at3hip.h"
+#include "at3_common.hpp"
+#include "at3_k_backend.hpp"
+#include "at3_k_frontend.hpp"
+#include "at3_k_gain.hpp"
+
+using namespace at3;
+
+namespace {
+
+const struct {
+    uint32_t bitrate;
+    uint16_t frame_sz;
+    uint8_t js;
+} kContainer[8] = {{66150, 192, 1},  {93713, 272, 1},  {104738, 304, 0}, {132300, 384, 0},
+                   {146081, 424, 0}, {176400, 512, 0}, {264600, 768, 0}, {352800, 1024, 0}};  // atrac3.h:211-220
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct at3hip_ctx {
+    at3hip_config cfg;
+    int frame_sz = 0;
+    int js = 0;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    char err[256] = {0};
+    long long blocks_fed = 0;   // per stream
+    int frames_per_wg = 8;
+
+    Tables* d_tables = nullptr;
+    float* d_pcm_in = nullptr;       // staging for host PCM [S][max_blocks][1024][2]
+    float* d_hist[2] = {nullptr, nullptr};
+    int hist_cur = 0;
+    float* d_sub = nullptr;
+    GainRec* d_rec = nullptr;
+    BandState* d_state = nullptr;
+    Curve* d_curves = nullptr;
+    float* d_specs = nullptr;
+    float* d_ges = nullptr;
+    PsyRec* d_psy = nullptr;
+    float* d_loud = nullptr;
+    float* d_loud_state = nullptr;
+    uint8_t* d_out = nullptr;
+    at3hip_timings tm = {};
+};
+
+namespace {
+
+int fail(at3hip_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        if (e != hipSuccess) snprintf(c->err, sizeof(c->err), "%s: %s", what, hipGetErrorString(e));
+        else snprintf(c->err, sizeof(c->err), "%s", what);
+    }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                  \
+    do {                                                                 \
+        hipError_t e_ = (call);                                          \
+        if (e_ != hipSuccess) return fail((c), AT3HIP_EDEVICE, #call, e_); \
+    } while (0)
+
+template <typename Tp>
+int dev_alloc(at3hip_ctx* c, Tp** p, size_t count)
+{
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(Tp) + 256);
+    if (e != hipSuccess) return fail(c, AT3HIP_ENOMEM, "hipMalloc", e);
+    *p = (Tp*)q;
+    return AT3HIP_OK;
+}
+
+int reset_state(at3hip_ctx* c)
+{
+    const size_t S = c->cfg.n_streams;
+    HIPCHK(c, hipMemsetAsync(c->d_hist[0], 0, S * kHist * 2 * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_hist[1], 0, S * kHist * 2 * sizeof(float), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_state, 0, S * 8 * sizeof(BandState), c->stream));
+    float* init = (float*)malloc(S * sizeof(float));
+    if (!init) return fail(c, AT3HIP_ENOMEM, "malloc");
+    for (size_t i = 0; i < S; ++i) init[i] = 0.006f;  // LoudFactor, atrac3denc.h:115-116
+    hipError_t e = hipMemcpyAsync(c->d_loud_state, init, S * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    free(init);
+    if (e != hipSuccess) return fail(c, AT3HIP_EDEVICE, "state upload", e);
+    c->blocks_fed = 0;
+    c->hist_cur = 0;
+    return AT3HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t at3hip_version(void) { return (1u << 16) | 0u; }
+
+int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
+{
+    if (!cfg || !out) return AT3HIP_EINVAL;
+    *out = nullptr;
+    if (cfg->channels != 2 || cfg->n_streams < 1 || cfg->max_blocks < 1 || cfg->bfu_idx_const < 0 ||
+        cfg->bfu_idx_const > 32)
+        return AT3HIP_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AT3HIP_EDEVICE;
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return AT3HIP_EINVAL;
+    at3hip_ctx* c = new (std::nothrow) at3hip_ctx();
+    if (!c) return AT3HIP_ENOMEM;
+    c->cfg = *cfg;
+    c->device = cfg->device_id;
+    const uint32_t br = cfg->bitrate == 0 ? 132300u : (uint32_t)cfg->bitrate;
+    int idx = 0;
+    while (idx < 7 && kContainer[idx].bitrate < br) ++idx;  // lower_bound, atrac3.cpp:47-53
+    c->frame_sz = kContainer[idx].frame_sz;
+    c->js = kContainer[idx].js;
+
+    int rc = AT3HIP_OK;
+    auto bail = [&](int code) {
+        at3hip_destroy(c);
+        return code;
+    };
+    if (hipSetDevice(c->device) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    if (hipStreamCreate(&c->own_stream) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    c->stream = c->own_stream;
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) return bail(AT3HIP_EDEVICE);
+
+    const size_t S = cfg->n_streams, B = cfg->max_blocks;
+    Tables* host_tables = new (std::nothrow) Tables();
+    if (!host_tables) return bail(AT3HIP_ENOMEM);
+    build_tables(host_tables);
+    rc = dev_alloc(c, &c->d_tables, 1);
+    if (rc == AT3HIP_OK) {
+        hipError_t e = hipMemcpy(c->d_tables, host_tables, sizeof(Tables), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = AT3HIP_EDEVICE;
+    }
+    delete host_tables;
+    if (rc != AT3HIP_OK) return bail(rc);
+
+    if ((rc = dev_alloc(c, &c->d_pcm_in, S * B * 2048)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_hist[0], S * kHist * 2)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_hist[1], S * kHist * 2)) != AT3HIP_OK) return bail(rc);
+    if (!cfg->no_gain_control) {
+        if ((rc = dev_alloc(c, &c->d_sub, S * 8 * (B + 2) * 256)) != AT3HIP_OK) return bail(rc);
+        if ((rc = dev_alloc(c, &c->d_rec, S * B * 6)) != AT3HIP_OK) return bail(rc);
+        if ((rc = dev_alloc(c, &c->d_ges, S * B * 8)) != AT3HIP_OK) return bail(rc);
+    }
+    if ((rc = dev_alloc(c, &c->d_state, S * 8)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_curves, S * B * 8)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_specs, S * B * 2048)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_psy, S * B * 2)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_loud, S * B)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_loud_state, S)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_out, S * B * (size_t)c->frame_sz)) != AT3HIP_OK) return bail(rc);
+    if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
+    const char* fpw = getenv("AT3HIP_FRAMES_PER_WG");
+    if (fpw && atoi(fpw) > 0) c->frames_per_wg = atoi(fpw);
+    *out = c;
+    return AT3HIP_OK;
+}
+
+void at3hip_destroy(at3hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    void* bufs[] = {c->d_tables, c->d_pcm_in, c->d_hist[0], c->d_hist[1], c->d_sub,  c->d_rec,        c->d_state,
+                    c->d_curves, c->d_specs,  c->d_ges,     c->d_psy,     c->d_loud, c->d_loud_state, c->d_out};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int at3hip_frame_size(const at3hip_ctx* c) { return c ? c->frame_sz : AT3HIP_EINVAL; }
+int at3hip_joint_stereo(const at3hip_ctx* c) { return c ? c->js : AT3HIP_EINVAL; }
+const char* at3hip_last_error(const at3hip_ctx* c) { return c ? c->err : "null context"; }
+
+int at3hip_set_stream(at3hip_ctx* c, void* hip_stream)
+{
+    if (!c) return AT3HIP_EINVAL;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return AT3HIP_OK;
+}
+
+int at3hip_reset(at3hip_ctx* c)
+{
+    if (!c) return AT3HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    return reset_state(c);
+}
+
+int at3hip_get_timings(const at3hip_ctx* c, at3hip_timings* out)
+{
+    if (!c || !out) return AT3HIP_EINVAL;
+    *out = c->tm;
+    return AT3HIP_OK;
+}
+
+int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* out_frames, int32_t* n_frames_out,
+                  uint32_t flags)
+{
+    if (!c || !pcm || n_blocks < 1 || n_blocks > c->cfg.max_blocks) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int S = c->cfg.n_streams;
+    const int f0 = (c->blocks_fed == 0) ? 1 : 0;
+    const int n_out = n_blocks - f0;
+    if (n_out > 0 && !out_frames) return fail(c, AT3HIP_EINVAL, "out_frames is null");
+    hipStream_t st = c->stream;
+    const bool gain = !c->cfg.no_gain_control;
+
+    const float* d_pcm = pcm;
+    if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
+        HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)S * n_blocks * 2048 * sizeof(float), hipMemcpyHostToDevice, st));
+        d_pcm = c->d_pcm_in;
+    }
+    uint8_t* d_out = (flags & AT3HIP_OUT_ON_DEVICE) ? out_frames : c->d_out;
+    const float* hist = c->d_hist[c->hist_cur];
+    float* hist_next = c->d_hist[c->hist_cur ^ 1];
+    memset(&c->tm, 0, sizeof(c->tm));
+
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    HIPCHK(c, hipMemsetAsync(c->d_curves, 0, (size_t)S * n_blocks * 8 * sizeof(Curve), st));
+    if (n_out > 0) {
+        FrontParams fp;
+        fp.pcm = d_pcm;
+        fp.hist = hist;
+        fp.curves = c->d_curves;
+        fp.state = c->d_state;
+        fp.specs = c->d_specs;
+        fp.ges = c->d_ges;
+        fp.sub = c->d_sub;
+        fp.n_blocks = n_blocks;
+        fp.f0 = f0;
+        fp.frames_per_wg = c->frames_per_wg;
+        fp.js = c->js;
+        if (gain) {
+            GainParams gp;
+            gp.sub = c->d_sub;
+            gp.rec = c->d_rec;
+            gp.state = c->d_state;
+            gp.curves = c->d_curves;
+            gp.n_blocks = n_blocks;
+            gp.f0 = f0;
+            gp.js = c->js;
+            hipLaunchKernelGGL(k_qmf_sub, dim3(S * (n_blocks + 2)), dim3(256), 0, st, fp, c->d_tables);
+            HIPCHK(c, hipEventRecord(c->ev[1], st));
+            hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(256), 0, st, gp, c->d_tables);
+            HIPCHK(c, hipEventRecord(c->ev[2], st));
+            hipLaunchKernelGGL(k_gain_scan, dim3((S * 6 + 63) / 64), dim3(64), 0, st, gp, S);
+            hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 63) / 64), dim3(64), 0, st, gp, c->d_tables, S);
+        } else {
+            HIPCHK(c, hipEventRecord(c->ev[1], st));
+            HIPCHK(c, hipEventRecord(c->ev[2], st));
+        }
+        HIPCHK(c, hipEventRecord(c->ev[3], st));
+        const int nchunks = (n_out + c->frames_per_wg - 1) / c->frames_per_wg;
+        if (gain) hipLaunchKernelGGL(k_qmf_mdct<true>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
+        else hipLaunchKernelGGL(k_qmf_mdct<false>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
+        HIPCHK(c, hipEventRecord(c->ev[4], st));
+
+        BackParams bp;
+        bp.specs = c->d_specs;
+        bp.ges = gain ? c->d_ges : nullptr;
+        bp.curves = c->d_curves;
+        bp.psy = c->d_psy;
+        bp.loud = c->d_loud;
+        bp.loud_state = c->d_loud_state;
+        bp.out = d_out;
+        bp.n_blocks = n_blocks;
+        bp.f0 = f0;
+        bp.n_streams = S;
+        bp.no_tonal = c->cfg.no_tonal;
+        bp.js = c->js;
+        bp.frame_sz = c->frame_sz;
+        bp.bfu_idx_const = c->cfg.bfu_idx_const;
+        hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
+        HIPCHK(c, hipEventRecord(c->ev[5], st));
+        hipLaunchKernelGGL(k_loudness, dim3((S + 63) / 64), dim3(64), 0, st, bp);
+        hipLaunchKernelGGL(k_alloc_pack, dim3(S * n_out * 2), dim3(64), 0, st, bp, c->d_tables);
+        HIPCHK(c, hipEventRecord(c->ev[6], st));
+    }
+    {
+        StateParams sp;
+        sp.pcm = d_pcm;
+        sp.hist_in = hist;
+        sp.hist_out = hist_next;
+        sp.curves = c->d_curves;
+        sp.state = c->d_state;
+        sp.n_blocks = n_blocks;
+        sp.n_streams = S;
+        hipLaunchKernelGGL(k_state_update, dim3((kHist + 255) / 256, S), dim3(256), 0, st, sp);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[7], st));
+    HIPCHK(c, hipGetLastError());
+    if (n_out > 0 && !(flags & AT3HIP_OUT_ON_DEVICE))
+        HIPCHK(c, hipMemcpyAsync(out_frames, c->d_out, (size_t)S * n_out * c->frame_sz, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->hist_cur ^= 1;
+    c->blocks_fed += n_blocks;
+    if (n_frames_out) *n_frames_out = n_out;
+    if (n_out > 0) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->tm.qmf_ms = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->tm.gain_ms = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->tm.curve_ms = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->tm.qmf_mdct_ms = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); c->tm.psy_ms = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->tm.alloc_ms = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[7]); c->tm.total_ms = ms;
+        c->tm.qmf_mdct_launches = 1;
+    }
+    return AT3HIP_OK;
+}
+
+int at3hip_mdct(at3hip_ctx* c, float* bands, float* specs, const int32_t* n_points, const int32_t* level,
+                const int32_t* loc, int32_t n_items, uint32_t flags)
+{
+    if (!c || !bands || !specs || n_items < 1) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    if ((n_points != nullptr) != (level != nullptr) || (n_points != nullptr) != (loc != nullptr))
+        return fail(c, AT3HIP_EINVAL, "n_points/level/loc must be all null or all set");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const bool dev = (flags & AT3HIP_PCM_ON_DEVICE) && (flags & AT3HIP_OUT_ON_DEVICE);
+    if (!dev && (flags & (AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE)))
+        return fail(c, AT3HIP_EINVAL, "mdct buffers must be all host or all device");
+    const size_t n = n_items;
+    if (!dev && n_points) {
+        for (size_t i = 0; i < n * 4; ++i) {
+            if (n_points[i] < 0 || n_points[i] > 7) return fail(c, AT3HIP_EINVAL, "n_points out of range");
+            for (int k = 0; k < n_points[i]; ++k)
+                if (level[i * 8 + k] < 0 || level[i * 8 + k] > 15 || loc[i * 8 + k] < 0 || loc[i * 8 + k] > 31)
+                    return fail(c, AT3HIP_EINVAL, "gain point out of range");
+        }
+    }
+    float *d_bands = bands, *d_specs = specs;
+    int32_t *d_np = (int32_t*)n_points, *d_lv = (int32_t*)level, *d_lc = (int32_t*)loc;
+    void* tmp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = AT3HIP_OK;
+    if (!dev) {
+        hipError_t e = hipMalloc(&tmp[0], n * 2048 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&tmp[1], n * 1024 * sizeof(float));
+        if (e == hipSuccess && n_points) {
+            e = hipMalloc(&tmp[2], n * 4 * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMalloc(&tmp[3], n * 32 * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMalloc(&tmp[4], n * 32 * sizeof(int32_t));
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(tmp[0], bands, n * 2048 * sizeof(float), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && n_points) {
+            e = hipMemcpyAsync(tmp[2], n_points, n * 4 * sizeof(int32_t), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(tmp[3], level, n * 32 * sizeof(int32_t), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(tmp[4], loc, n * 32 * sizeof(int32_t), hipMemcpyHostToDevice, st);
+        }
+        if (e != hipSuccess) rc = fail(c, AT3HIP_EDEVICE, "mdct staging", e);
+        d_bands = (float*)tmp[0];
+        d_specs = (float*)tmp[1];
+        d_np = (int32_t*)tmp[2];
+        d_lv = (int32_t*)tmp[3];
+        d_lc = (int32_t*)tmp[4];
+    }
+    if (rc == AT3HIP_OK) {
+        MdctItemsParams mp;
+        mp.bands = d_bands;
+        mp.specs = d_specs;
+        mp.n_points = n_points ? d_np : nullptr;
+        mp.level = d_lv;
+        mp.loc = d_lc;
+        hipLaunchKernelGGL(k_mdct_items, dim3((unsigned)n), dim3(128), 0, st, mp, c->d_tables);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && !dev) {
+            e = hipMemcpyAsync(bands, d_bands, n * 2048 * sizeof(float), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(specs, d_specs, n * 1024 * sizeof(float), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(c, AT3HIP_EDEVICE, "mdct", e);
+    }
+    for (void* t : tmp)
+        if (t) (void)hipFree(t);
+    return rc;
+}
+
+int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* specs, uint32_t flags)
+{
+    if (!c || !pcm || !specs || n_blocks < 2) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    if ((flags & (AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE)) != (AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE))
+        return fail(c, AT3HIP_EINVAL, "qmf_mdct needs device pointers");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int S = c->cfg.n_streams;
+    // start-of-stream history: an all-zero buffer (the spare history buffer is kept zeroed for this)
+    float* zero_hist = c->d_hist[c->hist_cur ^ 1];
+    HIPCHK(c, hipMemsetAsync(zero_hist, 0, (size_t)S * kHist * 2 * sizeof(float), st));
+    FrontParams fp;
+    fp.pcm = pcm;
+    fp.hist = zero_hist;
+    fp.curves = nullptr;
+    fp.state = nullptr;
+    fp.specs = specs;
+    fp.ges = nullptr;
+    fp.sub = nullptr;
+    fp.n_blocks = n_blocks;
+    fp.f0 = 1;
+    fp.frames_per_wg = c->frames_per_wg;
+    fp.js = c->js;
+    const int n_out = n_blocks - 1;
+    const int nchunks = (n_out + c->frames_per_wg - 1) / c->frames_per_wg;
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    hipLaunchKernelGGL(k_qmf_mdct<false>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    memset(&c->tm, 0, sizeof(c->tm));
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    c->tm.qmf_mdct_ms = ms;
+    c->tm.total_ms = ms;
+    c->tm.qmf_mdct_launches = 1;
+    return AT3HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py - ATRAC3 LP2 stereo encode throughput on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the whole hot path (QMF -> gain control -> MDCT -> psy -> bit allocation ->
+quantisation -> sound-unit packing) over one batch of synthetic PCM that is already resident in HBM:
+`--streams` independent streams x `--frames` new 1024-sample stereo frames each (default 64 x 64 = 4096
+frames = BASELINE configs[1]). Streams continue across steps (the encoder carries its state), so every
+step does identical, full work and emits streams*frames ATRAC3 frames into device memory.
+
+N GPUs: one process per GPU (torch.distributed / RCCL only for the barrier and the MAX of the elapsed
+time); streams are sharded, per-GPU work is fixed ("weak" scaling), there is no data-path collective.
+
+One JSON line on rank 0. Extra objects:
+  roofline     - fused QMF+MDCT kernel (k_qmf_mdct): algorithmic 16384 B/frame x frames per launch /
+                 average launch duration measured with HIP events on the ctx stream inside this run.
+  cpu_baseline - the real reference (oracle/_ref, kind "reference") or the C port (oracle/, kind "port")
+                 timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_BYTES_PER_FRAME_K1 = 16384   # 8192 B interleaved PCM in + 8192 B spectra out
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def synth_pcm(n_streams, n_blocks, seed):
+    """Uniform white noise, s16 in [-8192, 8191] / 32768 (SURVEY.md 8(d) 'noise'), per-stream seeds."""
+    rng = np.random.RandomState(seed)
+    return (rng.randint(-8192, 8192, size=(n_streams, n_blocks, 1024, 2)).astype(np.float32)
+            / np.float32(32768.0)).astype(np.float32)
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """Reference encoder on host cores, bounded sample; returns the dict for the JSON line."""
+    from concurrent.futures import ThreadPoolExecutor
+    import at3_testlib as tl
+    if tl.have_ref():
+        codec, kind = tl.ref(), "reference"
+    else:
+        tl.build_oracle()
+        codec, kind = tl.oracle(), "port"
+    probe = synth_pcm(1, 201, 12345)[0]
+    codec.encode(probe[:3])  # one-time table init, single threaded
+    t = time.perf_counter()
+    codec.encode(probe)
+    per_frame = (time.perf_counter() - t) / 200.0
+    nfr = int(max(200, min(20000, seconds_budget * 0.4 / per_frame)))
+    pcm = synth_pcm(1, nfr + 1, 777)[0]
+    t = time.perf_counter()
+    frames, _ = codec.encode(pcm)
+    dt1 = time.perf_counter() - t
+    single = frames.shape[0] / dt1
+    cores = os.cpu_count() or 1
+    nthreads = max(1, min(cores, 64))
+    nfr_mt = int(max(100, min(nfr, seconds_budget * 0.5 / per_frame)))
+    pcms = [synth_pcm(1, nfr_mt + 1, 1000 + i)[0] for i in range(nthreads)]
+    t = time.perf_counter()
+    with ThreadPoolExecutor(nthreads) as ex:   # ctypes releases the GIL during the foreign call
+        res = list(ex.map(lambda p: codec.encode(p)[0].shape[0], pcms))
+    dtm = time.perf_counter() - t
+    multi = sum(res) / dtm
+    return {
+        "value": round(single, 1), "unit": "frames/s", "cores": 1, "kind": kind,
+        "sample": f"{frames.shape[0]} frames of one LP2 stereo white-noise stream, single thread",
+        "all_cores_value": round(multi, 1), "all_cores": nthreads,
+        "all_cores_sample": f"{nthreads} threads x {nfr_mt} frames (one stream per thread)",
+        "x_realtime": round(single * 1024 / 44100.0, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
+    ap.add_argument("--frames", type=int, default=64, help="frames per stream per step")
+    ap.add_argument("--bitrate", type=int, default=132300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gain", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import atracdenc_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    S, F = args.streams, args.frames
+    enc = atracdenc_amd.At3Hip(n_streams=S, max_blocks=F + 1, bitrate=args.bitrate, no_gain=args.no_gain,
+                               device_id=local_rank)
+    fsz = enc.frame_size
+    # synthetic PCM resident in HBM before timing: a priming look-ahead block + (warmup+steps) distinct batches
+    # would be large; instead two alternating batches are kept resident and re-fed (the encoder does full work).
+    host = synth_pcm(S, 2 * F + 1, seed=1 + rank)
+    d_prime = torch.from_numpy(host[:, :1].copy()).cuda()
+    d_batches = [torch.from_numpy(host[:, 1 + i * F: 1 + (i + 1) * F].copy()).cuda() for i in range(2)]
+    d_out = torch.zeros((S, F, fsz), dtype=torch.uint8, device="cuda")
+    enc.encode_device(d_prime.data_ptr(), 1, d_out.data_ptr())     # LOOK_AHEAD call, emits nothing
+    for i in range(args.warmup):
+        n = enc.encode_device(d_batches[i % 2].data_ptr(), F, d_out.data_ptr())
+        assert n == F
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    k1_ms, stage_ms = [], {}
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        enc.encode_device(d_batches[(args.warmup + i) % 2].data_ptr(), F, d_out.data_ptr())
+        tm = enc.timings()
+        k1_ms.append(tm["qmf_mdct_ms"] / max(1, tm["qmf_mdct_launches"]))
+        for k, v in tm.items():
+            if k.endswith("_ms"):
+                stage_ms[k] = stage_ms.get(k, 0.0) + v
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    checksum = int(d_out.to(torch.int64).sum().item())
+
+    if rank == 0:
+        frames_total = world * S * F * args.steps
+        value = frames_total / elapsed
+        k1_avg_ms = float(np.mean(k1_ms))
+        achieved = ALGO_BYTES_PER_FRAME_K1 * S * F / (k1_avg_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "ATRAC3 1024-sample stereo frames/sec", "value": round(value, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "x_realtime": round(value * 1024 / 44100.0, 1),
+            "config": {"workload": f"ATRAC3 {'LP2 132 kbps' if fsz == 384 else str(fsz) + ' B/frame'} stereo, "
+                                   f"{S} streams x {F} frames = {S * F} frames per GPU per step, white-noise PCM "
+                                   f"resident in HBM, frames written to HBM (PCIe excluded)",
+                       "streams_per_gpu": S, "frames_per_stream_per_step": F, "frame_bytes": fsz,
+                       "gain_control": not args.no_gain, "tonal_components": True, "parallelism": f"streams/{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_qmf_mdct (fused QMF + gain modulation + windowed MDCT-512)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME_K1 * S * F,
+                         "avg_launch_ms": round(k1_avg_ms, 5)},
+            "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in sorted(stage_ms.items())},
+            "checksum": checksum,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    enc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+/*
+ * at3hip.h - C ABI of the MI355X-native ATRAC3 encode hot path.
+ *
+ * Drop-in boundary. The reference (dcherednik/atracdenc) has no FFI: its surface for this path
+ * is the C++ class pair TAtrac3Encoder / TAtrac3MDCT. Each entry point below names the
+ * reference interface it replaces (paths relative to the reference's src/); the host-side C++
+ * mirror of those classes lives in atracdenc_amd/host/at3hip_host.hpp and the binding a
+ * maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a
+ * negative AT3HIP_E* code (never throws, never prints); the caller owns all buffers; one ctx
+ * per device, used from one host thread at a time. The library has NO CPU fallback: when no
+ * gfx950 device / kernel image is usable, at3hip_create fails with AT3HIP_EDEVICE.
+ */
+#ifndef AT3HIP_H
+#define AT3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AT3HIP_OK 0
+#define AT3HIP_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define AT3HIP_EDEVICE (-2)  /* HIP runtime / device error (see at3hip_last_error) */
+#define AT3HIP_ENOMEM (-3)
+
+/* at3hip_encode / at3hip_mdct / at3hip_qmf_mdct flags */
+#define AT3HIP_PCM_ON_DEVICE 1u  /* input pointer is device memory (already resident in HBM) */
+#define AT3HIP_OUT_ON_DEVICE 2u  /* output pointer is device memory */
+
+typedef struct at3hip_ctx at3hip_ctx;
+
+/* Mirrors NAtrac3::TAtrac3EncoderSettings (atrac/at3/atrac3.h:260-277) plus batch geometry. */
+typedef struct at3hip_config {
+    int32_t bitrate;          /* bit/s as TAtrac3EncoderSettings takes it; 0 = LP2 (132300). The container
+                                 row {Bitrate, FrameSz, Js} is chosen like GetContainerParamsForBitrate
+                                 (atrac3.cpp:47-53): 66150 -> LP4 192 B joint stereo, 132300 -> LP2 384 B. */
+    int32_t channels;         /* SourceChannels; 2 (stereo). */
+    int32_t no_gain_control;  /* NoGainControll */
+    int32_t no_tonal;         /* NoTonalComponents */
+    int32_t bfu_idx_const;    /* BfuIdxConst (0 = automatic) */
+    int32_t n_streams;        /* independent audio streams encoded side by side (batch dimension) */
+    int32_t max_blocks;       /* upper bound of PCM blocks per stream per at3hip_encode call */
+    int32_t device_id;        /* HIP device ordinal */
+} at3hip_config;
+
+/* Per-call device timings in milliseconds (HIP events on the ctx stream), filled by the last
+ * at3hip_encode / at3hip_qmf_mdct call. */
+typedef struct at3hip_timings {
+    float total_ms;
+    float qmf_ms;        /* subband analysis for the gain path */
+    float gain_ms;       /* spectral upsampler + AnalyzeGain */
+    float curve_ms;      /* CalcCurve / point-0 logic / context scan */
+    float qmf_mdct_ms;   /* fused QMF + gain modulation + windowed MDCT-512 (the roofline kernel) */
+    float psy_ms;        /* loudness, flatness, tonal extraction, scale factors */
+    float alloc_ms;      /* loudness scan + bit allocation + quantisation + sound-unit packing */
+    int32_t qmf_mdct_launches; /* launches of the fused kernel covered by qmf_mdct_ms */
+} at3hip_timings;
+
+/* Replaces: TAtrac3Encoder::TAtrac3Encoder(TCompressedOutputPtr&&, TAtrac3EncoderSettings&&)
+ * (atrac3denc.cpp:93-103) for n_streams encoders at once. */
+int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out);
+void at3hip_destroy(at3hip_ctx* ctx);
+
+/* FrameSz of the selected container row (atrac3.h:211-220). */
+int at3hip_frame_size(const at3hip_ctx* ctx);
+/* 1 when the container row is joint stereo (LP4). */
+int at3hip_joint_stereo(const at3hip_ctx* ctx);
+/* Human-readable description of the last error on this ctx (never NULL). */
+const char* at3hip_last_error(const at3hip_ctx* ctx);
+
+/* Replaces: n_blocks consecutive calls of the TAtrac3Encoder::GetLambda() functor
+ * (atrac3denc.cpp:694-866) on every stream, plus the ICompressedOutput::WriteFrame calls they make
+ * (compressed_io.h:56-59, atrac3_bitstream.cpp:845).
+ *   pcm        [n_streams][n_blocks][1024][channels] float32, interleaved, +-1.0 (what TPCMEngine hands
+ *              to the lambda, pcmengin.h:173-184)
+ *   out_frames [n_streams][n_frames][frame_size] bytes, n_frames = *n_frames_out
+ * Stream state (QMF history, look-ahead, MDCT overlap, gain-curve context, loudness) is carried
+ * between calls, so a stream may be fed in pieces. As in the reference the very first block of a
+ * stream only primes the look-ahead (LOOK_AHEAD, atrac3denc.cpp:715-718): the first call returns
+ * n_blocks-1 frames per stream, later calls n_blocks. */
+int at3hip_encode(at3hip_ctx* ctx, const float* pcm, int32_t n_blocks, uint8_t* out_frames,
+                  int32_t* n_frames_out, uint32_t flags);
+
+/* Back to start-of-stream state for every stream (a fresh TAtrac3Encoder). */
+int at3hip_reset(at3hip_ctx* ctx);
+
+/* Replaces: TAtrac3MDCT::Mdct(float specs[1024], float* bands[4], TGainModulatorArray)
+ * (atrac3denc.h:80-86, atrac3denc.cpp:33-58) with modulators made by
+ * TGainProcessor::Modulate(points) (gain_processor.h:87-121), batched over n_items.
+ *   bands    [n_items][4][512] float32, each [overlap 256 | new 256]; MUTATED like the reference:
+ *            the overlap slot receives EncodeWindow*new and, for bands with gain points, the new
+ *            half is divided by the gain ramp.
+ *   specs    [n_items][1024] float32 out
+ *   n_points [n_items][4], level/loc [n_items][4][8] (int32) or all NULL for no gain modulation. */
+int at3hip_mdct(at3hip_ctx* ctx, float* bands, float* specs, const int32_t* n_points,
+                const int32_t* level, const int32_t* loc, int32_t n_items, uint32_t flags);
+
+/* The fused batched QMF + windowed MDCT-512 kernel on its own (start-of-stream state, no gain
+ * control): PCM [n_streams][n_blocks][1024][channels] -> spectra [n_streams][n_blocks-1][channels][1024].
+ * Replaces, per frame and channel: the /4.0 de-interleave + Atrac3AnalysisFilterBank::Analysis
+ * (atrac3denc.cpp:701-713, atrac/at3/atrac3_qmf.h:37-41) + TAtrac3MDCT::Mdct (atrac3denc.cpp:802-809).
+ * Both pointers must be device memory (flags must contain AT3HIP_PCM_ON_DEVICE|AT3HIP_OUT_ON_DEVICE). */
+int at3hip_qmf_mdct(at3hip_ctx* ctx, const float* pcm, int32_t n_blocks, float* specs, uint32_t flags);
+
+/* Timings of the last at3hip_encode / at3hip_qmf_mdct call. */
+int at3hip_get_timings(const at3hip_ctx* ctx, at3hip_timings* out);
+
+/* Bind all work of this ctx to a caller-provided hipStream_t (NULL = the ctx's own stream). */
+int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
+
+/* Library/ABI version: (major << 16) | minor. */
+uint32_t at3hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AT3HIP_H */

@@ -1,0 +1,164 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/at3hip.h) against the CPU oracle and the
+committed golden vectors. Bit-exact for frame bytes (integer work); spectra are compared as bit patterns
+too (the kernels keep the reference's fp32 operation order, contraction off), which is stricter than the
+1e-6 tolerance the reference's own MDCT tests use (atrac3denc_ut.cpp:96-1036)."""
+import numpy as np
+import pytest
+
+from at3_testlib import LP2, LP4, SIGNALS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import atracdenc_amd
+    return atracdenc_amd
+
+
+def oracle_frames(oracle, pcm, br, ng=0, nt=0):
+    return np.stack([oracle.encode(pcm[i], br, ng, nt)[0] for i in range(pcm.shape[0])])
+
+
+@pytest.mark.parametrize("br", [LP2, LP4])
+@pytest.mark.parametrize("opts", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_frames_all_signals(hip, oracle, br, opts):
+    ng, nt = opts
+    nb = 20
+    names = sorted(SIGNALS)
+    pcm = np.stack([SIGNALS[n](nb) for n in names])
+    enc = hip.At3Hip(n_streams=len(names), max_blocks=nb, bitrate=br, no_gain=ng, no_tonal=nt)
+    got = enc.encode(pcm)
+    enc.close()
+    exp = oracle_frames(oracle, pcm, br, ng, nt)
+    assert got.shape == exp.shape
+    bad = np.argwhere((got != exp).any(axis=2))
+    assert bad.size == 0, f"mismatching (stream, frame): {bad[:10].tolist()} of {names}"
+
+
+@pytest.mark.parametrize("mode", ["lp2", "lp4"])
+@pytest.mark.parametrize("tag", ["full", "nogain", "notonal"])
+def test_golden_frames(hip, golden_encode, mode, tag):
+    names = sorted(SIGNALS)
+    pcm = np.stack([golden_encode[f"{n}_pcm_s16"].astype(np.float32) / np.float32(32768.0) for n in names])
+    enc = hip.At3Hip(n_streams=len(names), max_blocks=pcm.shape[1], bitrate=LP2 if mode == "lp2" else LP4,
+                     no_gain=(tag == "nogain"), no_tonal=(tag == "notonal"))
+    got = enc.encode(pcm)
+    enc.close()
+    for i, n in enumerate(names):
+        assert np.array_equal(got[i], golden_encode[f"{n}_{mode}_{tag}_frames"]), n
+
+
+@pytest.mark.parametrize("br", [LP2, LP4])
+def test_streaming_pieces_equal_one_shot(hip, oracle, br):
+    # stream state (QMF history, overlap, curve context, loudness) carried across calls; first block = LOOK_AHEAD
+    nb = 30
+    pcm = np.stack([SIGNALS["burst"](nb), SIGNALS["mix"](nb, seed=5), SIGNALS["tones"](nb)])
+    enc = hip.At3Hip(n_streams=3, max_blocks=16, bitrate=br)
+    outs, pos = [], 0
+    for piece in (1, 1, 2, 3, 7, 16):
+        outs.append(enc.encode(pcm[:, pos:pos + piece]))
+        pos += piece
+    assert outs[0].shape[1] == 0
+    got = np.concatenate(outs, axis=1)
+    assert np.array_equal(got, oracle_frames(oracle, pcm, br))
+    enc.reset()
+    again = enc.encode(pcm[:, :16])
+    enc.close()
+    assert np.array_equal(again, got[:, :15])
+
+
+def test_frames_per_workgroup_invariance(hip, oracle, monkeypatch):
+    nb = 13
+    pcm = np.stack([SIGNALS["mix"](nb, seed=9), SIGNALS["burst"](nb, phase=700)])
+    exp = oracle_frames(oracle, pcm, LP2)
+    for fpw in ("1", "2", "5", "64"):
+        monkeypatch.setenv("AT3HIP_FRAMES_PER_WG", fpw)
+        enc = hip.At3Hip(n_streams=2, max_blocks=nb, bitrate=LP2)
+        got = enc.encode(pcm)
+        enc.close()
+        assert np.array_equal(got, exp), fpw
+
+
+def test_mdct_api(hip, oracle, golden_stages):
+    enc = hip.At3Hip(n_streams=1, max_blocks=2)
+    g = golden_stages
+    specs, bands = enc.mdct(g["mdct_bands_in"][None], g["mdct_npoints"][None], g["mdct_level"][None], g["mdct_loc"][None])
+    assert np.array_equal(specs[0].view(np.uint32), g["mdct_specs"].view(np.uint32))
+    assert np.array_equal(bands[0].view(np.uint32), g["mdct_bands_out"].view(np.uint32))
+    rng = np.random.RandomState(1)
+    n = 33
+    b = rng.uniform(-0.3, 0.3, (n, 4, 512)).astype(np.float32)
+    npnts = rng.randint(0, 8, (n, 4)).astype(np.int32)
+    level = rng.randint(0, 16, (n, 4, 8)).astype(np.int32)
+    loc = np.sort(rng.randint(0, 32, (n, 4, 8)), axis=2).astype(np.int32)
+    s, bo = enc.mdct(b, npnts, level, loc)
+    for i in range(n):
+        es, eb = oracle.mdct(b[i], npnts[i], level[i], loc[i])
+        assert np.array_equal(es.view(np.uint32), s[i].view(np.uint32)), i
+        assert np.array_equal(eb.view(np.uint32), bo[i].view(np.uint32)), i
+    # reference property tests: zero in -> zero out (atrac3denc_ut.cpp:96-123); no-gain call leaves new half alone
+    s0, b0 = enc.mdct(np.zeros((1, 4, 512), np.float32))
+    assert not s0.any() and not b0.any()
+    s1, b1 = enc.mdct(b[:1])
+    assert np.array_equal(b1[0, :, 256:], b[0, :, 256:])
+    with pytest.raises(hip.At3HipError):
+        enc.mdct(b[:1], np.full((1, 4), 9, np.int32), level[:1], loc[:1])
+    enc.close()
+
+
+def _oracle_spectra(oracle, pcm):
+    """[nb,1024,2] -> [nb-1, 2, 1024] spectra via the oracle's QMF + MDCT stage functions."""
+    nb = pcm.shape[0]
+    out = np.zeros((nb - 1, 2, 1024), np.float32)
+    for ch in range(2):
+        sub = oracle.qmf(np.ascontiguousarray(pcm[:, :, ch]).reshape(-1) * np.float32(0.25))
+        bands = np.zeros((4, 512), np.float32)
+        for f in range(nb - 1):
+            bands[:, 256:] = sub[:, f * 256:(f + 1) * 256]
+            specs, bands = oracle.mdct(bands)
+            out[f, ch] = specs
+    return out
+
+
+def test_fused_qmf_mdct_kernel(hip, oracle):
+    torch = pytest.importorskip("torch")
+    nb, S = 9, 3
+    pcm = np.stack([SIGNALS["noise"](nb, seed=4), SIGNALS["mix"](nb), SIGNALS["tones"](nb)])
+    enc = hip.At3Hip(n_streams=S, max_blocks=nb, no_gain=True)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    d_specs = torch.zeros((S, nb - 1, 2, 1024), dtype=torch.float32, device="cuda")
+    enc.qmf_mdct_device(d_pcm.data_ptr(), nb, d_specs.data_ptr())
+    got = d_specs.cpu().numpy()
+    enc.close()
+    for i in range(S):
+        exp = _oracle_spectra(oracle, pcm[i])
+        assert np.array_equal(got[i].view(np.uint32), exp.view(np.uint32)), i
+
+
+def test_full_batch_config_properties(hip, oracle):
+    """BASELINE config[1]: LP2 stereo, 4096 frames = 64 streams x 64 frames (+1 look-ahead block)."""
+    S, nb = 64, 65
+    base = [SIGNALS["noise"](nb, seed=100 + i) for i in range(4)] + [SIGNALS["mix"](nb, seed=i) for i in range(4)]
+    pcm = np.stack([base[i % 8] for i in range(S)])
+    enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2)
+    got = enc.encode(pcm)
+    again_enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2)
+    again = again_enc.encode(pcm)
+    enc.close(); again_enc.close()
+    assert got.shape == (S, 64, 384)
+    assert np.array_equal(got, again)                        # deterministic
+    for i in range(8, S):
+        assert np.array_equal(got[i], got[i % 8])             # identical streams -> identical frames (no cross-talk)
+    assert (got[:, :, 0] == 0xA3).all()                       # sound-unit id 0x28 << 2 | (numQmf - 1)
+    for i in (0, 5):                                          # spot streams against the oracle
+        assert np.array_equal(got[i], oracle.encode(pcm[i], LP2)[0]), i
+
+
+def test_error_handling(hip):
+    with pytest.raises(hip.At3HipError):
+        hip.At3Hip(n_streams=0)
+    enc = hip.At3Hip(n_streams=1, max_blocks=2)
+    with pytest.raises(hip.At3HipError):
+        enc.encode(np.zeros((1, 3, 1024, 2), np.float32))     # more blocks than max_blocks
+    enc.close()

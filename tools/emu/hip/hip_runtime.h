@@ -1,0 +1,73 @@
+// DEVELOPMENT HARNESS ONLY (tools/emu): a tiny single-threaded SIMT emulator that lets the unmodified
+// kernel sources under atracdenc_amd/csrc be compiled with g++ and stepped through on a CPU-only
+// machine (this build container has no GPU). It is NOT part of the product, is never shipped in
+// libat3hip.so, and no test or benchmark result is produced with it - it only shortens the
+// edit/debug loop for kernel *logic* (indexing, barriers, state machines) before a gpurun call.
+//
+// Model: one workgroup at a time; each work-item is a ucontext fiber; __syncthreads() yields to a
+// round-robin scheduler. __shared__ becomes `static` (one workgroup alive at a time).
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+using std::isfinite;
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 {
+    float x, y;
+};
+
+extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+
+void emu_syncthreads();
+#define __syncthreads() emu_syncthreads()
+
+static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline int __float2int_rn(float f) { return (int)lrintf(f); }
+template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorUnknown = 1 };
+typedef void* hipStream_t;
+typedef struct emu_event* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+
+static inline const char* hipGetErrorString(hipError_t) { return "emu error"; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); memset(*p, 0xCD, n); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+
+void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
