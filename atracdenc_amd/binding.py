@@ -51,6 +51,12 @@ def load_library(path=None):
     path = path or os.environ.get("AT3HIP_LIB") or LIB_PATH
     if path in _lib_cache:
         return _lib_cache[path]
+    # PyTorch wheels bundle their own HIP runtime; when torch shares the process (bench.py, tests) it has
+    # to be loaded first so that libat3hip.so binds to the same runtime instance instead of a second copy.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(path):
         raise At3HipError(f"{path} not found: build it with atracdenc_amd.build_library() / __graft_entry__.build(); "
                           "there is no CPU fallback")
