@@ -1,33 +1,34 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 outputs (kernel stats + PMC passes) into a short text summary for profiles/."""
-import csv, glob, os, sys
-from collections import defaultdict
+"""Condense rocprofv3 rocpd databases (kernel stats + PMC passes) into a short text summary for profiles/.
+usage: summarize_prof.py <dir with stats/ pmc_fetch/ pmc_write/ pmc_sq/>"""
+import glob, os, sqlite3, sys
 
 root = sys.argv[1]
 
-def find(pattern):
-    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+def dbs(sub):
+    return sorted(glob.glob(os.path.join(root, sub, "**", "*.db"), recursive=True))
 
-print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
-for f in find("*kernel_stats.csv"):
-    with open(f) as fh:
-        rows = list(csv.DictReader(fh))
-    for r in rows:
-        name = r.get("Name", "")[:70]
-        print(f"{name:70s} calls={r.get('Calls')} total_ns={r.get('TotalDurationNs')} avg_ns={r.get('AverageNs')} pct={r.get('Percentage')}")
+def short(n):
+    n = n.split("(")[0]
+    return n.replace("void ", "").replace("at3::", "")[:48]
 
-for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    files = find(f"{tag}/**/*counter_collection.csv") or glob.glob(os.path.join(root, tag, "**", "*counter_collection.csv"), recursive=True)
-    agg = defaultdict(lambda: defaultdict(float))
-    cnt = defaultdict(set)
-    for f in files:
-        with open(f) as fh:
-            for r in csv.DictReader(fh):
-                k = r.get("Kernel_Name", "")[:60]
-                agg[k][r.get("Counter_Name")] += float(r.get("Counter_Value", 0) or 0)
-                cnt[k].add(r.get("Dispatch_Id"))
-    if agg:
-        print(f"== {tag}: per-dispatch averages ==")
-        for k, d in sorted(agg.items()):
-            n = max(1, len(cnt[k]))
-            print(f"{k:60s} dispatches={n} " + " ".join(f"{c}={v / n:.4g}" for c, v in sorted(d.items())))
+for f in dbs("stats"):
+    db = sqlite3.connect(f)
+    print("== kernel stats: rocprofv3 --kernel-trace --stats (top_kernels view) ==")
+    print(f"{'kernel':48s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
+    rows = list(db.execute("select name, count(*), sum(end-start), avg(end-start) from kernels group by name order by 3 desc"))
+    tot = sum(r[2] for r in rows) or 1
+    for name, calls, total, avg in rows:
+        print(f"{short(name):48s} {calls:6d} {total/1e3:12.1f} {avg/1e3:10.2f} {100.0*total/tot:6.2f}")
+    print("-- resources --")
+    for r in db.execute("select distinct name, workgroup_x, grid_x, lds_size, scratch_size, vgpr_count, sgpr_count from kernels group by name"):
+        print(f"{short(r[0]):48s} wg={r[1]} grid={r[2]} lds={r[3]} scratch={r[4]} vgpr={r[5]} sgpr={r[6]}")
+
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for f in dbs(sub):
+        db = sqlite3.connect(f)
+        print(f"== {sub}: per-dispatch average counter values ==")
+        q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+             "group by kernel_name, counter_name order by kernel_name, counter_name")
+        for k, c, v, n in db.execute(q):
+            print(f"{short(k):48s} {c:24s} avg={v:.6g} (n={n})")
