@@ -399,33 +399,14 @@ __device__ inline void std_sort_abs(SortItem* a, int n)
     }
 }
 
-// QuantMantisas for one (bfu, wordlen) unit (atrac_scale.cpp:40-130). Writes int8 mantissas.
-__device__ inline float quant_unit(const float* in, int n, float mul, bool ea, int8_t* mant)
+// Energy-adaptive re-rounding pass of QuantMantisas (atrac_scale.cpp:86-128) over the already sorted
+// candidate list. Returns the updated e2.
+__device__ inline float ea_greedy(const float* in, float mul, float inv2, float e1, float e2, const uint8_t* cand, int nc,
+                                  int8_t* mant)
 {
-    float e1 = 0.0f, e2 = 0.0f;
-    const float inv2 = (float)(1.0 / (double)(mul * mul));
-    SortItem cand[128];
-    int nc = 0;
-    for (int j = 0; j < n; ++j) {
-        const float t = in[j] * mul;
-        e1 += in[j] * in[j];
-        const int m = __float2int_rn(t);
-        mant[j] = (int8_t)m;
-        e2 += (float)(m * m) * inv2;
-        if (ea) {
-            const float delta = t - (truncf(t) + 0.5f);
-            if (fabsf(delta) < 0.25f) {
-                cand[nc].key = delta;
-                cand[nc].idx = j;
-                ++nc;
-            }
-        }
-    }
-    if (!ea || nc == 0) return e1 / e2;
-    std_sort_abs(cand, nc);
     if (e2 < e1) {
         for (int c = 0; c < nc; ++c) {
-            const int j = cand[c].idx;
+            const int j = cand[c];
             const float t = in[j] * mul;
             const int m0 = mant[j];
             const float am = (float)(m0 < 0 ? -m0 : m0);
@@ -445,7 +426,7 @@ __device__ inline float quant_unit(const float* in, int n, float mul, bool ea, i
         }
     } else if (e2 > e1) {
         for (int c = 0; c < nc; ++c) {
-            const int j = cand[c].idx;
+            const int j = cand[c];
             const float t = in[j] * mul;
             const int m0 = mant[j];
             const float am = (float)(m0 < 0 ? -m0 : m0);
@@ -463,7 +444,20 @@ __device__ inline float quant_unit(const float* in, int n, float mul, bool ea, i
             }
         }
     }
-    return e1 / e2;
+    return e2;
+}
+
+// VLC bit cost of one quantised unit (VLCEnc with a null stream, atrac3_bitstream.cpp:115-149).
+__device__ inline uint32_t unit_vlc_bits(int wl, const int8_t* mant, int n)
+{
+    uint32_t vlc = 0;
+    if (wl > 1) {
+        for (int j = 0; j < n; ++j) vlc += huff_entry(wl, vlc_index(mant[j])) >> 8;
+    } else {
+        const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
+        for (int j = 0; j < n / 2; ++j) vlc += huff_entry(1, rt9[3 * (mant[2 * j] + 1) + (mant[2 * j + 1] + 1)]) >> 8;
+    }
+    return vlc;
 }
 
 // Tonal component side information: grouping (GroupTonalComponents, atrac3_bitstream.cpp:338-380) and
@@ -589,19 +583,34 @@ __device__ inline int tonal_encode(const PsyRec* rec, const uint8_t* tbits /* [k
     return used;
 }
 
-// One 64-lane workgroup per (stream, output frame, channel).
+// One 64-lane workgroup (a single wavefront) per (stream, output frame, channel).
+//
+// Phases: (A) all 7 x 1024 roundings in parallel; (B) the strictly ordered energy sums as 256 independent
+// chains (32 x e1, 224 x e2) spread over the lanes by length; (C) energy-adaptive re-rounding of BFUs 19..31:
+// candidate lists in LDS, parallel rank sort (falls back to the libstdc++-order sort when two candidates tie),
+// sequential greedy pass per unit; (D) rate loop with per-BFU closed forms for the tonal decrement and the
+// ConsiderEnergyErr fixed point; (E) cooperative MSB-first packing with a two-level prefix sum.
+constexpr int kEaLine0 = 288;            // first spectral line of BFU 19
+constexpr int kEaLines = 1024 - kEaLine0;  // 736
+
 __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T)
 {
-    __shared__ float s_val[1024];           // scaled values; later aliased by the per-element (code,len) arrays
+    __shared__ float s_val[1024];            // scaled values; aliased by the per-element (code,len) words when packing
     __shared__ int8_t s_mant[7 * 1024];
-    __shared__ float s_err[8 * 32];
+    __shared__ uint8_t s_cand[7 * kEaLines]; // candidate line indices (relative to the BFU) per wordlen plane
+    __shared__ uint8_t s_nc[7 * 13];
+    __shared__ uint8_t s_tie[7 * 13];
+    __shared__ float s_e1[32];
+    __shared__ float s_err[8 * 32];          // e2 during phase B/C, then e1 / e2
     __shared__ uint16_t s_clc[8 * 32];
     __shared__ uint16_t s_vlc[8 * 32];
-    __shared__ float s_csfi[32];
+    __shared__ float s_A[32];                // spread * (csfi / x) + (1 - spread) * fix
     __shared__ uint8_t s_gate[32];
+    __shared__ uint8_t s_tcount[32];
     __shared__ int s_alloc[32];
+    __shared__ uint32_t s_red[32];
     __shared__ uint8_t s_tbits[kMaxTonal * 8];
-    __shared__ uint32_t s_words[kBitWords];
+    __shared__ uint32_t s_words[kBitWords];  // bit buffer; doubles as scratch for the rare tie-order sort
     __shared__ int s_lsum[64];
     __shared__ int s_misc[8];
     __shared__ float s_spread;
@@ -617,8 +626,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     const PsyRec* rec = recs + ch;
     const Curve* curves = p.curves + ((size_t)s * p.n_blocks + f) * 8;
     const int half = p.frame_sz >> 1;
-
-    for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
+    const int n_tonal = rec->n_tonal;
 
     // ---- scaled values (TScaler::Scale) ----
     for (int b = 0; b < 32; ++b) {
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     target &= 0xffff;
     const float loudness = p.loud[(size_t)s * n_out + fo] / 0.006f;
 
-    // ---- TConfigure: spread, initial NumBfu ----
+    // ---- TConfigure: spread; per-BFU constants of CalcBitsAllocation ----
     if (lane == 0) {
         float sum = 0.0f;
         for (int i = 0; i < 32; ++i) sum += (float)rec->sfi[i];
@@ -675,6 +683,16 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         if (sigma > 14.0f) sigma = 14.0f;
         s_spread = sigma / 14.0f;
     }
+    // tonal blocks: VLC bit cost for every quantiser 2..7
+    for (int idx = lane; idx < n_tonal * 6; idx += 64) {
+        const int t = idx / 6, q = 2 + idx % 6;
+        const TonalBlock& tb = rec->tonal[t];
+        const float mul = c_max_quant[q];
+        int bits = 0;
+        for (int z = 0; z < tb.len; ++z) bits += (int)(huff_entry(q, vlc_index(__float2int_rn(tb.values[z] * mul))) >> 8);
+        s_tbits[t * 8 + q] = (uint8_t)bits;
+    }
+    __syncthreads();
     if (lane < 32) {
         const int i = lane;
         int band = 0;
@@ -687,43 +705,154 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         const float corrected = rec->energy[i] * g;
         const float ath = T->ath_bfu[i] * loudness;
         s_gate[i] = corrected < ath;
-        s_csfi[i] = fmaxf(0.0f, fminf(63.0f, (float)rec->sfi[i] + 1.5f * at3_log2f(T, g)));
+        const float csfi = fmaxf(0.0f, fminf(63.0f, (float)rec->sfi[i] + 1.5f * at3_log2f(T, g)));
+        float x = 6.0f;
+        if (i < 3) x = 2.8f;
+        else if (i < 10) x = 2.6f;
+        else if (i < 15) x = 3.3f;
+        else if (i <= 20) x = 3.6f;
+        else if (i <= 28) x = 4.2f;
+        const float spread = s_spread;
+        s_A[i] = spread * (csfi / x) + (1.0f - spread) * (float)c_fixed_alloc[i];
+        int tc = 0;
+        for (int t = 0; t < n_tonal; ++t) tc += (rec->tonal[t].bfu == i);
+        s_tcount[i] = (uint8_t)tc;
     }
-    // tonal blocks: VLC bit cost for every quantiser 2..7
-    for (int idx = lane; idx < rec->n_tonal * 6; idx += 64) {
-        const int t = idx / 6, q = 2 + idx % 6;
-        const TonalBlock& tb = rec->tonal[t];
-        const float mul = c_max_quant[q];
-        int bits = 0;
-        for (int z = 0; z < tb.len; ++z) bits += (int)(huff_entry(q, vlc_index(__float2int_rn(tb.values[z] * mul))) >> 8);
-        s_tbits[t * 8 + q] = (uint8_t)bits;
+
+    // ---- (A) mantissa = lrint(value * MaxQuant[wl]) for every wordlen ----
+    for (int idx = lane; idx < 7 * 1024; idx += 64) {
+        const int wl = 1 + (idx >> 10), i = idx & 1023;
+        s_mant[idx] = (int8_t)__float2int_rn(s_val[i] * c_max_quant[wl]);
     }
     __syncthreads();
 
-    // ---- all 32 x 7 quantised units (what TEncCache computes lazily), largest BFUs first ----
+    // ---- (B) ordered sums: chain c < 224 is e2 of unit c (bfu = 31 - c / 7, wl = 1 + c % 7); the rest are e1 ----
+    for (int c = lane; c < 256; c += 64) {
+        if (c < 224) {
+            const int bfu = 31 - c / 7, wl = 1 + c % 7;
+            const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+            const float mul = c_max_quant[wl];
+            const float inv2 = (float)(1.0 / (double)(mul * mul));
+            const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+            float e2 = 0.0f;
+            for (int j = 0; j < n; ++j) {
+                const int m = mant[j];
+                e2 += (float)(m * m) * inv2;
+            }
+            s_err[wl * 32 + bfu] = e2;
+            s_clc[wl * 32 + bfu] = (uint16_t)((wl > 1) ? c_clc_len[wl] * n : 2 * n);
+            if (bfu <= 18) s_vlc[wl * 32 + bfu] = (uint16_t)unit_vlc_bits(wl, mant, n);
+        } else {
+            const int bfu = 31 - (c - 224);
+            const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+            float e1 = 0.0f;
+            for (int j = 0; j < n; ++j) e1 += s_val[start + j] * s_val[start + j];
+            s_e1[bfu] = e1;
+        }
+    }
+    // ---- (C1) candidates of the energy-adaptive units (bfu > 18): unit u < 91 in the same order as above ----
+    for (int u = lane; u < 91; u += 64) {
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        const float mul = c_max_quant[wl];
+        uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
+        int nc = 0;
+        for (int j = 0; j < n; ++j) {
+            const float t = s_val[start + j] * mul;
+            const float delta = t - (truncf(t) + 0.5f);
+            if (fabsf(delta) < 0.25f) cand[nc++] = (uint8_t)j;
+        }
+        s_nc[(wl - 1) * 13 + (bfu - 19)] = (uint8_t)nc;
+        s_tie[(wl - 1) * 13 + (bfu - 19)] = 0;
+    }
+    __syncthreads();
+    // ---- (C2) rank sort by |delta|, one wordlen plane at a time (12 slots per lane held in registers) ----
+    for (int wl = 1; wl <= 7; ++wl) {
+        const float mul = c_max_quant[wl];
+        uint8_t* plane = s_cand + (wl - 1) * kEaLines;
+        int my_rank[12], my_idx[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            my_rank[r] = -1;
+            my_idx[r] = 0;
+            const int slot = lane + 64 * r;
+            if (slot < kEaLines) {
+                const int line = kEaLine0 + slot;
+                int bfu = 19;
+                while (c_bfu_start[bfu + 1] <= line) ++bfu;
+                const int start = c_bfu_start[bfu];
+                const int k = line - start;
+                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+                if (k < nc) {
+                    const uint8_t* cand = plane + (start - kEaLine0);
+                    const int j = cand[k];
+                    const float t = s_val[start + j] * mul;
+                    const float key = fabsf(t - (truncf(t) + 0.5f));
+                    int rank = 0;
+                    bool tie = false;
+                    for (int q = 0; q < nc; ++q) {
+                        const float tq = s_val[start + cand[q]] * mul;
+                        const float kq = fabsf(tq - (truncf(tq) + 0.5f));
+                        rank += (kq < key) || (kq == key && q < k);
+                        tie = tie || (kq == key && q != k);
+                    }
+                    if (tie) s_tie[(wl - 1) * 13 + (bfu - 19)] = 1;
+                    my_rank[r] = (start - kEaLine0) + rank;
+                    my_idx[r] = j;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 12; ++r)
+            if (my_rank[r] >= 0) plane[my_rank[r]] = (uint8_t)my_idx[r];
+        __syncthreads();
+    }
+    // ---- (C3) equal keys: libstdc++'s std::sort order decides (rare) ----
+    if (lane == 0) {
+        for (int u = 0; u < 91; ++u) {
+            const int bfu = 31 - u / 7, wl = 1 + u % 7;
+            if (!s_tie[(wl - 1) * 13 + (bfu - 19)]) continue;
+            const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+            const float mul = c_max_quant[wl];
+            SortItem* items = reinterpret_cast<SortItem*>(s_words);
+            int nc = 0;
+            for (int j = 0; j < n; ++j) {
+                const float t = s_val[start + j] * mul;
+                const float delta = t - (truncf(t) + 0.5f);
+                if (fabsf(delta) < 0.25f) {
+                    items[nc].key = delta;
+                    items[nc].idx = j;
+                    ++nc;
+                }
+            }
+            std_sort_abs(items, nc);
+            uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
+            for (int q = 0; q < nc; ++q) cand[q] = (uint8_t)items[q].idx;
+        }
+    }
+    __syncthreads();
+    // ---- (C4) greedy re-rounding per unit, then e1 / e2 and the VLC cost of the final mantissas ----
     for (int u = lane; u < 224; u += 64) {
         const int bfu = 31 - u / 7, wl = 1 + u % 7;
         const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
-        int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-        const float e = quant_unit(s_val + start, n, c_max_quant[wl], bfu > 18, mant);
-        uint32_t clc, vlc = 0;
-        if (wl > 1) {
-            clc = (uint32_t)c_clc_len[wl] * n;
-            for (int j = 0; j < n; ++j) vlc += huff_entry(wl, vlc_index(mant[j])) >> 8;
-        } else {
-            clc = 4u * n / 2;
-            const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
-            for (int j = 0; j < n / 2; ++j)
-                vlc += huff_entry(1, rt9[3 * (mant[2 * j] + 1) + (mant[2 * j + 1] + 1)]) >> 8;
+        const float e1 = s_e1[bfu];
+        float e2 = s_err[wl * 32 + bfu];
+        if (bfu > 18) {
+            const float mul = c_max_quant[wl];
+            const float inv2 = (float)(1.0 / (double)(mul * mul));
+            int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+            const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+            if (nc > 0)
+                e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_cand + (wl - 1) * kEaLines + (start - kEaLine0), nc, mant);
+            s_vlc[wl * 32 + bfu] = (uint16_t)unit_vlc_bits(wl, mant, n);
         }
-        s_err[wl * 32 + bfu] = e;
-        s_clc[wl * 32 + bfu] = (uint16_t)clc;
-        s_vlc[wl * 32 + bfu] = (uint16_t)vlc;
+        s_err[wl * 32 + bfu] = e1 / e2;
     }
+    for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
     __syncthreads();
 
-    // ---- rate loop: TConfigure / TAlloc under the bisection driver ----
-    const float spread = s_spread;
+    // ---- (D) rate loop: TConfigure / TAlloc under the bisection driver ----
     int num_bfu = p.bfu_idx_const ? p.bfu_idx_const : 32;
     if (target < 101) {
         int lim = 1;
@@ -748,60 +877,52 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
             if (lane < 32) {
                 int bits = 0;
                 const int i = lane;
-                if (i < num_bfu && !s_gate[i]) {
-                    float x = 6.0f;
-                    if (i < 3) x = 2.8f;
-                    else if (i < 10) x = 2.6f;
-                    else if (i < 15) x = 3.3f;
-                    else if (i <= 20) x = 3.6f;
-                    else if (i <= 28) x = 4.2f;
-                    const int tmp = (int)(spread * (s_csfi[i] / x) + (1.0f - spread) * (float)c_fixed_alloc[i] - lam);
-                    if (tmp > 7) bits = 7;
-                    else if (tmp < 0) bits = 0;
-                    else if (tmp == 0) bits = 1;
-                    else bits = tmp;
-                }
                 if (i < num_bfu) {
-                    for (int t = 0; t < rec->n_tonal; ++t)
-                        if (rec->tonal[t].bfu == i && bits > 2) bits -= 1;
+                    if (!s_gate[i]) {
+                        const int tmp = (int)(s_A[i] - lam);
+                        if (tmp > 7) bits = 7;
+                        else if (tmp < 0) bits = 0;
+                        else if (tmp == 0) bits = 1;
+                        else bits = tmp;
+                    }
+                    // one decrement per tonal block in this BFU while the wordlen is above 2 (:325-333)
+                    const int tc = s_tcount[i];
+                    if (bits > 2 && tc) bits = (bits - tc > 2) ? bits - tc : 2;
+                    // ConsiderEnergyErr fixed point: BFUs are independent (:241-257, :638-641)
+                    if (i < 10) {
+                        for (;;) {
+                            const float e = bits ? s_err[bits * 32 + i] : 0.0f;
+                            if (((e > 0 && e < 0.7f) || e > 1.2f) && bits < 7) ++bits;
+                            else break;
+                        }
+                    }
                 }
                 s_alloc[i] = bits;
+                uint32_t packed = 0;
+                if (i < num_bfu && bits) packed = (uint32_t)s_clc[bits * 32 + i] | ((uint32_t)s_vlc[bits * 32 + i] << 13) | (1u << 27);
+                s_red[i] = packed;
             }
             __syncthreads();
-            uint32_t used, clc, vlc;
-            for (;;) {
-                used = (uint32_t)num_bfu * 3;
-                clc = 0;
-                vlc = 0;
-                for (int i = 0; i < num_bfu; ++i) {
-                    const int wl = s_alloc[i];
-                    if (wl == 0) continue;
-                    used += 6;
-                    clc += s_clc[wl * 32 + i];
-                    vlc += s_vlc[wl * 32 + i];
+            uint32_t acc = 0;
+            {
+                const uint4* r4 = reinterpret_cast<const uint4*>(s_red);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint4 v = r4[q];
+                    acc += v.x + v.y + v.z + v.w;
                 }
-                // ConsiderEnergyErr: first 10 BFUs (atrac3_bitstream.cpp:241-257)
-                bool adjust = false;
-                const int lim = num_bfu < 10 ? num_bfu : 10;
-                for (int i = 0; i < lim; ++i) {
-                    const int wl = s_alloc[i];
-                    const float e = wl ? s_err[wl * 32 + i] : 0.0f;
-                    if (((e > 0 && e < 0.7f) || e > 1.2f) && (wl < 7)) adjust = true;
-                }
-                __syncthreads();
-                if (!adjust) break;
-                if (lane < lim) {
-                    const int wl = s_alloc[lane];
-                    const float e = wl ? s_err[wl * 32 + lane] : 0.0f;
-                    if (((e > 0 && e < 0.7f) || e > 1.2f) && (wl < 7)) s_alloc[lane] = wl + 1;
-                }
-                __syncthreads();
             }
+            const uint32_t clc = acc & 0x1fffu, vlc = (acc >> 13) & 0x3fffu, nz = acc >> 27;
             mode = clc <= vlc ? 1 : 0;
-            const uint32_t spec_bits = used + (mode ? clc : vlc);
-            if (lane == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
-            __syncthreads();
-            const uint32_t total = spec_bits + (uint32_t)(s_misc[0] & 0xffff);
+            const uint32_t spec_bits = (uint32_t)num_bfu * 3 + 6 * nz + (mode ? clc : vlc);
+            uint32_t tonal_bits = 5;
+            if (n_tonal > 0) {
+                if (lane == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
+                __syncthreads();
+                tonal_bits = (uint32_t)(s_misc[0] & 0xffff);
+            }
+            const uint32_t total = spec_bits + tonal_bits;
+            const int last_alloc = s_alloc[num_bfu - 1];
             __syncthreads();
             bool done;
             if (exhausted) {
@@ -817,17 +938,17 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
                 done = true;
             }
             if (!done) continue;
-            if (!p.bfu_idx_const && num_bfu > 1 && s_alloc[num_bfu - 1] == 0) {
+            if (!p.bfu_idx_const && num_bfu > 1 && last_alloc == 0) {
                 num_bfu--;
                 restart = true;
             }
             break;
         }
-        __syncthreads();
         if (!restart) break;
     }
+    // s_alloc holds the final allocation of the last evaluation (all lanes passed its trailing barrier)
 
-    // ---- emission (WriteSoundUnit header, EncodeSpecs) ----
+    // ---- (E) emission (WriteSoundUnit header, EncodeSpecs) ----
     int pos = 0;
     if (lane == 0) {
         if (p.js && ch == 1) {
@@ -874,21 +995,20 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     }
     __syncthreads();
     // mantissas: per-element (code,len), two-level prefix sum over 64 lanes x 16 elements
-    uint32_t* s_code = reinterpret_cast<uint32_t*>(s_val);  // 1024 x (code | len << 16), aliases s_val
+    uint32_t* s_code = reinterpret_cast<uint32_t*>(s_val);  // s_val is dead: last read in phase C
     {
         const int base = lane * 16;
         int sum = 0;
-        // which BFU does element `base` belong to (BFU sizes are multiples of 8, lanes cover 16 lines)
+        int b = 0;
+        while (c_bfu_start[b + 1] <= base) ++b;
         for (int k = 0; k < 16; ++k) {
             const int i = base + k;
-            int b = 0;
-            while (c_bfu_start[b + 1] <= i) ++b;
+            if (c_bfu_start[b + 1] <= i) ++b;   // BFU sizes are multiples of 8: at most one step per element
             uint32_t cl = 0;
             if (b < num_bfu && s_alloc[b]) {
                 const int wl = s_alloc[b];
                 cl = spec_code(wl, mode == 1, s_mant + (wl - 1) * 1024 + c_bfu_start[b], i - c_bfu_start[b]);
             }
-            // s_val is dead: every lane finished reading it before the quantisation barrier
             s_code[i] = cl;
             sum += (int)(cl >> 16);
         }

@@ -26,6 +26,12 @@ struct dim3 {
 struct float2 {
     float x, y;
 };
+struct float4 {
+    float x, y, z, w;
+};
+struct uint4 {
+    unsigned x, y, z, w;
+};
 
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
