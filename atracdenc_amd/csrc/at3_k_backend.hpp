@@ -583,39 +583,50 @@ __device__ inline int tonal_encode(const PsyRec* rec, const uint8_t* tbits /* [k
     return used;
 }
 
-// One 64-lane workgroup (a single wavefront) per (stream, output frame, channel).
+// One 256-thread workgroup per (stream, output frame, channel).
 //
 // Phases: (A) all 7 x 1024 roundings in parallel; (B) the strictly ordered energy sums as 256 independent
-// chains (32 x e1, 224 x e2) spread over the lanes by length; (C) energy-adaptive re-rounding of BFUs 19..31:
-// candidate lists in LDS, parallel rank sort (falls back to the libstdc++-order sort when two candidates tie),
-// sequential greedy pass per unit; (D) rate loop with per-BFU closed forms for the tonal decrement and the
-// ConsiderEnergyErr fixed point; (E) cooperative MSB-first packing with a two-level prefix sum.
-constexpr int kEaLine0 = 288;            // first spectral line of BFU 19
+// chains (32 x e1, 224 x e2), one per thread, longest chains on the first wave; (C) energy-adaptive
+// re-rounding of BFUs 19..31: candidate lists in LDS, parallel rank sort (falls back to the libstdc++-order
+// sort when two candidates tie), sequential greedy pass per unit; (D) rate loop with per-BFU closed forms for
+// the tonal decrement and the ConsiderEnergyErr fixed point; (E) cooperative MSB-first packing with a
+// two-level prefix sum.
+constexpr int kEaLine0 = 288;              // first spectral line of BFU 19
 constexpr int kEaLines = 1024 - kEaLine0;  // 736
+constexpr int kAllocThreads = 256;
 
-__global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T)
+__device__ __forceinline__ uint32_t lds_huff(const uint16_t* s_huff, int sel, uint32_t idx)
 {
-    __shared__ float s_val[1024];            // scaled values; aliased by the per-element (code,len) words when packing
+    return s_huff[c_huff_off[sel - 1] + idx];
+}
+
+__global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, const Tables* T)
+{
+    __shared__ float s_val[1024];              // scaled values; aliased by the per-element (code,len) words when packing
     __shared__ int8_t s_mant[7 * 1024];
-    __shared__ uint8_t s_cand[7 * kEaLines]; // candidate line indices (relative to the BFU) per wordlen plane
+    __shared__ uint8_t s_cand[7 * kEaLines];   // candidate line indices (relative to the BFU), scan order
+    __shared__ uint8_t s_sorted[7 * kEaLines]; // the same, ordered by |delta|
+    __shared__ float s_key[7 * kEaLines / 7];  // |delta| of one wordlen plane at a time
     __shared__ uint8_t s_nc[7 * 13];
     __shared__ uint8_t s_tie[7 * 13];
     __shared__ float s_e1[32];
-    __shared__ float s_err[8 * 32];          // e2 during phase B/C, then e1 / e2
+    __shared__ float s_err[8 * 32];            // e2 during phases B/C, then e1 / e2
     __shared__ uint16_t s_clc[8 * 32];
-    __shared__ uint16_t s_vlc[8 * 32];
-    __shared__ float s_A[32];                // spread * (csfi / x) + (1 - spread) * fix
+    __shared__ uint32_t s_vlc[8 * 32];
+    __shared__ float s_A[32];                  // spread * (csfi / x) + (1 - spread) * fix
     __shared__ uint8_t s_gate[32];
     __shared__ uint8_t s_tcount[32];
     __shared__ int s_alloc[32];
     __shared__ uint32_t s_red[32];
     __shared__ uint8_t s_tbits[kMaxTonal * 8];
-    __shared__ uint32_t s_words[kBitWords];  // bit buffer; doubles as scratch for the rare tie-order sort
-    __shared__ int s_lsum[64];
+    __shared__ uint16_t s_huff[130];
+    __shared__ uint32_t s_words[kBitWords];    // bit buffer; doubles as scratch for the rare tie-order sort
+    __shared__ int s_lsum[kAllocThreads];
+    __shared__ int s_wsum[kAllocThreads / 64];
     __shared__ int s_misc[8];
     __shared__ float s_spread;
 
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int n_out = p.n_blocks - p.f0;
     const int ch = blockIdx.x & 1;
     const int fo = (blockIdx.x >> 1) % n_out;
@@ -628,14 +639,20 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     const int half = p.frame_sz >> 1;
     const int n_tonal = rec->n_tonal;
 
-    // ---- scaled values (TScaler::Scale) ----
-    for (int b = 0; b < 32; ++b) {
-        const int start = c_bfu_start[b], len = c_bfu_start[b + 1] - start;
+    if (tid < 130) s_huff[tid] = c_huff[tid];
+    for (int i = tid; i < 8 * 32; i += kAllocThreads) s_vlc[i] = 0;
+    // ---- scaled values (TScaler::Scale): thread t owns lines 4t..4t+3 (BFU sizes are multiples of 8) ----
+    {
+        const int i0 = tid * 4;
+        int b = 0;
+        while (c_bfu_start[b + 1] <= i0) ++b;
         const float sf = T->scale[rec->sfi[b]];
-        for (int i = lane; i < len; i += 64) {
-            float v = specs[start + i] / sf;
-            if (fabsf(v) >= 1.0f) v = (v > 0) ? 0.99999f : -0.99999f;
-            s_val[start + i] = v;
+        const float4 x = *reinterpret_cast<const float4*>(specs + i0);
+        float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (fabsf(v[k]) >= 1.0f) v[k] = (v[k] > 0) ? 0.99999f : -0.99999f;
+            s_val[i0 + k] = v[k];
         }
     }
 
@@ -667,8 +684,8 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     target &= 0xffff;
     const float loudness = p.loud[(size_t)s * n_out + fo] / 0.006f;
 
-    // ---- TConfigure: spread; per-BFU constants of CalcBitsAllocation ----
-    if (lane == 0) {
+    // ---- TConfigure: spread ----
+    if (tid == 64) {
         float sum = 0.0f;
         for (int i = 0; i < 32; ++i) sum += (float)rec->sfi[i];
         sum /= 32;
@@ -684,7 +701,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         s_spread = sigma / 14.0f;
     }
     // tonal blocks: VLC bit cost for every quantiser 2..7
-    for (int idx = lane; idx < n_tonal * 6; idx += 64) {
+    for (int idx = tid; idx < n_tonal * 6; idx += kAllocThreads) {
         const int t = idx / 6, q = 2 + idx % 6;
         const TonalBlock& tb = rec->tonal[t];
         const float mul = c_max_quant[q];
@@ -693,8 +710,9 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         s_tbits[t * 8 + q] = (uint8_t)bits;
     }
     __syncthreads();
-    if (lane < 32) {
-        const int i = lane;
+    // per-BFU constants of CalcBitsAllocation
+    if (tid >= 128 && tid < 160) {
+        const int i = tid - 128;
         int band = 0;
         if (i >= 18) band = 1;
         if (i >= 26) band = 2;
@@ -720,38 +738,38 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     }
 
     // ---- (A) mantissa = lrint(value * MaxQuant[wl]) for every wordlen ----
-    for (int idx = lane; idx < 7 * 1024; idx += 64) {
+    for (int idx = tid; idx < 7 * 1024; idx += kAllocThreads) {
         const int wl = 1 + (idx >> 10), i = idx & 1023;
         s_mant[idx] = (int8_t)__float2int_rn(s_val[i] * c_max_quant[wl]);
     }
     __syncthreads();
 
-    // ---- (B) ordered sums: chain c < 224 is e2 of unit c (bfu = 31 - c / 7, wl = 1 + c % 7); the rest are e1 ----
-    for (int c = lane; c < 256; c += 64) {
-        if (c < 224) {
-            const int bfu = 31 - c / 7, wl = 1 + c % 7;
-            const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
-            const float mul = c_max_quant[wl];
-            const float inv2 = (float)(1.0 / (double)(mul * mul));
-            const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-            float e2 = 0.0f;
-            for (int j = 0; j < n; ++j) {
-                const int m = mant[j];
-                e2 += (float)(m * m) * inv2;
-            }
-            s_err[wl * 32 + bfu] = e2;
-            s_clc[wl * 32 + bfu] = (uint16_t)((wl > 1) ? c_clc_len[wl] * n : 2 * n);
-            if (bfu <= 18) s_vlc[wl * 32 + bfu] = (uint16_t)unit_vlc_bits(wl, mant, n);
-        } else {
-            const int bfu = 31 - (c - 224);
-            const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
-            float e1 = 0.0f;
-            for (int j = 0; j < n; ++j) e1 += s_val[start + j] * s_val[start + j];
-            s_e1[bfu] = e1;
+    // ---- (B) ordered sums, one chain per thread: tid < 32 -> e1 of bfu 31 - tid; else e2 of unit tid - 32 ----
+    //      unit u: bfu = 31 - u / 7, wl = 1 + u % 7 (largest BFUs first so long chains share a wavefront)
+    if (tid < 32) {
+        const int bfu = 31 - tid;
+        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        float e1 = 0.0f;
+        for (int j = 0; j < n; ++j) e1 += s_val[start + j] * s_val[start + j];
+        s_e1[bfu] = e1;
+    } else {
+        const int u = tid - 32;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        const float mul = c_max_quant[wl];
+        const float inv2 = (float)(1.0 / (double)(mul * mul));
+        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+        float e2 = 0.0f;
+        for (int j = 0; j < n; ++j) {
+            const int m = mant[j];
+            e2 += (float)(m * m) * inv2;
         }
+        s_err[wl * 32 + bfu] = e2;
+        s_clc[wl * 32 + bfu] = (uint16_t)((wl > 1) ? c_clc_len[wl] * n : 2 * n);
     }
-    // ---- (C1) candidates of the energy-adaptive units (bfu > 18): unit u < 91 in the same order as above ----
-    for (int u = lane; u < 91; u += 64) {
+    // ---- (C1) candidates of the energy-adaptive units (bfu > 18) ----
+    if (tid >= 160 && tid < 160 + 91) {
+        const int u = tid - 160;
         const int bfu = 31 - u / 7, wl = 1 + u % 7;
         const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
         const float mul = c_max_quant[wl];
@@ -766,76 +784,79 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         s_tie[(wl - 1) * 13 + (bfu - 19)] = 0;
     }
     __syncthreads();
-    // ---- (C2) rank sort by |delta|, one wordlen plane at a time (12 slots per lane held in registers) ----
+    // ---- (C2) rank sort by |delta|, one wordlen plane at a time ----
     for (int wl = 1; wl <= 7; ++wl) {
         const float mul = c_max_quant[wl];
-        uint8_t* plane = s_cand + (wl - 1) * kEaLines;
-        int my_rank[12], my_idx[12];
+        const uint8_t* plane = s_cand + (wl - 1) * kEaLines;
+        uint8_t* sorted = s_sorted + (wl - 1) * kEaLines;
+        int slot_bfu[3], slot_k[3];
 #pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            my_rank[r] = -1;
-            my_idx[r] = 0;
-            const int slot = lane + 64 * r;
+        for (int r = 0; r < 3; ++r) {
+            const int slot = tid + kAllocThreads * r;
+            slot_k[r] = -1;
+            slot_bfu[r] = 19;
             if (slot < kEaLines) {
                 const int line = kEaLine0 + slot;
                 int bfu = 19;
                 while (c_bfu_start[bfu + 1] <= line) ++bfu;
                 const int start = c_bfu_start[bfu];
                 const int k = line - start;
-                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
-                if (k < nc) {
-                    const uint8_t* cand = plane + (start - kEaLine0);
-                    const int j = cand[k];
-                    const float t = s_val[start + j] * mul;
-                    const float key = fabsf(t - (truncf(t) + 0.5f));
-                    int rank = 0;
-                    bool tie = false;
-                    for (int q = 0; q < nc; ++q) {
-                        const float tq = s_val[start + cand[q]] * mul;
-                        const float kq = fabsf(tq - (truncf(tq) + 0.5f));
-                        rank += (kq < key) || (kq == key && q < k);
-                        tie = tie || (kq == key && q != k);
-                    }
-                    if (tie) s_tie[(wl - 1) * 13 + (bfu - 19)] = 1;
-                    my_rank[r] = (start - kEaLine0) + rank;
-                    my_idx[r] = j;
+                if (k < s_nc[(wl - 1) * 13 + (bfu - 19)]) {
+                    const float t = s_val[start + plane[slot]] * mul;
+                    s_key[slot] = fabsf(t - (truncf(t) + 0.5f));
+                    slot_k[r] = k;
+                    slot_bfu[r] = bfu;
                 }
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 12; ++r)
-            if (my_rank[r] >= 0) plane[my_rank[r]] = (uint8_t)my_idx[r];
+        for (int r = 0; r < 3; ++r) {
+            if (slot_k[r] >= 0) {
+                const int bfu = slot_bfu[r], k = slot_k[r];
+                const int base = c_bfu_start[bfu] - kEaLine0;
+                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+                const float key = s_key[base + k];
+                int rank = 0;
+                bool tie = false;
+                for (int q = 0; q < nc; ++q) {
+                    const float kq = s_key[base + q];
+                    rank += (kq < key) || (kq == key && q < k);
+                    tie = tie || (kq == key && q != k);
+                }
+                if (tie) s_tie[(wl - 1) * 13 + (bfu - 19)] = 1;
+                sorted[base + rank] = plane[base + k];
+            }
+        }
         __syncthreads();
     }
     // ---- (C3) equal keys: libstdc++'s std::sort order decides (rare) ----
-    if (lane == 0) {
+    if (tid == 0) {
         for (int u = 0; u < 91; ++u) {
             const int bfu = 31 - u / 7, wl = 1 + u % 7;
             if (!s_tie[(wl - 1) * 13 + (bfu - 19)]) continue;
-            const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+            const int start = c_bfu_start[bfu];
             const float mul = c_max_quant[wl];
             SortItem* items = reinterpret_cast<SortItem*>(s_words);
-            int nc = 0;
-            for (int j = 0; j < n; ++j) {
+            const uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
+            const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+            for (int q = 0; q < nc; ++q) {
+                const int j = cand[q];
                 const float t = s_val[start + j] * mul;
-                const float delta = t - (truncf(t) + 0.5f);
-                if (fabsf(delta) < 0.25f) {
-                    items[nc].key = delta;
-                    items[nc].idx = j;
-                    ++nc;
-                }
+                items[q].key = t - (truncf(t) + 0.5f);
+                items[q].idx = j;
             }
             std_sort_abs(items, nc);
-            uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
-            for (int q = 0; q < nc; ++q) cand[q] = (uint8_t)items[q].idx;
+            uint8_t* sorted = s_sorted + (wl - 1) * kEaLines + (start - kEaLine0);
+            for (int q = 0; q < nc; ++q) sorted[q] = (uint8_t)items[q].idx;
         }
     }
     __syncthreads();
-    // ---- (C4) greedy re-rounding per unit, then e1 / e2 and the VLC cost of the final mantissas ----
-    for (int u = lane; u < 224; u += 64) {
+    // ---- (C4) greedy re-rounding per energy-adaptive unit; e1 / e2 for every unit ----
+    if (tid < 224) {
+        const int u = tid;
         const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        const int start = c_bfu_start[bfu];
         const float e1 = s_e1[bfu];
         float e2 = s_err[wl * 32 + bfu];
         if (bfu > 18) {
@@ -844,15 +865,36 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
             int8_t* mant = s_mant + (wl - 1) * 1024 + start;
             const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
             if (nc > 0)
-                e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_cand + (wl - 1) * kEaLines + (start - kEaLine0), nc, mant);
-            s_vlc[wl * 32 + bfu] = (uint16_t)unit_vlc_bits(wl, mant, n);
+                e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_sorted + (wl - 1) * kEaLines + (start - kEaLine0), nc, mant);
         }
         s_err[wl * 32 + bfu] = e1 / e2;
     }
-    for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
+    for (int i = tid; i < kBitWords; i += kAllocThreads) s_words[i] = 0;
+    __syncthreads();
+    // ---- VLC cost of the final mantissas: 8 partial sums per unit, combined with LDS atomics ----
+    for (int task = tid; task < 224 * 8; task += kAllocThreads) {
+        const int u = task >> 3, part = task & 7;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+        const int per = n >> 3;  // 1, 2, 4, 8 or 16 lines per task (n is a multiple of 8)
+        uint32_t bits = 0;
+        if (wl > 1) {
+            for (int j = part * per; j < (part + 1) * per; ++j) bits += lds_huff(s_huff, wl, vlc_index(mant[j])) >> 8;
+        } else {
+            const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
+            if (per >= 2) {
+                for (int j = part * per; j < (part + 1) * per; j += 2)
+                    bits += lds_huff(s_huff, 1, rt9[3 * (mant[j] + 1) + (mant[j + 1] + 1)]) >> 8;
+            } else if ((part & 1) == 0) {   // 8-line BFU: one pair per two tasks
+                bits += lds_huff(s_huff, 1, rt9[3 * (mant[part] + 1) + (mant[part + 1] + 1)]) >> 8;
+            }
+        }
+        atomicAdd(&s_vlc[wl * 32 + bfu], bits);
+    }
     __syncthreads();
 
-    // ---- (D) rate loop: TConfigure / TAlloc under the bisection driver ----
+    // ---- (D) rate loop: TConfigure / TAlloc under the bisection driver (uniform control flow) ----
     int num_bfu = p.bfu_idx_const ? p.bfu_idx_const : 32;
     if (target < 101) {
         int lim = 1;
@@ -874,9 +916,9 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
                 curL = (maxL + minL) * 0.5f;
                 lam = curL;
             }
-            if (lane < 32) {
+            if (tid < 32) {
                 int bits = 0;
-                const int i = lane;
+                const int i = tid;
                 if (i < num_bfu) {
                     if (!s_gate[i]) {
                         const int tmp = (int)(s_A[i] - lam);
@@ -899,7 +941,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
                 }
                 s_alloc[i] = bits;
                 uint32_t packed = 0;
-                if (i < num_bfu && bits) packed = (uint32_t)s_clc[bits * 32 + i] | ((uint32_t)s_vlc[bits * 32 + i] << 13) | (1u << 27);
+                if (i < num_bfu && bits) packed = (uint32_t)s_clc[bits * 32 + i] | (s_vlc[bits * 32 + i] << 13) | (1u << 27);
                 s_red[i] = packed;
             }
             __syncthreads();
@@ -917,7 +959,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
             const uint32_t spec_bits = (uint32_t)num_bfu * 3 + 6 * nz + (mode ? clc : vlc);
             uint32_t tonal_bits = 5;
             if (n_tonal > 0) {
-                if (lane == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
+                if (tid == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
                 __syncthreads();
                 tonal_bits = (uint32_t)(s_misc[0] & 0xffff);
             }
@@ -946,11 +988,11 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         }
         if (!restart) break;
     }
-    // s_alloc holds the final allocation of the last evaluation (all lanes passed its trailing barrier)
+    // s_alloc holds the final allocation of the last evaluation (all threads passed its trailing barrier)
 
     // ---- (E) emission (WriteSoundUnit header, EncodeSpecs) ----
     int pos = 0;
-    if (lane == 0) {
+    if (tid == 0) {
         if (p.js && ch == 1) {
             put_bits(s_words, 0, 0, 1);
             put_bits(s_words, 1, 7, 3);
@@ -981,12 +1023,12 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     }
     __syncthreads();
     pos = s_misc[1];
-    if (lane < num_bfu) put_bits(s_words, pos + 3 * lane, (uint32_t)s_alloc[lane], 3);
+    if (tid < num_bfu) put_bits(s_words, pos + 3 * tid, (uint32_t)s_alloc[tid], 3);
     pos += 3 * num_bfu;
-    if (lane < num_bfu && s_alloc[lane]) {
+    if (tid < num_bfu && s_alloc[tid]) {
         int before = 0;
-        for (int i = 0; i < lane; ++i) before += (s_alloc[i] != 0);
-        put_bits(s_words, pos + 6 * before, rec->sfi[lane], 6);
+        for (int i = 0; i < tid; ++i) before += (s_alloc[i] != 0);
+        put_bits(s_words, pos + 6 * before, rec->sfi[tid], 6);
     }
     {
         int nz = 0;
@@ -994,32 +1036,38 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         pos += 6 * nz;
     }
     __syncthreads();
-    // mantissas: per-element (code,len), two-level prefix sum over 64 lanes x 16 elements
+    // mantissas: per-element (code,len); prefix sum = 4 lines per thread -> 64 threads per wave -> 4 waves
     uint32_t* s_code = reinterpret_cast<uint32_t*>(s_val);  // s_val is dead: last read in phase C
     {
-        const int base = lane * 16;
-        int sum = 0;
+        const int base = tid * 4;
         int b = 0;
         while (c_bfu_start[b + 1] <= base) ++b;
-        for (int k = 0; k < 16; ++k) {
-            const int i = base + k;
-            if (c_bfu_start[b + 1] <= i) ++b;   // BFU sizes are multiples of 8: at most one step per element
+        int sum = 0;
+        const int wl = (b < num_bfu) ? s_alloc[b] : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             uint32_t cl = 0;
-            if (b < num_bfu && s_alloc[b]) {
-                const int wl = s_alloc[b];
-                cl = spec_code(wl, mode == 1, s_mant + (wl - 1) * 1024 + c_bfu_start[b], i - c_bfu_start[b]);
-            }
-            s_code[i] = cl;
+            if (wl) cl = spec_code(wl, mode == 1, s_mant + (wl - 1) * 1024 + c_bfu_start[b], base + k - c_bfu_start[b]);
+            s_code[base + k] = cl;
             sum += (int)(cl >> 16);
         }
-        s_lsum[lane] = sum;
+        s_lsum[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < kAllocThreads / 64) {
+        int wsum = 0;
+        for (int l = 0; l < 64; ++l) wsum += s_lsum[tid * 64 + l];
+        s_wsum[tid] = wsum;
     }
     __syncthreads();
     {
         int off = pos;
-        for (int l = 0; l < lane; ++l) off += s_lsum[l];
-        const int base = lane * 16;
-        for (int k = 0; k < 16; ++k) {
+        const int w = tid >> 6;
+        for (int q = 0; q < w; ++q) off += s_wsum[q];
+        for (int l = w * 64; l < tid; ++l) off += s_lsum[l];
+        const int base = tid * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             const uint32_t cl = s_code[base + k];
             const int n = (int)(cl >> 16);
             if (n) {
@@ -1033,7 +1081,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     // ---- frame assembly (atrac3_bitstream.cpp:826-834): ch0 bytes, then ch1 (byte-reversed when JS) ----
     uint8_t* frame = p.out + ((size_t)s * n_out + fo) * p.frame_sz;
     const int dst0 = (ch == 0) ? 0 : half + shift;
-    for (int j = lane; j < nbytes; j += 64) {
+    for (int j = tid; j < nbytes; j += kAllocThreads) {
         const int src = (p.js && ch == 1) ? (nbytes - 1 - j) : j;
         const uint8_t byte = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
         frame[dst0 + j] = byte;
