@@ -199,6 +199,36 @@ __device__ __forceinline__ void fft_lds(cpx* F, int NS, int nfft, const cpx* tw,
     }
 }
 
+// ---- wavefront (64 lanes) cross-lane helpers on DPP / readlane; call from wave-uniform code only ----
+#define AT3_DPP(v, ctrl, bc) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, (bc))
+
+// Sum over the 16-lane row that contains the lane (rotate-and-add: every lane of the row gets the total).
+__device__ __forceinline__ uint32_t row_allreduce_add(uint32_t v)
+{
+    v += (uint32_t)AT3_DPP(v, 0x128, false);  // row_ror:8
+    v += (uint32_t)AT3_DPP(v, 0x124, false);  // row_ror:4
+    v += (uint32_t)AT3_DPP(v, 0x122, false);  // row_ror:2
+    v += (uint32_t)AT3_DPP(v, 0x121, false);  // row_ror:1
+    return v;
+}
+
+// Inclusive prefix sum over the 64 lanes (Hillis-Steele inside each row with row_shr + bound_ctrl,
+// then the three row totals are added through readlane).
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
+{
+    v += AT3_DPP(v, 0x111, true);  // row_shr:1
+    v += AT3_DPP(v, 0x112, true);  // row_shr:2
+    v += AT3_DPP(v, 0x114, true);  // row_shr:4
+    v += AT3_DPP(v, 0x118, true);  // row_shr:8
+    const int r0 = __builtin_amdgcn_readlane(v, 15);
+    const int r1 = __builtin_amdgcn_readlane(v, 31);
+    const int r2 = __builtin_amdgcn_readlane(v, 47);
+    if (lane >= 16) v += r0;
+    if (lane >= 32) v += r1;
+    if (lane >= 48) v += r2;
+    return v;
+}
+
 // Divisor applied to sample i of the "new" half for a gain curve: the running-product ramp of
 // TGainProcessor::Modulate (gain_processor.h:93-112) / BuildSampleDivisors (atrac3denc.cpp:154-173).
 // Returns 1.0f for samples the curve does not touch (x / 1.0f == x, so dividing is a no-op there).

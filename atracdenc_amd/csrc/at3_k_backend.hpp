@@ -30,6 +30,13 @@ struct BackParams {
     int js;
     int frame_sz;
     int bfu_idx_const;
+    struct QuantRec* quant;  // [S][n_out][2] per-unit tables written by k_quant, read by k_rate_pack
+    int8_t* mant;            // [S][n_out][2][7][1024] mantissas for every wordlen
+};
+
+struct QuantRec {            // per (stream, frame, channel)
+    float err[7][32];        // e1 / e2 per (wordlen - 1, bfu)
+    uint32_t cost[7][32];    // CLC bits | VLC bits << 13
 };
 
 // atrac_scale.cpp:141-172. Returns sfi; values/energy optional.
@@ -583,64 +590,47 @@ __device__ inline int tonal_encode(const PsyRec* rec, const uint8_t* tbits /* [k
     return used;
 }
 
-// One 256-thread workgroup per (stream, output frame, channel).
+// ---- quantisation kernel: one 256-thread workgroup per (stream, output frame, channel) -----------------
 //
-// Phases: (A) all 7 x 1024 roundings in parallel; (B) the strictly ordered energy sums as 256 independent
-// chains (32 x e1, 224 x e2), one per thread, longest chains on the first wave; (C) energy-adaptive
-// re-rounding of BFUs 19..31: candidate lists in LDS, parallel rank sort (falls back to the libstdc++-order
-// sort when two candidates tie), sequential greedy pass per unit; (D) rate loop with per-BFU closed forms for
-// the tonal decrement and the ConsiderEnergyErr fixed point; (E) cooperative MSB-first packing with a
-// two-level prefix sum.
+// Computes what TEncCache would compute lazily - every (bfu, wordlen) unit - so the rate loop that follows
+// is pure table look-up: (A) all 7 x 1024 roundings in parallel; (B) the strictly ordered energy sums as 256
+// independent chains (32 x e1, 224 x e2), one per thread, longest chains on the first wave; (C) the
+// energy-adaptive re-rounding of BFUs 19..31: candidate lists in LDS, parallel rank sort (falls back to the
+// libstdc++-order sort when two candidates tie), sequential greedy pass per unit; (D) CLC / VLC bit costs.
 constexpr int kEaLine0 = 288;              // first spectral line of BFU 19
 constexpr int kEaLines = 1024 - kEaLine0;  // 736
-constexpr int kAllocThreads = 256;
+constexpr int kQuantThreads = 256;
 
 __device__ __forceinline__ uint32_t lds_huff(const uint16_t* s_huff, int sel, uint32_t idx)
 {
     return s_huff[c_huff_off[sel - 1] + idx];
 }
 
-__global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, const Tables* T)
+__global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tables* T)
 {
-    __shared__ float s_val[1024];              // scaled values; aliased by the per-element (code,len) words when packing
-    __shared__ int8_t s_mant[7 * 1024];
-    __shared__ uint8_t s_cand[7 * kEaLines];   // candidate line indices (relative to the BFU), scan order
-    __shared__ uint8_t s_sorted[7 * kEaLines]; // the same, ordered by |delta|
-    __shared__ float s_key[7 * kEaLines / 7];  // |delta| of one wordlen plane at a time
+    __shared__ __attribute__((aligned(16))) float s_val[1024];
+    __shared__ __attribute__((aligned(16))) int8_t s_mant[7 * 1024];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cand[7 * kEaLines];   // candidate lines (relative to the BFU), scan order
+    __shared__ __attribute__((aligned(16))) uint8_t s_sorted[7 * kEaLines]; // the same, ordered by |delta|
+    __shared__ __attribute__((aligned(16))) float s_key[kEaLines];          // |delta| of one wordlen plane at a time
     __shared__ uint8_t s_nc[7 * 13];
     __shared__ uint8_t s_tie[7 * 13];
     __shared__ float s_e1[32];
     __shared__ float s_err[8 * 32];            // e2 during phases B/C, then e1 / e2
-    __shared__ uint16_t s_clc[8 * 32];
     __shared__ uint32_t s_vlc[8 * 32];
-    __shared__ float s_A[32];                  // spread * (csfi / x) + (1 - spread) * fix
-    __shared__ uint8_t s_gate[32];
-    __shared__ uint8_t s_tcount[32];
-    __shared__ int s_alloc[32];
-    __shared__ uint32_t s_red[32];
-    __shared__ uint8_t s_tbits[kMaxTonal * 8];
     __shared__ uint16_t s_huff[130];
-    __shared__ uint32_t s_words[kBitWords];    // bit buffer; doubles as scratch for the rare tie-order sort
-    __shared__ int s_lsum[kAllocThreads];
-    __shared__ int s_wsum[kAllocThreads / 64];
-    __shared__ int s_misc[8];
-    __shared__ float s_spread;
+    __shared__ SortItem s_items[128];          // scratch of the rare tie-order sort
+    __shared__ int s_anytie;
 
     const int tid = threadIdx.x;
     const int n_out = p.n_blocks - p.f0;
-    const int ch = blockIdx.x & 1;
-    const int fo = (blockIdx.x >> 1) % n_out;
-    const int s = (blockIdx.x >> 1) / n_out;
-    const int f = fo + p.f0;
-    const float* specs = p.specs + (((size_t)s * n_out + fo) * 2 + ch) * 1024;
-    const PsyRec* recs = p.psy + ((size_t)s * n_out + fo) * 2;
-    const PsyRec* rec = recs + ch;
-    const Curve* curves = p.curves + ((size_t)s * p.n_blocks + f) * 8;
-    const int half = p.frame_sz >> 1;
-    const int n_tonal = rec->n_tonal;
+    const size_t cf = blockIdx.x;  // (s * n_out + fo) * 2 + ch
+    const float* specs = p.specs + cf * 1024;
+    const PsyRec* rec = p.psy + cf;
 
     if (tid < 130) s_huff[tid] = c_huff[tid];
-    for (int i = tid; i < 8 * 32; i += kAllocThreads) s_vlc[i] = 0;
+    if (tid == 0) s_anytie = 0;
+    s_vlc[tid] = 0;
     // ---- scaled values (TScaler::Scale): thread t owns lines 4t..4t+3 (BFU sizes are multiples of 8) ----
     {
         const int i0 = tid * 4;
@@ -650,11 +640,245 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
         const float4 x = *reinterpret_cast<const float4*>(specs + i0);
         float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4; ++k)
             if (fabsf(v[k]) >= 1.0f) v[k] = (v[k] > 0) ? 0.99999f : -0.99999f;
-            s_val[i0 + k] = v[k];
+        float4 o;
+        o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+        *reinterpret_cast<float4*>(s_val + i0) = o;
+        // ---- (A) mantissa = lrint(value * MaxQuant[wl]) for every wordlen ----
+#pragma unroll
+        for (int wl = 1; wl <= 7; ++wl) {
+            const float mul = c_max_quant[wl];
+            const uint32_t pk = ((uint32_t)(uint8_t)__float2int_rn(v[0] * mul)) | ((uint32_t)(uint8_t)__float2int_rn(v[1] * mul) << 8) |
+                                ((uint32_t)(uint8_t)__float2int_rn(v[2] * mul) << 16) | ((uint32_t)(uint8_t)__float2int_rn(v[3] * mul) << 24);
+            *reinterpret_cast<uint32_t*>(s_mant + (wl - 1) * 1024 + i0) = pk;
         }
     }
+    __syncthreads();
+
+    // ---- (B) ordered sums, one chain per thread: tid < 32 -> e1 of bfu 31 - tid; else e2 of unit tid - 32 ----
+    //      unit u: bfu = 31 - u / 7, wl = 1 + u % 7 (largest BFUs first so long chains share a wavefront)
+    if (tid < 32) {
+        const int bfu = 31 - tid;
+        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        float e1 = 0.0f;
+        for (int j = 0; j < n; j += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(s_val + start + j);
+            e1 += v.x * v.x;
+            e1 += v.y * v.y;
+            e1 += v.z * v.z;
+            e1 += v.w * v.w;
+        }
+        s_e1[bfu] = e1;
+    } else {
+        const int u = tid - 32;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        const float mul = c_max_quant[wl];
+        const float inv2 = (float)(1.0 / (double)(mul * mul));
+        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+        float e2 = 0.0f;
+        for (int j = 0; j < n; j += 8) {
+            const uint2 pk = *reinterpret_cast<const uint2*>(mant + j);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int m = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
+                e2 += (float)(m * m) * inv2;
+            }
+        }
+        s_err[wl * 32 + bfu] = e2;
+    }
+    // ---- (C1) candidates of the energy-adaptive units (bfu > 18) ----
+    if (tid >= 160 && tid < 160 + 91) {
+        const int u = tid - 160;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        const float mul = c_max_quant[wl];
+        uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
+        int nc = 0;
+        for (int j = 0; j < n; j += 4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(s_val + start + j);
+            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = vv[k] * mul;
+                const float delta = t - (truncf(t) + 0.5f);
+                if (fabsf(delta) < 0.25f) cand[nc++] = (uint8_t)(j + k);
+            }
+        }
+        s_nc[(wl - 1) * 13 + (bfu - 19)] = (uint8_t)nc;
+        s_tie[(wl - 1) * 13 + (bfu - 19)] = 0;
+    }
+    __syncthreads();
+    // ---- (C2) rank sort by |delta|, one wordlen plane at a time; unused key slots hold +inf ----
+    for (int wl = 1; wl <= 7; ++wl) {
+        const float mul = c_max_quant[wl];
+        const uint8_t* plane = s_cand + (wl - 1) * kEaLines;
+        uint8_t* sorted = s_sorted + (wl - 1) * kEaLines;
+        int slot_bfu[3], slot_k[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int slot = tid + kQuantThreads * r;
+            slot_k[r] = -1;
+            slot_bfu[r] = 19;
+            if (slot < kEaLines) {
+                const int line = kEaLine0 + slot;
+                int bfu = 19;
+                while (c_bfu_start[bfu + 1] <= line) ++bfu;
+                const int start = c_bfu_start[bfu];
+                const int k = line - start;
+                float key = __builtin_huge_valf();
+                if (k < s_nc[(wl - 1) * 13 + (bfu - 19)]) {
+                    const float t = s_val[start + plane[slot]] * mul;
+                    key = fabsf(t - (truncf(t) + 0.5f));
+                    slot_k[r] = k;
+                    slot_bfu[r] = bfu;
+                }
+                s_key[slot] = key;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (slot_k[r] >= 0) {
+                const int bfu = slot_bfu[r], k = slot_k[r];
+                const int base = c_bfu_start[bfu] - kEaLine0;
+                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+                const float key = s_key[base + k];
+                int rank = 0, eq = 0;
+                for (int q = 0; q < nc; q += 4) {
+                    const float4 kq = *reinterpret_cast<const float4*>(s_key + base + q);
+                    rank += (kq.x < key) + (kq.y < key) + (kq.z < key) + (kq.w < key);
+                    rank += (kq.x == key && q + 0 < k) + (kq.y == key && q + 1 < k) + (kq.z == key && q + 2 < k) + (kq.w == key && q + 3 < k);
+                    eq += (kq.x == key) + (kq.y == key) + (kq.z == key) + (kq.w == key);
+                }
+                if (eq > 1) {
+                    s_tie[(wl - 1) * 13 + (bfu - 19)] = 1;
+                    s_anytie = 1;
+                }
+                sorted[base + rank] = plane[base + k];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- (C3) equal keys: libstdc++'s std::sort order decides (rare) ----
+    if (s_anytie) {
+        if (tid == 0) {
+            for (int u = 0; u < 91; ++u) {
+                const int bfu = 31 - u / 7, wl = 1 + u % 7;
+                if (!s_tie[(wl - 1) * 13 + (bfu - 19)]) continue;
+                const int start = c_bfu_start[bfu];
+                const float mul = c_max_quant[wl];
+                const uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
+                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+                for (int q = 0; q < nc; ++q) {
+                    const int j = cand[q];
+                    const float t = s_val[start + j] * mul;
+                    s_items[q].key = t - (truncf(t) + 0.5f);
+                    s_items[q].idx = j;
+                }
+                std_sort_abs(s_items, nc);
+                uint8_t* sorted = s_sorted + (wl - 1) * kEaLines + (start - kEaLine0);
+                for (int q = 0; q < nc; ++q) sorted[q] = (uint8_t)s_items[q].idx;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- (C4) greedy re-rounding per energy-adaptive unit; e1 / e2 for every unit ----
+    if (tid < 224) {
+        const int u = tid;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+        const int start = c_bfu_start[bfu];
+        const float e1 = s_e1[bfu];
+        float e2 = s_err[wl * 32 + bfu];
+        if (bfu > 18) {
+            const float mul = c_max_quant[wl];
+            const float inv2 = (float)(1.0 / (double)(mul * mul));
+            int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+            const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+            if (nc > 0)
+                e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_sorted + (wl - 1) * kEaLines + (start - kEaLine0), nc, mant);
+        }
+        s_err[wl * 32 + bfu] = e1 / e2;
+    }
+    __syncthreads();
+    // ---- (D) VLC cost of the final mantissas: 8 partial sums per unit, combined with LDS atomics ----
+    for (int task = tid; task < 224 * 8; task += kQuantThreads) {
+        const int u = task >> 3, part = task & 7;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+        const int per = n >> 3;  // 1, 2, 4, 8 or 16 lines per task (n is a multiple of 8)
+        uint32_t bits = 0;
+        if (wl > 1) {
+            for (int j = part * per; j < (part + 1) * per; ++j) bits += lds_huff(s_huff, wl, vlc_index(mant[j])) >> 8;
+        } else {
+            const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
+            if (per >= 2) {
+                for (int j = part * per; j < (part + 1) * per; j += 2)
+                    bits += lds_huff(s_huff, 1, rt9[3 * (mant[j] + 1) + (mant[j + 1] + 1)]) >> 8;
+            } else if ((part & 1) == 0) {   // 8-line BFU: one pair per two tasks
+                bits += lds_huff(s_huff, 1, rt9[3 * (mant[part] + 1) + (mant[part + 1] + 1)]) >> 8;
+            }
+        }
+        atomicAdd(&s_vlc[wl * 32 + bfu], bits);
+    }
+    __syncthreads();
+    // ---- results to HBM ----
+    QuantRec* q = p.quant + cf;
+    if (tid < 224) {
+        const int wl = 1 + tid / 32, bfu = tid % 32;
+        const int n = c_bfu_start[bfu + 1] - c_bfu_start[bfu];
+        const uint32_t clc = (wl > 1) ? (uint32_t)c_clc_len[wl] * n : 2u * n;
+        q->err[wl - 1][bfu] = s_err[wl * 32 + bfu];
+        q->cost[wl - 1][bfu] = clc | (s_vlc[wl * 32 + bfu] << 13);
+    }
+    {
+        uint4* dst = reinterpret_cast<uint4*>(p.mant + cf * 7168);
+        const uint4* src = reinterpret_cast<const uint4*>(s_mant);
+        for (int i = tid; i < 7168 / 16; i += kQuantThreads) dst[i] = src[i];
+    }
+}
+
+// ---- rate loop + packing: one wavefront (64 lanes) per (stream, output frame, channel) ------------------
+//
+// Lane i < 32 owns BFU i and keeps its seven (error, cost) pairs and the ConsiderEnergyErr fixed-point map in
+// registers, so one evaluation of CalcBitsAllocation + CalcSpecsBitsConsumption is a handful of VALU ops, a
+// DPP row reduction and two readlanes; no LDS round trip and no barrier sits inside the bisection.
+template <typename Tv>
+__device__ __forceinline__ Tv pick8(const Tv (&a)[8], int idx)
+{
+    Tv r = a[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r = (idx == k) ? a[k] : r;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
+{
+    __shared__ uint32_t s_words[kBitWords];
+    __shared__ int s_alloc[32];
+    __shared__ uint8_t s_tbits[kMaxTonal * 8];
+    __shared__ uint16_t s_huff[130];
+    __shared__ int s_misc[4];
+
+    const int lane = threadIdx.x;
+    const int n_out = p.n_blocks - p.f0;
+    const size_t cf = blockIdx.x;
+    const int ch = (int)(cf & 1);
+    const int fo = (int)((cf >> 1) % n_out);
+    const int s = (int)((cf >> 1) / n_out);
+    const int f = fo + p.f0;
+    const PsyRec* recs = p.psy + (cf & ~(size_t)1);
+    const PsyRec* rec = recs + ch;
+    const Curve* curves = p.curves + ((size_t)s * p.n_blocks + f) * 8;
+    const QuantRec* q = p.quant + cf;
+    const int8_t* gmant = p.mant + cf * 7168;
+    const int half = p.frame_sz >> 1;
+    const int n_tonal = rec->n_tonal;
+
+    for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
+    for (int i = lane; i < 130; i += 64) s_huff[i] = c_huff[i];
 
     // ---- header + gain info bits, joint-stereo byte shift, target bits (WriteSoundUnit :759-810) ----
     int hdr[2];
@@ -684,35 +908,40 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
     target &= 0xffff;
     const float loudness = p.loud[(size_t)s * n_out + fo] / 0.006f;
 
-    // ---- TConfigure: spread ----
-    if (tid == 64) {
+    // ---- TConfigure: spread (sequential float sums, every lane computes the same value) ----
+    const int i = lane & 31;   // BFU owned by this lane (lanes 32..63 mirror 0..31 but never contribute)
+    float spread;
+    {
         float sum = 0.0f;
-        for (int i = 0; i < 32; ++i) sum += (float)rec->sfi[i];
+        for (int k = 0; k < 32; ++k) sum += (float)rec->sfi[k];
         sum /= 32;
         float sigma = 0.0f;
-        for (int i = 0; i < 32; ++i) {
-            float t = ((float)rec->sfi[i] - sum);
+        for (int k = 0; k < 32; ++k) {
+            float t = ((float)rec->sfi[k] - sum);
             t *= t;
             sigma += t;
         }
         sigma /= 32;
         sigma = sqrtf(sigma);
         if (sigma > 14.0f) sigma = 14.0f;
-        s_spread = sigma / 14.0f;
+        spread = sigma / 14.0f;
     }
     // tonal blocks: VLC bit cost for every quantiser 2..7
-    for (int idx = tid; idx < n_tonal * 6; idx += kAllocThreads) {
-        const int t = idx / 6, q = 2 + idx % 6;
+    for (int idx = lane; idx < n_tonal * 6; idx += 64) {
+        const int t = idx / 6, qq = 2 + idx % 6;
         const TonalBlock& tb = rec->tonal[t];
-        const float mul = c_max_quant[q];
+        const float mul = c_max_quant[qq];
         int bits = 0;
-        for (int z = 0; z < tb.len; ++z) bits += (int)(huff_entry(q, vlc_index(__float2int_rn(tb.values[z] * mul))) >> 8);
-        s_tbits[t * 8 + q] = (uint8_t)bits;
+        for (int z = 0; z < tb.len; ++z) bits += (int)(huff_entry(qq, vlc_index(__float2int_rn(tb.values[z] * mul))) >> 8);
+        s_tbits[t * 8 + qq] = (uint8_t)bits;
     }
-    __syncthreads();
-    // per-BFU constants of CalcBitsAllocation
-    if (tid >= 128 && tid < 160) {
-        const int i = tid - 128;
+    // per-BFU constants of CalcBitsAllocation (atrac3_bitstream.cpp:272-336)
+    float A;
+    bool gate;
+    int tcount = 0;
+    float err[8];
+    uint32_t cost[8];
+    {
         int band = 0;
         if (i >= 18) band = 1;
         if (i >= 26) band = 2;
@@ -722,7 +951,7 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
         if (!(isfinite(g) && g > 0.0f)) g = 1.0f;
         const float corrected = rec->energy[i] * g;
         const float ath = T->ath_bfu[i] * loudness;
-        s_gate[i] = corrected < ath;
+        gate = corrected < ath;
         const float csfi = fmaxf(0.0f, fminf(63.0f, (float)rec->sfi[i] + 1.5f * at3_log2f(T, g)));
         float x = 6.0f;
         if (i < 3) x = 2.8f;
@@ -730,171 +959,34 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
         else if (i < 15) x = 3.3f;
         else if (i <= 20) x = 3.6f;
         else if (i <= 28) x = 4.2f;
-        const float spread = s_spread;
-        s_A[i] = spread * (csfi / x) + (1.0f - spread) * (float)c_fixed_alloc[i];
-        int tc = 0;
-        for (int t = 0; t < n_tonal; ++t) tc += (rec->tonal[t].bfu == i);
-        s_tcount[i] = (uint8_t)tc;
-    }
-
-    // ---- (A) mantissa = lrint(value * MaxQuant[wl]) for every wordlen ----
-    for (int idx = tid; idx < 7 * 1024; idx += kAllocThreads) {
-        const int wl = 1 + (idx >> 10), i = idx & 1023;
-        s_mant[idx] = (int8_t)__float2int_rn(s_val[i] * c_max_quant[wl]);
-    }
-    __syncthreads();
-
-    // ---- (B) ordered sums, one chain per thread: tid < 32 -> e1 of bfu 31 - tid; else e2 of unit tid - 32 ----
-    //      unit u: bfu = 31 - u / 7, wl = 1 + u % 7 (largest BFUs first so long chains share a wavefront)
-    if (tid < 32) {
-        const int bfu = 31 - tid;
-        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
-        float e1 = 0.0f;
-        for (int j = 0; j < n; ++j) e1 += s_val[start + j] * s_val[start + j];
-        s_e1[bfu] = e1;
-    } else {
-        const int u = tid - 32;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
-        const float mul = c_max_quant[wl];
-        const float inv2 = (float)(1.0 / (double)(mul * mul));
-        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-        float e2 = 0.0f;
-        for (int j = 0; j < n; ++j) {
-            const int m = mant[j];
-            e2 += (float)(m * m) * inv2;
-        }
-        s_err[wl * 32 + bfu] = e2;
-        s_clc[wl * 32 + bfu] = (uint16_t)((wl > 1) ? c_clc_len[wl] * n : 2 * n);
-    }
-    // ---- (C1) candidates of the energy-adaptive units (bfu > 18) ----
-    if (tid >= 160 && tid < 160 + 91) {
-        const int u = tid - 160;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
-        const float mul = c_max_quant[wl];
-        uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
-        int nc = 0;
-        for (int j = 0; j < n; ++j) {
-            const float t = s_val[start + j] * mul;
-            const float delta = t - (truncf(t) + 0.5f);
-            if (fabsf(delta) < 0.25f) cand[nc++] = (uint8_t)j;
-        }
-        s_nc[(wl - 1) * 13 + (bfu - 19)] = (uint8_t)nc;
-        s_tie[(wl - 1) * 13 + (bfu - 19)] = 0;
-    }
-    __syncthreads();
-    // ---- (C2) rank sort by |delta|, one wordlen plane at a time ----
-    for (int wl = 1; wl <= 7; ++wl) {
-        const float mul = c_max_quant[wl];
-        const uint8_t* plane = s_cand + (wl - 1) * kEaLines;
-        uint8_t* sorted = s_sorted + (wl - 1) * kEaLines;
-        int slot_bfu[3], slot_k[3];
+        A = spread * (csfi / x) + (1.0f - spread) * (float)c_fixed_alloc[i];
+        for (int t = 0; t < n_tonal; ++t) tcount += (rec->tonal[t].bfu == i);
+        err[0] = 0.0f;
+        cost[0] = 0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int slot = tid + kAllocThreads * r;
-            slot_k[r] = -1;
-            slot_bfu[r] = 19;
-            if (slot < kEaLines) {
-                const int line = kEaLine0 + slot;
-                int bfu = 19;
-                while (c_bfu_start[bfu + 1] <= line) ++bfu;
-                const int start = c_bfu_start[bfu];
-                const int k = line - start;
-                if (k < s_nc[(wl - 1) * 13 + (bfu - 19)]) {
-                    const float t = s_val[start + plane[slot]] * mul;
-                    s_key[slot] = fabsf(t - (truncf(t) + 0.5f));
-                    slot_k[r] = k;
-                    slot_bfu[r] = bfu;
-                }
-            }
+        for (int wl = 1; wl <= 7; ++wl) {
+            err[wl] = q->err[wl - 1][i];
+            cost[wl] = q->cost[wl - 1][i] | (1u << 27);
         }
-        __syncthreads();
+    }
+    // ConsiderEnergyErr as a per-BFU map wl -> wl' (first 10 BFUs, atrac3_bitstream.cpp:241-257, :638-641):
+    // BFUs are independent, so iterating the reference's do/while to its fixed point is a closure per BFU.
+    uint32_t gmap = 0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (slot_k[r] >= 0) {
-                const int bfu = slot_bfu[r], k = slot_k[r];
-                const int base = c_bfu_start[bfu] - kEaLine0;
-                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
-                const float key = s_key[base + k];
-                int rank = 0;
-                bool tie = false;
-                for (int q = 0; q < nc; ++q) {
-                    const float kq = s_key[base + q];
-                    rank += (kq < key) || (kq == key && q < k);
-                    tie = tie || (kq == key && q != k);
-                }
-                if (tie) s_tie[(wl - 1) * 13 + (bfu - 19)] = 1;
-                sorted[base + rank] = plane[base + k];
+    for (int wl = 0; wl <= 7; ++wl) {
+        int gq = wl;
+        if (i < 10) {
+#pragma unroll
+            for (int it = 0; it < 7; ++it) {
+                const float e = pick8(err, gq);
+                if (gq > 0 && ((e > 0 && e < 0.7f) || e > 1.2f) && gq < 7) ++gq;
             }
         }
-        __syncthreads();
-    }
-    // ---- (C3) equal keys: libstdc++'s std::sort order decides (rare) ----
-    if (tid == 0) {
-        for (int u = 0; u < 91; ++u) {
-            const int bfu = 31 - u / 7, wl = 1 + u % 7;
-            if (!s_tie[(wl - 1) * 13 + (bfu - 19)]) continue;
-            const int start = c_bfu_start[bfu];
-            const float mul = c_max_quant[wl];
-            SortItem* items = reinterpret_cast<SortItem*>(s_words);
-            const uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
-            const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
-            for (int q = 0; q < nc; ++q) {
-                const int j = cand[q];
-                const float t = s_val[start + j] * mul;
-                items[q].key = t - (truncf(t) + 0.5f);
-                items[q].idx = j;
-            }
-            std_sort_abs(items, nc);
-            uint8_t* sorted = s_sorted + (wl - 1) * kEaLines + (start - kEaLine0);
-            for (int q = 0; q < nc; ++q) sorted[q] = (uint8_t)items[q].idx;
-        }
-    }
-    __syncthreads();
-    // ---- (C4) greedy re-rounding per energy-adaptive unit; e1 / e2 for every unit ----
-    if (tid < 224) {
-        const int u = tid;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = c_bfu_start[bfu];
-        const float e1 = s_e1[bfu];
-        float e2 = s_err[wl * 32 + bfu];
-        if (bfu > 18) {
-            const float mul = c_max_quant[wl];
-            const float inv2 = (float)(1.0 / (double)(mul * mul));
-            int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-            const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
-            if (nc > 0)
-                e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_sorted + (wl - 1) * kEaLines + (start - kEaLine0), nc, mant);
-        }
-        s_err[wl * 32 + bfu] = e1 / e2;
-    }
-    for (int i = tid; i < kBitWords; i += kAllocThreads) s_words[i] = 0;
-    __syncthreads();
-    // ---- VLC cost of the final mantissas: 8 partial sums per unit, combined with LDS atomics ----
-    for (int task = tid; task < 224 * 8; task += kAllocThreads) {
-        const int u = task >> 3, part = task & 7;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
-        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-        const int per = n >> 3;  // 1, 2, 4, 8 or 16 lines per task (n is a multiple of 8)
-        uint32_t bits = 0;
-        if (wl > 1) {
-            for (int j = part * per; j < (part + 1) * per; ++j) bits += lds_huff(s_huff, wl, vlc_index(mant[j])) >> 8;
-        } else {
-            const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
-            if (per >= 2) {
-                for (int j = part * per; j < (part + 1) * per; j += 2)
-                    bits += lds_huff(s_huff, 1, rt9[3 * (mant[j] + 1) + (mant[j + 1] + 1)]) >> 8;
-            } else if ((part & 1) == 0) {   // 8-line BFU: one pair per two tasks
-                bits += lds_huff(s_huff, 1, rt9[3 * (mant[part] + 1) + (mant[part + 1] + 1)]) >> 8;
-            }
-        }
-        atomicAdd(&s_vlc[wl * 32 + bfu], bits);
+        gmap |= (uint32_t)gq << (3 * wl);
     }
     __syncthreads();
 
-    // ---- (D) rate loop: TConfigure / TAlloc under the bisection driver (uniform control flow) ----
+    // ---- rate loop: TConfigure / TAlloc under the bisection driver (uniform control flow) ----
     int num_bfu = p.bfu_idx_const ? p.bfu_idx_const : 32;
     if (target < 101) {
         int lim = 1;
@@ -904,6 +996,7 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
     }
     if (num_bfu < 1) num_bfu = 1;
     int mode = 1;
+    int bits = 0;
     for (;;) {
         float minL = -8.0f, maxL = 20.0f, curL = 0.0f, lastL = 20.0f;
         bool restart = false;
@@ -916,56 +1009,35 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
                 curL = (maxL + minL) * 0.5f;
                 lam = curL;
             }
-            if (tid < 32) {
-                int bits = 0;
-                const int i = tid;
-                if (i < num_bfu) {
-                    if (!s_gate[i]) {
-                        const int tmp = (int)(s_A[i] - lam);
-                        if (tmp > 7) bits = 7;
-                        else if (tmp < 0) bits = 0;
-                        else if (tmp == 0) bits = 1;
-                        else bits = tmp;
-                    }
-                    // one decrement per tonal block in this BFU while the wordlen is above 2 (:325-333)
-                    const int tc = s_tcount[i];
-                    if (bits > 2 && tc) bits = (bits - tc > 2) ? bits - tc : 2;
-                    // ConsiderEnergyErr fixed point: BFUs are independent (:241-257, :638-641)
-                    if (i < 10) {
-                        for (;;) {
-                            const float e = bits ? s_err[bits * 32 + i] : 0.0f;
-                            if (((e > 0 && e < 0.7f) || e > 1.2f) && bits < 7) ++bits;
-                            else break;
-                        }
-                    }
+            bits = 0;
+            if (lane < num_bfu) {
+                if (!gate) {
+                    const int tmp = (int)(A - lam);
+                    if (tmp > 7) bits = 7;
+                    else if (tmp < 0) bits = 0;
+                    else if (tmp == 0) bits = 1;
+                    else bits = tmp;
                 }
-                s_alloc[i] = bits;
-                uint32_t packed = 0;
-                if (i < num_bfu && bits) packed = (uint32_t)s_clc[bits * 32 + i] | (s_vlc[bits * 32 + i] << 13) | (1u << 27);
-                s_red[i] = packed;
+                // one decrement per tonal block in this BFU while the wordlen is above 2 (:325-333)
+                if (bits > 2 && tcount) bits = (bits - tcount > 2) ? bits - tcount : 2;
+                bits = (int)((gmap >> (3 * bits)) & 7u);
             }
-            __syncthreads();
-            uint32_t acc = 0;
-            {
-                const uint4* r4 = reinterpret_cast<const uint4*>(s_red);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const uint4 v = r4[q];
-                    acc += v.x + v.y + v.z + v.w;
-                }
-            }
+            const uint32_t mine = (lane < num_bfu) ? pick8(cost, bits) : 0u;
+            const uint32_t rsum = row_allreduce_add(mine);
+            const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
             const uint32_t clc = acc & 0x1fffu, vlc = (acc >> 13) & 0x3fffu, nz = acc >> 27;
             mode = clc <= vlc ? 1 : 0;
             const uint32_t spec_bits = (uint32_t)num_bfu * 3 + 6 * nz + (mode ? clc : vlc);
             uint32_t tonal_bits = 5;
             if (n_tonal > 0) {
-                if (tid == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
+                if (lane < 32) s_alloc[lane] = bits;
+                __syncthreads();
+                if (lane == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
                 __syncthreads();
                 tonal_bits = (uint32_t)(s_misc[0] & 0xffff);
             }
             const uint32_t total = spec_bits + tonal_bits;
-            const int last_alloc = s_alloc[num_bfu - 1];
-            __syncthreads();
+            const int last_alloc = __builtin_amdgcn_readlane(bits, (num_bfu - 1) & 31);
             bool done;
             if (exhausted) {
                 done = true;
@@ -988,15 +1060,16 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
         }
         if (!restart) break;
     }
-    // s_alloc holds the final allocation of the last evaluation (all threads passed its trailing barrier)
+    if (lane < 32) s_alloc[lane] = bits;
+    __syncthreads();
 
-    // ---- (E) emission (WriteSoundUnit header, EncodeSpecs) ----
+    // ---- emission (WriteSoundUnit header, EncodeSpecs) ----
     int pos = 0;
-    if (tid == 0) {
+    if (lane == 0) {
         if (p.js && ch == 1) {
             put_bits(s_words, 0, 0, 1);
             put_bits(s_words, 1, 7, 3);
-            for (int i = 0; i < 4; ++i) put_bits(s_words, 4 + 2 * i, 3, 2);
+            for (int k = 0; k < 4; ++k) put_bits(s_words, 4 + 2 * k, 3, 2);
             put_bits(s_words, 12, 3, 2);
             pos = 14;
         } else {
@@ -1009,9 +1082,9 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
             const Curve& c = curves[ch * 4 + b];
             put_bits(s_words, pos, c.n, 3);
             pos += 3;
-            for (int i = 0; i < c.n; ++i) {
-                put_bits(s_words, pos, c.level[i], 4);
-                put_bits(s_words, pos + 4, c.loc[i], 5);
+            for (int k = 0; k < c.n; ++k) {
+                put_bits(s_words, pos, c.level[k], 4);
+                put_bits(s_words, pos + 4, c.loc[k], 5);
                 pos += 9;
             }
         }
@@ -1023,55 +1096,60 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
     }
     __syncthreads();
     pos = s_misc[1];
-    if (tid < num_bfu) put_bits(s_words, pos + 3 * tid, (uint32_t)s_alloc[tid], 3);
+    const unsigned long long nzmask = __ballot(lane < num_bfu && bits != 0);
+    if (lane < num_bfu) put_bits(s_words, pos + 3 * lane, (uint32_t)bits, 3);
     pos += 3 * num_bfu;
-    if (tid < num_bfu && s_alloc[tid]) {
-        int before = 0;
-        for (int i = 0; i < tid; ++i) before += (s_alloc[i] != 0);
-        put_bits(s_words, pos + 6 * before, rec->sfi[tid], 6);
-    }
+    if (lane < num_bfu && bits)
+        put_bits(s_words, pos + 6 * __popcll(nzmask & ((1ull << lane) - 1ull)), rec->sfi[lane], 6);
+    pos += 6 * __popcll(nzmask);
+    // mantissas: 16 spectral lines per lane (BFU sizes are multiples of 8, so at most two BFUs per lane)
     {
-        int nz = 0;
-        for (int i = 0; i < num_bfu; ++i) nz += (s_alloc[i] != 0);
-        pos += 6 * nz;
-    }
-    __syncthreads();
-    // mantissas: per-element (code,len); prefix sum = 4 lines per thread -> 64 threads per wave -> 4 waves
-    uint32_t* s_code = reinterpret_cast<uint32_t*>(s_val);  // s_val is dead: last read in phase C
-    {
-        const int base = tid * 4;
-        int b = 0;
-        while (c_bfu_start[b + 1] <= base) ++b;
+        const int base = lane * 16;
+        uint32_t code[16];
         int sum = 0;
-        const int wl = (b < num_bfu) ? s_alloc[b] : 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t cl = 0;
-            if (wl) cl = spec_code(wl, mode == 1, s_mant + (wl - 1) * 1024 + c_bfu_start[b], base + k - c_bfu_start[b]);
-            s_code[base + k] = cl;
-            sum += (int)(cl >> 16);
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int i0 = base + 8 * hlf;
+            int b = 0;
+            while (c_bfu_start[b + 1] <= i0) ++b;
+            const int wl = (b < num_bfu) ? s_alloc[b] : 0;
+            int8_t m8[8];
+            if (wl) {
+                const uint2 pk = *reinterpret_cast<const uint2*>(gmant + (wl - 1) * 1024 + i0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m8[k] = (int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t cl = 0;
+                if (wl > 1) {
+                    if (mode == 1) {
+                        const int nb = c_clc_len[wl];
+                        cl = ((uint32_t)m8[k] & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
+                    } else {
+                        const uint32_t e = lds_huff(s_huff, wl, vlc_index(m8[k]));
+                        cl = (e & 0xffu) | ((e >> 8) << 16);
+                    }
+                } else if (wl == 1 && (k & 1) == 0) {
+                    if (mode == 1) {
+                        const uint32_t rt[4] = {2, 3, 0, 1};
+                        cl = ((rt[m8[k] + 2] << 2) | rt[m8[k + 1] + 2]) | (4u << 16);
+                    } else {
+                        const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
+                        const uint32_t e = lds_huff(s_huff, 1, rt9[3 * (m8[k] + 1) + (m8[k + 1] + 1)]);
+                        cl = (e & 0xffu) | ((e >> 8) << 16);
+                    }
+                }
+                code[8 * hlf + k] = cl;
+                sum += (int)(cl >> 16);
+            }
         }
-        s_lsum[tid] = sum;
-    }
-    __syncthreads();
-    if (tid < kAllocThreads / 64) {
-        int wsum = 0;
-        for (int l = 0; l < 64; ++l) wsum += s_lsum[tid * 64 + l];
-        s_wsum[tid] = wsum;
-    }
-    __syncthreads();
-    {
-        int off = pos;
-        const int w = tid >> 6;
-        for (int q = 0; q < w; ++q) off += s_wsum[q];
-        for (int l = w * 64; l < tid; ++l) off += s_lsum[l];
-        const int base = tid * 4;
+        int off = pos + wave_inclusive_scan(sum, lane) - sum;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t cl = s_code[base + k];
-            const int n = (int)(cl >> 16);
+        for (int k = 0; k < 16; ++k) {
+            const int n = (int)(code[k] >> 16);
             if (n) {
-                put_bits(s_words, off, cl & 0xffffu, n);
+                put_bits(s_words, off, code[k] & 0xffffu, n);
                 off += n;
             }
         }
@@ -1081,7 +1159,7 @@ __global__ __launch_bounds__(kAllocThreads) void k_alloc_pack(BackParams p, cons
     // ---- frame assembly (atrac3_bitstream.cpp:826-834): ch0 bytes, then ch1 (byte-reversed when JS) ----
     uint8_t* frame = p.out + ((size_t)s * n_out + fo) * p.frame_sz;
     const int dst0 = (ch == 0) ? 0 : half + shift;
-    for (int j = tid; j < nbytes; j += kAllocThreads) {
+    for (int j = lane; j < nbytes; j += 64) {
         const int src = (p.js && ch == 1) ? (nbytes - 1 - j) : j;
         const uint8_t byte = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
         frame[dst0 + j] = byte;

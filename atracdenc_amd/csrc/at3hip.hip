@@ -58,6 +58,8 @@ struct at3hip_ctx {
     float* d_loud = nullptr;
     float* d_loud_state = nullptr;
     uint8_t* d_out = nullptr;
+    QuantRec* d_quant = nullptr;
+    int8_t* d_mant = nullptr;
     at3hip_timings tm = {};
 };
 
@@ -170,6 +172,8 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_loud, S * B)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_loud_state, S)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_out, S * B * (size_t)c->frame_sz)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_quant, S * B * 2)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_mant, S * B * 2 * 7168)) != AT3HIP_OK) return bail(rc);
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
     const char* fpw = getenv("AT3HIP_FRAMES_PER_WG");
     if (fpw && atoi(fpw) > 0) c->frames_per_wg = atoi(fpw);
@@ -183,7 +187,7 @@ void at3hip_destroy(at3hip_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void* bufs[] = {c->d_tables, c->d_pcm_in, c->d_hist[0], c->d_hist[1], c->d_sub,  c->d_rec,        c->d_state,
-                    c->d_curves, c->d_specs,  c->d_ges,     c->d_psy,     c->d_loud, c->d_loud_state, c->d_out};
+                    c->d_curves, c->d_specs,  c->d_ges,     c->d_psy,     c->d_loud, c->d_loud_state, c->d_out, c->d_quant, c->d_mant};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : c->ev)
@@ -294,10 +298,13 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.js = c->js;
         bp.frame_sz = c->frame_sz;
         bp.bfu_idx_const = c->cfg.bfu_idx_const;
+        bp.quant = c->d_quant;
+        bp.mant = c->d_mant;
         hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(c->ev[5], st));
         hipLaunchKernelGGL(k_loudness, dim3((S + 63) / 64), dim3(64), 0, st, bp);
-        hipLaunchKernelGGL(k_alloc_pack, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
+        hipLaunchKernelGGL(k_quant, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
+        hipLaunchKernelGGL(k_rate_pack, dim3(S * n_out * 2), dim3(64), 0, st, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(c->ev[6], st));
     }
     {

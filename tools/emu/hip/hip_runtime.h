@@ -29,6 +29,9 @@ struct float2 {
 struct float4 {
     float x, y, z, w;
 };
+struct uint2 {
+    unsigned x, y;
+};
 struct uint4 {
     unsigned x, y, z, w;
 };
@@ -74,6 +77,16 @@ static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKi
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+
+// ---- wave-level (64 lanes) cross-lane primitives: implemented with a wave-wide rendezvous ----
+unsigned emu_wave_exchange(unsigned value, unsigned* all64);   // deposit `value`, returns active mask lo; all64 = values
+unsigned long long emu_ballot(bool pred);
+static inline unsigned long long __ballot(bool pred) { return emu_ballot(pred); }
+int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl);
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
+int emu_readlane(int v, int lane);
+#define __builtin_amdgcn_readlane(v, lane) emu_readlane((int)(v), (lane))
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
