@@ -345,7 +345,7 @@ __device__ inline void s_insertion_sort(SortItem* a, int first, int last)
     }
 }
 
-__device__ inline void std_sort_abs(SortItem* a, int n)
+__device__ __attribute__((noinline)) void std_sort_abs(SortItem* a, int n)
 {
     if (n <= 0) return;
     int lg = 0;
@@ -471,7 +471,7 @@ __device__ inline uint32_t unit_vlc_bits(int wl, const int8_t* mant, int n)
 // cost / emission (EncodeTonalComponents :382-524). Serial (one lane). With EMIT the bits go to `words`
 // starting at bit `pos`; returns the number of bits.
 template <bool EMIT>
-__device__ inline int tonal_encode(const PsyRec* rec, const uint8_t* tbits /* [kMaxTonal][8] */, const int* alloc,
+__device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const uint8_t* tbits /* [kMaxTonal][8] */, const int* alloc,
                                    int n_alloc, uint32_t* words, int pos)
 {
     const int nt = rec->n_tonal;
