@@ -36,7 +36,7 @@ SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint
 
 def build_library(verbose=False):
     """Compile libat3hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
            "-o", LIB_PATH, os.path.join(CSRC, "at3hip.hip"), os.path.join(CSRC, "at3_tables.cpp")]
     if verbose:
         print(" ".join(cmd))

@@ -229,6 +229,15 @@ __device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
     return v;
 }
 
+// Wave-level rendezvous for data exchanged through LDS between lanes of ONE wavefront: the LDS pipeline
+// executes a wave's DS instructions in issue order, so only compiler reordering has to be fenced.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Divisor applied to sample i of the "new" half for a gain curve: the running-product ramp of
 // TGainProcessor::Modulate (gain_processor.h:93-112) / BuildSampleDivisors (atrac3denc.cpp:154-173).
 // Returns 1.0f for samples the curve does not touch (x / 1.0f == x, so dividing is a no-op there).

@@ -115,16 +115,53 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
     }
 }
 
+// ---- fused QMF + gain modulation + windowed MDCT-512 ------------------------------------------------------
+//
+// Register-blocked FIR: one work-item produces four consecutive (lower, upper) output pairs of one two-band
+// filter. Output m uses the sample pairs (x[2p], x[2p+1]) for p = m-23 .. m, so four outputs share 27 pairs
+// that are fetched from LDS with seven 16-byte reads and then stay in registers for all 192 multiply-adds;
+// the 48 taps are wave-uniform scalars. Accumulation order per output is tap 0..23, multiply then add
+// (no contraction), exactly as qmf.h:54-63.
+__device__ __forceinline__ void qmf4(const float* __restrict__ xb /* LDS, 16-byte aligned pair base */,
+                                     const float (&W)[48] /* taps, wave-uniform (scalar registers) */,
+                                     float (&lower)[4], float (&upper)[4])
+{
+    float x[56];
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + 4 * q);
+        x[4 * q + 0] = v.x;
+        x[4 * q + 1] = v.y;
+        x[4 * q + 2] = v.z;
+        x[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            lo += W[2 * i] * x[2 * (r + 23 - i) + 1];
+            hi += W[2 * i + 1] * x[2 * (r + 23 - i)];
+        }
+        lower[r] = lo + hi;
+        upper[r] = lo - hi;
+    }
+}
+
+constexpr int kPcmRing = 1072;  // [46 history | 1024 new] per channel (+2 pad keeps 16-byte alignment)
+constexpr int kS1Ring = 560;    // [46 history | 512 new] per channel and half (+2 pad)
+
 template <bool GAIN>
 __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T)
 {
-    __shared__ float s_a[kRegionA];          // QMF working set | MDCT input / output staging (aliased)
-    __shared__ float s_sub[2 * 4 * 256];     // current block's subbands [ch][band][256]
-    __shared__ float s_prevw[2 * 4 * 256];   // overlap half carried to the next frame (windowed, modulated)
-    __shared__ cpx s_fft[8 * 128];
-    __shared__ float s_div[GAIN ? 8 * 256 : 1];
-    __shared__ float s_qw[48];
-    __shared__ float s_win[256];
+    __shared__ __attribute__((aligned(16))) float s_pcm[2 * kPcmRing];
+    __shared__ __attribute__((aligned(16))) float s_lo[2 * kS1Ring];
+    __shared__ __attribute__((aligned(16))) float s_hi[2 * kS1Ring];
+    __shared__ __attribute__((aligned(16))) float s_sub[2 * 4 * 256];     // current block's subbands [ch][band][256]
+    __shared__ __attribute__((aligned(16))) float s_prevw[2 * 4 * 256];   // overlap half carried to the next frame
+    __shared__ __attribute__((aligned(16))) cpx s_fft[8 * 128];
+    __shared__ __attribute__((aligned(16))) float s_div[GAIN ? 8 * 256 : 4];
+    __shared__ __attribute__((aligned(16))) float s_win[256];
     __shared__ float s_cs[256];
     __shared__ cpx s_tw[128];
     __shared__ Curve s_curve[8];
@@ -139,27 +176,61 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
     int fb = fa + p.frames_per_wg;
     if (fb > p.n_blocks) fb = p.n_blocks;
     const int n_out = p.n_blocks - p.f0;
+    float W[48];   // the 48 taps live in scalar registers for the whole run
+#pragma unroll
+    for (int i = 0; i < 48; ++i) W[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T->qmf_win[i])));
+    const float2* pcm2 = reinterpret_cast<const float2*>(p.pcm) + (size_t)s * p.n_blocks * 1024;
+    const float2* hist2 = reinterpret_cast<const float2*>(p.hist) + (size_t)s * kHist;
 
-    float* s_pcm = s_a;
-    float* s_lo = s_a + 2 * kPcmLen;
-    float* s_hi = s_lo + 2 * kS1Len;
-    float* s_tmp = s_a;  // [8][512]
-
-    if (tid < 48) s_qw[tid] = T->qmf_win[tid];
     s_win[tid] = T->enc_win[tid];
     s_cs[tid] = T->mdct_sincos[tid];
     if (tid < 128) s_tw[tid] = T->tw128[tid];
     if (tid < 8) s_nextscale[tid] = 1.0f;
+    for (int i = tid; i < 2048; i += 256) s_prevw[i] = 0.0f;
 
-    const int c = tid >> 5;      // (channel, band) combo owning this thread in the MDCT phase
+    // ---- prologue: FIR histories of the first block (b0 = fa - 2) ----
+    // stage-1 outputs m = -46..-1 need samples -138..-1; they are computed once per workgroup run.
+    const int b0 = fa - 2;
+    for (int k = tid; k < 138; k += 256) {
+        const int g = b0 * 1024 - 138 + k;
+        const float2 v = (g >= 0) ? pcm2[g] : hist2[kHist + g];
+        s_pcm[k] = v.x * 0.25f;
+        s_pcm[kPcmRing + k] = v.y * 0.25f;
+    }
+    __syncthreads();
+    float keep = 0.0f;
+    if (tid < 92) {
+        const int ch = tid / 46, mm = tid % 46;   // output m = mm - 46, pair base = 2 * mm in the temp layout
+        const float* x = s_pcm + ch * kPcmRing + 2 * mm;
+        float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            lo += W[2 * i] * x[47 - 2 * i];
+            hi += W[2 * i + 1] * x[46 - 2 * i];
+        }
+        s_lo[ch * kS1Ring + mm] = lo + hi;
+        s_hi[ch * kS1Ring + mm] = lo - hi;
+        keep = s_pcm[ch * kPcmRing + 92 + mm];    // samples -46..-1 move to the front of the ring
+    }
+    __syncthreads();
+    if (tid < 92) s_pcm[(tid / 46) * kPcmRing + (tid % 46)] = keep;
+
+    const int c = tid >> 5;      // (channel, band) combo owning this thread in the MDCT phase; a wave owns 2
     const int lane = tid & 31;
 
     // block b carries frame f = b + 1; the block before the first frame only primes the overlap.
-    for (int b = fa - 2; b <= fb - 2; ++b) {
+    for (int b = b0; b <= fb - 2; ++b) {
         const int f = b + 1;
         const bool is_frame = (f >= fa);
-        __syncthreads();  // previous iteration finished reading s_tmp / tables are loaded
-        load_pcm_tile(p, s, b, s_pcm, tid);
+        // ---- PCM tile: 1024 new stereo samples, coalesced float2 loads, /4.0 ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = tid + 256 * q;
+            const int g = b * 1024 + k;
+            const float2 v = (g >= 0) ? pcm2[g] : hist2[kHist + g];
+            s_pcm[46 + k] = v.x * 0.25f;
+            s_pcm[kPcmRing + 46 + k] = v.y * 0.25f;
+        }
         if (GAIN && tid < 8) {
             Curve cv;
             if (f < 0) cv = p.state[(size_t)s * 8 + tid].prev_curve;
@@ -167,7 +238,49 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
             s_curve[tid] = cv;
         }
         __syncthreads();
-        qmf_block(s_qw, s_pcm, s_lo, s_hi, s_sub, tid);
+        // ---- stage 1 (Qmf1): 2 channels x 128 tasks x 4 outputs ----
+        {
+            const int ch = tid >> 7, g = tid & 127;
+            float lw[4], up[4];
+            qmf4(s_pcm + ch * kPcmRing + 8 * g, W, lw, up);
+            float4 a, bq;
+            a.x = lw[0]; a.y = lw[1]; a.z = lw[2]; a.w = lw[3];
+            bq.x = up[0]; bq.y = up[1]; bq.z = up[2]; bq.w = up[3];
+            // ring index of output m is 46 + m: 8-byte aligned only -> two float2 stores
+            float2* dl = reinterpret_cast<float2*>(s_lo + ch * kS1Ring + 46 + 4 * g);
+            float2* dh = reinterpret_cast<float2*>(s_hi + ch * kS1Ring + 46 + 4 * g);
+            float2 t0, t1;
+            t0.x = a.x; t0.y = a.y; t1.x = a.z; t1.y = a.w;
+            dl[0] = t0; dl[1] = t1;
+            t0.x = bq.x; t0.y = bq.y; t1.x = bq.z; t1.y = bq.w;
+            dh[0] = t0; dh[1] = t1;
+        }
+        __syncthreads();
+        // PCM history for the next block (stage 1 is done with the ring)
+        if (tid < 92) {
+            const int ch = tid / 46, k = tid % 46;
+            keep = s_pcm[ch * kPcmRing + 1024 + k];
+        }
+        // ---- stage 2: Qmf2 on the lower half -> bands 0, 1; Qmf3 on the upper half -> bands 3, 2 ----
+        {
+            const int ch = tid >> 7, which = (tid >> 6) & 1, g = tid & 63;
+            float lw[4], up[4];
+            qmf4((which ? s_hi : s_lo) + ch * kS1Ring + 8 * g, W, lw, up);
+            float4 a, bq;
+            a.x = lw[0]; a.y = lw[1]; a.z = lw[2]; a.w = lw[3];
+            bq.x = up[0]; bq.y = up[1]; bq.z = up[2]; bq.w = up[3];
+            float* out = s_sub + ch * 1024;
+            *reinterpret_cast<float4*>(out + (which ? 3 : 0) * 256 + 4 * g) = a;
+            *reinterpret_cast<float4*>(out + (which ? 2 : 1) * 256 + 4 * g) = bq;
+        }
+        if (tid < 92) s_pcm[(tid / 46) * kPcmRing + (tid % 46)] = keep;
+        __syncthreads();
+        // stage-1 history for the next block (stage 2 is done with the rings)
+        if (tid < 184) {
+            const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
+            float* ring = (hlf ? s_hi : s_lo) + ch * kS1Ring;
+            ring[k] = ring[512 + k];
+        }
         if (p.js) {  // M/S matrixing in the subband domain
             for (int idx = tid; idx < 1024; idx += 256) {
                 const float l = s_sub[idx], r = s_sub[1024 + idx];
@@ -177,44 +290,66 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
             __syncthreads();
         }
 
-        float prev_scale = 1.0f;  // NextOverlapScale of the previous block == PrevOverlapGainScale
+        // ======== from here on every wavefront works on its own two (channel, band) combos ========
+        float* xs = s_sub + c * 256;
+        float* pw = s_prevw + c * 256;
         bool has_curve = false;
+        float scale = 1.0f;
         if (GAIN) {
-            prev_scale = s_nextscale[c];
+            const float prev_scale = s_nextscale[c];
             has_curve = s_curve[c].n > 0;
             if (has_curve) {
+                scale = T->gain_level[s_curve[c].level[0]];
                 for (int i = lane; i < 256; i += 32) s_div[c * 256 + i] = curve_divisor(T, s_curve[c], i);
             }
-            __syncthreads();
+            wave_sync();
             // CalcGainEnergyScale: five strictly sequential 256-term sums, one lane each.
             const bool need = has_curve || prev_scale != 1.0f;
             if (need && lane < 5) {
-                const float* x = s_sub + c * 256;
-                const float* pw = s_prevw + c * 256;
                 const float* dv = s_div + c * 256;
                 float acc = 0.0f;
                 if (lane == 0) {
-                    for (int i = 0; i < 256; ++i) acc += pw[i] * pw[i];
+                    for (int i = 0; i < 256; i += 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(pw + i);
+                        acc += v.x * v.x;
+                        acc += v.y * v.y;
+                        acc += v.z * v.z;
+                        acc += v.w * v.w;
+                    }
                 } else {
-                    const bool modulated = (lane == 2 || lane == 4);
+                    const bool modulated = (lane == 2 || lane == 4) && has_curve;
                     const bool next = (lane >= 3);
-                    for (int i = 0; i < 256; ++i) {
-                        float v = x[i];
-                        if (modulated && has_curve) v = v / dv[i];
-                        const float w = next ? s_win[i] : s_win[255 - i];
-                        const float vw = v * w;
-                        acc += vw * vw;
+                    for (int i = 0; i < 256; i += 4) {
+                        const float4 x4 = *reinterpret_cast<const float4*>(xs + i);
+                        float v[4] = {x4.x, x4.y, x4.z, x4.w};
+                        if (modulated) {
+                            const float4 d4 = *reinterpret_cast<const float4*>(dv + i);
+                            v[0] = v[0] / d4.x; v[1] = v[1] / d4.y; v[2] = v[2] / d4.z; v[3] = v[3] / d4.w;
+                        }
+                        float w[4];
+                        if (next) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(s_win + i);
+                            w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+                        } else {
+                            const float4 w4 = *reinterpret_cast<const float4*>(s_win + 252 - i);
+                            w[0] = w4.w; w[1] = w4.z; w[2] = w4.y; w[3] = w4.x;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float vw = v[k] * w[k];
+                            acc += vw * vw;
+                        }
                     }
                 }
                 s_sum[c][lane] = acc;
             }
-            __syncthreads();
+            wave_sync();
             if (lane == 0) {
                 float frame_scale = 1.0f, next_scale = 1.0f;
                 if (need) {
                     float ps = prev_scale;
                     if (!isfinite(ps) || ps <= 0.0f) ps = 1.0f;
-                    const float prevDiv = has_curve ? T->gain_level[s_curve[c].level[0]] : 1.0f;
+                    const float prevDiv = has_curve ? scale : 1.0f;
                     const float prevStored = s_sum[c][0];
                     const float prevOrig = prevStored * ps;
                     const float prevMod = prevStored / (prevDiv * prevDiv);
@@ -224,41 +359,26 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
                 s_nextscale[c] = next_scale;
                 if (is_frame) p.ges[((size_t)s * p.n_blocks + f) * 8 + c] = frame_scale;
             }
-        }
-
-        // Modulate + window (atrac3denc.cpp:39-49). s_tmp aliases the QMF region: all QMF reads are done.
-        {
-            float* tmp = s_tmp + c * 512;
-            float* pw = s_prevw + c * 256;
-            const float* x = s_sub + c * 256;
-            const float scale = (GAIN && has_curve) ? T->gain_level[s_curve[c].level[0]] : 1.0f;
-            for (int i = lane; i < 256; i += 32) {
-                float ov = pw[i];
-                float v = x[i];
-                if (GAIN && has_curve) {
-                    ov = ov / scale;
-                    v = v / s_div[c * 256 + i];
+            if (has_curve) {   // Modulate (gain_processor.h:87-121): new half / ramp, overlap half / first level
+                for (int i = lane; i < 256; i += 32) {
+                    xs[i] = xs[i] / s_div[c * 256 + i];
+                    pw[i] = pw[i] / scale;
                 }
-                tmp[i] = ov;
-                pw[i] = s_win[i] * v;
-                tmp[256 + i] = s_win[255 - i] * v;
             }
+            wave_sync();
         }
-        __syncthreads();
-        if (!is_frame) continue;
-
-        // MDCT-512 = fold + pre-rotation -> 128-pt FFT -> post-rotation (mdct.h:51-104)
-        {
-            const float* in = s_tmp + c * 512;
+        if (is_frame) {
+            // MDCT-512 fold + pre-rotation straight from the overlap and the windowed new half
+            // (in[k] = overlap[k] for k < 256, EncodeWindow[511 - k] * new[k - 256] otherwise; mdct.h:64-86)
             for (int n2 = lane; n2 < 128; n2 += 32) {
                 const int n = 2 * n2;
                 float r0, i0;
                 if (n < 128) {
-                    r0 = in[383 - n] + in[384 + n];
-                    i0 = in[128 + n] - in[127 - n];
+                    r0 = s_win[128 + n] * xs[127 - n] + s_win[127 - n] * xs[128 + n];
+                    i0 = pw[128 + n] - pw[127 - n];
                 } else {
-                    r0 = in[383 - n] - in[n - 128];
-                    i0 = in[128 + n] + in[639 - n];
+                    r0 = pw[383 - n] - pw[n - 128];
+                    i0 = s_win[383 - n] * xs[n - 128] + s_win[n - 128] * xs[383 - n];
                 }
                 const float cc = s_cs[n], ss = s_cs[n + 1];
                 cpx v;
@@ -267,26 +387,73 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
                 s_fft[c * 128 + fft_leaf_pos<128>(n2)] = v;
             }
         }
-        __syncthreads();
-        fft_lds<128, false>(s_fft, 128, 8, s_tw, tid, 256);
-        {
-            float* out = s_tmp + c * 512;  // reuse as output staging [256]
-            const bool odd = (c & 1);
-            for (int n2 = lane; n2 < 128; n2 += 32) {
-                const int n = 2 * n2;
-                const float r0 = s_fft[c * 128 + n2].r, i0 = s_fft[c * 128 + n2].i;
-                const float cc = s_cs[n], ss = s_cs[n + 1];
-                const float a = -r0 * cc - i0 * ss;
-                const float bq = -r0 * ss + i0 * cc;
-                out[odd ? 255 - n : n] = a;           // odd bands are stored reversed (atrac3denc.cpp:53-55)
-                out[odd ? n : 255 - n] = bq;
+        wave_sync();
+        // next frame's overlap = EncodeWindow[i] * new[i] (atrac3denc.cpp:47)
+        for (int i = lane; i < 256; i += 32) pw[i] = s_win[i] * xs[i];
+        if (is_frame) {
+            // 128-point FFT of this combo by its 32 lanes: radix-2 leaves, then three radix-4 passes
+            cpx* F = s_fft + c * 128;
+            {
+                const cpx w = s_tw[0];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    cpx* a = F + 2 * (lane + 32 * q);
+                    const cpx a0 = a[0], a1 = a[1];
+                    const cpx t = cmul(a1, w);
+                    cpx o0, o1;
+                    o1.r = a0.r - t.r; o1.i = a0.i - t.i;
+                    o0.r = a0.r + t.r; o0.i = a0.i + t.i;
+                    a[0] = o0; a[1] = o1;
+                }
             }
+            wave_sync();
+#pragma unroll
+            for (int m = 2; m < 128; m <<= 2) {
+                const int fstride = 128 / (4 * m);
+                const int g = lane / m, k = lane % m;
+                cpx* B = F + g * 4 * m + k;
+                const cpx s0 = cmul(B[m], s_tw[k * fstride]);
+                const cpx s1 = cmul(B[2 * m], s_tw[2 * k * fstride]);
+                const cpx s2 = cmul(B[3 * m], s_tw[3 * k * fstride]);
+                cpx s5, s3, s4, f0 = B[0];
+                s5.r = f0.r - s1.r; s5.i = f0.i - s1.i;
+                f0.r += s1.r; f0.i += s1.i;
+                s3.r = s0.r + s2.r; s3.i = s0.i + s2.i;
+                s4.r = s0.r - s2.r; s4.i = s0.i - s2.i;
+                cpx o2, o1, o3;
+                o2.r = f0.r - s3.r; o2.i = f0.i - s3.i;
+                f0.r += s3.r; f0.i += s3.i;
+                o1.r = s5.r + s4.i; o1.i = s5.i - s4.r;
+                o3.r = s5.r - s4.i; o3.i = s5.i + s4.r;
+                B[0] = f0; B[m] = o1; B[2 * m] = o2; B[3 * m] = o3;
+                wave_sync();
+            }
+            // post-rotation (mdct.h:92-101) in place: read this lane's four bins, then scatter the 256 lines
+            float oa[4], ob[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n2 = lane + 32 * q, n = 2 * n2;
+                const float r0 = F[n2].r, i0 = F[n2].i;
+                const float cc = s_cs[n], ss = s_cs[n + 1];
+                oa[q] = -r0 * cc - i0 * ss;
+                ob[q] = -r0 * ss + i0 * cc;
+            }
+            wave_sync();
+            float* out = reinterpret_cast<float*>(F);
+            const bool odd = (c & 1);   // odd bands are stored reversed (atrac3denc.cpp:53-55)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 2 * (lane + 32 * q);
+                out[odd ? 255 - n : n] = oa[q];
+                out[odd ? n : 255 - n] = ob[q];
+            }
+            wave_sync();
+            float* dst = p.specs + ((size_t)s * n_out + (f - p.f0)) * 2048 + c * 256;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                *reinterpret_cast<float4*>(dst + 4 * (lane + 32 * q)) = *reinterpret_cast<const float4*>(out + 4 * (lane + 32 * q));
         }
-        __syncthreads();
-        {
-            float* dst = p.specs + ((size_t)s * n_out + (f - p.f0)) * 2048;
-            for (int idx = tid; idx < 2048; idx += 256) dst[idx] = s_tmp[(idx >> 8) * 512 + (idx & 255)];
-        }
+        __syncthreads();   // s_sub / rings are rewritten by the next block
     }
 }
 

@@ -73,6 +73,12 @@ unsigned emu_wave_exchange(unsigned value, unsigned* all64)
     return 0;
 }
 
+void emu_wave_barrier()
+{
+    unsigned all[64];
+    emu_wave_exchange(0u, all);
+}
+
 unsigned long long emu_ballot(bool pred)
 {
     unsigned all[64];

@@ -86,6 +86,10 @@ int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
 int emu_readlane(int v, int lane);
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((int)(v), (lane))
+void emu_wave_barrier();
+#define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
