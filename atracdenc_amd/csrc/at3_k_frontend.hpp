@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
     __shared__ Curve s_curve[8];
     __shared__ float s_nextscale[8];         // NextOverlapScale of the block just processed
     __shared__ float s_sum[8][5];
+    __shared__ __attribute__((aligned(16))) float s_terms[GAIN ? 8 * 160 : 4];
+    __shared__ Curve s_curves_all[GAIN ? 33 * 8 : 1];   // curves of frames fa-1 .. fb-1 (frames_per_wg <= 32)
 
     const int tid = threadIdx.x;
     const int nchunks = (p.n_blocks - p.f0 + p.frames_per_wg - 1) / p.frames_per_wg;
@@ -187,6 +189,13 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
     if (tid < 128) s_tw[tid] = T->tw128[tid];
     if (tid < 8) s_nextscale[tid] = 1.0f;
     for (int i = tid; i < 2048; i += 256) s_prevw[i] = 0.0f;
+    if (GAIN) {
+        // gain curves of every frame this run touches (frame fa-1 only shapes the carried overlap)
+        for (int i = tid; i < (fb - fa + 1) * 8; i += 256) {
+            const int f = fa - 1 + i / 8, cb = i % 8;
+            s_curves_all[i] = (f < 0) ? p.state[(size_t)s * 8 + cb].prev_curve : p.curves[((size_t)s * p.n_blocks + f) * 8 + cb];
+        }
+    }
 
     // ---- prologue: FIR histories of the first block (b0 = fa - 2) ----
     // stage-1 outputs m = -46..-1 need samples -138..-1; they are computed once per workgroup run.
@@ -231,12 +240,7 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
             s_pcm[46 + k] = v.x * 0.25f;
             s_pcm[kPcmRing + 46 + k] = v.y * 0.25f;
         }
-        if (GAIN && tid < 8) {
-            Curve cv;
-            if (f < 0) cv = p.state[(size_t)s * 8 + tid].prev_curve;
-            else cv = p.curves[((size_t)s * p.n_blocks + f) * 8 + tid];
-            s_curve[tid] = cv;
-        }
+        if (GAIN && tid < 8) s_curve[tid] = s_curves_all[(f - (fa - 1)) * 8 + tid];
         __syncthreads();
         // ---- stage 1 (Qmf1): 2 channels x 128 tasks x 4 outputs ----
         {
@@ -303,45 +307,39 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
                 for (int i = lane; i < 256; i += 32) s_div[c * 256 + i] = curve_divisor(T, s_curve[c], i);
             }
             wave_sync();
-            // CalcGainEnergyScale: five strictly sequential 256-term sums, one lane each.
+            // CalcGainEnergyScale (atrac3denc.cpp:189-216): five strictly ordered 256-term sums. The terms are
+            // produced 32 at a time by all lanes of the combo; lanes 0..4 then extend one chain each.
             const bool need = has_curve || prev_scale != 1.0f;
-            if (need && lane < 5) {
-                const float* dv = s_div + c * 256;
+            if (__ballot(need) != 0ull) {   // wave-uniform: both combos of the wavefront walk the chunks together
+                float* terms = s_terms + c * 160;   // [5][32]
                 float acc = 0.0f;
-                if (lane == 0) {
-                    for (int i = 0; i < 256; i += 4) {
-                        const float4 v = *reinterpret_cast<const float4*>(pw + i);
-                        acc += v.x * v.x;
-                        acc += v.y * v.y;
-                        acc += v.z * v.z;
-                        acc += v.w * v.w;
-                    }
-                } else {
-                    const bool modulated = (lane == 2 || lane == 4) && has_curve;
-                    const bool next = (lane >= 3);
-                    for (int i = 0; i < 256; i += 4) {
-                        const float4 x4 = *reinterpret_cast<const float4*>(xs + i);
-                        float v[4] = {x4.x, x4.y, x4.z, x4.w};
-                        if (modulated) {
-                            const float4 d4 = *reinterpret_cast<const float4*>(dv + i);
-                            v[0] = v[0] / d4.x; v[1] = v[1] / d4.y; v[2] = v[2] / d4.z; v[3] = v[3] / d4.w;
-                        }
-                        float w[4];
-                        if (next) {
-                            const float4 w4 = *reinterpret_cast<const float4*>(s_win + i);
-                            w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
-                        } else {
-                            const float4 w4 = *reinterpret_cast<const float4*>(s_win + 252 - i);
-                            w[0] = w4.w; w[1] = w4.z; w[2] = w4.y; w[3] = w4.x;
-                        }
+                for (int base = 0; base < 256; base += 32) {
+                    const int i = base + lane;
+                    const float x = xs[i];
+                    const float mod = has_curve ? x / s_div[c * 256 + i] : x;
+                    const float wc = s_win[255 - i], wn = s_win[i];
+                    const float pv = pw[i];
+                    const float cw = x * wc, mw = mod * wc, nw = x * wn, mnw = mod * wn;
+                    terms[0 * 32 + lane] = pv * pv;
+                    terms[1 * 32 + lane] = cw * cw;
+                    terms[2 * 32 + lane] = mw * mw;
+                    terms[3 * 32 + lane] = nw * nw;
+                    terms[4 * 32 + lane] = mnw * mnw;
+                    wave_sync();
+                    if (lane < 5) {
+                        const float4* t4 = reinterpret_cast<const float4*>(terms + lane * 32);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float vw = v[k] * w[k];
-                            acc += vw * vw;
+                        for (int q = 0; q < 8; ++q) {
+                            const float4 v = t4[q];
+                            acc += v.x;
+                            acc += v.y;
+                            acc += v.z;
+                            acc += v.w;
                         }
                     }
+                    wave_sync();
                 }
-                s_sum[c][lane] = acc;
+                if (need && lane < 5) s_sum[c][lane] = acc;
             }
             wave_sync();
             if (lane == 0) {

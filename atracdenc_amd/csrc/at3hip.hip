@@ -42,7 +42,8 @@ struct at3hip_ctx {
     hipEvent_t ev[8] = {};
     char err[256] = {0};
     long long blocks_fed = 0;   // per stream
-    int frames_per_wg = 8;
+    int frames_per_wg = 0;
+    int n_cus = 256;
 
     Tables* d_tables = nullptr;
     float* d_pcm_in = nullptr;       // staging for host PCM [S][max_blocks][1024][2]
@@ -88,6 +89,18 @@ int dev_alloc(at3hip_ctx* c, Tp** p, size_t count)
     if (e != hipSuccess) return fail(c, AT3HIP_ENOMEM, "hipMalloc", e);
     *p = (Tp*)q;
     return AT3HIP_OK;
+}
+
+// Frames per workgroup run of the fused kernel: long runs amortise the one-block prologue, short runs keep
+// every CU busy on small batches (three workgroups are resident per CU).
+int pick_frames_per_wg(const at3hip_ctx* c, int n_out)
+{
+    if (c->frames_per_wg > 0) return c->frames_per_wg;
+    const long long total = (long long)c->cfg.n_streams * n_out;
+    long long f = total / ((long long)c->n_cus * 3);
+    if (f < 4) f = 4;
+    if (f > 32) f = 32;
+    return (int)f;
 }
 
 int reset_state(at3hip_ctx* c)
@@ -176,7 +189,10 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_mant, S * B * 2 * 7168)) != AT3HIP_OK) return bail(rc);
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
     const char* fpw = getenv("AT3HIP_FRAMES_PER_WG");
-    if (fpw && atoi(fpw) > 0) c->frames_per_wg = atoi(fpw);
+    c->frames_per_wg = (fpw && atoi(fpw) > 0) ? atoi(fpw) : 0;   // 0 = choose per call
+    if (c->frames_per_wg > 32) c->frames_per_wg = 32;
+    hipDeviceProp_t prop;
+    c->n_cus = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     *out = c;
     return AT3HIP_OK;
 }
@@ -256,7 +272,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         fp.sub = c->d_sub;
         fp.n_blocks = n_blocks;
         fp.f0 = f0;
-        fp.frames_per_wg = c->frames_per_wg;
+        fp.frames_per_wg = pick_frames_per_wg(c, n_out);
         fp.js = c->js;
         if (gain) {
             GainParams gp;
@@ -278,7 +294,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             HIPCHK(c, hipEventRecord(c->ev[2], st));
         }
         HIPCHK(c, hipEventRecord(c->ev[3], st));
-        const int nchunks = (n_out + c->frames_per_wg - 1) / c->frames_per_wg;
+        const int nchunks = (n_out + fp.frames_per_wg - 1) / fp.frames_per_wg;
         if (gain) hipLaunchKernelGGL(k_qmf_mdct<true>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
         else hipLaunchKernelGGL(k_qmf_mdct<false>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
         HIPCHK(c, hipEventRecord(c->ev[4], st));
@@ -427,10 +443,10 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
     fp.sub = nullptr;
     fp.n_blocks = n_blocks;
     fp.f0 = 1;
-    fp.frames_per_wg = c->frames_per_wg;
-    fp.js = c->js;
     const int n_out = n_blocks - 1;
-    const int nchunks = (n_out + c->frames_per_wg - 1) / c->frames_per_wg;
+    fp.frames_per_wg = pick_frames_per_wg(c, n_out);
+    fp.js = c->js;
+    const int nchunks = (n_out + fp.frames_per_wg - 1) / fp.frames_per_wg;
     HIPCHK(c, hipEventRecord(c->ev[0], st));
     hipLaunchKernelGGL(k_qmf_mdct<false>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
