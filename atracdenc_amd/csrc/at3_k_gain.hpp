@@ -321,264 +321,314 @@ __device__ inline float boundary_score(const float* env, int loc)
     return fmaxf(attack, release);
 }
 
-// atrac3denc.cpp:228-297
-__device__ inline float early_mismatch_score(const Tables* T, const float* gain, float target, const Curve& c)
+// ---- CalcCurve + CreateSubbandInfo tail, 32 lanes per (stream, frame, channel, band<3) item ------------------
+// Lane j of a half-wavefront owns sub-frame j. Everything that is order-free (median filter, level
+// quantisation, boundary scores, log2 terms) runs on all 32 lanes; the order-dependent parts (sticky level chain,
+// right-to-left transition scan, float sums) are wave-uniform loops that broadcast one lane per step with
+// readlane, so both items of a wavefront advance in lockstep without LDS round trips or barriers.
+__device__ __forceinline__ float grp_readlane_f(float v, int idx, int half)
 {
-    if (target <= 1e-9f) return 0.0f;
-    float div[32];
-    for (int sf = 0; sf < 32; ++sf) {
-        float sum = 0.0f;
-        for (int k = 0; k < 8; ++k) sum += curve_divisor(T, c, sf * 8 + k);
-        div[sf] = sum / 8.0f;
-    }
-    uint32_t maxLoc = 0;
-    for (int i = 0; i < c.n; ++i) maxLoc = c.loc[i] > maxLoc ? c.loc[i] : maxLoc;
-    uint32_t evalSf = maxLoc + 3 > 3 ? maxLoc + 3 : 3;
-    if (evalSf > 32) evalSf = 32;
-    const float eps = 1e-9f;
-    float fit = 0.0f;
-    for (uint32_t sf = 0; sf < evalSf; ++sf) {
-        const float mod = gain[sf] / fmaxf(div[sf], eps);
-        const float e = at3_log2f(T, fmaxf(mod, eps) / fmaxf(target, eps));
-        fit += e * e;
-    }
-    fit /= evalSf;
-    float leak = 0.0f, wsum = 0.0f;
-    for (uint32_t sf = 0; sf + 1 < evalSf; ++sf) {
-        const float a = at3_log2f(T, fmaxf(div[sf], eps));
-        const float b = at3_log2f(T, fmaxf(div[sf + 1], eps));
-        const float d = b - a;
-        const float w = 0.5f * (gain[sf] + gain[sf + 1]);
-        leak += d * d * w;
-        wsum += w;
-    }
-    if (wsum > eps) leak /= wsum;
-    return fit + 0.25f * leak;
+    const int a = __builtin_amdgcn_readlane((int)__float_as_uint(v), idx);
+    const int b = __builtin_amdgcn_readlane((int)__float_as_uint(v), 32 + idx);
+    return __uint_as_float((uint32_t)(half ? b : a));
+}
+__device__ __forceinline__ int grp_readlane_i(int v, int idx, int half)
+{
+    const int a = __builtin_amdgcn_readlane(v, idx);
+    const int b = __builtin_amdgcn_readlane(v, 32 + idx);
+    return half ? b : a;
 }
 
-// One thread per (stream, frame, channel, band<3): CalcCurve + CreateSubbandInfo tail.
-__global__ void k_gain_curve(GainParams p, const Tables* T, int n_streams)
+struct CurvePts {   // register-resident curve (redundant in every lane of the item)
+    int n;
+    int level[7];
+    int loc[7];
+};
+
+// CalcCurveEarlyMismatchScore (atrac3denc.cpp:228-297); in_j / in_next are this lane's gain[j], gain[j+1].
+__device__ __forceinline__ float early_mismatch_score_grp(const Tables* T, float in_j, float in_next, float target,
+                                                          const CurvePts& cp, float* s_tmp, int j, int half)
 {
+    Curve c;
+    c.n = (uint8_t)cp.n;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        c.level[i] = (uint8_t)cp.level[i];
+        c.loc[i] = (uint8_t)cp.loc[i];
+    }
+    float dsum = 0.0f;
+    for (int k = 0; k < 8; ++k) dsum += curve_divisor(T, c, j * 8 + k);
+    const float div = dsum / 8.0f;
+    int maxLoc = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+        if (i < cp.n && cp.loc[i] > maxLoc) maxLoc = cp.loc[i];
+    int evalSf = maxLoc + 3 > 3 ? maxLoc + 3 : 3;
+    if (evalSf > 32) evalSf = 32;
+    const float eps = 1e-9f;
+    const float mod = in_j / fmaxf(div, eps);
+    const float e = at3_log2f(T, fmaxf(mod, eps) / fmaxf(target, eps));
+    const float sq = e * e;
+    const float a = at3_log2f(T, fmaxf(div, eps));
+    s_tmp[j] = a;
+    wave_sync();
+    const float a_next = s_tmp[j < 31 ? j + 1 : 31];
+    wave_sync();
+    const float d = a_next - a;
+    const float w = 0.5f * (in_j + in_next);
+    const float lterm = d * d * w;
+    float fit = 0.0f, leak = 0.0f, wsum = 0.0f;
+    for (int sf = 0; sf < 32; ++sf) {   // ordered sums
+        const float v = grp_readlane_f(sq, sf, half);
+        const float lt = grp_readlane_f(lterm, sf, half);
+        const float ww = grp_readlane_f(w, sf, half);
+        if (sf < evalSf) fit += v;
+        if (sf + 1 < evalSf) {
+            leak += lt;
+            wsum += ww;
+        }
+    }
+    fit /= (float)evalSf;
+    if (wsum > eps) leak /= wsum;
+    const float score = fit + 0.25f * leak;
+    return (target <= 1e-9f) ? 0.0f : score;
+}
+
+// 256 threads = 8 items per workgroup.
+__global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* T, int n_streams)
+{
+    __shared__ float s_in[8][32];
+    __shared__ float s_filt[8][32];
+    __shared__ float s_tmp[8][32];
+    __shared__ int s_tloc[8][32];
+    __shared__ int s_tdelta[8][32];
+    __shared__ int s_tlev[8][32];
+    const int tid = threadIdx.x;
+    const int grp = tid >> 5, j = tid & 31, half = grp & 1;
     const int nfr = p.n_blocks - p.f0;
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_streams * nfr * 6) return;
+    const int n_items = n_streams * nfr * 6;
+    int item = blockIdx.x * 8 + grp;
+    const bool valid = item < n_items;
+    if (!valid) item = n_items - 1;   // keep the wavefront uniform; results are discarded
+    int idx = item;
     const int band = idx % 3; idx /= 3;
     const int ch = idx % 2; idx /= 2;
     const int f = p.f0 + idx % nfr;
     const int s = idx / nfr;
     const GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
-    Curve out;
-    out.n = 0;
-    out.pad = 0;
-    for (int i = 0; i < 7; ++i) {
-        out.level[i] = 0;
-        out.loc[i] = 0;
-    }
     Curve* dst = p.curves + ((size_t)s * p.n_blocks + f) * 8 + ch * 4 + band;
+
     const float hfr = rec->hfr;
-    if (hfr < 0.05f) {
-        *dst = out;
-        return;
-    }
-    float in[32], lo[32], hi[32], filtered[32];
-    for (int i = 0; i < 32; ++i) {
-        in[i] = rec->gain[i];
-        lo[i] = rec->lo[i];
-        hi[i] = rec->hi[i];
-    }
-    const float curHpf = rec->cur_hpf;
-    const float prevHpf = rec->ctx_hpf;
+    const float in_j = rec->gain[j], lo_j = rec->lo[j], hi_j = rec->hi[j];
+    const float curHpf = rec->cur_hpf, prevHpf = rec->ctx_hpf;
+    const float prevTarget = rec->ctx_target, savedLastLevel = rec->ctx_level;
+    const float target = rec->target;   // == ctx.LastTarget after CalcCurve
     const float hpfRatio = (curHpf > 1e-9f && prevHpf > 1e-9f) ? (prevHpf / curHpf) : 1.0f;
     const float minScore = 1.9f * fminf(1.5f, fmaxf(1.0f, hpfRatio));
-    const float prevTarget = rec->ctx_target;
-    const float savedLastLevel = rec->ctx_level;
-    const float target = rec->target;   // == ctx.LastTarget after CalcCurve
-    median3_32(in, filtered);
+
+    s_in[grp][j] = in_j;
+    wave_sync();
+    // 3-point median (transient_detector.cpp:151-166); the 2-element edge windows return the larger value
+    float filt_j;
+    {
+        const float a = s_in[grp][j > 0 ? j - 1 : 0], c = s_in[grp][j < 31 ? j + 1 : 31];
+        if (j == 0) filt_j = fmaxf(in_j, c);
+        else if (j == 31) filt_j = fmaxf(a, in_j);
+        else filt_j = fmaxf(fminf(a, in_j), fminf(fmaxf(a, in_j), c));
+    }
+    const float in_next = s_in[grp][j < 31 ? j + 1 : 31];
+    s_filt[grp][j] = filt_j;
+    float maxGain = 0.0f;
+    for (int k = 0; k < 32; ++k) maxGain = fmaxf(maxGain, s_in[grp][k]);
+    wave_sync();
 
     // ---- CalcCurve (transient_detector.cpp:299-482) ----
-    Curve pts = out;
-    bool have = false;
-    if (!(target < 1e-6f) && !(savedLastLevel < 1e-6f)) {
-        float maxGainC = 0.0f;
-        for (int i = 0; i < 32; ++i) maxGainC = fmaxf(maxGainC, in[i]);
-        const float intraRatio = maxGainC / fmaxf(target, 1e-9f);
-        float interRatio = 1.0f;
-        if (prevTarget > 1e-6f) {
-            const float h = fmaxf(prevTarget, target);
-            const float l = fminf(prevTarget, target);
-            interRatio = h / fmaxf(l, 1e-9f);
+    const bool active = valid && !(hfr < 0.05f) && !(target < 1e-6f) && !(savedLastLevel < 1e-6f);
+    const float intraRatio = maxGain / fmaxf(target, 1e-9f);
+    float interRatio = 1.0f;
+    if (prevTarget > 1e-6f) interRatio = fmaxf(prevTarget, target) / fmaxf(fminf(prevTarget, target), 1e-9f);
+    const bool sticky = intraRatio <= 7.0f && interRatio <= 10.0f;
+    const int raw = relation_to_idx(filt_j / target);
+    int minIdx = 0, maxIdx = 0;
+    {
+        float ratioLo = lo_j / target, ratioHi = hi_j / target;
+        if (ratioLo > ratioHi) {
+            const float t = ratioLo;
+            ratioLo = ratioHi;
+            ratioHi = t;
         }
-        const bool sticky = intraRatio <= 7.0f && interRatio <= 10.0f;
-        uint8_t sfLevel[32];
-        for (int i = 0; i < 32; ++i) {
-            int level = relation_to_idx(filtered[i] / target);
-            if (i > 0 && sticky) {
-                float ratioLo = lo[i] / target;
-                float ratioHi = hi[i] / target;
-                if (ratioLo > ratioHi) {
-                    const float t = ratioLo;
-                    ratioLo = ratioHi;
-                    ratioHi = t;
-                }
-                const int idxLo = relation_to_idx(ratioLo);
-                const int idxHi = relation_to_idx(ratioHi);
-                const int minIdx = idxLo < idxHi ? idxLo : idxHi;
-                const int maxIdx = idxLo < idxHi ? idxHi : idxLo;
-                const int prev = sfLevel[i - 1];
-                const int d = level - prev;
-                if (maxIdx - minIdx <= 1 && (d == 1 || d == -1) && prev >= minIdx && prev <= maxIdx) level = prev;
-            }
-            sfLevel[i] = (uint8_t)level;
-        }
-        int targetSf = 0;
-        for (int sf = 30; sf >= 0; --sf)
-            if (sfLevel[sf] != 4) {
-                targetSf = sf + 1;
-                break;
-            }
-        if (targetSf > 0) {
-            int tloc[32], tdelta[32];
-            uint8_t tlev[32];
-            int nt = 0;
-            int prev = 4;
-            for (int sf = targetSf - 1; sf >= 0; --sf) {
-                const int lev = sfLevel[sf];
-                if (lev != prev) {
-                    const int loc = sf + 1;
-                    const int delta = lev > prev ? lev - prev : prev - lev;
-                    bool keep = (loc == targetSf) || (delta >= 2);
-                    if (!keep) keep = boundary_score(filtered, loc) >= minScore;
-                    if (keep) {
-                        tloc[nt] = loc;
-                        tlev[nt] = (uint8_t)lev;
-                        tdelta[nt] = delta;
-                        ++nt;
-                        prev = lev;
+        const int idxLo = relation_to_idx(ratioLo), idxHi = relation_to_idx(ratioHi);
+        minIdx = idxLo < idxHi ? idxLo : idxHi;
+        maxIdx = idxLo < idxHi ? idxHi : idxLo;
+    }
+    int L = raw;
+    for (int jj = 1; jj < 32; ++jj) {   // sticky quantisation chain (:360-383)
+        const int prev = grp_readlane_i(L, jj - 1, half);
+        const int d = raw - prev;
+        if (j == jj && sticky && maxIdx - minIdx <= 1 && (d == 1 || d == -1) && prev >= minIdx && prev <= maxIdx) L = prev;
+    }
+    const unsigned long long nzm = __ballot(active && j <= 30 && L != 4);
+    const uint32_t gm = (uint32_t)(nzm >> (32 * half));
+    const int targetSf = gm ? 32 - __builtin_clz(gm) : 0;
+    // BoundaryTransientScore for loc = j (:255-274)
+    float bs = 1.0f;
+    if (j >= 1) {
+        float leftMax = 0.0f, rightMax = 0.0f;
+        for (int i = (j - 3 > 0 ? j - 3 : 0); i < j; ++i) leftMax = fmaxf(leftMax, s_filt[grp][i]);
+        for (int i = j; i < (j + 3 < 32 ? j + 3 : 32); ++i) rightMax = fmaxf(rightMax, s_filt[grp][i]);
+        const float eps = 1e-9f;
+        bs = fmaxf((rightMax + eps) / (leftMax + eps), (leftMax + eps) / (rightMax + eps));
+    }
+    // right-to-left transition scan (:404-450)
+    int nt = 0;
+    {
+        int prev = 4;
+        for (int sf = 30; sf >= 0; --sf) {
+            const int lev = grp_readlane_i(L, sf, half);
+            const float sc = grp_readlane_f(bs, sf + 1, half);
+            if (sf < targetSf && lev != prev) {
+                const int loc = sf + 1;
+                const int delta = lev > prev ? lev - prev : prev - lev;
+                const bool keep = (loc == targetSf) || (delta >= 2) || (sc >= minScore);
+                if (keep) {
+                    if (j == 0) {
+                        s_tloc[grp][nt] = loc;
+                        s_tlev[grp][nt] = lev;
+                        s_tdelta[grp][nt] = delta;
                     }
-                }
-            }
-            // entries are in descending loc order; the reference reverses to ascending
-            for (int i = 0, j = nt - 1; i < j; ++i, --j) {
-                const int a = tloc[i]; tloc[i] = tloc[j]; tloc[j] = a;
-                const int b = tdelta[i]; tdelta[i] = tdelta[j]; tdelta[j] = b;
-                const uint8_t cc = tlev[i]; tlev[i] = tlev[j]; tlev[j] = cc;
-            }
-            if (nt > 6) {
-                // stable sort by (delta desc, loc desc), keep 6, re-sort by loc
-                for (int i = 1; i < nt; ++i) {
-                    const int l0 = tloc[i], d0 = tdelta[i];
-                    const uint8_t v0 = tlev[i];
-                    int j = i - 1;
-                    while (j >= 0 && ((d0 != tdelta[j]) ? (d0 > tdelta[j]) : (l0 > tloc[j]))) {
-                        tloc[j + 1] = tloc[j]; tdelta[j + 1] = tdelta[j]; tlev[j + 1] = tlev[j];
-                        --j;
-                    }
-                    tloc[j + 1] = l0; tdelta[j + 1] = d0; tlev[j + 1] = v0;
-                }
-                nt = 6;
-                for (int i = 1; i < nt; ++i) {
-                    const int l0 = tloc[i], d0 = tdelta[i];
-                    const uint8_t v0 = tlev[i];
-                    int j = i - 1;
-                    while (j >= 0 && l0 < tloc[j]) {
-                        tloc[j + 1] = tloc[j]; tdelta[j + 1] = tdelta[j]; tlev[j + 1] = tlev[j];
-                        --j;
-                    }
-                    tloc[j + 1] = l0; tdelta[j + 1] = d0; tlev[j + 1] = v0;
-                }
-            }
-            if (nt > 0) {
-                have = true;
-                pts.n = (uint8_t)nt;
-                for (int i = 0; i < nt; ++i) {
-                    pts.level[i] = tlev[i];
-                    pts.loc[i] = (uint8_t)tloc[i];
+                    ++nt;
+                    prev = lev;
                 }
             }
         }
     }
-    if (!have) {  // "skip: no_curve" (atrac3denc.cpp:395-400)
-        *dst = out;
-        return;
+    wave_sync();
+    if (j == 0 && nt > 0) {
+        int* tloc = s_tloc[grp];
+        int* tlev = s_tlev[grp];
+        int* tdelta = s_tdelta[grp];
+        for (int a = 0, b = nt - 1; a < b; ++a, --b) {   // descending loc -> ascending
+            const int x0 = tloc[a]; tloc[a] = tloc[b]; tloc[b] = x0;
+            const int x1 = tdelta[a]; tdelta[a] = tdelta[b]; tdelta[b] = x1;
+            const int x2 = tlev[a]; tlev[a] = tlev[b]; tlev[b] = x2;
+        }
+        if (nt > 6) {   // keep the 6 largest |delta| (ties: rightmost), stable; then back to loc order (:462-475)
+            for (int i = 1; i < nt; ++i) {
+                const int l0 = tloc[i], d0 = tdelta[i], v0 = tlev[i];
+                int k = i - 1;
+                while (k >= 0 && ((d0 != tdelta[k]) ? (d0 > tdelta[k]) : (l0 > tloc[k]))) {
+                    tloc[k + 1] = tloc[k]; tdelta[k + 1] = tdelta[k]; tlev[k + 1] = tlev[k];
+                    --k;
+                }
+                tloc[k + 1] = l0; tdelta[k + 1] = d0; tlev[k + 1] = v0;
+            }
+            for (int i = 1; i < 6; ++i) {
+                const int l0 = tloc[i], d0 = tdelta[i], v0 = tlev[i];
+                int k = i - 1;
+                while (k >= 0 && l0 < tloc[k]) {
+                    tloc[k + 1] = tloc[k]; tdelta[k + 1] = tdelta[k]; tlev[k + 1] = tlev[k];
+                    --k;
+                }
+                tloc[k + 1] = l0; tdelta[k + 1] = d0; tlev[k + 1] = v0;
+            }
+        }
     }
+    wave_sync();
+    if (nt > 6) nt = 6;
+    CurvePts pts;
+    pts.n = (active && targetSf > 0) ? nt : 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        pts.level[i] = (i < pts.n) ? s_tlev[grp][i] : 0;
+        pts.loc[i] = (i < pts.n) ? s_tloc[grp][i] : 0;
+    }
+    const bool have = pts.n > 0;   // else "skip: no_curve" (atrac3denc.cpp:395-400)
 
     // ---- CreateSubbandInfo tail (atrac3denc.cpp:410-577), band < 3 ----
-    float maxGain = 0.0f;
-    for (int i = 0; i < 32; ++i) maxGain = fmaxf(maxGain, in[i]);
     if (maxGain < 1e-4f) pts.n = 0;
     if (hfr < 0.3f) pts.n = 0;
+    const CurvePts before = pts;
+    bool changed = false;
+    float hpfRmsNextMod = 0.0f;
+    bool validMod = false;
     {
-        const Curve before = pts;
-        bool changed = false;
-        float hpfRmsNextMod = 0.0f;
-        bool valid = false;
+        const int nBefore = (pts.n > 0) ? pts.loc[0] : 32;
+        float sum = 0.0f;
+        for (int sf = 0; sf < 32; ++sf) {   // ordered sum of the first nBefore gains
+            const float v = s_in[grp][sf];
+            if (sf < nBefore) sum += v;
+        }
         if (pts.n > 0 && pts.loc[0] > 0) {
-            const uint32_t nBefore = pts.loc[0];
-            const float divisor = T->gain_level[pts.level[0]];
-            float sum = 0.0f;
-            for (uint32_t sf = 0; sf < nBefore; ++sf) sum += in[sf];
-            hpfRmsNextMod = (sum / nBefore) / divisor;
-            valid = true;
+            hpfRmsNextMod = (sum / (float)nBefore) / T->gain_level[pts.level[0]];
+            validMod = true;
         } else if (pts.n == 0) {
-            float sum = 0.0f;
-            for (int i = 0; i < 32; ++i) sum += in[i];
             hpfRmsNextMod = sum / 32;
-            valid = true;
-        }
-        const bool p0ok = valid && prevTarget > 1e-6f && hpfRmsNextMod > 1e-6f;
-        if (p0ok) {
-            const int p0 = relation_to_idx_hdr(prevTarget / hpfRmsNextMod);
-            int it = -1;
-            for (int i = 0; i < pts.n; ++i)
-                if (pts.loc[i] == 0) {
-                    it = i;
-                    break;
-                }
-            if (it >= 0) {
-                if (pts.level[it] != p0) {
-                    pts.level[it] = (uint8_t)p0;
-                    changed = true;
-                }
-            } else if (p0 != 4 || pts.n > 0) {
-                for (int i = pts.n; i > 0; --i) {
-                    pts.level[i] = pts.level[i - 1];
-                    pts.loc[i] = pts.loc[i - 1];
-                }
-                pts.level[0] = (uint8_t)p0;
-                pts.loc[0] = 0;
-                pts.n++;
-                changed = true;
-            }
-        }
-        if (changed) {
-            const float scoreBefore = early_mismatch_score(T, in, target, before);
-            const float scoreAfter = early_mismatch_score(T, in, target, pts);
-            bool keepByBoundary = false;
-            if (p0ok) {
-                const float x = prevTarget / hpfRmsNextMod;
-                const float desired = fminf(fmaxf(x, T->gain_level[15]), T->gain_level[0]);
-                const float scaleBefore = T->gain_level[before.n == 0 ? 4 : before.level[0]];
-                const float scaleAfter = T->gain_level[pts.n == 0 ? 4 : pts.level[0]];
-                const float eps = 1e-9f;
-                const float errBefore = fabsf(at3_log2f(T, fmaxf(scaleBefore, eps) / fmaxf(desired, eps)));
-                const float errAfter = fabsf(at3_log2f(T, fmaxf(scaleAfter, eps) / fmaxf(desired, eps)));
-                keepByBoundary = (errAfter + 0.20f < errBefore);
-            }
-            if (!keepByBoundary && scoreAfter > scoreBefore * (1.0f + 0.02f)) pts = before;
+            validMod = true;
         }
     }
+    const bool p0ok = validMod && prevTarget > 1e-6f && hpfRmsNextMod > 1e-6f;
+    if (p0ok) {
+        const int p0 = relation_to_idx_hdr(prevTarget / hpfRmsNextMod);
+        int it = -1;
+#pragma unroll
+        for (int i = 6; i >= 0; --i)
+            if (i < pts.n && pts.loc[i] == 0) it = i;
+        if (it >= 0) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+                if (i == it && pts.level[i] != p0) {
+                    pts.level[i] = p0;
+                    changed = true;
+                }
+        } else if (p0 != 4 || pts.n > 0) {
+#pragma unroll
+            for (int i = 6; i > 0; --i) {
+                pts.level[i] = pts.level[i - 1];
+                pts.loc[i] = pts.loc[i - 1];
+            }
+            pts.level[0] = p0;
+            pts.loc[0] = 0;
+            pts.n++;
+            changed = true;
+        }
+    }
+    // both scores are evaluated unconditionally (wave-uniform control flow); used only when `changed`
+    const float scoreBefore = early_mismatch_score_grp(T, in_j, in_next, target, before, s_tmp[grp], j, half);
+    const float scoreAfter = early_mismatch_score_grp(T, in_j, in_next, target, pts, s_tmp[grp], j, half);
+    if (changed) {
+        bool keepByBoundary = false;
+        if (p0ok) {
+            const float x = prevTarget / hpfRmsNextMod;
+            const float desired = fminf(fmaxf(x, T->gain_level[15]), T->gain_level[0]);
+            const float scaleBefore = T->gain_level[before.n == 0 ? 4 : before.level[0]];
+            const float scaleAfter = T->gain_level[pts.n == 0 ? 4 : pts.level[0]];
+            const float eps = 1e-9f;
+            const float errBefore = fabsf(at3_log2f(T, fmaxf(scaleBefore, eps) / fmaxf(desired, eps)));
+            const float errAfter = fabsf(at3_log2f(T, fmaxf(scaleAfter, eps) / fmaxf(desired, eps)));
+            keepByBoundary = (errAfter + 0.20f < errBefore);
+        }
+        if (!keepByBoundary && scoreAfter > scoreBefore * (1.0f + 0.02f)) pts = before;
+    }
     if (pts.n >= 2 && pts.loc[0] == 0 && pts.level[0] == pts.level[1]) {
-        for (int i = 1; i < pts.n; ++i) {
+#pragma unroll
+        for (int i = 1; i < 7; ++i) {
             pts.level[i - 1] = pts.level[i];
             pts.loc[i - 1] = pts.loc[i];
         }
         pts.n--;
     }
-    for (int i = pts.n; i < 7; ++i) {
-        pts.level[i] = 0;
-        pts.loc[i] = 0;
+    if (valid && j == 0) {
+        Curve out;
+        out.pad = 0;
+        out.n = (uint8_t)(have ? pts.n : 0);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const bool on = have && i < pts.n;
+            out.level[i] = (uint8_t)(on ? pts.level[i] : 0);
+            out.loc[i] = (uint8_t)(on ? pts.loc[i] : 0);
+        }
+        *dst = out;
     }
-    *dst = pts;
 }
 
 }  // namespace at3
