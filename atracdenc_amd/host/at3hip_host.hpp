@@ -1,0 +1,202 @@
+// Host-side C++ mirror of the reference's surface for the ATRAC3 encode hot path, over the C ABI
+// (include/at3hip.h). Same names, argument meaning and error behaviour as the reference classes:
+//
+//   TAtrac3MDCT      atrac3denc.h:56-92   (Mdct with in-place band mutation, CalcGainEnergyScale omitted:
+//                                          it is computed inside the fused kernel of the encoder)
+//   TAtrac3Encoder   atrac3denc.h:94-134  (IProcessor::GetLambda() -> functor called once per 1024-sample
+//                                          block; ICompressedOutput::WriteFrame once per encoded frame)
+//
+// The reference encoder is one stream, one frame per lambda call. The GPU path wants thousands of frames
+// per launch, so TAtrac3Encoder here buffers `BatchBlocks` lambda calls, returns PROCESSED immediately
+// (LOOK_AHEAD for the very first call, as the reference does) and flushes WriteFrame calls in order when
+// the batch is full or on Flush()/destruction: observable behaviour equals the reference except latency.
+// TAtrac3EncoderBatch is the natural multi-stream form (n independent streams side by side).
+//
+// Header-only; link with -lat3hip. Exceptions: std::runtime_error on any at3hip error (the reference
+// throws from its sinks and aborts on impossible states; it never returns error codes).
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/at3hip.h"
+
+namespace NAtracDEncHip {
+
+// ---- the two reference interfaces on either side of the hot path (pcmengin.h:111-199, compressed_io.h:56-59)
+struct ProcessMeta {
+    const uint16_t Channels;
+};
+enum class EProcessResult { LOOK_AHEAD, PROCESSED };
+using TProcessLambda = std::function<EProcessResult(float* data, const ProcessMeta& meta)>;
+
+class ICompressedOutput {
+public:
+    virtual ~ICompressedOutput() = default;
+    virtual void WriteFrame(std::vector<char> data) = 0;
+    virtual std::string GetName() const = 0;
+    virtual size_t GetChannelNum() const = 0;
+};
+using TCompressedOutputPtr = std::unique_ptr<ICompressedOutput>;
+
+// NAtrac3::TAtrac3EncoderSettings (atrac/at3/atrac3.h:260-277)
+struct TAtrac3EncoderSettings {
+    uint32_t Bitrate = 0;            // bit/s; 0 = LP2 132300 (atrac3.cpp:47-53)
+    bool NoGainControll = false;
+    bool NoTonalComponents = false;
+    uint8_t SourceChannels = 2;
+    uint32_t BfuIdxConst = 0;
+};
+
+struct TGainPoint {                  // TAtrac3Data::SubbandInfo::TGainPoint (atrac3.h:224-227)
+    uint32_t Level;
+    uint32_t Location;
+};
+
+inline void Check(int rc, at3hip_ctx* ctx, const char* what)
+{
+    if (rc != AT3HIP_OK)
+        throw std::runtime_error(std::string(what) + ": " + (ctx ? at3hip_last_error(ctx) : "at3hip error " + std::to_string(rc)));
+}
+
+// ---- TAtrac3MDCT (atrac3denc.h:56-92) ------------------------------------------------------------------
+class TAtrac3MDCT {
+public:
+    using TGainCurves = std::array<std::vector<TGainPoint>, 4>;  // what MakeGainModulatorArray receives
+
+    explicit TAtrac3MDCT(int deviceId = 0)
+    {
+        at3hip_config cfg{};
+        cfg.channels = 2;
+        cfg.n_streams = 1;
+        cfg.max_blocks = 2;
+        cfg.device_id = deviceId;
+        cfg.no_gain_control = 1;
+        Check(at3hip_create(&cfg, &Ctx), nullptr, "at3hip_create");
+    }
+    ~TAtrac3MDCT() { at3hip_destroy(Ctx); }
+    TAtrac3MDCT(const TAtrac3MDCT&) = delete;
+    TAtrac3MDCT& operator=(const TAtrac3MDCT&) = delete;
+
+    // Same contract as the reference: bands[b] -> 512 floats [overlap | new], mutated in place.
+    void Mdct(float specs[1024], float* bands[4], const TGainCurves& curves = TGainCurves())
+    {
+        float packed[4 * 512];
+        int32_t n[4], level[32] = {0}, loc[32] = {0};
+        bool any = false;
+        for (int b = 0; b < 4; ++b) {
+            memcpy(packed + 512 * b, bands[b], 512 * sizeof(float));
+            n[b] = (int32_t)curves[b].size();
+            any = any || n[b] > 0;
+            for (int i = 0; i < n[b] && i < 8; ++i) {
+                level[8 * b + i] = (int32_t)curves[b][i].Level;
+                loc[8 * b + i] = (int32_t)curves[b][i].Location;
+            }
+        }
+        Check(at3hip_mdct(Ctx, packed, specs, any ? n : nullptr, any ? level : nullptr, any ? loc : nullptr, 1, 0), Ctx,
+              "at3hip_mdct");
+        for (int b = 0; b < 4; ++b) memcpy(bands[b], packed + 512 * b, 512 * sizeof(float));
+    }
+
+private:
+    at3hip_ctx* Ctx = nullptr;
+};
+
+// ---- n streams side by side: the batch form of TAtrac3Encoder --------------------------------------------
+class TAtrac3EncoderBatch {
+public:
+    TAtrac3EncoderBatch(const TAtrac3EncoderSettings& s, int nStreams, int maxBlocks, int deviceId = 0)
+        : NStreams(nStreams)
+    {
+        at3hip_config cfg{};
+        cfg.bitrate = (int32_t)s.Bitrate;
+        cfg.channels = s.SourceChannels;
+        cfg.no_gain_control = s.NoGainControll;
+        cfg.no_tonal = s.NoTonalComponents;
+        cfg.bfu_idx_const = (int32_t)s.BfuIdxConst;
+        cfg.n_streams = nStreams;
+        cfg.max_blocks = maxBlocks;
+        cfg.device_id = deviceId;
+        Check(at3hip_create(&cfg, &Ctx), nullptr, "at3hip_create");
+        FrameSz = at3hip_frame_size(Ctx);
+    }
+    ~TAtrac3EncoderBatch() { at3hip_destroy(Ctx); }
+    TAtrac3EncoderBatch(const TAtrac3EncoderBatch&) = delete;
+    TAtrac3EncoderBatch& operator=(const TAtrac3EncoderBatch&) = delete;
+
+    int FrameSize() const { return FrameSz; }
+    // pcm [nStreams][nBlocks][1024][2] -> frames [nStreams][nFrames][FrameSize()]; returns nFrames per stream.
+    int Encode(const float* pcm, int nBlocks, std::vector<uint8_t>& frames)
+    {
+        frames.resize((size_t)NStreams * nBlocks * FrameSz);
+        int32_t nf = 0;
+        Check(at3hip_encode(Ctx, pcm, nBlocks, frames.data(), &nf, 0), Ctx, "at3hip_encode");
+        frames.resize((size_t)NStreams * nf * FrameSz);
+        return nf;
+    }
+    void Reset() { Check(at3hip_reset(Ctx), Ctx, "at3hip_reset"); }
+    at3hip_ctx* Handle() { return Ctx; }
+
+private:
+    at3hip_ctx* Ctx = nullptr;
+    int NStreams;
+    int FrameSz = 0;
+};
+
+// ---- TAtrac3Encoder (atrac3denc.h:94-134): lambda in, WriteFrame out -------------------------------------
+class TAtrac3Encoder {
+public:
+    TAtrac3Encoder(TCompressedOutputPtr&& oma, TAtrac3EncoderSettings&& settings, int batchBlocks = 64, int deviceId = 0)
+        : Oma(std::move(oma)), Params(settings), BatchBlocks(batchBlocks), Batch(settings, 1, batchBlocks, deviceId)
+    {
+        if (Params.SourceChannels != 2) throw std::runtime_error("TAtrac3Encoder(hip): stereo input only");
+        Pending.reserve((size_t)BatchBlocks * 2048);
+    }
+    ~TAtrac3Encoder()
+    {
+        try {
+            Flush();
+        } catch (...) {
+        }
+    }
+
+    TProcessLambda GetLambda()
+    {
+        return [this](float* data, const ProcessMeta& meta) {
+            if (meta.Channels != 2) throw std::runtime_error("TAtrac3Encoder(hip): stereo input only");
+            Pending.insert(Pending.end(), data, data + 2048);
+            const bool first = (Calls++ == 0);
+            if ((int)(Pending.size() / 2048) == BatchBlocks) Flush();
+            return first ? EProcessResult::LOOK_AHEAD : EProcessResult::PROCESSED;   // atrac3denc.cpp:715-718, 865
+        };
+    }
+
+    // Encode what is buffered and hand the frames to the sink in order.
+    void Flush()
+    {
+        const int nb = (int)(Pending.size() / 2048);
+        if (nb == 0) return;
+        std::vector<uint8_t> frames;
+        const int nf = Batch.Encode(Pending.data(), nb, frames);
+        Pending.clear();
+        const int fsz = Batch.FrameSize();
+        for (int i = 0; i < nf; ++i)
+            Oma->WriteFrame(std::vector<char>(frames.begin() + (size_t)i * fsz, frames.begin() + (size_t)(i + 1) * fsz));
+    }
+
+private:
+    TCompressedOutputPtr Oma;
+    const TAtrac3EncoderSettings Params;
+    const int BatchBlocks;
+    TAtrac3EncoderBatch Batch;
+    std::vector<float> Pending;
+    uint64_t Calls = 0;
+};
+
+}  // namespace NAtracDEncHip

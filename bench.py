@@ -92,9 +92,8 @@ def main():
     import torch
     import atracdenc_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from atracdenc_amd import dist as at3dist
+    rank, local_rank, world = at3dist.env_world()
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -102,9 +101,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = at3dist.init("nccl", local_rank)   # RCCL: barrier + MAX of elapsed time only, no data-path collective
 
     S, F = args.streams, args.frames
     enc = atracdenc_amd.At3Hip(n_streams=S, max_blocks=F + 1, bitrate=args.bitrate, no_gain=args.no_gain,
@@ -139,10 +136,7 @@ def main():
                 stage_ms[k] = stage_ms.get(k, 0.0) + v
     sync()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = at3dist.max_over_ranks(elapsed, dist, device="cuda")
     checksum = int(d_out.to(torch.int64).sum().item())
 
     if rank == 0:

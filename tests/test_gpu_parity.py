@@ -162,3 +162,19 @@ def test_error_handling(hip):
     with pytest.raises(hip.At3HipError):
         enc.encode(np.zeros((1, 3, 1024, 2), np.float32))     # more blocks than max_blocks
     enc.close()
+
+
+def test_host_cpp_shim(hip, oracle, tmp_path):
+    """The C++ mirror of TAtrac3Encoder / TAtrac3MDCT (atracdenc_amd/host/at3hip_host.hpp) over the C ABI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_host_shim")
+    libdir = os.path.join(root, "atracdenc_amd")
+    odir = os.path.join(root, "oracle")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "tests", "host", "test_host_shim.cpp"), "-o", exe,
+                           f"-L{libdir}", "-lat3hip", f"-L{odir}", "-lat3oracle", f"-Wl,-rpath,{libdir}",
+                           f"-Wl,-rpath,{odir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "HOST SHIM TEST OK" in out.stdout
