@@ -93,6 +93,29 @@ __device__ static const uint16_t c_huff[130] = {
     HE(0xFC, 8), HE(0xFD, 8), HE(0xFE, 8), HE(0xFF, 8), HE(0x2, 4), HE(0x3, 4)};
 #undef HE
 
+// Arithmetic forms of the small tables: a dependent global-memory look-up inside a loop costs hundreds of
+// cycles per iteration, these cost a few VALU ops.
+__device__ __forceinline__ int bfu_start(int b)   // == c_bfu_start[b], 0 <= b <= 32
+{
+    return b < 8 ? 8 * b : b < 16 ? 64 + 16 * (b - 8) : b < 26 ? 192 + 32 * (b - 16) : b < 30 ? 512 + 64 * (b - 26) : 768 + 128 * (b - 30);
+}
+__device__ __forceinline__ int bfu_of_line(int i)  // BFU that holds spectral line i, 0 <= i < 1024
+{
+    return i < 64 ? i >> 3 : i < 192 ? 8 + ((i - 64) >> 4) : i < 512 ? 16 + ((i - 192) >> 5) : i < 768 ? 26 + ((i - 512) >> 6) : 30 + ((i - 768) >> 7);
+}
+__device__ __forceinline__ float max_quant(int wl)  // == c_max_quant[wl]
+{
+    return wl <= 4 ? (wl == 0 ? 0.0f : (float)wl + 0.5f) : wl == 5 ? 7.5f : wl == 6 ? 15.5f : 31.5f;
+}
+__device__ __forceinline__ int clc_len(int wl)      // == c_clc_len[wl]
+{
+    return wl == 0 ? 0 : wl == 1 ? 4 : wl <= 3 ? 3 : wl <= 5 ? 4 : wl == 6 ? 5 : 6;
+}
+__device__ __forceinline__ int huff_off(int sel)    // == c_huff_off[sel - 1]
+{
+    return sel == 2 ? 9 : sel == 3 ? 14 : sel == 5 ? 21 : sel == 6 ? 36 : sel == 7 ? 67 : 0;
+}
+
 __device__ __forceinline__ cpx cmul(cpx a, cpx b)
 {
     cpx m;

@@ -32,6 +32,7 @@ struct BackParams {
     int bfu_idx_const;
     struct QuantRec* quant;  // [S][n_out][2] per-unit tables written by k_quant, read by k_rate_pack
     int8_t* mant;            // [S][n_out][2][7][1024] mantissas for every wordlen
+    int debug_stop;          // profiling aid (env AT3HIP_DEBUG_STOP): leave k_quant after phase N; 0 = run everything
 };
 
 struct QuantRec {            // per (stream, frame, channel)
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
 
     if (!p.no_tonal && tid >= 8 && tid < 29) {
         const int b = tid;
-        const int start = c_bfu_start[b], end = c_bfu_start[b + 1], len = end - start;
+        const int start = bfu_start(b), end = bfu_start(b + 1), len = end - start;
         double arith = 0.0, meanLog = 0.0;
         for (int i = start; i < end; ++i) {
             arith += (double)fmaxf(0.0f, s_e[i]);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     __syncthreads();
 
     if (tid < 32) {
-        const int start = c_bfu_start[tid], len = c_bfu_start[tid + 1] - start;
+        const int start = bfu_start(tid), len = bfu_start(tid + 1) - start;
         float e;
         const int sfi = scale_block(T, s_spec + start, len, nullptr, &e);
         rec->sfi[tid] = (uint8_t)sfi;
@@ -231,7 +232,7 @@ __device__ inline void put_bits(uint32_t* words, int pos, uint32_t val, int n)
     }
 }
 
-__device__ inline uint32_t huff_entry(int sel, uint32_t idx) { return c_huff[c_huff_off[sel - 1] + idx]; }
+__device__ inline uint32_t huff_entry(int sel, uint32_t idx) { return c_huff[huff_off(sel) + idx]; }
 
 __device__ inline uint32_t vlc_index(int m)
 {
@@ -246,7 +247,7 @@ __device__ inline uint32_t spec_code(int wl, bool clc, const int8_t* m, int i)
 {
     if (wl > 1) {
         if (clc) {
-            const int nb = c_clc_len[wl];
+            const int nb = clc_len(wl);
             return ((uint32_t)m[i] & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
         }
         const uint32_t e = huff_entry(wl, vlc_index(m[i]));
@@ -573,7 +574,7 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
                         put_bits(words, pos + used, tb.sfi, 6);
                         put_bits(words, pos + used + 6, (uint32_t)tb.pos - (uint32_t)j * 64, 6);
                         int bp = pos + used + 12;
-                        const float mul = c_max_quant[q < 7 ? q : 7];
+                        const float mul = max_quant(q < 7 ? q : 7);
                         for (int z = 0; z < tb.len; ++z) {
                             const int m = __float2int_rn(tb.values[z] * mul);
                             const uint32_t e = huff_entry(q, vlc_index(m));
@@ -603,7 +604,7 @@ constexpr int kQuantThreads = 256;
 
 __device__ __forceinline__ uint32_t lds_huff(const uint16_t* s_huff, int sel, uint32_t idx)
 {
-    return s_huff[c_huff_off[sel - 1] + idx];
+    return s_huff[huff_off(sel) + idx];
 }
 
 __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tables* T)
@@ -634,8 +635,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     // ---- scaled values (TScaler::Scale): thread t owns lines 4t..4t+3 (BFU sizes are multiples of 8) ----
     {
         const int i0 = tid * 4;
-        int b = 0;
-        while (c_bfu_start[b + 1] <= i0) ++b;
+        const int b = bfu_of_line(i0);
         const float sf = T->scale[rec->sfi[b]];
         const float4 x = *reinterpret_cast<const float4*>(specs + i0);
         float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         // ---- (A) mantissa = lrint(value * MaxQuant[wl]) for every wordlen ----
 #pragma unroll
         for (int wl = 1; wl <= 7; ++wl) {
-            const float mul = c_max_quant[wl];
+            const float mul = max_quant(wl);
             const uint32_t pk = ((uint32_t)(uint8_t)__float2int_rn(v[0] * mul)) | ((uint32_t)(uint8_t)__float2int_rn(v[1] * mul) << 8) |
                                 ((uint32_t)(uint8_t)__float2int_rn(v[2] * mul) << 16) | ((uint32_t)(uint8_t)__float2int_rn(v[3] * mul) << 24);
             *reinterpret_cast<uint32_t*>(s_mant + (wl - 1) * 1024 + i0) = pk;
@@ -656,11 +656,12 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     }
     __syncthreads();
 
+    if (p.debug_stop == 1) return;
     // ---- (B) ordered sums, one chain per thread: tid < 32 -> e1 of bfu 31 - tid; else e2 of unit tid - 32 ----
     //      unit u: bfu = 31 - u / 7, wl = 1 + u % 7 (largest BFUs first so long chains share a wavefront)
     if (tid < 32) {
         const int bfu = 31 - tid;
-        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
         float e1 = 0.0f;
         for (int j = 0; j < n; j += 4) {
             const float4 v = *reinterpret_cast<const float4*>(s_val + start + j);
@@ -673,8 +674,8 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     } else {
         const int u = tid - 32;
         const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
-        const float mul = c_max_quant[wl];
+        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
+        const float mul = max_quant(wl);
         const float inv2 = (float)(1.0 / (double)(mul * mul));
         const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
         float e2 = 0.0f;
@@ -688,12 +689,13 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         }
         s_err[wl * 32 + bfu] = e2;
     }
+    if (p.debug_stop == 2) return;
     // ---- (C1) candidates of the energy-adaptive units (bfu > 18) ----
     if (tid >= 160 && tid < 160 + 91) {
         const int u = tid - 160;
         const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
-        const float mul = c_max_quant[wl];
+        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
+        const float mul = max_quant(wl);
         uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
         int nc = 0;
         for (int j = 0; j < n; j += 4) {
@@ -710,9 +712,10 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         s_tie[(wl - 1) * 13 + (bfu - 19)] = 0;
     }
     __syncthreads();
+    if (p.debug_stop == 3) return;
     // ---- (C2) rank sort by |delta|, one wordlen plane at a time; unused key slots hold +inf ----
     for (int wl = 1; wl <= 7; ++wl) {
-        const float mul = c_max_quant[wl];
+        const float mul = max_quant(wl);
         const uint8_t* plane = s_cand + (wl - 1) * kEaLines;
         uint8_t* sorted = s_sorted + (wl - 1) * kEaLines;
         int slot_bfu[3], slot_k[3];
@@ -723,9 +726,8 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
             slot_bfu[r] = 19;
             if (slot < kEaLines) {
                 const int line = kEaLine0 + slot;
-                int bfu = 19;
-                while (c_bfu_start[bfu + 1] <= line) ++bfu;
-                const int start = c_bfu_start[bfu];
+                const int bfu = bfu_of_line(line);
+                const int start = bfu_start(bfu);
                 const int k = line - start;
                 float key = __builtin_huge_valf();
                 if (k < s_nc[(wl - 1) * 13 + (bfu - 19)]) {
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         for (int r = 0; r < 3; ++r) {
             if (slot_k[r] >= 0) {
                 const int bfu = slot_bfu[r], k = slot_k[r];
-                const int base = c_bfu_start[bfu] - kEaLine0;
+                const int base = bfu_start(bfu) - kEaLine0;
                 const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
                 const float key = s_key[base + k];
                 int rank = 0, eq = 0;
@@ -761,14 +763,15 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         }
         __syncthreads();
     }
+    if (p.debug_stop == 4) return;
     // ---- (C3) equal keys: libstdc++'s std::sort order decides (rare) ----
     if (s_anytie) {
         if (tid == 0) {
             for (int u = 0; u < 91; ++u) {
                 const int bfu = 31 - u / 7, wl = 1 + u % 7;
                 if (!s_tie[(wl - 1) * 13 + (bfu - 19)]) continue;
-                const int start = c_bfu_start[bfu];
-                const float mul = c_max_quant[wl];
+                const int start = bfu_start(bfu);
+                const float mul = max_quant(wl);
                 const uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
                 const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
                 for (int q = 0; q < nc; ++q) {
@@ -784,15 +787,16 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         }
         __syncthreads();
     }
+    if (p.debug_stop == 5) return;
     // ---- (C4) greedy re-rounding per energy-adaptive unit; e1 / e2 for every unit ----
     if (tid < 224) {
         const int u = tid;
         const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = c_bfu_start[bfu];
+        const int start = bfu_start(bfu);
         const float e1 = s_e1[bfu];
         float e2 = s_err[wl * 32 + bfu];
         if (bfu > 18) {
-            const float mul = c_max_quant[wl];
+            const float mul = max_quant(wl);
             const float inv2 = (float)(1.0 / (double)(mul * mul));
             int8_t* mant = s_mant + (wl - 1) * 1024 + start;
             const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
@@ -802,11 +806,12 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         s_err[wl * 32 + bfu] = e1 / e2;
     }
     __syncthreads();
+    if (p.debug_stop == 6) return;
     // ---- (D) VLC cost of the final mantissas: 8 partial sums per unit, combined with LDS atomics ----
     for (int task = tid; task < 224 * 8; task += kQuantThreads) {
         const int u = task >> 3, part = task & 7;
         const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = c_bfu_start[bfu], n = c_bfu_start[bfu + 1] - start;
+        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
         const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
         const int per = n >> 3;  // 1, 2, 4, 8 or 16 lines per task (n is a multiple of 8)
         uint32_t bits = 0;
@@ -824,12 +829,13 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         atomicAdd(&s_vlc[wl * 32 + bfu], bits);
     }
     __syncthreads();
+    if (p.debug_stop == 7) return;
     // ---- results to HBM ----
     QuantRec* q = p.quant + cf;
     if (tid < 224) {
         const int wl = 1 + tid / 32, bfu = tid % 32;
-        const int n = c_bfu_start[bfu + 1] - c_bfu_start[bfu];
-        const uint32_t clc = (wl > 1) ? (uint32_t)c_clc_len[wl] * n : 2u * n;
+        const int n = bfu_start(bfu + 1) - bfu_start(bfu);
+        const uint32_t clc = (wl > 1) ? (uint32_t)clc_len(wl) * n : 2u * n;
         q->err[wl - 1][bfu] = s_err[wl * 32 + bfu];
         q->cost[wl - 1][bfu] = clc | (s_vlc[wl * 32 + bfu] << 13);
     }
@@ -930,7 +936,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
     for (int idx = lane; idx < n_tonal * 6; idx += 64) {
         const int t = idx / 6, qq = 2 + idx % 6;
         const TonalBlock& tb = rec->tonal[t];
-        const float mul = c_max_quant[qq];
+        const float mul = max_quant(qq);
         int bits = 0;
         for (int z = 0; z < tb.len; ++z) bits += (int)(huff_entry(qq, vlc_index(__float2int_rn(tb.values[z] * mul))) >> 8);
         s_tbits[t * 8 + qq] = (uint8_t)bits;
@@ -1110,8 +1116,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int i0 = base + 8 * hlf;
-            int b = 0;
-            while (c_bfu_start[b + 1] <= i0) ++b;
+            const int b = bfu_of_line(i0);
             const int wl = (b < num_bfu) ? s_alloc[b] : 0;
             int8_t m8[8];
             if (wl) {
@@ -1124,7 +1129,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
                 uint32_t cl = 0;
                 if (wl > 1) {
                     if (mode == 1) {
-                        const int nb = c_clc_len[wl];
+                        const int nb = clc_len(wl);
                         cl = ((uint32_t)m8[k] & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
                     } else {
                         const uint32_t e = lds_huff(s_huff, wl, vlc_index(m8[k]));

@@ -314,6 +314,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.js = c->js;
         bp.frame_sz = c->frame_sz;
         bp.bfu_idx_const = c->cfg.bfu_idx_const;
+        bp.debug_stop = getenv("AT3HIP_DEBUG_STOP") ? atoi(getenv("AT3HIP_DEBUG_STOP")) : 0;
         bp.quant = c->d_quant;
         bp.mant = c->d_mant;
         hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
