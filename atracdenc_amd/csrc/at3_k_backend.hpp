@@ -591,16 +591,17 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
     return used;
 }
 
-// ---- quantisation kernel: one 256-thread workgroup per (stream, output frame, channel) -----------------
+// ---- quantisation kernel: one 128-thread workgroup per (stream, output frame, channel, wordlen) ----------
 //
-// Computes what TEncCache would compute lazily - every (bfu, wordlen) unit - so the rate loop that follows
-// is pure table look-up: (A) all 7 x 1024 roundings in parallel; (B) the strictly ordered energy sums as 256
-// independent chains (32 x e1, 224 x e2), one per thread, longest chains on the first wave; (C) the
-// energy-adaptive re-rounding of BFUs 19..31: candidate lists in LDS, parallel rank sort (falls back to the
-// libstdc++-order sort when two candidates tie), sequential greedy pass per unit; (D) CLC / VLC bit costs.
+// Computes what TEncCache would compute lazily - every (bfu, wordlen) unit - so the rate loop that follows is
+// pure table look-up. Per workgroup (one wordlen plane): 1024 roundings; the strictly ordered energy sums as 64
+// independent chains (32 x e1, 32 x e2), one per thread; the energy-adaptive re-rounding of BFUs 19..31
+// (candidate lists in LDS, parallel rank sort by |delta| that falls back to the libstdc++-order sort when two
+// candidates tie, sequential greedy pass per unit); CLC / VLC bit costs. Seven small workgroups per channel-frame
+// instead of one big one: no loop over planes, 10 KB of LDS, sixteen workgroups resident per CU.
 constexpr int kEaLine0 = 288;              // first spectral line of BFU 19
 constexpr int kEaLines = 1024 - kEaLine0;  // 736
-constexpr int kQuantThreads = 256;
+constexpr int kQuantThreads = 128;
 
 __device__ __forceinline__ uint32_t lds_huff(const uint16_t* s_huff, int sel, uint32_t idx)
 {
@@ -610,55 +611,58 @@ __device__ __forceinline__ uint32_t lds_huff(const uint16_t* s_huff, int sel, ui
 __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) float s_val[1024];
-    __shared__ __attribute__((aligned(16))) int8_t s_mant[7 * 1024];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cand[7 * kEaLines];   // candidate lines (relative to the BFU), scan order
-    __shared__ __attribute__((aligned(16))) uint8_t s_sorted[7 * kEaLines]; // the same, ordered by |delta|
-    __shared__ __attribute__((aligned(16))) float s_key[kEaLines];          // |delta| of one wordlen plane at a time
-    __shared__ uint8_t s_nc[7 * 13];
-    __shared__ uint8_t s_tie[7 * 13];
+    __shared__ __attribute__((aligned(16))) int8_t s_mant[1024];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cand[kEaLines];    // candidate lines (relative to the BFU), scan order
+    __shared__ __attribute__((aligned(16))) uint8_t s_sorted[kEaLines];  // the same, ordered by |delta|
+    __shared__ __attribute__((aligned(16))) float s_key[kEaLines];       // |delta| per candidate slot, +inf when unused
+    __shared__ uint8_t s_nc[13];
+    __shared__ uint8_t s_tie[13];
     __shared__ float s_e1[32];
-    __shared__ float s_err[8 * 32];            // e2 during phases B/C, then e1 / e2
-    __shared__ uint32_t s_vlc[8 * 32];
+    __shared__ float s_e2[32];
+    __shared__ uint32_t s_vlc[32];
     __shared__ uint16_t s_huff[130];
     __shared__ SortItem s_items[128];          // scratch of the rare tie-order sort
     __shared__ int s_anytie;
 
     const int tid = threadIdx.x;
-    const int n_out = p.n_blocks - p.f0;
-    const size_t cf = blockIdx.x;  // (s * n_out + fo) * 2 + ch
+    const int wl = 1 + (int)(blockIdx.x % 7);
+    const size_t cf = blockIdx.x / 7;          // (s * n_out + fo) * 2 + ch
     const float* specs = p.specs + cf * 1024;
     const PsyRec* rec = p.psy + cf;
+    const float mul = max_quant(wl);
+    const float inv2 = (float)(1.0 / (double)(mul * mul));
 
-    if (tid < 130) s_huff[tid] = c_huff[tid];
+    for (int i = tid; i < 130; i += kQuantThreads) s_huff[i] = c_huff[i];
     if (tid == 0) s_anytie = 0;
-    s_vlc[tid] = 0;
-    // ---- scaled values (TScaler::Scale): thread t owns lines 4t..4t+3 (BFU sizes are multiples of 8) ----
+    if (tid < 32) s_vlc[tid] = 0;
+    if (tid < 13) s_tie[tid] = 0;
+    // ---- scaled values (TScaler::Scale) and mantissa = lrint(value * MaxQuant[wl]): 8 lines per thread ----
     {
-        const int i0 = tid * 4;
-        const int b = bfu_of_line(i0);
-        const float sf = T->scale[rec->sfi[b]];
-        const float4 x = *reinterpret_cast<const float4*>(specs + i0);
-        float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
+        const int i0 = tid * 8;
+        const float sf = T->scale[rec->sfi[bfu_of_line(i0)]];
+        uint32_t pk[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (fabsf(v[k]) >= 1.0f) v[k] = (v[k] > 0) ? 0.99999f : -0.99999f;
-        float4 o;
-        o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-        *reinterpret_cast<float4*>(s_val + i0) = o;
-        // ---- (A) mantissa = lrint(value * MaxQuant[wl]) for every wordlen ----
+        for (int h = 0; h < 2; ++h) {
+            const float4 x = *reinterpret_cast<const float4*>(specs + i0 + 4 * h);
+            float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
 #pragma unroll
-        for (int wl = 1; wl <= 7; ++wl) {
-            const float mul = max_quant(wl);
-            const uint32_t pk = ((uint32_t)(uint8_t)__float2int_rn(v[0] * mul)) | ((uint32_t)(uint8_t)__float2int_rn(v[1] * mul) << 8) |
-                                ((uint32_t)(uint8_t)__float2int_rn(v[2] * mul) << 16) | ((uint32_t)(uint8_t)__float2int_rn(v[3] * mul) << 24);
-            *reinterpret_cast<uint32_t*>(s_mant + (wl - 1) * 1024 + i0) = pk;
+            for (int k = 0; k < 4; ++k)
+                if (fabsf(v[k]) >= 1.0f) v[k] = (v[k] > 0) ? 0.99999f : -0.99999f;
+            float4 o;
+            o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+            *reinterpret_cast<float4*>(s_val + i0 + 4 * h) = o;
+            pk[h] = ((uint32_t)(uint8_t)__float2int_rn(v[0] * mul)) | ((uint32_t)(uint8_t)__float2int_rn(v[1] * mul) << 8) |
+                    ((uint32_t)(uint8_t)__float2int_rn(v[2] * mul) << 16) | ((uint32_t)(uint8_t)__float2int_rn(v[3] * mul) << 24);
         }
+        uint2 o2;
+        o2.x = pk[0];
+        o2.y = pk[1];
+        *reinterpret_cast<uint2*>(s_mant + i0) = o2;
     }
     __syncthreads();
-
     if (p.debug_stop == 1) return;
-    // ---- (B) ordered sums, one chain per thread: tid < 32 -> e1 of bfu 31 - tid; else e2 of unit tid - 32 ----
-    //      unit u: bfu = 31 - u / 7, wl = 1 + u % 7 (largest BFUs first so long chains share a wavefront)
+
+    // ---- ordered sums: tid < 32 -> e1 of bfu 31 - tid; 32..63 -> e2; 64..76 -> candidate scan of bfu 31..19 ----
     if (tid < 32) {
         const int bfu = 31 - tid;
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
@@ -671,13 +675,10 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
             e1 += v.w * v.w;
         }
         s_e1[bfu] = e1;
-    } else {
-        const int u = tid - 32;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+    } else if (tid < 64) {
+        const int bfu = 31 - (tid - 32);
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const float mul = max_quant(wl);
-        const float inv2 = (float)(1.0 / (double)(mul * mul));
-        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+        const int8_t* mant = s_mant + start;
         float e2 = 0.0f;
         for (int j = 0; j < n; j += 8) {
             const uint2 pk = *reinterpret_cast<const uint2*>(mant + j);
@@ -687,16 +688,12 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                 e2 += (float)(m * m) * inv2;
             }
         }
-        s_err[wl * 32 + bfu] = e2;
-    }
-    if (p.debug_stop == 2) return;
-    // ---- (C1) candidates of the energy-adaptive units (bfu > 18) ----
-    if (tid >= 160 && tid < 160 + 91) {
-        const int u = tid - 160;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+        s_e2[bfu] = e2;
+    } else if (tid < 64 + 13) {
+        const int bfu = 31 - (tid - 64);
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const float mul = max_quant(wl);
-        uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
+        uint8_t* cand = s_cand + (start - kEaLine0);
+        float* key = s_key + (start - kEaLine0);
         int nc = 0;
         for (int j = 0; j < n; j += 4) {
             const float4 v4 = *reinterpret_cast<const float4*>(s_val + start + j);
@@ -705,48 +702,29 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
             for (int k = 0; k < 4; ++k) {
                 const float t = vv[k] * mul;
                 const float delta = t - (truncf(t) + 0.5f);
-                if (fabsf(delta) < 0.25f) cand[nc++] = (uint8_t)(j + k);
+                if (fabsf(delta) < 0.25f) {
+                    cand[nc] = (uint8_t)(j + k);
+                    key[nc] = fabsf(delta);
+                    ++nc;
+                }
             }
         }
-        s_nc[(wl - 1) * 13 + (bfu - 19)] = (uint8_t)nc;
-        s_tie[(wl - 1) * 13 + (bfu - 19)] = 0;
+        for (int k = nc; k < ((nc + 3) & ~3); ++k) key[k] = __builtin_huge_valf();   // pad the last float4
+        s_nc[bfu - 19] = (uint8_t)nc;
     }
     __syncthreads();
-    if (p.debug_stop == 3) return;
-    // ---- (C2) rank sort by |delta|, one wordlen plane at a time; unused key slots hold +inf ----
-    for (int wl = 1; wl <= 7; ++wl) {
-        const float mul = max_quant(wl);
-        const uint8_t* plane = s_cand + (wl - 1) * kEaLines;
-        uint8_t* sorted = s_sorted + (wl - 1) * kEaLines;
-        int slot_bfu[3], slot_k[3];
+    if (p.debug_stop == 2) return;
+    // ---- rank sort by |delta| ----
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int slot = tid + kQuantThreads * r;
-            slot_k[r] = -1;
-            slot_bfu[r] = 19;
-            if (slot < kEaLines) {
-                const int line = kEaLine0 + slot;
-                const int bfu = bfu_of_line(line);
-                const int start = bfu_start(bfu);
-                const int k = line - start;
-                float key = __builtin_huge_valf();
-                if (k < s_nc[(wl - 1) * 13 + (bfu - 19)]) {
-                    const float t = s_val[start + plane[slot]] * mul;
-                    key = fabsf(t - (truncf(t) + 0.5f));
-                    slot_k[r] = k;
-                    slot_bfu[r] = bfu;
-                }
-                s_key[slot] = key;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (slot_k[r] >= 0) {
-                const int bfu = slot_bfu[r], k = slot_k[r];
-                const int base = bfu_start(bfu) - kEaLine0;
-                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
-                const float key = s_key[base + k];
+    for (int r = 0; r < 6; ++r) {
+        const int slot = tid + kQuantThreads * r;
+        if (slot < kEaLines) {
+            const int bfu = bfu_of_line(kEaLine0 + slot);
+            const int base = bfu_start(bfu) - kEaLine0;
+            const int k = slot - base;
+            const int nc = s_nc[bfu - 19];
+            if (k < nc) {
+                const float key = s_key[slot];
                 int rank = 0, eq = 0;
                 for (int q = 0; q < nc; q += 4) {
                     const float4 kq = *reinterpret_cast<const float4*>(s_key + base + q);
@@ -755,25 +733,23 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                     eq += (kq.x == key) + (kq.y == key) + (kq.z == key) + (kq.w == key);
                 }
                 if (eq > 1) {
-                    s_tie[(wl - 1) * 13 + (bfu - 19)] = 1;
+                    s_tie[bfu - 19] = 1;
                     s_anytie = 1;
                 }
-                sorted[base + rank] = plane[base + k];
+                s_sorted[base + rank] = s_cand[slot];
             }
         }
-        __syncthreads();
     }
-    if (p.debug_stop == 4) return;
-    // ---- (C3) equal keys: libstdc++'s std::sort order decides (rare) ----
+    __syncthreads();
+    if (p.debug_stop == 3) return;
+    // ---- equal keys: libstdc++'s std::sort order decides (rare) ----
     if (s_anytie) {
         if (tid == 0) {
-            for (int u = 0; u < 91; ++u) {
-                const int bfu = 31 - u / 7, wl = 1 + u % 7;
-                if (!s_tie[(wl - 1) * 13 + (bfu - 19)]) continue;
+            for (int bfu = 19; bfu < 32; ++bfu) {
+                if (!s_tie[bfu - 19]) continue;
                 const int start = bfu_start(bfu);
-                const float mul = max_quant(wl);
-                const uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
-                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+                const uint8_t* cand = s_cand + (start - kEaLine0);
+                const int nc = s_nc[bfu - 19];
                 for (int q = 0; q < nc; ++q) {
                     const int j = cand[q];
                     const float t = s_val[start + j] * mul;
@@ -781,68 +757,55 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                     s_items[q].idx = j;
                 }
                 std_sort_abs(s_items, nc);
-                uint8_t* sorted = s_sorted + (wl - 1) * kEaLines + (start - kEaLine0);
+                uint8_t* sorted = s_sorted + (start - kEaLine0);
                 for (int q = 0; q < nc; ++q) sorted[q] = (uint8_t)s_items[q].idx;
             }
         }
         __syncthreads();
     }
-    if (p.debug_stop == 5) return;
-    // ---- (C4) greedy re-rounding per energy-adaptive unit; e1 / e2 for every unit ----
-    if (tid < 224) {
-        const int u = tid;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+    if (p.debug_stop == 4) return;
+    // ---- greedy re-rounding per energy-adaptive unit; e1 / e2 for every unit ----
+    if (tid < 32) {
+        const int bfu = 31 - tid;
         const int start = bfu_start(bfu);
         const float e1 = s_e1[bfu];
-        float e2 = s_err[wl * 32 + bfu];
+        float e2 = s_e2[bfu];
         if (bfu > 18) {
-            const float mul = max_quant(wl);
-            const float inv2 = (float)(1.0 / (double)(mul * mul));
-            int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-            const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
-            if (nc > 0)
-                e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_sorted + (wl - 1) * kEaLines + (start - kEaLine0), nc, mant);
+            const int nc = s_nc[bfu - 19];
+            if (nc > 0) e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_sorted + (start - kEaLine0), nc, s_mant + start);
         }
-        s_err[wl * 32 + bfu] = e1 / e2;
+        s_e2[bfu] = e1 / e2;
     }
     __syncthreads();
-    if (p.debug_stop == 6) return;
-    // ---- (D) VLC cost of the final mantissas: 8 partial sums per unit, combined with LDS atomics ----
-    for (int task = tid; task < 224 * 8; task += kQuantThreads) {
-        const int u = task >> 3, part = task & 7;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
+    if (p.debug_stop == 5) return;
+    // ---- VLC cost of the final mantissas: 4 partial sums per unit, combined with LDS atomics ----
+    {
+        const int bfu = 31 - (tid >> 2), part = tid & 3;
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-        const int per = n >> 3;  // 1, 2, 4, 8 or 16 lines per task (n is a multiple of 8)
+        const int8_t* mant = s_mant + start;
+        const int per = n >> 2;  // 2, 4, 8, 16 or 32 lines per task
         uint32_t bits = 0;
         if (wl > 1) {
             for (int j = part * per; j < (part + 1) * per; ++j) bits += lds_huff(s_huff, wl, vlc_index(mant[j])) >> 8;
         } else {
             const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
-            if (per >= 2) {
-                for (int j = part * per; j < (part + 1) * per; j += 2)
-                    bits += lds_huff(s_huff, 1, rt9[3 * (mant[j] + 1) + (mant[j + 1] + 1)]) >> 8;
-            } else if ((part & 1) == 0) {   // 8-line BFU: one pair per two tasks
-                bits += lds_huff(s_huff, 1, rt9[3 * (mant[part] + 1) + (mant[part + 1] + 1)]) >> 8;
-            }
+            for (int j = part * per; j < (part + 1) * per; j += 2)
+                bits += lds_huff(s_huff, 1, rt9[3 * (mant[j] + 1) + (mant[j + 1] + 1)]) >> 8;
         }
-        atomicAdd(&s_vlc[wl * 32 + bfu], bits);
+        atomicAdd(&s_vlc[bfu], bits);
     }
     __syncthreads();
-    if (p.debug_stop == 7) return;
     // ---- results to HBM ----
     QuantRec* q = p.quant + cf;
-    if (tid < 224) {
-        const int wl = 1 + tid / 32, bfu = tid % 32;
-        const int n = bfu_start(bfu + 1) - bfu_start(bfu);
+    if (tid < 32) {
+        const int n = bfu_start(tid + 1) - bfu_start(tid);
         const uint32_t clc = (wl > 1) ? (uint32_t)clc_len(wl) * n : 2u * n;
-        q->err[wl - 1][bfu] = s_err[wl * 32 + bfu];
-        q->cost[wl - 1][bfu] = clc | (s_vlc[wl * 32 + bfu] << 13);
+        q->err[wl - 1][tid] = s_e2[tid];
+        q->cost[wl - 1][tid] = clc | (s_vlc[tid] << 13);
     }
-    {
-        uint4* dst = reinterpret_cast<uint4*>(p.mant + cf * 7168);
-        const uint4* src = reinterpret_cast<const uint4*>(s_mant);
-        for (int i = tid; i < 7168 / 16; i += kQuantThreads) dst[i] = src[i];
+    if (tid < 64) {
+        uint4* dst = reinterpret_cast<uint4*>(p.mant + cf * 7168 + (size_t)(wl - 1) * 1024);
+        dst[tid] = reinterpret_cast<const uint4*>(s_mant)[tid];
     }
 }
 
