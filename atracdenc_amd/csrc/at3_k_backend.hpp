@@ -407,46 +407,42 @@ __device__ __attribute__((noinline)) void std_sort_abs(SortItem* a, int n)
     }
 }
 
-// Energy-adaptive re-rounding pass of QuantMantisas (atrac_scale.cpp:86-128) over the already sorted
-// candidate list. Returns the updated e2.
-__device__ inline float ea_greedy(const float* in, float mul, float inv2, float e1, float e2, const uint8_t* cand, int nc,
+// Energy-adaptive re-rounding pass of QuantMantisas (atrac_scale.cpp:86-128) over the candidates already
+// ordered by |delta|. ts[c] = in[j] * mul of candidate c, idx[c] = j. The candidate's current mantissa is still
+// lrint(t) (every index occurs once), so nothing but the two sorted arrays is read. Returns the updated e2.
+__device__ inline float ea_greedy(const float* ts, const uint8_t* idx, int nc, float mul, float inv2, float e1, float e2,
                                   int8_t* mant)
 {
-    if (e2 < e1) {
-        for (int c = 0; c < nc; ++c) {
-            const int j = cand[c];
-            const float t = in[j] * mul;
-            const int m0 = mant[j];
+    const bool grow = e2 < e1;
+    if (!grow && !(e2 > e1)) return e2;
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(ts + c0);          // prefetched as a group of four
+        const uint32_t i4 = *reinterpret_cast<const uint32_t*>(idx + c0);
+        const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c0 + k >= nc) break;
+            const float t = tt[k];
+            const int m0 = __float2int_rn(t);
             const float am = (float)(m0 < 0 ? -m0 : m0);
-            if (am < fabsf(t) && am < (mul - 1)) {
-                int m = m0;
+            int m = m0;
+            bool ok;
+            if (grow) {
+                ok = am < fabsf(t) && am < (mul - 1);
                 if (m > 0) m++;
                 if (m < 0) m--;
                 if (m == 0) m = t > 0 ? 1 : -1;
-                float ex = e2;
-                ex -= (float)(m0 * m0) * inv2;
-                ex += (float)(m * m) * inv2;
-                if (fabsf(ex - e1) < fabsf(e2 - e1)) {
-                    mant[j] = (int8_t)m;
-                    e2 = ex;
-                }
-            }
-        }
-    } else if (e2 > e1) {
-        for (int c = 0; c < nc; ++c) {
-            const int j = cand[c];
-            const float t = in[j] * mul;
-            const int m0 = mant[j];
-            const float am = (float)(m0 < 0 ? -m0 : m0);
-            if (am > fabsf(t)) {
-                int m = m0;
+            } else {
+                ok = am > fabsf(t);
                 if (m > 0) m--;
-                if (m < 0) m++;
+                else if (m < 0) m++;
+            }
+            if (ok) {
                 float ex = e2;
                 ex -= (float)(m0 * m0) * inv2;
                 ex += (float)(m * m) * inv2;
                 if (fabsf(ex - e1) < fabsf(e2 - e1)) {
-                    mant[j] = (int8_t)m;
+                    mant[(i4 >> (8 * k)) & 0xff] = (int8_t)m;
                     e2 = ex;
                 }
             }
@@ -614,7 +610,8 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     __shared__ __attribute__((aligned(16))) int8_t s_mant[1024];
     __shared__ __attribute__((aligned(16))) uint8_t s_cand[kEaLines];    // candidate lines (relative to the BFU), scan order
     __shared__ __attribute__((aligned(16))) uint8_t s_sorted[kEaLines];  // the same, ordered by |delta|
-    __shared__ __attribute__((aligned(16))) float s_key[kEaLines];       // |delta| per candidate slot, +inf when unused
+    __shared__ __attribute__((aligned(16))) float s_tc[kEaLines];        // value * mul per candidate (scan order), +inf pad
+    __shared__ __attribute__((aligned(16))) float s_ts[kEaLines];        // the same, ordered by |delta|
     __shared__ uint8_t s_nc[13];
     __shared__ uint8_t s_tie[13];
     __shared__ float s_e1[32];
@@ -663,53 +660,74 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     if (p.debug_stop == 1) return;
 
     // ---- ordered sums: tid < 32 -> e1 of bfu 31 - tid; 32..63 -> e2; 64..76 -> candidate scan of bfu 31..19 ----
+    // (loads of the next 8 lines are issued before the 8 dependent adds of the current ones)
     if (tid < 32) {
         const int bfu = 31 - tid;
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
+        const float4* v4 = reinterpret_cast<const float4*>(s_val + start);
         float e1 = 0.0f;
-        for (int j = 0; j < n; j += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(s_val + start + j);
-            e1 += v.x * v.x;
-            e1 += v.y * v.y;
-            e1 += v.z * v.z;
-            e1 += v.w * v.w;
+        float4 a = v4[0], b = v4[1];
+        for (int j = 0; j < n; j += 8) {
+            float4 na = a, nb = b;
+            if (j + 8 < n) {
+                na = v4[(j >> 2) + 2];
+                nb = v4[(j >> 2) + 3];
+            }
+            e1 += a.x * a.x; e1 += a.y * a.y; e1 += a.z * a.z; e1 += a.w * a.w;
+            e1 += b.x * b.x; e1 += b.y * b.y; e1 += b.z * b.z; e1 += b.w * b.w;
+            a = na;
+            b = nb;
         }
         s_e1[bfu] = e1;
     } else if (tid < 64) {
         const int bfu = 31 - (tid - 32);
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const int8_t* mant = s_mant + start;
+        const uint2* m2 = reinterpret_cast<const uint2*>(s_mant + start);
         float e2 = 0.0f;
+        uint2 pk = m2[0];
         for (int j = 0; j < n; j += 8) {
-            const uint2 pk = *reinterpret_cast<const uint2*>(mant + j);
+            uint2 npk = pk;
+            if (j + 8 < n) npk = m2[(j >> 3) + 1];
+            float sq[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int m = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
-                e2 += (float)(m * m) * inv2;
+                sq[k] = (float)(m * m) * inv2;
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e2 += sq[k];
+            pk = npk;
         }
         s_e2[bfu] = e2;
     } else if (tid < 64 + 13) {
         const int bfu = 31 - (tid - 64);
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
         uint8_t* cand = s_cand + (start - kEaLine0);
-        float* key = s_key + (start - kEaLine0);
+        float* tc = s_tc + (start - kEaLine0);
+        const float4* v4 = reinterpret_cast<const float4*>(s_val + start);
         int nc = 0;
-        for (int j = 0; j < n; j += 4) {
-            const float4 v4 = *reinterpret_cast<const float4*>(s_val + start + j);
-            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        float4 a = v4[0], b = v4[1];
+        for (int j = 0; j < n; j += 8) {
+            float4 na = a, nb = b;
+            if (j + 8 < n) {
+                na = v4[(j >> 2) + 2];
+                nb = v4[(j >> 2) + 3];
+            }
+            const float vv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const float t = vv[k] * mul;
                 const float delta = t - (truncf(t) + 0.5f);
                 if (fabsf(delta) < 0.25f) {
                     cand[nc] = (uint8_t)(j + k);
-                    key[nc] = fabsf(delta);
+                    tc[nc] = t;
                     ++nc;
                 }
             }
+            a = na;
+            b = nb;
         }
-        for (int k = nc; k < ((nc + 3) & ~3); ++k) key[k] = __builtin_huge_valf();   // pad the last float4
+        for (int k = nc; k < ((nc + 3) & ~3); ++k) tc[k] = __builtin_huge_valf();   // pad: key of +inf is NaN, never counted
         s_nc[bfu - 19] = (uint8_t)nc;
     }
     __syncthreads();
@@ -724,19 +742,27 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
             const int k = slot - base;
             const int nc = s_nc[bfu - 19];
             if (k < nc) {
-                const float key = s_key[slot];
+                const float tk = s_tc[slot];
+                const float key = fabsf(tk - (truncf(tk) + 0.5f));
                 int rank = 0, eq = 0;
+                const float4* t4 = reinterpret_cast<const float4*>(s_tc + base);
+                float4 cur = t4[0];
                 for (int q = 0; q < nc; q += 4) {
-                    const float4 kq = *reinterpret_cast<const float4*>(s_key + base + q);
-                    rank += (kq.x < key) + (kq.y < key) + (kq.z < key) + (kq.w < key);
-                    rank += (kq.x == key && q + 0 < k) + (kq.y == key && q + 1 < k) + (kq.z == key && q + 2 < k) + (kq.w == key && q + 3 < k);
-                    eq += (kq.x == key) + (kq.y == key) + (kq.z == key) + (kq.w == key);
+                    float4 nxt = cur;
+                    if (q + 4 < nc) nxt = t4[(q >> 2) + 1];
+                    const float k0 = fabsf(cur.x - (truncf(cur.x) + 0.5f)), k1 = fabsf(cur.y - (truncf(cur.y) + 0.5f));
+                    const float k2 = fabsf(cur.z - (truncf(cur.z) + 0.5f)), k3 = fabsf(cur.w - (truncf(cur.w) + 0.5f));
+                    rank += (k0 < key) + (k1 < key) + (k2 < key) + (k3 < key);
+                    rank += (k0 == key && q + 0 < k) + (k1 == key && q + 1 < k) + (k2 == key && q + 2 < k) + (k3 == key && q + 3 < k);
+                    eq += (k0 == key) + (k1 == key) + (k2 == key) + (k3 == key);
+                    cur = nxt;
                 }
                 if (eq > 1) {
                     s_tie[bfu - 19] = 1;
                     s_anytie = 1;
                 }
                 s_sorted[base + rank] = s_cand[slot];
+                s_ts[base + rank] = tk;
             }
         }
     }
@@ -758,7 +784,10 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                 }
                 std_sort_abs(s_items, nc);
                 uint8_t* sorted = s_sorted + (start - kEaLine0);
-                for (int q = 0; q < nc; ++q) sorted[q] = (uint8_t)s_items[q].idx;
+                for (int q = 0; q < nc; ++q) {
+                    sorted[q] = (uint8_t)s_items[q].idx;
+                    s_ts[(start - kEaLine0) + q] = s_val[start + s_items[q].idx] * mul;
+                }
             }
         }
         __syncthreads();
@@ -772,7 +801,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         float e2 = s_e2[bfu];
         if (bfu > 18) {
             const int nc = s_nc[bfu - 19];
-            if (nc > 0) e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_sorted + (start - kEaLine0), nc, s_mant + start);
+            if (nc > 0) e2 = ea_greedy(s_ts + (start - kEaLine0), s_sorted + (start - kEaLine0), nc, mul, inv2, e1, e2, s_mant + start);
         }
         s_e2[bfu] = e1 / e2;
     }
