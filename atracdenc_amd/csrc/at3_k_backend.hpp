@@ -407,42 +407,46 @@ __device__ __attribute__((noinline)) void std_sort_abs(SortItem* a, int n)
     }
 }
 
-// Energy-adaptive re-rounding pass of QuantMantisas (atrac_scale.cpp:86-128) over the candidates already
-// ordered by |delta|. ts[c] = in[j] * mul of candidate c, idx[c] = j. The candidate's current mantissa is still
-// lrint(t) (every index occurs once), so nothing but the two sorted arrays is read. Returns the updated e2.
-__device__ inline float ea_greedy(const float* ts, const uint8_t* idx, int nc, float mul, float inv2, float e1, float e2,
+// Energy-adaptive re-rounding pass of QuantMantisas (atrac_scale.cpp:86-128) over the already sorted
+// candidate list. Returns the updated e2.
+__device__ inline float ea_greedy(const float* in, float mul, float inv2, float e1, float e2, const uint8_t* cand, int nc,
                                   int8_t* mant)
 {
-    const bool grow = e2 < e1;
-    if (!grow && !(e2 > e1)) return e2;
-    for (int c0 = 0; c0 < nc; c0 += 4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(ts + c0);          // prefetched as a group of four
-        const uint32_t i4 = *reinterpret_cast<const uint32_t*>(idx + c0);
-        const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (c0 + k >= nc) break;
-            const float t = tt[k];
-            const int m0 = __float2int_rn(t);
+    if (e2 < e1) {
+        for (int c = 0; c < nc; ++c) {
+            const int j = cand[c];
+            const float t = in[j] * mul;
+            const int m0 = mant[j];
             const float am = (float)(m0 < 0 ? -m0 : m0);
-            int m = m0;
-            bool ok;
-            if (grow) {
-                ok = am < fabsf(t) && am < (mul - 1);
+            if (am < fabsf(t) && am < (mul - 1)) {
+                int m = m0;
                 if (m > 0) m++;
                 if (m < 0) m--;
                 if (m == 0) m = t > 0 ? 1 : -1;
-            } else {
-                ok = am > fabsf(t);
-                if (m > 0) m--;
-                else if (m < 0) m++;
-            }
-            if (ok) {
                 float ex = e2;
                 ex -= (float)(m0 * m0) * inv2;
                 ex += (float)(m * m) * inv2;
                 if (fabsf(ex - e1) < fabsf(e2 - e1)) {
-                    mant[(i4 >> (8 * k)) & 0xff] = (int8_t)m;
+                    mant[j] = (int8_t)m;
+                    e2 = ex;
+                }
+            }
+        }
+    } else if (e2 > e1) {
+        for (int c = 0; c < nc; ++c) {
+            const int j = cand[c];
+            const float t = in[j] * mul;
+            const int m0 = mant[j];
+            const float am = (float)(m0 < 0 ? -m0 : m0);
+            if (am > fabsf(t)) {
+                int m = m0;
+                if (m > 0) m--;
+                if (m < 0) m++;
+                float ex = e2;
+                ex -= (float)(m0 * m0) * inv2;
+                ex += (float)(m * m) * inv2;
+                if (fabsf(ex - e1) < fabsf(e2 - e1)) {
+                    mant[j] = (int8_t)m;
                     e2 = ex;
                 }
             }
@@ -587,17 +591,16 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
     return used;
 }
 
-// ---- quantisation kernel: one 128-thread workgroup per (stream, output frame, channel, wordlen) ----------
+// ---- quantisation kernel: one 256-thread workgroup per (stream, output frame, channel) -----------------
 //
-// Computes what TEncCache would compute lazily - every (bfu, wordlen) unit - so the rate loop that follows is
-// pure table look-up. Per workgroup (one wordlen plane): 1024 roundings; the strictly ordered energy sums as 64
-// independent chains (32 x e1, 32 x e2), one per thread; the energy-adaptive re-rounding of BFUs 19..31
-// (candidate lists in LDS, parallel rank sort by |delta| that falls back to the libstdc++-order sort when two
-// candidates tie, sequential greedy pass per unit); CLC / VLC bit costs. Seven small workgroups per channel-frame
-// instead of one big one: no loop over planes, 10 KB of LDS, sixteen workgroups resident per CU.
+// Computes what TEncCache would compute lazily - every (bfu, wordlen) unit - so the rate loop that follows
+// is pure table look-up: (A) all 7 x 1024 roundings in parallel; (B) the strictly ordered energy sums as 256
+// independent chains (32 x e1, 224 x e2), one per thread, longest chains on the first wave; (C) the
+// energy-adaptive re-rounding of BFUs 19..31: candidate lists in LDS, parallel rank sort (falls back to the
+// libstdc++-order sort when two candidates tie), sequential greedy pass per unit; (D) CLC / VLC bit costs.
 constexpr int kEaLine0 = 288;              // first spectral line of BFU 19
 constexpr int kEaLines = 1024 - kEaLine0;  // 736
-constexpr int kQuantThreads = 128;
+constexpr int kQuantThreads = 256;
 
 __device__ __forceinline__ uint32_t lds_huff(const uint16_t* s_huff, int sel, uint32_t idx)
 {
@@ -607,175 +610,170 @@ __device__ __forceinline__ uint32_t lds_huff(const uint16_t* s_huff, int sel, ui
 __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) float s_val[1024];
-    __shared__ __attribute__((aligned(16))) int8_t s_mant[1024];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cand[kEaLines];    // candidate lines (relative to the BFU), scan order
-    __shared__ __attribute__((aligned(16))) uint8_t s_sorted[kEaLines];  // the same, ordered by |delta|
-    __shared__ __attribute__((aligned(16))) float s_tc[kEaLines];        // value * mul per candidate (scan order), +inf pad
-    __shared__ __attribute__((aligned(16))) float s_ts[kEaLines];        // the same, ordered by |delta|
-    __shared__ uint8_t s_nc[13];
-    __shared__ uint8_t s_tie[13];
+    __shared__ __attribute__((aligned(16))) int8_t s_mant[7 * 1024];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cand[7 * kEaLines];   // candidate lines (relative to the BFU), scan order
+    __shared__ __attribute__((aligned(16))) uint8_t s_sorted[7 * kEaLines]; // the same, ordered by |delta|
+    __shared__ __attribute__((aligned(16))) float s_key[kEaLines];          // |delta| of one wordlen plane at a time
+    __shared__ uint8_t s_nc[7 * 13];
+    __shared__ uint8_t s_tie[7 * 13];
     __shared__ float s_e1[32];
-    __shared__ float s_e2[32];
-    __shared__ uint32_t s_vlc[32];
+    __shared__ float s_err[8 * 32];            // e2 during phases B/C, then e1 / e2
+    __shared__ uint32_t s_vlc[8 * 32];
     __shared__ uint16_t s_huff[130];
     __shared__ SortItem s_items[128];          // scratch of the rare tie-order sort
     __shared__ int s_anytie;
 
     const int tid = threadIdx.x;
-    const int wl = 1 + (int)(blockIdx.x % 7);
-    const size_t cf = blockIdx.x / 7;          // (s * n_out + fo) * 2 + ch
+    const int n_out = p.n_blocks - p.f0;
+    const size_t cf = blockIdx.x;  // (s * n_out + fo) * 2 + ch
     const float* specs = p.specs + cf * 1024;
     const PsyRec* rec = p.psy + cf;
-    const float mul = max_quant(wl);
-    const float inv2 = (float)(1.0 / (double)(mul * mul));
 
-    for (int i = tid; i < 130; i += kQuantThreads) s_huff[i] = c_huff[i];
+    if (tid < 130) s_huff[tid] = c_huff[tid];
     if (tid == 0) s_anytie = 0;
-    if (tid < 32) s_vlc[tid] = 0;
-    if (tid < 13) s_tie[tid] = 0;
-    // ---- scaled values (TScaler::Scale) and mantissa = lrint(value * MaxQuant[wl]): 8 lines per thread ----
+    s_vlc[tid] = 0;
+    // ---- scaled values (TScaler::Scale): thread t owns lines 4t..4t+3 (BFU sizes are multiples of 8) ----
     {
-        const int i0 = tid * 8;
-        const float sf = T->scale[rec->sfi[bfu_of_line(i0)]];
-        uint32_t pk[2];
+        const int i0 = tid * 4;
+        const int b = bfu_of_line(i0);
+        const float sf = T->scale[rec->sfi[b]];
+        const float4 x = *reinterpret_cast<const float4*>(specs + i0);
+        float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float4 x = *reinterpret_cast<const float4*>(specs + i0 + 4 * h);
-            float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
+        for (int k = 0; k < 4; ++k)
+            if (fabsf(v[k]) >= 1.0f) v[k] = (v[k] > 0) ? 0.99999f : -0.99999f;
+        float4 o;
+        o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+        *reinterpret_cast<float4*>(s_val + i0) = o;
+        // ---- (A) mantissa = lrint(value * MaxQuant[wl]) for every wordlen ----
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (fabsf(v[k]) >= 1.0f) v[k] = (v[k] > 0) ? 0.99999f : -0.99999f;
-            float4 o;
-            o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-            *reinterpret_cast<float4*>(s_val + i0 + 4 * h) = o;
-            pk[h] = ((uint32_t)(uint8_t)__float2int_rn(v[0] * mul)) | ((uint32_t)(uint8_t)__float2int_rn(v[1] * mul) << 8) |
-                    ((uint32_t)(uint8_t)__float2int_rn(v[2] * mul) << 16) | ((uint32_t)(uint8_t)__float2int_rn(v[3] * mul) << 24);
+        for (int wl = 1; wl <= 7; ++wl) {
+            const float mul = max_quant(wl);
+            const uint32_t pk = ((uint32_t)(uint8_t)__float2int_rn(v[0] * mul)) | ((uint32_t)(uint8_t)__float2int_rn(v[1] * mul) << 8) |
+                                ((uint32_t)(uint8_t)__float2int_rn(v[2] * mul) << 16) | ((uint32_t)(uint8_t)__float2int_rn(v[3] * mul) << 24);
+            *reinterpret_cast<uint32_t*>(s_mant + (wl - 1) * 1024 + i0) = pk;
         }
-        uint2 o2;
-        o2.x = pk[0];
-        o2.y = pk[1];
-        *reinterpret_cast<uint2*>(s_mant + i0) = o2;
     }
     __syncthreads();
-    if (p.debug_stop == 1) return;
 
-    // ---- ordered sums: tid < 32 -> e1 of bfu 31 - tid; 32..63 -> e2; 64..76 -> candidate scan of bfu 31..19 ----
-    // (loads of the next 8 lines are issued before the 8 dependent adds of the current ones)
+    if (p.debug_stop == 1) return;
+    // ---- (B) ordered sums, one chain per thread: tid < 32 -> e1 of bfu 31 - tid; else e2 of unit tid - 32 ----
+    //      unit u: bfu = 31 - u / 7, wl = 1 + u % 7 (largest BFUs first so long chains share a wavefront)
     if (tid < 32) {
         const int bfu = 31 - tid;
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const float4* v4 = reinterpret_cast<const float4*>(s_val + start);
         float e1 = 0.0f;
-        float4 a = v4[0], b = v4[1];
-        for (int j = 0; j < n; j += 8) {
-            float4 na = a, nb = b;
-            if (j + 8 < n) {
-                na = v4[(j >> 2) + 2];
-                nb = v4[(j >> 2) + 3];
-            }
-            e1 += a.x * a.x; e1 += a.y * a.y; e1 += a.z * a.z; e1 += a.w * a.w;
-            e1 += b.x * b.x; e1 += b.y * b.y; e1 += b.z * b.z; e1 += b.w * b.w;
-            a = na;
-            b = nb;
+        for (int j = 0; j < n; j += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(s_val + start + j);
+            e1 += v.x * v.x;
+            e1 += v.y * v.y;
+            e1 += v.z * v.z;
+            e1 += v.w * v.w;
         }
         s_e1[bfu] = e1;
-    } else if (tid < 64) {
-        const int bfu = 31 - (tid - 32);
+    } else {
+        const int u = tid - 32;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const uint2* m2 = reinterpret_cast<const uint2*>(s_mant + start);
+        const float mul = max_quant(wl);
+        const float inv2 = (float)(1.0 / (double)(mul * mul));
+        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
         float e2 = 0.0f;
-        uint2 pk = m2[0];
         for (int j = 0; j < n; j += 8) {
-            uint2 npk = pk;
-            if (j + 8 < n) npk = m2[(j >> 3) + 1];
-            float sq[8];
+            const uint2 pk = *reinterpret_cast<const uint2*>(mant + j);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int m = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
-                sq[k] = (float)(m * m) * inv2;
+                e2 += (float)(m * m) * inv2;
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) e2 += sq[k];
-            pk = npk;
         }
-        s_e2[bfu] = e2;
-    } else if (tid < 64 + 13) {
-        const int bfu = 31 - (tid - 64);
+        s_err[wl * 32 + bfu] = e2;
+    }
+    if (p.debug_stop == 2) return;
+    // ---- (C1) candidates of the energy-adaptive units (bfu > 18) ----
+    if (tid >= 160 && tid < 160 + 91) {
+        const int u = tid - 160;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        uint8_t* cand = s_cand + (start - kEaLine0);
-        float* tc = s_tc + (start - kEaLine0);
-        const float4* v4 = reinterpret_cast<const float4*>(s_val + start);
+        const float mul = max_quant(wl);
+        uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
         int nc = 0;
-        float4 a = v4[0], b = v4[1];
-        for (int j = 0; j < n; j += 8) {
-            float4 na = a, nb = b;
-            if (j + 8 < n) {
-                na = v4[(j >> 2) + 2];
-                nb = v4[(j >> 2) + 3];
-            }
-            const float vv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        for (int j = 0; j < n; j += 4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(s_val + start + j);
+            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 const float t = vv[k] * mul;
                 const float delta = t - (truncf(t) + 0.5f);
-                if (fabsf(delta) < 0.25f) {
-                    cand[nc] = (uint8_t)(j + k);
-                    tc[nc] = t;
-                    ++nc;
-                }
-            }
-            a = na;
-            b = nb;
-        }
-        for (int k = nc; k < ((nc + 3) & ~3); ++k) tc[k] = __builtin_huge_valf();   // pad: key of +inf is NaN, never counted
-        s_nc[bfu - 19] = (uint8_t)nc;
-    }
-    __syncthreads();
-    if (p.debug_stop == 2) return;
-    // ---- rank sort by |delta| ----
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        const int slot = tid + kQuantThreads * r;
-        if (slot < kEaLines) {
-            const int bfu = bfu_of_line(kEaLine0 + slot);
-            const int base = bfu_start(bfu) - kEaLine0;
-            const int k = slot - base;
-            const int nc = s_nc[bfu - 19];
-            if (k < nc) {
-                const float tk = s_tc[slot];
-                const float key = fabsf(tk - (truncf(tk) + 0.5f));
-                int rank = 0, eq = 0;
-                const float4* t4 = reinterpret_cast<const float4*>(s_tc + base);
-                float4 cur = t4[0];
-                for (int q = 0; q < nc; q += 4) {
-                    float4 nxt = cur;
-                    if (q + 4 < nc) nxt = t4[(q >> 2) + 1];
-                    const float k0 = fabsf(cur.x - (truncf(cur.x) + 0.5f)), k1 = fabsf(cur.y - (truncf(cur.y) + 0.5f));
-                    const float k2 = fabsf(cur.z - (truncf(cur.z) + 0.5f)), k3 = fabsf(cur.w - (truncf(cur.w) + 0.5f));
-                    rank += (k0 < key) + (k1 < key) + (k2 < key) + (k3 < key);
-                    rank += (k0 == key && q + 0 < k) + (k1 == key && q + 1 < k) + (k2 == key && q + 2 < k) + (k3 == key && q + 3 < k);
-                    eq += (k0 == key) + (k1 == key) + (k2 == key) + (k3 == key);
-                    cur = nxt;
-                }
-                if (eq > 1) {
-                    s_tie[bfu - 19] = 1;
-                    s_anytie = 1;
-                }
-                s_sorted[base + rank] = s_cand[slot];
-                s_ts[base + rank] = tk;
+                if (fabsf(delta) < 0.25f) cand[nc++] = (uint8_t)(j + k);
             }
         }
+        s_nc[(wl - 1) * 13 + (bfu - 19)] = (uint8_t)nc;
+        s_tie[(wl - 1) * 13 + (bfu - 19)] = 0;
     }
     __syncthreads();
     if (p.debug_stop == 3) return;
-    // ---- equal keys: libstdc++'s std::sort order decides (rare) ----
+    // ---- (C2) rank sort by |delta|, one wordlen plane at a time; unused key slots hold +inf ----
+    for (int wl = 1; wl <= 7; ++wl) {
+        const float mul = max_quant(wl);
+        const uint8_t* plane = s_cand + (wl - 1) * kEaLines;
+        uint8_t* sorted = s_sorted + (wl - 1) * kEaLines;
+        int slot_bfu[3], slot_k[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int slot = tid + kQuantThreads * r;
+            slot_k[r] = -1;
+            slot_bfu[r] = 19;
+            if (slot < kEaLines) {
+                const int line = kEaLine0 + slot;
+                const int bfu = bfu_of_line(line);
+                const int start = bfu_start(bfu);
+                const int k = line - start;
+                float key = __builtin_huge_valf();
+                if (k < s_nc[(wl - 1) * 13 + (bfu - 19)]) {
+                    const float t = s_val[start + plane[slot]] * mul;
+                    key = fabsf(t - (truncf(t) + 0.5f));
+                    slot_k[r] = k;
+                    slot_bfu[r] = bfu;
+                }
+                s_key[slot] = key;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (slot_k[r] >= 0) {
+                const int bfu = slot_bfu[r], k = slot_k[r];
+                const int base = bfu_start(bfu) - kEaLine0;
+                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+                const float key = s_key[base + k];
+                int rank = 0, eq = 0;
+                for (int q = 0; q < nc; q += 4) {
+                    const float4 kq = *reinterpret_cast<const float4*>(s_key + base + q);
+                    rank += (kq.x < key) + (kq.y < key) + (kq.z < key) + (kq.w < key);
+                    rank += (kq.x == key && q + 0 < k) + (kq.y == key && q + 1 < k) + (kq.z == key && q + 2 < k) + (kq.w == key && q + 3 < k);
+                    eq += (kq.x == key) + (kq.y == key) + (kq.z == key) + (kq.w == key);
+                }
+                if (eq > 1) {
+                    s_tie[(wl - 1) * 13 + (bfu - 19)] = 1;
+                    s_anytie = 1;
+                }
+                sorted[base + rank] = plane[base + k];
+            }
+        }
+        __syncthreads();
+    }
+    if (p.debug_stop == 4) return;
+    // ---- (C3) equal keys: libstdc++'s std::sort order decides (rare) ----
     if (s_anytie) {
         if (tid == 0) {
-            for (int bfu = 19; bfu < 32; ++bfu) {
-                if (!s_tie[bfu - 19]) continue;
+            for (int u = 0; u < 91; ++u) {
+                const int bfu = 31 - u / 7, wl = 1 + u % 7;
+                if (!s_tie[(wl - 1) * 13 + (bfu - 19)]) continue;
                 const int start = bfu_start(bfu);
-                const uint8_t* cand = s_cand + (start - kEaLine0);
-                const int nc = s_nc[bfu - 19];
+                const float mul = max_quant(wl);
+                const uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
+                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
                 for (int q = 0; q < nc; ++q) {
                     const int j = cand[q];
                     const float t = s_val[start + j] * mul;
@@ -783,58 +781,68 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                     s_items[q].idx = j;
                 }
                 std_sort_abs(s_items, nc);
-                uint8_t* sorted = s_sorted + (start - kEaLine0);
-                for (int q = 0; q < nc; ++q) {
-                    sorted[q] = (uint8_t)s_items[q].idx;
-                    s_ts[(start - kEaLine0) + q] = s_val[start + s_items[q].idx] * mul;
-                }
+                uint8_t* sorted = s_sorted + (wl - 1) * kEaLines + (start - kEaLine0);
+                for (int q = 0; q < nc; ++q) sorted[q] = (uint8_t)s_items[q].idx;
             }
         }
         __syncthreads();
     }
-    if (p.debug_stop == 4) return;
-    // ---- greedy re-rounding per energy-adaptive unit; e1 / e2 for every unit ----
-    if (tid < 32) {
-        const int bfu = 31 - tid;
+    if (p.debug_stop == 5) return;
+    // ---- (C4) greedy re-rounding per energy-adaptive unit; e1 / e2 for every unit ----
+    if (tid < 224) {
+        const int u = tid;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
         const int start = bfu_start(bfu);
         const float e1 = s_e1[bfu];
-        float e2 = s_e2[bfu];
+        float e2 = s_err[wl * 32 + bfu];
         if (bfu > 18) {
-            const int nc = s_nc[bfu - 19];
-            if (nc > 0) e2 = ea_greedy(s_ts + (start - kEaLine0), s_sorted + (start - kEaLine0), nc, mul, inv2, e1, e2, s_mant + start);
+            const float mul = max_quant(wl);
+            const float inv2 = (float)(1.0 / (double)(mul * mul));
+            int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+            const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
+            if (nc > 0)
+                e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_sorted + (wl - 1) * kEaLines + (start - kEaLine0), nc, mant);
         }
-        s_e2[bfu] = e1 / e2;
+        s_err[wl * 32 + bfu] = e1 / e2;
     }
     __syncthreads();
-    if (p.debug_stop == 5) return;
-    // ---- VLC cost of the final mantissas: 4 partial sums per unit, combined with LDS atomics ----
-    {
-        const int bfu = 31 - (tid >> 2), part = tid & 3;
+    if (p.debug_stop == 6) return;
+    // ---- (D) VLC cost of the final mantissas: 8 partial sums per unit, combined with LDS atomics ----
+    for (int task = tid; task < 224 * 8; task += kQuantThreads) {
+        const int u = task >> 3, part = task & 7;
+        const int bfu = 31 - u / 7, wl = 1 + u % 7;
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const int8_t* mant = s_mant + start;
-        const int per = n >> 2;  // 2, 4, 8, 16 or 32 lines per task
+        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
+        const int per = n >> 3;  // 1, 2, 4, 8 or 16 lines per task (n is a multiple of 8)
         uint32_t bits = 0;
         if (wl > 1) {
             for (int j = part * per; j < (part + 1) * per; ++j) bits += lds_huff(s_huff, wl, vlc_index(mant[j])) >> 8;
         } else {
             const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
-            for (int j = part * per; j < (part + 1) * per; j += 2)
-                bits += lds_huff(s_huff, 1, rt9[3 * (mant[j] + 1) + (mant[j + 1] + 1)]) >> 8;
+            if (per >= 2) {
+                for (int j = part * per; j < (part + 1) * per; j += 2)
+                    bits += lds_huff(s_huff, 1, rt9[3 * (mant[j] + 1) + (mant[j + 1] + 1)]) >> 8;
+            } else if ((part & 1) == 0) {   // 8-line BFU: one pair per two tasks
+                bits += lds_huff(s_huff, 1, rt9[3 * (mant[part] + 1) + (mant[part + 1] + 1)]) >> 8;
+            }
         }
-        atomicAdd(&s_vlc[bfu], bits);
+        atomicAdd(&s_vlc[wl * 32 + bfu], bits);
     }
     __syncthreads();
+    if (p.debug_stop == 7) return;
     // ---- results to HBM ----
     QuantRec* q = p.quant + cf;
-    if (tid < 32) {
-        const int n = bfu_start(tid + 1) - bfu_start(tid);
+    if (tid < 224) {
+        const int wl = 1 + tid / 32, bfu = tid % 32;
+        const int n = bfu_start(bfu + 1) - bfu_start(bfu);
         const uint32_t clc = (wl > 1) ? (uint32_t)clc_len(wl) * n : 2u * n;
-        q->err[wl - 1][tid] = s_e2[tid];
-        q->cost[wl - 1][tid] = clc | (s_vlc[tid] << 13);
+        q->err[wl - 1][bfu] = s_err[wl * 32 + bfu];
+        q->cost[wl - 1][bfu] = clc | (s_vlc[wl * 32 + bfu] << 13);
     }
-    if (tid < 64) {
-        uint4* dst = reinterpret_cast<uint4*>(p.mant + cf * 7168 + (size_t)(wl - 1) * 1024);
-        dst[tid] = reinterpret_cast<const uint4*>(s_mant)[tid];
+    {
+        uint4* dst = reinterpret_cast<uint4*>(p.mant + cf * 7168);
+        const uint4* src = reinterpret_cast<const uint4*>(s_mant);
+        for (int i = tid; i < 7168 / 16; i += kQuantThreads) dst[i] = src[i];
     }
 }
 

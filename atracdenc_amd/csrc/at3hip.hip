@@ -320,7 +320,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(c->ev[5], st));
         hipLaunchKernelGGL(k_loudness, dim3((S + 63) / 64), dim3(64), 0, st, bp);
-        hipLaunchKernelGGL(k_quant, dim3(S * n_out * 2 * 7), dim3(128), 0, st, bp, c->d_tables);
+        hipLaunchKernelGGL(k_quant, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
         hipLaunchKernelGGL(k_rate_pack, dim3(S * n_out * 2), dim3(64), 0, st, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(c->ev[6], st));
     }
