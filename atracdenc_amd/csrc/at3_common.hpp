@@ -171,14 +171,16 @@ __device__ __forceinline__ int fft_leaf_pos(int i)
     return o;
 }
 
-template <int N, bool INVERSE>
+template <int N, bool INVERSE, bool LEAF_DONE = false>
 __device__ __forceinline__ void fft_lds(cpx* F, int NS, int nfft, const cpx* tw, int tid, int nthr)
 {
-    // number of radix-4 stages and whether a radix-2 leaf stage exists
+    // number of radix-4 stages and whether a radix-2 leaf stage exists; LEAF_DONE: the caller already stored
+    // the outputs of the radix-2 leaf butterflies (used when the leaf inputs are mostly exact zeros)
     int lg = 0;
     for (int t = N; t > 1; t >>= 1) ++lg;
     int m = 1;
-    if (lg & 1) {
+    if ((lg & 1) && LEAF_DONE) m = 2;
+    if ((lg & 1) && !LEAF_DONE) {
         // radix-2 leaves: m = 1, fstride = N/2, twiddle index 0
         const cpx w = tw[0];
         for (int j = tid; j < nfft * (N / 2); j += nthr) {
