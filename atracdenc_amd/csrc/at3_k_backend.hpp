@@ -69,8 +69,9 @@ __device__ inline int scale_block(const Tables* T, const float* in, int len, flo
 // One workgroup per (stream, output frame, channel).
 __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
 {
-    __shared__ float s_spec[1024];
-    __shared__ float s_e[1024];
+    __shared__ __attribute__((aligned(16))) float s_spec[1024];
+    __shared__ __attribute__((aligned(16))) float s_e[1024];
+    __shared__ __attribute__((aligned(16))) float s_term[1024];
     __shared__ double s_log[768];
     __shared__ int s_run_start[32];
     __shared__ int s_run_len[32];
@@ -86,30 +87,50 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     float* specs = p.specs + (((size_t)s * n_out + fo) * 2 + ch) * 1024;
     PsyRec* rec = p.psy + ((size_t)s * n_out + fo) * 2 + ch;
 
-    for (int i = tid; i < 1024; i += 256) {
-        const float x = specs[i];
-        s_spec[i] = x;
-        s_e[i] = x * x;
+    // energies, loudness terms (e * GainEnergyScale.Frame * LoudnessCurve, atrac3denc.cpp:811-818) and - for the
+    // flatness measure - log(max(e, floor)) are produced by all work-items; only the additions are ordered.
+    {
+        float g[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (p.ges)
+            for (int b = 0; b < 4; ++b) g[b] = p.ges[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + b];
+        const float4 x4 = *reinterpret_cast<const float4*>(specs + 4 * tid);
+        const float4 c4 = *reinterpret_cast<const float4*>(T->loud_curve + 4 * tid);
+        const float gg = g[tid >> 6];
+        float4 e4, t4;
+        e4.x = x4.x * x4.x; e4.y = x4.y * x4.y; e4.z = x4.z * x4.z; e4.w = x4.w * x4.w;
+        t4.x = e4.x * gg * c4.x; t4.y = e4.y * gg * c4.y; t4.z = e4.z * gg * c4.z; t4.w = e4.w * gg * c4.w;
+        *reinterpret_cast<float4*>(s_spec + 4 * tid) = x4;
+        *reinterpret_cast<float4*>(s_e + 4 * tid) = e4;
+        *reinterpret_cast<float4*>(s_term + 4 * tid) = t4;
+        if (!p.no_tonal && 4 * tid >= 64 && 4 * tid < 768) {
+            const double floor_ = (double)1e-12f;
+            const float ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double e = (double)fmaxf(0.0f, ev[k]);
+                s_log[4 * tid + k] = log(e > floor_ ? e : floor_);
+            }
+        }
     }
     if (tid < 32) s_run_len[tid] = 0;
     __syncthreads();
 
-    if (tid == 255) {
-        // loudness: strictly sequential 1024-term sum (atrac3denc.cpp:811-820)
-        float g[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (p.ges)
-            for (int b = 0; b < 4; ++b) g[b] = p.ges[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + b];
+    if (tid == 192) {
+        // loudness: strictly sequential 1024-term sum, on its own wavefront
+        const float4* t4 = reinterpret_cast<const float4*>(s_term);
         float l = 0.0f;
-        for (int i = 0; i < 1024; ++i) l += s_e[i] * g[i >> 8] * T->loud_curve[i];
-        rec->loud_ch = l;
-    } else if (!p.no_tonal) {
-        const double floor_ = (double)1e-12f;
-        for (int i = 64 + tid; i < 768; i += 255) {
-            const double e = (double)fmaxf(0.0f, s_e[i]);
-            s_log[i] = log(e > floor_ ? e : floor_);
+        float4 cur = t4[0];
+        for (int i = 0; i < 256; ++i) {
+            float4 nxt = cur;
+            if (i + 1 < 256) nxt = t4[i + 1];
+            l += cur.x;
+            l += cur.y;
+            l += cur.z;
+            l += cur.w;
+            cur = nxt;
         }
+        rec->loud_ch = l;
     }
-    __syncthreads();
 
     if (!p.no_tonal && tid >= 8 && tid < 29) {
         const int b = tid;

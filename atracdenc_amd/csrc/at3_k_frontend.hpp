@@ -160,15 +160,17 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
     __shared__ __attribute__((aligned(16))) float s_sub[2 * 4 * 256];     // current block's subbands [ch][band][256]
     __shared__ __attribute__((aligned(16))) float s_prevw[2 * 4 * 256];   // overlap half carried to the next frame
     __shared__ __attribute__((aligned(16))) cpx s_fft[8 * 128];
-    __shared__ __attribute__((aligned(16))) float s_div[GAIN ? 8 * 256 : 4];
     __shared__ __attribute__((aligned(16))) float s_win[256];
     __shared__ float s_cs[256];
     __shared__ cpx s_tw[128];
     __shared__ Curve s_curve[8];
     __shared__ float s_nextscale[8];         // NextOverlapScale of the block just processed
     __shared__ float s_sum[8][5];
-    __shared__ __attribute__((aligned(16))) float s_terms[GAIN ? 8 * 160 : 4];
     __shared__ Curve s_curves_all[GAIN ? 33 * 8 : 1];   // curves of frames fa-1 .. fb-1 (frames_per_wg <= 32)
+    // Gain-path scratch aliases buffers that are dead between stage 2 and the MDCT fold of the same block:
+    // the per-sample divisors live in the FFT buffer (written by the fold afterwards), the energy-term staging in
+    // each channel's PCM ring behind the 46-sample history (rewritten by the next block's tile load).
+    float* s_div = reinterpret_cast<float*>(s_fft);          // [8][256]
 
     const int tid = threadIdx.x;
     const int nchunks = (p.n_blocks - p.f0 + p.frames_per_wg - 1) / p.frames_per_wg;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
             // produced 32 at a time by all lanes of the combo; lanes 0..4 then extend one chain each.
             const bool need = has_curve || prev_scale != 1.0f;
             if (__ballot(need) != 0ull) {   // wave-uniform: both combos of the wavefront walk the chunks together
-                float* terms = s_terms + c * 160;   // [5][32]
+                float* terms = s_pcm + (c >> 2) * kPcmRing + 64 + (c & 3) * 160;   // [5][32], in the dead part of the PCM ring
                 float acc = 0.0f;
                 for (int base = 0; base < 256; base += 32) {
                     const int i = base + lane;
