@@ -710,23 +710,34 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         }
         s_err[wl * 32 + bfu] = e2;
     }
+    __syncthreads();
     if (p.debug_stop == 2) return;
     // ---- (C1) candidates of the energy-adaptive units (bfu > 18) ----
+    // A candidate (|delta| < 0.25) can only ever be re-rounded when it passes the side test of the pass that
+    // will run (e2 < e1: rounded down and below the top code; e2 > e1: rounded up; equal: nothing runs), and a
+    // skipped candidate changes no state - so only those are listed, in the same scan order (atrac_scale.cpp:86-126).
     if (tid >= 160 && tid < 160 + 91) {
         const int u = tid - 160;
         const int bfu = 31 - u / 7, wl = 1 + u % 7;
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
         const float mul = max_quant(wl);
+        const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
+        const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
         uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
         int nc = 0;
-        for (int j = 0; j < n; j += 4) {
-            const float4 v4 = *reinterpret_cast<const float4*>(s_val + start + j);
-            const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (dir != 0) {
+            for (int j = 0; j < n; j += 4) {
+                const float4 v4 = *reinterpret_cast<const float4*>(s_val + start + j);
+                const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float t = vv[k] * mul;
-                const float delta = t - (truncf(t) + 0.5f);
-                if (fabsf(delta) < 0.25f) cand[nc++] = (uint8_t)(j + k);
+                for (int k = 0; k < 4; ++k) {
+                    const float t = vv[k] * mul;
+                    const float delta = t - (truncf(t) + 0.5f);
+                    const int m0 = __float2int_rn(t);
+                    const float am = (float)(m0 < 0 ? -m0 : m0);
+                    const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (am > fabsf(t));
+                    if (fabsf(delta) < 0.25f && side) cand[nc++] = (uint8_t)(j + k);
+                }
             }
         }
         s_nc[(wl - 1) * 13 + (bfu - 19)] = (uint8_t)nc;
@@ -735,27 +746,29 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     __syncthreads();
     if (p.debug_stop == 3) return;
     // ---- (C2) rank sort by |delta|, one wordlen plane at a time; unused key slots hold +inf ----
+    int sl_bfu[3], sl_base[3], sl_k[3];   // slot -> (bfu, first slot of the bfu, index inside the bfu): same for every plane
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int slot = tid + kQuantThreads * r;
+        const int line = kEaLine0 + (slot < kEaLines ? slot : 0);
+        sl_bfu[r] = bfu_of_line(line);
+        sl_base[r] = bfu_start(sl_bfu[r]) - kEaLine0;
+        sl_k[r] = (slot < kEaLines) ? slot - sl_base[r] : 1 << 20;
+    }
     for (int wl = 1; wl <= 7; ++wl) {
         const float mul = max_quant(wl);
         const uint8_t* plane = s_cand + (wl - 1) * kEaLines;
         uint8_t* sorted = s_sorted + (wl - 1) * kEaLines;
-        int slot_bfu[3], slot_k[3];
+        bool act[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int slot = tid + kQuantThreads * r;
-            slot_k[r] = -1;
-            slot_bfu[r] = 19;
+            act[r] = sl_k[r] < (int)s_nc[(wl - 1) * 13 + (sl_bfu[r] - 19)];
             if (slot < kEaLines) {
-                const int line = kEaLine0 + slot;
-                const int bfu = bfu_of_line(line);
-                const int start = bfu_start(bfu);
-                const int k = line - start;
                 float key = __builtin_huge_valf();
-                if (k < s_nc[(wl - 1) * 13 + (bfu - 19)]) {
-                    const float t = s_val[start + plane[slot]] * mul;
+                if (act[r]) {
+                    const float t = s_val[sl_base[r] + kEaLine0 + plane[slot]] * mul;
                     key = fabsf(t - (truncf(t) + 0.5f));
-                    slot_k[r] = k;
-                    slot_bfu[r] = bfu;
                 }
                 s_key[slot] = key;
             }
@@ -763,9 +776,9 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            if (slot_k[r] >= 0) {
-                const int bfu = slot_bfu[r], k = slot_k[r];
-                const int base = bfu_start(bfu) - kEaLine0;
+            if (act[r]) {
+                const int bfu = sl_bfu[r], k = sl_k[r];
+                const int base = sl_base[r];
                 const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
                 const float key = s_key[base + k];
                 int rank = 0, eq = 0;
@@ -785,25 +798,39 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         __syncthreads();
     }
     if (p.debug_stop == 4) return;
-    // ---- (C3) equal keys: libstdc++'s std::sort order decides (rare) ----
+    // ---- (C3) equal keys among listed candidates: libstdc++'s std::sort order decides (rare). The order of equal
+    //      elements depends on the whole array the reference sorts, so the full |delta| < 0.25 list is rebuilt,
+    //      sorted with the restated algorithm and then filtered. ----
     if (s_anytie) {
         if (tid == 0) {
             for (int u = 0; u < 91; ++u) {
                 const int bfu = 31 - u / 7, wl = 1 + u % 7;
                 if (!s_tie[(wl - 1) * 13 + (bfu - 19)]) continue;
-                const int start = bfu_start(bfu);
+                const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
                 const float mul = max_quant(wl);
-                const uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
-                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
-                for (int q = 0; q < nc; ++q) {
-                    const int j = cand[q];
+                int nall = 0;
+                for (int j = 0; j < n; ++j) {
                     const float t = s_val[start + j] * mul;
-                    s_items[q].key = t - (truncf(t) + 0.5f);
-                    s_items[q].idx = j;
+                    const float delta = t - (truncf(t) + 0.5f);
+                    if (fabsf(delta) < 0.25f) {
+                        s_items[nall].key = delta;
+                        s_items[nall].idx = j;
+                        ++nall;
+                    }
                 }
-                std_sort_abs(s_items, nc);
+                std_sort_abs(s_items, nall);
+                const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
+                const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
                 uint8_t* sorted = s_sorted + (wl - 1) * kEaLines + (start - kEaLine0);
-                for (int q = 0; q < nc; ++q) sorted[q] = (uint8_t)s_items[q].idx;
+                int nc = 0;
+                for (int q = 0; q < nall; ++q) {
+                    const int j = s_items[q].idx;
+                    const float t = s_val[start + j] * mul;
+                    const int m0 = __float2int_rn(t);
+                    const float am = (float)(m0 < 0 ? -m0 : m0);
+                    const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (dir < 0) ? (am > fabsf(t)) : false;
+                    if (side) sorted[nc++] = (uint8_t)j;
+                }
             }
         }
         __syncthreads();
@@ -836,7 +863,22 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
         const int per = n >> 3;  // 1, 2, 4, 8 or 16 lines per task (n is a multiple of 8)
         uint32_t bits = 0;
-        if (wl > 1) {
+        if (per >= 8) {
+            for (int j = part * per; j < (part + 1) * per; j += 8) {
+                const uint2 pk = *reinterpret_cast<const uint2*>(mant + j);
+                int m8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m8[k] = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
+                if (wl > 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) bits += lds_huff(s_huff, wl, vlc_index(m8[k])) >> 8;
+                } else {
+                    const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) bits += lds_huff(s_huff, 1, rt9[3 * (m8[k] + 1) + (m8[k + 1] + 1)]) >> 8;
+                }
+            }
+        } else if (wl > 1) {
             for (int j = part * per; j < (part + 1) * per; ++j) bits += lds_huff(s_huff, wl, vlc_index(mant[j])) >> 8;
         } else {
             const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
@@ -850,7 +892,6 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         atomicAdd(&s_vlc[wl * 32 + bfu], bits);
     }
     __syncthreads();
-    if (p.debug_stop == 7) return;
     // ---- results to HBM ----
     QuantRec* q = p.quant + cf;
     if (tid < 224) {
