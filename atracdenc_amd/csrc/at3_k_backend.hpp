@@ -218,21 +218,37 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     }
 }
 
-// TrackLoudness chain: one thread per stream, sequential over frames (atrac3denc.cpp:833-841).
-__global__ void k_loudness(BackParams p)
+// TrackLoudness chain (atrac3denc.cpp:833-841, atrac_psy_common.h:46-54): one wavefront per stream. The 64 lanes
+// fetch the per-frame channel loudness values in parallel (the chain itself would otherwise wait for one
+// dependent global load per frame), lane 0 runs the f64 recurrence out of LDS, all lanes store the results.
+constexpr int kLoudChunk = 1024;
+__global__ __launch_bounds__(64) void k_loudness(BackParams p)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= p.n_streams) return;
+    __shared__ float s_t[kLoudChunk];
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
     const int n_out = p.n_blocks - p.f0;
     float L = p.loud_state[s];
-    for (int fo = 0; fo < n_out; ++fo) {
-        const PsyRec* r = p.psy + ((size_t)s * n_out + fo) * 2;
-        const float l0 = r[0].loud_ch, l1 = r[1].loud_ch;
-        if (p.js) L = (float)(0.98 * (double)L + 0.02 * (double)l0);
-        else L = (float)(0.98 * (double)L + 0.01 * (double)(l0 + l1));
-        p.loud[(size_t)s * n_out + fo] = L;
+    for (int base = 0; base < n_out; base += kLoudChunk) {
+        const int cnt = (n_out - base < kLoudChunk) ? n_out - base : kLoudChunk;
+        for (int i = lane; i < cnt; i += 64) {
+            const PsyRec* r = p.psy + ((size_t)s * n_out + base + i) * 2;
+            const float l0 = r[0].loud_ch, l1 = r[1].loud_ch;
+            s_t[i] = p.js ? l0 : (l0 + l1);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const double k = p.js ? 0.02 : 0.01;
+            for (int i = 0; i < cnt; ++i) {
+                L = (float)(0.98 * (double)L + k * (double)s_t[i]);
+                s_t[i] = L;
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < cnt; i += 64) p.loud[(size_t)s * n_out + base + i] = s_t[i];
+        __syncthreads();
     }
-    p.loud_state[s] = L;
+    if (lane == 0) p.loud_state[s] = L;
 }
 
 // ---- bit writer on an LDS word buffer (MSB first) -------------------------------------------------
@@ -428,46 +444,36 @@ __device__ __attribute__((noinline)) void std_sort_abs(SortItem* a, int n)
     }
 }
 
-// Energy-adaptive re-rounding pass of QuantMantisas (atrac_scale.cpp:86-128) over the already sorted
-// candidate list. Returns the updated e2.
-__device__ inline float ea_greedy(const float* in, float mul, float inv2, float e1, float e2, const uint8_t* cand, int nc,
+// Energy-adaptive re-rounding pass of QuantMantisas (atrac_scale.cpp:86-128) over the candidates already
+// ordered by |delta| (sidx[c] = line inside the BFU; the list is padded to a multiple of four). Only candidates
+// that pass the side test of the running pass are listed, and each line occurs once, so the current mantissa of
+// a candidate is still lrint(t). Values of four candidates are fetched together; the decisions stay sequential.
+__device__ inline float ea_greedy(const float* in, const uint8_t* sidx, int nc, float mul, float inv2, float e1, float e2,
                                   int8_t* mant)
 {
-    if (e2 < e1) {
-        for (int c = 0; c < nc; ++c) {
-            const int j = cand[c];
-            const float t = in[j] * mul;
-            const int m0 = mant[j];
-            const float am = (float)(m0 < 0 ? -m0 : m0);
-            if (am < fabsf(t) && am < (mul - 1)) {
+    const bool grow = e2 < e1;
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+        const uint32_t i4 = *reinterpret_cast<const uint32_t*>(sidx + c0);
+        const float tt[4] = {in[i4 & 0xff] * mul, in[(i4 >> 8) & 0xff] * mul, in[(i4 >> 16) & 0xff] * mul, in[i4 >> 24] * mul};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c0 + k < nc) {
+                const float t = tt[k];
+                const int m0 = __float2int_rn(t);
                 int m = m0;
-                if (m > 0) m++;
-                if (m < 0) m--;
-                if (m == 0) m = t > 0 ? 1 : -1;
-                float ex = e2;
-                ex -= (float)(m0 * m0) * inv2;
-                ex += (float)(m * m) * inv2;
-                if (fabsf(ex - e1) < fabsf(e2 - e1)) {
-                    mant[j] = (int8_t)m;
-                    e2 = ex;
+                if (grow) {
+                    if (m > 0) m++;
+                    if (m < 0) m--;
+                    if (m == 0) m = t > 0 ? 1 : -1;
+                } else {
+                    if (m > 0) m--;
+                    else if (m < 0) m++;
                 }
-            }
-        }
-    } else if (e2 > e1) {
-        for (int c = 0; c < nc; ++c) {
-            const int j = cand[c];
-            const float t = in[j] * mul;
-            const int m0 = mant[j];
-            const float am = (float)(m0 < 0 ? -m0 : m0);
-            if (am > fabsf(t)) {
-                int m = m0;
-                if (m > 0) m--;
-                if (m < 0) m++;
                 float ex = e2;
                 ex -= (float)(m0 * m0) * inv2;
                 ex += (float)(m * m) * inv2;
                 if (fabsf(ex - e1) < fabsf(e2 - e1)) {
-                    mant[j] = (int8_t)m;
+                    mant[(i4 >> (8 * k)) & 0xff] = (int8_t)m;
                     e2 = ex;
                 }
             }
@@ -614,14 +620,19 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
 
 // ---- quantisation kernel: one 256-thread workgroup per (stream, output frame, channel) -----------------
 //
-// Computes what TEncCache would compute lazily - every (bfu, wordlen) unit - so the rate loop that follows
-// is pure table look-up: (A) all 7 x 1024 roundings in parallel; (B) the strictly ordered energy sums as 256
-// independent chains (32 x e1, 224 x e2), one per thread, longest chains on the first wave; (C) the
-// energy-adaptive re-rounding of BFUs 19..31: candidate lists in LDS, parallel rank sort (falls back to the
-// libstdc++-order sort when two candidates tie), sequential greedy pass per unit; (D) CLC / VLC bit costs.
+// Computes what TEncCache would compute lazily - every (bfu, wordlen) unit - so the rate loop that follows is
+// pure table look-up. The work is laid out so that wave instructions carry full lanes:
+//  (A) 1024 scaled values and all 7 x 1024 roundings, four lines per work-item;
+//  (B) the 256 strictly ordered energy sums (32 x e1, 224 x e2) on ONE wavefront: chains are packed so that every
+//      lane adds exactly 128 terms (1 x 128, 2 x 64, 4 x 32, 8 x 16 or 16 x 8 lines), i.e. 128 lock-step steps;
+//  (C) energy-adaptive re-rounding of BFUs 19..31 in two halves of the wordlen range: ballot/popcount compaction of
+//      the candidates that can be re-rounded, flat rank sort by |delta| over all candidates of the half (falls back
+//      to the libstdc++-order sort when two listed candidates tie), one lane per unit for the sequential pass;
+//  (D) CLC / VLC bit costs of the final mantissas.
 constexpr int kEaLine0 = 288;              // first spectral line of BFU 19
 constexpr int kEaLines = 1024 - kEaLine0;  // 736
 constexpr int kQuantThreads = 256;
+constexpr int kHalfSlots = 4 * kEaLines;   // candidate slots of up to four wordlen planes
 
 __device__ __forceinline__ uint32_t lds_huff(const uint16_t* s_huff, int sel, uint32_t idx)
 {
@@ -632,11 +643,12 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
 {
     __shared__ __attribute__((aligned(16))) float s_val[1024];
     __shared__ __attribute__((aligned(16))) int8_t s_mant[7 * 1024];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cand[7 * kEaLines];   // candidate lines (relative to the BFU), scan order
-    __shared__ __attribute__((aligned(16))) uint8_t s_sorted[7 * kEaLines]; // the same, ordered by |delta|
-    __shared__ __attribute__((aligned(16))) float s_key[kEaLines];          // |delta| of one wordlen plane at a time
-    __shared__ uint8_t s_nc[7 * 13];
-    __shared__ uint8_t s_tie[7 * 13];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ci[kHalfSlots];   // listed candidates (line inside the BFU), scan order
+    __shared__ __attribute__((aligned(16))) float s_ct[kHalfSlots];     // value * mul of the same candidates (+inf padded)
+    __shared__ __attribute__((aligned(16))) uint8_t s_si[kHalfSlots];   // candidates ordered by |delta|
+    __shared__ uint8_t s_nc[4 * 13];
+    __shared__ uint8_t s_tie[4 * 13];
+    __shared__ int s_off[4 * 13 + 1];
     __shared__ float s_e1[32];
     __shared__ float s_err[8 * 32];            // e2 during phases B/C, then e1 / e2
     __shared__ uint32_t s_vlc[8 * 32];
@@ -645,19 +657,17 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     __shared__ int s_anytie;
 
     const int tid = threadIdx.x;
-    const int n_out = p.n_blocks - p.f0;
+    const int wave = tid >> 6, lane = tid & 63;
     const size_t cf = blockIdx.x;  // (s * n_out + fo) * 2 + ch
     const float* specs = p.specs + cf * 1024;
     const PsyRec* rec = p.psy + cf;
 
     if (tid < 130) s_huff[tid] = c_huff[tid];
-    if (tid == 0) s_anytie = 0;
     s_vlc[tid] = 0;
-    // ---- scaled values (TScaler::Scale): thread t owns lines 4t..4t+3 (BFU sizes are multiples of 8) ----
+    // ---- (A) scaled values (TScaler::Scale) and mantissa = lrint(value * MaxQuant[wl]) ----
     {
         const int i0 = tid * 4;
-        const int b = bfu_of_line(i0);
-        const float sf = T->scale[rec->sfi[b]];
+        const float sf = T->scale[rec->sfi[bfu_of_line(i0)]];
         const float4 x = *reinterpret_cast<const float4*>(specs + i0);
         float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
 #pragma unroll
@@ -666,7 +676,6 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         float4 o;
         o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
         *reinterpret_cast<float4*>(s_val + i0) = o;
-        // ---- (A) mantissa = lrint(value * MaxQuant[wl]) for every wordlen ----
 #pragma unroll
         for (int wl = 1; wl <= 7; ++wl) {
             const float mul = max_quant(wl);
@@ -676,186 +685,198 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         }
     }
     __syncthreads();
-
     if (p.debug_stop == 1) return;
-    // ---- (B) ordered sums, one chain per thread: tid < 32 -> e1 of bfu 31 - tid; else e2 of unit tid - 32 ----
-    //      unit u: bfu = 31 - u / 7, wl = 1 + u % 7 (largest BFUs first so long chains share a wavefront)
-    if (tid < 32) {
-        const int bfu = 31 - tid;
-        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        float e1 = 0.0f;
-        for (int j = 0; j < n; j += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(s_val + start + j);
-            e1 += v.x * v.x;
-            e1 += v.y * v.y;
-            e1 += v.z * v.z;
-            e1 += v.w * v.w;
-        }
-        s_e1[bfu] = e1;
-    } else {
-        const int u = tid - 32;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const float mul = max_quant(wl);
-        const float inv2 = (float)(1.0 / (double)(mul * mul));
-        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-        float e2 = 0.0f;
-        for (int j = 0; j < n; j += 8) {
-            const uint2 pk = *reinterpret_cast<const uint2*>(mant + j);
+
+    // ---- (B) ordered sums on wavefront 0: lane -> `per` chains of `len` lines, chain c = (bfu, kind),
+    //      kind 0 = e1 (sum of value^2), kind 1..7 = e2 of that wordlen (sum of mantissa^2 / mul^2) ----
+    if (wave == 0) {
+        int len, first_chain, bfu_top;
+        if (lane < 16) { len = 128; first_chain = lane; bfu_top = 31; }
+        else if (lane < 32) { len = 64; first_chain = (lane - 16) * 2; bfu_top = 29; }
+        else if (lane < 52) { len = 32; first_chain = (lane - 32) * 4; bfu_top = 25; }
+        else if (lane < 60) { len = 16; first_chain = (lane - 52) * 8; bfu_top = 15; }
+        else { len = 8; first_chain = (lane - 60) * 16; bfu_top = 7; }
+        float acc = 0.0f;
+        for (int pos = 0; pos < 128; pos += 8) {
+            const int c = first_chain + pos / len, off = pos % len;
+            const int bfu = bfu_top - (c >> 3), kind = c & 7;
+            const int start = bfu_start(bfu);
+            if (off == 0) acc = 0.0f;
+            if (kind == 0) {
+                const float4 a = *reinterpret_cast<const float4*>(s_val + start + off);
+                const float4 b = *reinterpret_cast<const float4*>(s_val + start + off + 4);
+                acc += a.x * a.x; acc += a.y * a.y; acc += a.z * a.z; acc += a.w * a.w;
+                acc += b.x * b.x; acc += b.y * b.y; acc += b.z * b.z; acc += b.w * b.w;
+            } else {
+                const float mul = max_quant(kind);
+                const float inv2 = (float)(1.0 / (double)(mul * mul));
+                const uint2 pk = *reinterpret_cast<const uint2*>(s_mant + (kind - 1) * 1024 + start + off);
+                float sq[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int m = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
-                e2 += (float)(m * m) * inv2;
+                for (int k = 0; k < 8; ++k) {
+                    const int m = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
+                    sq[k] = (float)(m * m) * inv2;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += sq[k];
+            }
+            if (off + 8 == len) {
+                if (kind == 0) s_e1[bfu] = acc;
+                else s_err[kind * 32 + bfu] = acc;
             }
         }
-        s_err[wl * 32 + bfu] = e2;
     }
     __syncthreads();
     if (p.debug_stop == 2) return;
-    // ---- (C1) candidates of the energy-adaptive units (bfu > 18) ----
-    // A candidate (|delta| < 0.25) can only ever be re-rounded when it passes the side test of the pass that
-    // will run (e2 < e1: rounded down and below the top code; e2 > e1: rounded up; equal: nothing runs), and a
-    // skipped candidate changes no state - so only those are listed, in the same scan order (atrac_scale.cpp:86-126).
-    if (tid >= 160 && tid < 160 + 91) {
-        const int u = tid - 160;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const float mul = max_quant(wl);
-        const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
-        const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
-        uint8_t* cand = s_cand + (wl - 1) * kEaLines + (start - kEaLine0);
-        int nc = 0;
-        if (dir != 0) {
-            for (int j = 0; j < n; j += 4) {
-                const float4 v4 = *reinterpret_cast<const float4*>(s_val + start + j);
-                const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float t = vv[k] * mul;
+
+    // ---- (C) energy-adaptive units (bfu > 18), wordlens [wl_lo, wl_hi] per half ----
+    for (int half = 0; half < 2; ++half) {
+        const int wl_lo = half ? 5 : 1, n_planes = half ? 3 : 4;
+        const int n_units = n_planes * 13;
+        if (tid == 0) s_anytie = 0;
+        // (C1) compaction: unit = (plane, bfu); one wavefront pass per 64 lines, ballot + popcount positions.
+        // A candidate (|delta| < 0.25) can only ever be re-rounded when it passes the side test of the pass that
+        // will run (e2 < e1: rounded down and below the top code; e2 > e1: rounded up; equal: nothing runs), and a
+        // skipped candidate changes no state - so only those are listed, in scan order (atrac_scale.cpp:66-126).
+        for (int u = wave; u < n_units; u += 4) {
+            const int pl = u / 13, bfu = 19 + u % 13, wl = wl_lo + pl;
+            const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
+            const int base = pl * kEaLines + (start - kEaLine0);
+            const float mul = max_quant(wl);
+            const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
+            const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
+            int nc = 0;
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                bool flag = false;
+                float t = 0.0f;
+                if (j < n && dir != 0) {
+                    t = s_val[start + j] * mul;
                     const float delta = t - (truncf(t) + 0.5f);
                     const int m0 = __float2int_rn(t);
                     const float am = (float)(m0 < 0 ? -m0 : m0);
                     const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (am > fabsf(t));
-                    if (fabsf(delta) < 0.25f && side) cand[nc++] = (uint8_t)(j + k);
+                    flag = fabsf(delta) < 0.25f && side;
+                }
+                const unsigned long long mask = __ballot(flag);
+                if (flag) {
+                    const int pos = nc + __popcll(mask & ((1ull << lane) - 1ull));
+                    s_ci[base + pos] = (uint8_t)j;
+                    s_ct[base + pos] = t;
+                }
+                nc += __popcll(mask);
+            }
+            if (lane < 4) {   // pad to a multiple of four: +inf has a NaN key (never counted), index 0 is harmless
+                const int k = nc + lane;
+                if (k < ((nc + 3) & ~3)) {
+                    s_ct[base + k] = __builtin_huge_valf();
+                    s_ci[base + k] = 0;
                 }
             }
-        }
-        s_nc[(wl - 1) * 13 + (bfu - 19)] = (uint8_t)nc;
-        s_tie[(wl - 1) * 13 + (bfu - 19)] = 0;
-    }
-    __syncthreads();
-    if (p.debug_stop == 3) return;
-    // ---- (C2) rank sort by |delta|, one wordlen plane at a time; unused key slots hold +inf ----
-    int sl_bfu[3], sl_base[3], sl_k[3];   // slot -> (bfu, first slot of the bfu, index inside the bfu): same for every plane
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int slot = tid + kQuantThreads * r;
-        const int line = kEaLine0 + (slot < kEaLines ? slot : 0);
-        sl_bfu[r] = bfu_of_line(line);
-        sl_base[r] = bfu_start(sl_bfu[r]) - kEaLine0;
-        sl_k[r] = (slot < kEaLines) ? slot - sl_base[r] : 1 << 20;
-    }
-    for (int wl = 1; wl <= 7; ++wl) {
-        const float mul = max_quant(wl);
-        const uint8_t* plane = s_cand + (wl - 1) * kEaLines;
-        uint8_t* sorted = s_sorted + (wl - 1) * kEaLines;
-        bool act[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int slot = tid + kQuantThreads * r;
-            act[r] = sl_k[r] < (int)s_nc[(wl - 1) * 13 + (sl_bfu[r] - 19)];
-            if (slot < kEaLines) {
-                float key = __builtin_huge_valf();
-                if (act[r]) {
-                    const float t = s_val[sl_base[r] + kEaLine0 + plane[slot]] * mul;
-                    key = fabsf(t - (truncf(t) + 0.5f));
-                }
-                s_key[slot] = key;
+            if (lane == 0) {
+                s_nc[u] = (uint8_t)nc;
+                s_tie[u] = 0;
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (act[r]) {
-                const int bfu = sl_bfu[r], k = sl_k[r];
-                const int base = sl_base[r];
-                const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
-                const float key = s_key[base + k];
-                int rank = 0, eq = 0;
-                for (int q = 0; q < nc; q += 4) {
-                    const float4 kq = *reinterpret_cast<const float4*>(s_key + base + q);
-                    rank += (kq.x < key) + (kq.y < key) + (kq.z < key) + (kq.w < key);
-                    rank += (kq.x == key && q + 0 < k) + (kq.y == key && q + 1 < k) + (kq.z == key && q + 2 < k) + (kq.w == key && q + 3 < k);
-                    eq += (kq.x == key) + (kq.y == key) + (kq.z == key) + (kq.w == key);
-                }
-                if (eq > 1) {
-                    s_tie[(wl - 1) * 13 + (bfu - 19)] = 1;
-                    s_anytie = 1;
-                }
-                sorted[base + rank] = plane[base + k];
-            }
+        // (C2) flat rank sort: candidate e of the half -> (unit, k) through the prefix sums of the unit sizes
+        if (tid <= n_units) {
+            int off = 0;
+            for (int u = 0; u < tid; ++u) off += s_nc[u];
+            s_off[tid] = off;
         }
         __syncthreads();
-    }
-    if (p.debug_stop == 4) return;
-    // ---- (C3) equal keys among listed candidates: libstdc++'s std::sort order decides (rare). The order of equal
-    //      elements depends on the whole array the reference sorts, so the full |delta| < 0.25 list is rebuilt,
-    //      sorted with the restated algorithm and then filtered. ----
-    if (s_anytie) {
-        if (tid == 0) {
-            for (int u = 0; u < 91; ++u) {
-                const int bfu = 31 - u / 7, wl = 1 + u % 7;
-                if (!s_tie[(wl - 1) * 13 + (bfu - 19)]) continue;
-                const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-                const float mul = max_quant(wl);
-                int nall = 0;
-                for (int j = 0; j < n; ++j) {
-                    const float t = s_val[start + j] * mul;
-                    const float delta = t - (truncf(t) + 0.5f);
-                    if (fabsf(delta) < 0.25f) {
-                        s_items[nall].key = delta;
-                        s_items[nall].idx = j;
-                        ++nall;
+        const int total = s_off[n_units];
+        for (int e = tid; e < total; e += kQuantThreads) {
+            int lo = 0, hi = n_units - 1;           // last unit with s_off[u] <= e
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_off[mid] <= e) lo = mid;
+                else hi = mid - 1;
+            }
+            const int u = lo, k = e - s_off[u];
+            const int pl = u / 13, bfu = 19 + u % 13;
+            const int base = pl * kEaLines + (bfu_start(bfu) - kEaLine0);
+            const int nc = s_nc[u];
+            const float tk = s_ct[base + k];
+            const float key = fabsf(tk - (truncf(tk) + 0.5f));
+            int rank = 0, eq = 0;
+            const float4* t4 = reinterpret_cast<const float4*>(s_ct + base);
+            for (int q = 0; q < nc; q += 4) {
+                const float4 cur = t4[q >> 2];
+                const float k0 = fabsf(cur.x - (truncf(cur.x) + 0.5f)), k1 = fabsf(cur.y - (truncf(cur.y) + 0.5f));
+                const float k2 = fabsf(cur.z - (truncf(cur.z) + 0.5f)), k3 = fabsf(cur.w - (truncf(cur.w) + 0.5f));
+                rank += (k0 < key) + (k1 < key) + (k2 < key) + (k3 < key);
+                rank += (k0 == key && q + 0 < k) + (k1 == key && q + 1 < k) + (k2 == key && q + 2 < k) + (k3 == key && q + 3 < k);
+                eq += (k0 == key) + (k1 == key) + (k2 == key) + (k3 == key);
+            }
+            if (eq > 1) {
+                s_tie[u] = 1;
+                s_anytie = 1;
+            }
+            s_si[base + rank] = s_ci[base + k];
+        }
+        __syncthreads();
+        // (C3) equal keys among listed candidates: libstdc++'s std::sort order decides (rare). The order of equal
+        //      elements depends on the whole array the reference sorts, so the full |delta| < 0.25 list is rebuilt,
+        //      sorted with the restated algorithm and then filtered.
+        if (s_anytie) {
+            if (tid == 0) {
+                for (int u = 0; u < n_units; ++u) {
+                    if (!s_tie[u]) continue;
+                    const int pl = u / 13, bfu = 19 + u % 13, wl = wl_lo + pl;
+                    const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
+                    const float mul = max_quant(wl);
+                    int nall = 0;
+                    for (int j = 0; j < n; ++j) {
+                        const float t = s_val[start + j] * mul;
+                        const float delta = t - (truncf(t) + 0.5f);
+                        if (fabsf(delta) < 0.25f) {
+                            s_items[nall].key = delta;
+                            s_items[nall].idx = j;
+                            ++nall;
+                        }
+                    }
+                    std_sort_abs(s_items, nall);
+                    const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
+                    const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
+                    uint8_t* sorted = s_si + pl * kEaLines + (start - kEaLine0);
+                    int nc = 0;
+                    for (int q = 0; q < nall; ++q) {
+                        const int j = s_items[q].idx;
+                        const float t = s_val[start + j] * mul;
+                        const int m0 = __float2int_rn(t);
+                        const float am = (float)(m0 < 0 ? -m0 : m0);
+                        const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (dir < 0) ? (am > fabsf(t)) : false;
+                        if (side) sorted[nc++] = (uint8_t)j;
                     }
                 }
-                std_sort_abs(s_items, nall);
-                const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
-                const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
-                uint8_t* sorted = s_sorted + (wl - 1) * kEaLines + (start - kEaLine0);
-                int nc = 0;
-                for (int q = 0; q < nall; ++q) {
-                    const int j = s_items[q].idx;
-                    const float t = s_val[start + j] * mul;
-                    const int m0 = __float2int_rn(t);
-                    const float am = (float)(m0 < 0 ? -m0 : m0);
-                    const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (dir < 0) ? (am > fabsf(t)) : false;
-                    if (side) sorted[nc++] = (uint8_t)j;
-                }
+            }
+            __syncthreads();
+        }
+        // (C4) sequential re-rounding pass, one lane per unit
+        if (tid < n_units) {
+            const int u = tid;
+            const int pl = u / 13, bfu = 19 + u % 13, wl = wl_lo + pl;
+            const int start = bfu_start(bfu);
+            const int nc = s_nc[u];
+            if (nc > 0) {
+                const float mul = max_quant(wl);
+                const float inv2 = (float)(1.0 / (double)(mul * mul));
+                const float e1 = s_e1[bfu];
+                s_err[wl * 32 + bfu] = ea_greedy(s_val + start, s_si + pl * kEaLines + (start - kEaLine0), nc, mul, inv2, e1,
+                                                 s_err[wl * 32 + bfu], s_mant + (wl - 1) * 1024 + start);
             }
         }
         __syncthreads();
+        if (p.debug_stop == 3 + half) return;
     }
-    if (p.debug_stop == 5) return;
-    // ---- (C4) greedy re-rounding per energy-adaptive unit; e1 / e2 for every unit ----
+
+    // ---- (D) e1 / e2 and VLC cost of the final mantissas: 8 partial sums per unit, combined with LDS atomics ----
     if (tid < 224) {
-        const int u = tid;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = bfu_start(bfu);
-        const float e1 = s_e1[bfu];
-        float e2 = s_err[wl * 32 + bfu];
-        if (bfu > 18) {
-            const float mul = max_quant(wl);
-            const float inv2 = (float)(1.0 / (double)(mul * mul));
-            int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-            const int nc = s_nc[(wl - 1) * 13 + (bfu - 19)];
-            if (nc > 0)
-                e2 = ea_greedy(s_val + start, mul, inv2, e1, e2, s_sorted + (wl - 1) * kEaLines + (start - kEaLine0), nc, mant);
-        }
-        s_err[wl * 32 + bfu] = e1 / e2;
+        const int wl = 1 + tid / 32, bfu = tid % 32;
+        s_err[wl * 32 + bfu] = s_e1[bfu] / s_err[wl * 32 + bfu];
     }
-    __syncthreads();
-    if (p.debug_stop == 6) return;
-    // ---- (D) VLC cost of the final mantissas: 8 partial sums per unit, combined with LDS atomics ----
     for (int task = tid; task < 224 * 8; task += kQuantThreads) {
         const int u = task >> 3, part = task & 7;
         const int bfu = 31 - u / 7, wl = 1 + u % 7;

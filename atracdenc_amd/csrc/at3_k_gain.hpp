@@ -343,33 +343,61 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
     }
 }
 
-// Context chain (TCurveBuilderCtx): one thread per (stream, channel, band<3), sequential over frames.
-// Frames with hfr < 0.05 reset LastLevel and leave LastTarget / LastHpfEnergy untouched
-// (atrac3denc.cpp:319-327); otherwise LastHpfEnergy = mean(gain) (:342-346), LastLevel = gain[31],
-// LastTarget = target (transient_detector.cpp:307-310).
-__global__ void k_gain_scan(GainParams p, int n_streams)
+// Context chain (TCurveBuilderCtx): one wavefront per (stream, channel, band<3). Frames with hfr < 0.05 reset
+// LastLevel and leave LastTarget / LastHpfEnergy untouched (atrac3denc.cpp:319-327); otherwise
+// LastHpfEnergy = mean(gain) (:342-346), LastLevel = gain[31], LastTarget = target (transient_detector.cpp:307-310).
+// The lanes fetch the per-frame inputs in parallel, lane 0 walks the chain out of LDS, all lanes store the
+// context each frame starts from.
+constexpr int kScanChunk = 512;
+__global__ __launch_bounds__(64) void k_gain_scan(GainParams p, int n_streams)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_hfr[kScanChunk], s_g31[kScanChunk], s_tgt[kScanChunk], s_hpf[kScanChunk];
+    const int lane = threadIdx.x;
+    const int idx = blockIdx.x;
     if (idx >= n_streams * 6) return;
     const int band = idx % 3, ch = (idx / 3) % 2, s = idx / 6;
     BandState* st = p.state + (size_t)s * 8 + ch * 4 + band;
     float lvl = st->last_level, tgt = st->last_target, hpf = st->last_hpf;
-    for (int f = p.f0; f < p.n_blocks; ++f) {
-        GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
-        rec->ctx_level = lvl;
-        rec->ctx_target = tgt;
-        rec->ctx_hpf = hpf;
-        if (rec->hfr < 0.05f) {
-            lvl = 0.0f;
-        } else {
-            lvl = rec->gain[31];
-            tgt = rec->target;
-            hpf = rec->cur_hpf;
+    const int nfr = p.n_blocks - p.f0;
+    for (int base = 0; base < nfr; base += kScanChunk) {
+        const int cnt = (nfr - base < kScanChunk) ? nfr - base : kScanChunk;
+        for (int i = lane; i < cnt; i += 64) {
+            const GainRec* rec = p.rec + (((size_t)s * p.n_blocks + p.f0 + base + i) * 2 + ch) * 3 + band;
+            s_hfr[i] = rec->hfr;
+            s_g31[i] = rec->gain[31];
+            s_tgt[i] = rec->target;
+            s_hpf[i] = rec->cur_hpf;
         }
+        __syncthreads();
+        if (lane == 0) {
+            for (int i = 0; i < cnt; ++i) {
+                const float h = s_hfr[i], g = s_g31[i], t = s_tgt[i], e = s_hpf[i];
+                s_g31[i] = lvl;    // context before this frame
+                s_tgt[i] = tgt;
+                s_hpf[i] = hpf;
+                if (h < 0.05f) {
+                    lvl = 0.0f;
+                } else {
+                    lvl = g;
+                    tgt = t;
+                    hpf = e;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < cnt; i += 64) {
+            GainRec* rec = p.rec + (((size_t)s * p.n_blocks + p.f0 + base + i) * 2 + ch) * 3 + band;
+            rec->ctx_level = s_g31[i];
+            rec->ctx_target = s_tgt[i];
+            rec->ctx_hpf = s_hpf[i];
+        }
+        __syncthreads();
     }
-    st->last_level = lvl;
-    st->last_target = tgt;
-    st->last_hpf = hpf;
+    if (lane == 0) {
+        st->last_level = lvl;
+        st->last_target = tgt;
+        st->last_hpf = hpf;
+    }
 }
 
 __device__ inline uint32_t first_set_bit(uint32_t x)

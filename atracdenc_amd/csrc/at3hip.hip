@@ -287,7 +287,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             HIPCHK(c, hipEventRecord(c->ev[1], st));
             hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(256), 0, st, gp, c->d_tables);
             HIPCHK(c, hipEventRecord(c->ev[2], st));
-            hipLaunchKernelGGL(k_gain_scan, dim3((S * 6 + 63) / 64), dim3(64), 0, st, gp, S);
+            hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), 0, st, gp, S);
             hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), 0, st, gp, c->d_tables, S);
         } else {
             HIPCHK(c, hipEventRecord(c->ev[1], st));
@@ -319,7 +319,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.mant = c->d_mant;
         hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(c->ev[5], st));
-        hipLaunchKernelGGL(k_loudness, dim3((S + 63) / 64), dim3(64), 0, st, bp);
+        hipLaunchKernelGGL(k_loudness, dim3(S), dim3(64), 0, st, bp);
         hipLaunchKernelGGL(k_quant, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
         hipLaunchKernelGGL(k_rate_pack, dim3(S * n_out * 2), dim3(64), 0, st, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(c->ev[6], st));
