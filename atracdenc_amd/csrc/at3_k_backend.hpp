@@ -621,18 +621,19 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
 // ---- quantisation kernel: one 256-thread workgroup per (stream, output frame, channel) -----------------
 //
 // Computes what TEncCache would compute lazily - every (bfu, wordlen) unit - so the rate loop that follows is
-// pure table look-up. The work is laid out so that wave instructions carry full lanes:
+// pure table look-up. The work is laid out so that wave instructions carry full lanes and the order-dependent
+// parts stay short:
 //  (A) 1024 scaled values and all 7 x 1024 roundings, four lines per work-item;
 //  (B) the 256 strictly ordered energy sums (32 x e1, 224 x e2) on ONE wavefront: chains are packed so that every
 //      lane adds exactly 128 terms (1 x 128, 2 x 64, 4 x 32, 8 x 16 or 16 x 8 lines), i.e. 128 lock-step steps;
-//  (C) energy-adaptive re-rounding of BFUs 19..31 in two halves of the wordlen range: ballot/popcount compaction of
-//      the candidates that can be re-rounded, flat rank sort by |delta| over all candidates of the half (falls back
-//      to the libstdc++-order sort when two listed candidates tie), one lane per unit for the sequential pass;
-//  (D) CLC / VLC bit costs of the final mantissas.
+//  (C) energy-adaptive re-rounding of BFUs 19..31, the 91 units dealt round-robin to the four wavefronts, each
+//      working wave-locally (no workgroup barrier): ballot/popcount compaction of the candidates that can be
+//      re-rounded into a private scratch, rank sort by |delta| with one lane per candidate (falls back to the
+//      libstdc++-order sort when two listed candidates tie); then one lane per unit runs the sequential pass;
+//  (D) CLC / VLC bit costs of the final mantissas, four lines x seven wordlens per work-item.
 constexpr int kEaLine0 = 288;              // first spectral line of BFU 19
 constexpr int kEaLines = 1024 - kEaLine0;  // 736
 constexpr int kQuantThreads = 256;
-constexpr int kHalfSlots = 4 * kEaLines;   // candidate slots of up to four wordlen planes
 
 __device__ __forceinline__ uint32_t lds_huff(const uint16_t* s_huff, int sel, uint32_t idx)
 {
@@ -643,12 +644,11 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
 {
     __shared__ __attribute__((aligned(16))) float s_val[1024];
     __shared__ __attribute__((aligned(16))) int8_t s_mant[7 * 1024];
-    __shared__ __attribute__((aligned(16))) uint8_t s_ci[kHalfSlots];   // listed candidates (line inside the BFU), scan order
-    __shared__ __attribute__((aligned(16))) float s_ct[kHalfSlots];     // value * mul of the same candidates (+inf padded)
-    __shared__ __attribute__((aligned(16))) uint8_t s_si[kHalfSlots];   // candidates ordered by |delta|
-    __shared__ uint8_t s_nc[4 * 13];
-    __shared__ uint8_t s_tie[4 * 13];
-    __shared__ int s_off[4 * 13 + 1];
+    __shared__ __attribute__((aligned(16))) uint8_t s_si[7 * kEaLines];   // per unit: candidates ordered by |delta|
+    __shared__ __attribute__((aligned(16))) float s_ct[4][128 + 4];       // per wave: value * mul of the listed candidates
+    __shared__ __attribute__((aligned(16))) uint8_t s_ci[4][128 + 4];     // per wave: their lines inside the BFU
+    __shared__ uint8_t s_nc[91];
+    __shared__ uint8_t s_tie[91];
     __shared__ float s_e1[32];
     __shared__ float s_err[8 * 32];            // e2 during phases B/C, then e1 / e2
     __shared__ uint32_t s_vlc[8 * 32];
@@ -664,6 +664,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
 
     if (tid < 130) s_huff[tid] = c_huff[tid];
     s_vlc[tid] = 0;
+    if (tid == 0) s_anytie = 0;
     // ---- (A) scaled values (TScaler::Scale) and mantissa = lrint(value * MaxQuant[wl]) ----
     {
         const int i0 = tid * 4;
@@ -696,30 +697,32 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         else if (lane < 52) { len = 32; first_chain = (lane - 32) * 4; bfu_top = 25; }
         else if (lane < 60) { len = 16; first_chain = (lane - 52) * 8; bfu_top = 15; }
         else { len = 8; first_chain = (lane - 60) * 16; bfu_top = 7; }
+        const int lsh = 31 - __builtin_clz(len);   // log2(len)
         float acc = 0.0f;
         for (int pos = 0; pos < 128; pos += 8) {
-            const int c = first_chain + pos / len, off = pos % len;
+            const int c = first_chain + (pos >> lsh), off = pos & (len - 1);
             const int bfu = bfu_top - (c >> 3), kind = c & 7;
             const int start = bfu_start(bfu);
             if (off == 0) acc = 0.0f;
+            // both element kinds are fetched as 8 raw bytes / 8 floats; terms first, then the 8 dependent adds
+            float term[8];
             if (kind == 0) {
                 const float4 a = *reinterpret_cast<const float4*>(s_val + start + off);
                 const float4 b = *reinterpret_cast<const float4*>(s_val + start + off + 4);
-                acc += a.x * a.x; acc += a.y * a.y; acc += a.z * a.z; acc += a.w * a.w;
-                acc += b.x * b.x; acc += b.y * b.y; acc += b.z * b.z; acc += b.w * b.w;
+                term[0] = a.x * a.x; term[1] = a.y * a.y; term[2] = a.z * a.z; term[3] = a.w * a.w;
+                term[4] = b.x * b.x; term[5] = b.y * b.y; term[6] = b.z * b.z; term[7] = b.w * b.w;
             } else {
                 const float mul = max_quant(kind);
                 const float inv2 = (float)(1.0 / (double)(mul * mul));
                 const uint2 pk = *reinterpret_cast<const uint2*>(s_mant + (kind - 1) * 1024 + start + off);
-                float sq[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int m = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
-                    sq[k] = (float)(m * m) * inv2;
+                    term[k] = (float)(m * m) * inv2;
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc += sq[k];
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += term[k];
             if (off + 8 == len) {
                 if (kind == 0) s_e1[bfu] = acc;
                 else s_err[kind * 32 + bfu] = acc;
@@ -729,188 +732,150 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     __syncthreads();
     if (p.debug_stop == 2) return;
 
-    // ---- (C) energy-adaptive units (bfu > 18), wordlens [wl_lo, wl_hi] per half ----
-    for (int half = 0; half < 2; ++half) {
-        const int wl_lo = half ? 5 : 1, n_planes = half ? 3 : 4;
-        const int n_units = n_planes * 13;
-        if (tid == 0) s_anytie = 0;
-        // (C1) compaction: unit = (plane, bfu); one wavefront pass per 64 lines, ballot + popcount positions.
-        // A candidate (|delta| < 0.25) can only ever be re-rounded when it passes the side test of the pass that
-        // will run (e2 < e1: rounded down and below the top code; e2 > e1: rounded up; equal: nothing runs), and a
-        // skipped candidate changes no state - so only those are listed, in scan order (atrac_scale.cpp:66-126).
-        for (int u = wave; u < n_units; u += 4) {
-            const int pl = u / 13, bfu = 19 + u % 13, wl = wl_lo + pl;
-            const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-            const int base = pl * kEaLines + (start - kEaLine0);
-            const float mul = max_quant(wl);
-            const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
-            const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
-            int nc = 0;
-            for (int j0 = 0; j0 < n; j0 += 64) {
-                const int j = j0 + lane;
-                bool flag = false;
-                float t = 0.0f;
-                if (j < n && dir != 0) {
-                    t = s_val[start + j] * mul;
+    // ---- (C) energy-adaptive units (bfu > 18): unit u = (wl - 1) * 13 + (bfu - 19), wave-local processing ----
+    // A candidate (|delta| < 0.25) can only ever be re-rounded when it passes the side test of the pass that will
+    // run (e2 < e1: rounded down and below the top code; e2 > e1: rounded up; equal: nothing runs), and a skipped
+    // candidate changes no state - so only those are listed, in scan order (atrac_scale.cpp:66-126).
+    for (int u = wave; u < 91; u += 4) {
+        const int wl = 1 + u / 13, bfu = 19 + u % 13;
+        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
+        const float mul = max_quant(wl);
+        const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
+        const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
+        float* ct = s_ct[wave];
+        uint8_t* ci = s_ci[wave];
+        int nc = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            bool flag = false;
+            float t = 0.0f;
+            if (j < n && dir != 0) {
+                t = s_val[start + j] * mul;
+                const float delta = t - (truncf(t) + 0.5f);
+                const int m0 = __float2int_rn(t);
+                const float am = (float)(m0 < 0 ? -m0 : m0);
+                const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (am > fabsf(t));
+                flag = fabsf(delta) < 0.25f && side;
+            }
+            const unsigned long long mask = __ballot(flag);
+            if (flag) {
+                const int pos = nc + __popcll(mask & ((1ull << lane) - 1ull));
+                ci[pos] = (uint8_t)j;
+                ct[pos] = t;
+            }
+            nc += __popcll(mask);
+        }
+        if (lane < 4) ct[nc + lane] = __builtin_huge_valf();   // pad: the key of +inf is NaN and never counted
+        wave_sync();
+        // rank of candidate k among the unit's candidates (one lane each, two passes when nc > 64)
+        uint8_t* sorted = s_si + (wl - 1) * kEaLines + (start - kEaLine0);
+        bool tie = false;
+        for (int k0 = 0; k0 < nc; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < nc) {
+                const float tk = ct[k];
+                const float key = fabsf(tk - (truncf(tk) + 0.5f));
+                int rank = 0, eq = 0;
+                const float4* t4 = reinterpret_cast<const float4*>(ct);
+                for (int q = 0; q < nc; q += 4) {
+                    const float4 cur = t4[q >> 2];
+                    const float k0f = fabsf(cur.x - (truncf(cur.x) + 0.5f)), k1f = fabsf(cur.y - (truncf(cur.y) + 0.5f));
+                    const float k2f = fabsf(cur.z - (truncf(cur.z) + 0.5f)), k3f = fabsf(cur.w - (truncf(cur.w) + 0.5f));
+                    rank += (k0f < key) + (k1f < key) + (k2f < key) + (k3f < key);
+                    rank += (k0f == key && q + 0 < k) + (k1f == key && q + 1 < k) + (k2f == key && q + 2 < k) + (k3f == key && q + 3 < k);
+                    eq += (k0f == key) + (k1f == key) + (k2f == key) + (k3f == key);
+                }
+                tie = tie || eq > 1;
+                sorted[rank] = ci[k];
+            }
+        }
+        const bool any_tie = __ballot(tie) != 0ull;
+        if (lane < 4 && nc + lane < ((nc + 3) & ~3)) sorted[nc + lane] = 0;   // pad to a multiple of four
+        if (lane == 0) {
+            s_nc[u] = (uint8_t)nc;
+            s_tie[u] = any_tie;
+            if (any_tie) s_anytie = 1;
+        }
+        wave_sync();   // scratch is reused by the next unit
+    }
+    __syncthreads();
+    if (p.debug_stop == 3) return;
+    // (C3) equal keys among listed candidates: libstdc++'s std::sort order decides (rare). The order of equal
+    //      elements depends on the whole array the reference sorts, so the full |delta| < 0.25 list is rebuilt,
+    //      sorted with the restated algorithm and then filtered.
+    if (s_anytie) {
+        if (tid == 0) {
+            for (int u = 0; u < 91; ++u) {
+                if (!s_tie[u]) continue;
+                const int wl = 1 + u / 13, bfu = 19 + u % 13;
+                const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
+                const float mul = max_quant(wl);
+                int nall = 0;
+                for (int j = 0; j < n; ++j) {
+                    const float t = s_val[start + j] * mul;
                     const float delta = t - (truncf(t) + 0.5f);
+                    if (fabsf(delta) < 0.25f) {
+                        s_items[nall].key = delta;
+                        s_items[nall].idx = j;
+                        ++nall;
+                    }
+                }
+                std_sort_abs(s_items, nall);
+                const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
+                const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
+                uint8_t* sorted = s_si + (wl - 1) * kEaLines + (start - kEaLine0);
+                int nc = 0;
+                for (int q = 0; q < nall; ++q) {
+                    const int j = s_items[q].idx;
+                    const float t = s_val[start + j] * mul;
                     const int m0 = __float2int_rn(t);
                     const float am = (float)(m0 < 0 ? -m0 : m0);
-                    const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (am > fabsf(t));
-                    flag = fabsf(delta) < 0.25f && side;
+                    const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (dir < 0) ? (am > fabsf(t)) : false;
+                    if (side) sorted[nc++] = (uint8_t)j;
                 }
-                const unsigned long long mask = __ballot(flag);
-                if (flag) {
-                    const int pos = nc + __popcll(mask & ((1ull << lane) - 1ull));
-                    s_ci[base + pos] = (uint8_t)j;
-                    s_ct[base + pos] = t;
-                }
-                nc += __popcll(mask);
-            }
-            if (lane < 4) {   // pad to a multiple of four: +inf has a NaN key (never counted), index 0 is harmless
-                const int k = nc + lane;
-                if (k < ((nc + 3) & ~3)) {
-                    s_ct[base + k] = __builtin_huge_valf();
-                    s_ci[base + k] = 0;
-                }
-            }
-            if (lane == 0) {
-                s_nc[u] = (uint8_t)nc;
-                s_tie[u] = 0;
             }
         }
         __syncthreads();
-        // (C2) flat rank sort: candidate e of the half -> (unit, k) through the prefix sums of the unit sizes
-        if (tid <= n_units) {
-            int off = 0;
-            for (int u = 0; u < tid; ++u) off += s_nc[u];
-            s_off[tid] = off;
-        }
-        __syncthreads();
-        const int total = s_off[n_units];
-        for (int e = tid; e < total; e += kQuantThreads) {
-            int lo = 0, hi = n_units - 1;           // last unit with s_off[u] <= e
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_off[mid] <= e) lo = mid;
-                else hi = mid - 1;
-            }
-            const int u = lo, k = e - s_off[u];
-            const int pl = u / 13, bfu = 19 + u % 13;
-            const int base = pl * kEaLines + (bfu_start(bfu) - kEaLine0);
-            const int nc = s_nc[u];
-            const float tk = s_ct[base + k];
-            const float key = fabsf(tk - (truncf(tk) + 0.5f));
-            int rank = 0, eq = 0;
-            const float4* t4 = reinterpret_cast<const float4*>(s_ct + base);
-            for (int q = 0; q < nc; q += 4) {
-                const float4 cur = t4[q >> 2];
-                const float k0 = fabsf(cur.x - (truncf(cur.x) + 0.5f)), k1 = fabsf(cur.y - (truncf(cur.y) + 0.5f));
-                const float k2 = fabsf(cur.z - (truncf(cur.z) + 0.5f)), k3 = fabsf(cur.w - (truncf(cur.w) + 0.5f));
-                rank += (k0 < key) + (k1 < key) + (k2 < key) + (k3 < key);
-                rank += (k0 == key && q + 0 < k) + (k1 == key && q + 1 < k) + (k2 == key && q + 2 < k) + (k3 == key && q + 3 < k);
-                eq += (k0 == key) + (k1 == key) + (k2 == key) + (k3 == key);
-            }
-            if (eq > 1) {
-                s_tie[u] = 1;
-                s_anytie = 1;
-            }
-            s_si[base + rank] = s_ci[base + k];
-        }
-        __syncthreads();
-        // (C3) equal keys among listed candidates: libstdc++'s std::sort order decides (rare). The order of equal
-        //      elements depends on the whole array the reference sorts, so the full |delta| < 0.25 list is rebuilt,
-        //      sorted with the restated algorithm and then filtered.
-        if (s_anytie) {
-            if (tid == 0) {
-                for (int u = 0; u < n_units; ++u) {
-                    if (!s_tie[u]) continue;
-                    const int pl = u / 13, bfu = 19 + u % 13, wl = wl_lo + pl;
-                    const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-                    const float mul = max_quant(wl);
-                    int nall = 0;
-                    for (int j = 0; j < n; ++j) {
-                        const float t = s_val[start + j] * mul;
-                        const float delta = t - (truncf(t) + 0.5f);
-                        if (fabsf(delta) < 0.25f) {
-                            s_items[nall].key = delta;
-                            s_items[nall].idx = j;
-                            ++nall;
-                        }
-                    }
-                    std_sort_abs(s_items, nall);
-                    const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
-                    const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
-                    uint8_t* sorted = s_si + pl * kEaLines + (start - kEaLine0);
-                    int nc = 0;
-                    for (int q = 0; q < nall; ++q) {
-                        const int j = s_items[q].idx;
-                        const float t = s_val[start + j] * mul;
-                        const int m0 = __float2int_rn(t);
-                        const float am = (float)(m0 < 0 ? -m0 : m0);
-                        const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (dir < 0) ? (am > fabsf(t)) : false;
-                        if (side) sorted[nc++] = (uint8_t)j;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        // (C4) sequential re-rounding pass, one lane per unit
-        if (tid < n_units) {
-            const int u = tid;
-            const int pl = u / 13, bfu = 19 + u % 13, wl = wl_lo + pl;
-            const int start = bfu_start(bfu);
-            const int nc = s_nc[u];
-            if (nc > 0) {
-                const float mul = max_quant(wl);
-                const float inv2 = (float)(1.0 / (double)(mul * mul));
-                const float e1 = s_e1[bfu];
-                s_err[wl * 32 + bfu] = ea_greedy(s_val + start, s_si + pl * kEaLines + (start - kEaLine0), nc, mul, inv2, e1,
-                                                 s_err[wl * 32 + bfu], s_mant + (wl - 1) * 1024 + start);
-            }
-        }
-        __syncthreads();
-        if (p.debug_stop == 3 + half) return;
     }
+    // (C4) sequential re-rounding pass, one lane per unit
+    if (tid < 91) {
+        const int u = tid;
+        const int wl = 1 + u / 13, bfu = 19 + u % 13;
+        const int start = bfu_start(bfu);
+        const int nc = s_nc[u];
+        if (nc > 0) {
+            const float mul = max_quant(wl);
+            const float inv2 = (float)(1.0 / (double)(mul * mul));
+            s_err[wl * 32 + bfu] = ea_greedy(s_val + start, s_si + (wl - 1) * kEaLines + (start - kEaLine0), nc, mul, inv2, s_e1[bfu],
+                                             s_err[wl * 32 + bfu], s_mant + (wl - 1) * 1024 + start);
+        }
+    }
+    __syncthreads();
+    if (p.debug_stop == 4) return;
 
-    // ---- (D) e1 / e2 and VLC cost of the final mantissas: 8 partial sums per unit, combined with LDS atomics ----
+    // ---- (D) e1 / e2; VLC cost of the final mantissas: four lines (one BFU) x seven wordlens per work-item ----
     if (tid < 224) {
         const int wl = 1 + tid / 32, bfu = tid % 32;
         s_err[wl * 32 + bfu] = s_e1[bfu] / s_err[wl * 32 + bfu];
     }
-    for (int task = tid; task < 224 * 8; task += kQuantThreads) {
-        const int u = task >> 3, part = task & 7;
-        const int bfu = 31 - u / 7, wl = 1 + u % 7;
-        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
-        const int8_t* mant = s_mant + (wl - 1) * 1024 + start;
-        const int per = n >> 3;  // 1, 2, 4, 8 or 16 lines per task (n is a multiple of 8)
-        uint32_t bits = 0;
-        if (per >= 8) {
-            for (int j = part * per; j < (part + 1) * per; j += 8) {
-                const uint2 pk = *reinterpret_cast<const uint2*>(mant + j);
-                int m8[8];
+    {
+        const int i0 = tid * 4;
+        const int bfu = bfu_of_line(i0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) m8[k] = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
-                if (wl > 1) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) bits += lds_huff(s_huff, wl, vlc_index(m8[k])) >> 8;
-                } else {
-                    const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
-#pragma unroll
-                    for (int k = 0; k < 8; k += 2) bits += lds_huff(s_huff, 1, rt9[3 * (m8[k] + 1) + (m8[k + 1] + 1)]) >> 8;
-                }
+        for (int wl = 1; wl <= 7; ++wl) {
+            const uint32_t pk = *reinterpret_cast<const uint32_t*>(s_mant + (wl - 1) * 1024 + i0);
+            const int m0 = (int)(int8_t)(pk & 0xff), m1 = (int)(int8_t)((pk >> 8) & 0xff);
+            const int m2 = (int)(int8_t)((pk >> 16) & 0xff), m3 = (int)(int8_t)(pk >> 24);
+            uint32_t bits;
+            if (wl > 1) {
+                bits = (lds_huff(s_huff, wl, vlc_index(m0)) >> 8) + (lds_huff(s_huff, wl, vlc_index(m1)) >> 8) +
+                       (lds_huff(s_huff, wl, vlc_index(m2)) >> 8) + (lds_huff(s_huff, wl, vlc_index(m3)) >> 8);
+            } else {
+                const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
+                bits = (lds_huff(s_huff, 1, rt9[3 * (m0 + 1) + (m1 + 1)]) >> 8) + (lds_huff(s_huff, 1, rt9[3 * (m2 + 1) + (m3 + 1)]) >> 8);
             }
-        } else if (wl > 1) {
-            for (int j = part * per; j < (part + 1) * per; ++j) bits += lds_huff(s_huff, wl, vlc_index(mant[j])) >> 8;
-        } else {
-            const uint32_t rt9[9] = {8, 4, 7, 2, 0, 1, 6, 3, 5};
-            if (per >= 2) {
-                for (int j = part * per; j < (part + 1) * per; j += 2)
-                    bits += lds_huff(s_huff, 1, rt9[3 * (mant[j] + 1) + (mant[j + 1] + 1)]) >> 8;
-            } else if ((part & 1) == 0) {   // 8-line BFU: one pair per two tasks
-                bits += lds_huff(s_huff, 1, rt9[3 * (mant[part] + 1) + (mant[part + 1] + 1)]) >> 8;
-            }
+            atomicAdd(&s_vlc[wl * 32 + bfu], bits);
         }
-        atomicAdd(&s_vlc[wl * 32 + bfu], bits);
     }
     __syncthreads();
     // ---- results to HBM ----
