@@ -229,18 +229,29 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
     const int c = tid >> 5;      // (channel, band) combo owning this thread in the MDCT phase; a wave owns 2
     const int lane = tid & 31;
 
+    float2 nxt[4];   // PCM of the block about to be processed, one block of look-ahead in registers
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int g = b0 * 1024 + tid + 256 * q;
+        nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
+    }
     // block b carries frame f = b + 1; the block before the first frame only primes the overlap.
     for (int b = b0; b <= fb - 2; ++b) {
         const int f = b + 1;
         const bool is_frame = (f >= fa);
-        // ---- PCM tile: 1024 new stereo samples, coalesced float2 loads, /4.0 ----
+        // ---- PCM tile: 1024 new stereo samples (fetched one block ahead into registers), /4.0 ----
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = tid + 256 * q;
-            const int g = b * 1024 + k;
-            const float2 v = (g >= 0) ? pcm2[g] : hist2[kHist + g];
-            s_pcm[46 + k] = v.x * 0.25f;
-            s_pcm[kPcmRing + 46 + k] = v.y * 0.25f;
+            s_pcm[46 + k] = nxt[q].x * 0.25f;
+            s_pcm[kPcmRing + 46 + k] = nxt[q].y * 0.25f;
+        }
+        if (b + 1 <= fb - 2) {   // issue the next block's coalesced float2 loads now; they land during this block's math
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = (b + 1) * 1024 + tid + 256 * q;
+                nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
+            }
         }
         if (GAIN && tid < 8) s_curve[tid] = s_curves_all[(f - (fa - 1)) * 8 + tid];
         __syncthreads();

@@ -96,9 +96,13 @@ int dev_alloc(at3hip_ctx* c, Tp** p, size_t count)
 int pick_frames_per_wg(const at3hip_ctx* c, int n_out)
 {
     if (c->frames_per_wg > 0) return c->frames_per_wg;
-    const long long total = (long long)c->cfg.n_streams * n_out;
-    long long f = total / ((long long)c->n_cus * 3);
-    if (f < 4) f = 4;
+    // three workgroups of the fused kernel are resident per CU: cut every stream into as many runs as fit in ONE
+    // round of the grid (a partial second round would double the kernel time on small batches)
+    const long long slots = (long long)c->n_cus * 3;
+    long long runs_per_stream = slots / c->cfg.n_streams;
+    if (runs_per_stream < 1) runs_per_stream = 1;
+    long long f = (n_out + runs_per_stream - 1) / runs_per_stream;
+    if (f < 1) f = 1;
     if (f > 32) f = 32;
     return (int)f;
 }
