@@ -124,6 +124,81 @@ __device__ __forceinline__ cpx cmul(cpx a, cpx b)
     return m;
 }
 
+// ---- packed fp32 --------------------------------------------------------------------------------------------
+// CDNA issues a wave64 fp32 VALU instruction over four cycles; v_pk_mul_f32 / v_pk_add_f32 (VOP3P) carry TWO
+// independent IEEE fp32 operations per lane in the same four cycles. The reference arithmetic has no fused
+// multiply-add (-ffp-contract=off is part of the parity contract), so mul/add-bound code is issue bound and packing
+// doubles its rate without changing a single rounding. `f2` maps to an aligned VGPR pair; plain vector expressions
+// are selected as packed instructions by the compiler, the three complex forms whose lanes need DIFFERENT negate /
+// half-select modifiers are spelled out below.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 ld2(const cpx* q) { return *reinterpret_cast<const f2*>(q); }
+__device__ __forceinline__ void st2(cpx* q, f2 v) { *reinterpret_cast<f2*>(q) = v; }
+__device__ __forceinline__ f2 mk2(float x, float y)
+{
+    f2 v;
+    v.x = x;
+    v.y = y;
+    return v;
+}
+
+#if defined(AT3_EMU_HOST)   // tools/emu development harness: same operations, one at a time
+__device__ __forceinline__ f2 pk_cmul(f2 a, f2 w) { return mk2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+__device__ __forceinline__ f2 pk_add_ib(f2 a, f2 b) { return mk2(a.x - b.y, a.y + b.x); }
+__device__ __forceinline__ f2 pk_sub_ib(f2 a, f2 b) { return mk2(a.x + b.y, a.y - b.x); }
+#else
+// a * w, complex: (a.x w.x - a.y w.y, a.x w.y + a.y w.x) - the four products and two sums of C_MUL (_kiss_fft_guts.h)
+__device__ __forceinline__ f2 pk_cmul(f2 a, f2 w)
+{
+    f2 t1, t2, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t1) : "v"(a), "v"(w));                  // (a.x w.x, a.x w.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t2) : "v"(a), "v"(w));     // (a.y w.y, a.y w.x)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t1), "v"(t2));                    // (t1.x - t2.x, t1.y + t2.y)
+    return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ f2 pk_add_ib(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ f2 pk_sub_ib(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#endif
+
+// kf_bfly4 (kiss_fft.c:42-90) on four points held in registers; w1..w3 = tw[k fstride], tw[2k fstride], tw[3k fstride]
+template <bool INVERSE>
+__device__ __forceinline__ void bfly4(f2& x0, f2& x1, f2& x2, f2& x3, f2 w1, f2 w2, f2 w3)
+{
+    const f2 s0 = pk_cmul(x1, w1), s1 = pk_cmul(x2, w2), s2 = pk_cmul(x3, w3);
+    const f2 s5 = x0 - s1;
+    f2 f0 = x0 + s1;
+    const f2 s3 = s0 + s2, s4 = s0 - s2;
+    x2 = f0 - s3;
+    x0 = f0 + s3;
+    if (INVERSE) {
+        x1 = pk_add_ib(s5, s4);
+        x3 = pk_sub_ib(s5, s4);
+    } else {
+        x1 = pk_sub_ib(s5, s4);
+        x3 = pk_add_ib(s5, s4);
+    }
+}
+// kf_bfly2 (kiss_fft.c:21-40)
+__device__ __forceinline__ void bfly2(f2& x0, f2& x1, f2 w)
+{
+    const f2 t = pk_cmul(x1, w);
+    x1 = x0 - t;
+    x0 = x0 + t;
+}
+
 // log2f with the exact operation sequence of glibc 2.35's FMA build (see at3_tables.cpp); x > 0, finite.
 __device__ __forceinline__ float at3_log2f(const Tables* T, float x)
 {
@@ -182,15 +257,14 @@ __device__ __forceinline__ void fft_lds(cpx* F, int NS, int nfft, const cpx* tw,
     if ((lg & 1) && LEAF_DONE) m = 2;
     if ((lg & 1) && !LEAF_DONE) {
         // radix-2 leaves: m = 1, fstride = N/2, twiddle index 0
-        const cpx w = tw[0];
+        const f2 w = ld2(tw);
         for (int j = tid; j < nfft * (N / 2); j += nthr) {
             const int f = j / (N / 2), p = j % (N / 2);
             cpx* a = F + f * NS + 2 * p;
-            const cpx t = cmul(a[1], w);
-            a[1].r = a[0].r - t.r;
-            a[1].i = a[0].i - t.i;
-            a[0].r += t.r;
-            a[0].i += t.i;
+            f2 a0 = ld2(a), a1 = ld2(a + 1);
+            bfly2(a0, a1, w);
+            st2(a, a0);
+            st2(a + 1, a1);
         }
         __syncthreads();
         m = 2;
@@ -201,24 +275,12 @@ __device__ __forceinline__ void fft_lds(cpx* F, int NS, int nfft, const cpx* tw,
             const int f = j / (N / 4), r = j % (N / 4);
             const int g = r / m, k = r % m;
             cpx* B = F + f * NS + g * 4 * m + k;
-            const cpx s0 = cmul(B[m], tw[k * fstride]);
-            const cpx s1 = cmul(B[2 * m], tw[2 * k * fstride]);
-            const cpx s2 = cmul(B[3 * m], tw[3 * k * fstride]);
-            cpx s5, s3, s4, f0 = B[0];
-            s5.r = f0.r - s1.r; s5.i = f0.i - s1.i;
-            f0.r += s1.r; f0.i += s1.i;
-            s3.r = s0.r + s2.r; s3.i = s0.i + s2.i;
-            s4.r = s0.r - s2.r; s4.i = s0.i - s2.i;
-            B[2 * m].r = f0.r - s3.r; B[2 * m].i = f0.i - s3.i;
-            f0.r += s3.r; f0.i += s3.i;
-            B[0] = f0;
-            if (INVERSE) {
-                B[m].r = s5.r - s4.i; B[m].i = s5.i + s4.r;
-                B[3 * m].r = s5.r + s4.i; B[3 * m].i = s5.i - s4.r;
-            } else {
-                B[m].r = s5.r + s4.i; B[m].i = s5.i - s4.r;
-                B[3 * m].r = s5.r - s4.i; B[3 * m].i = s5.i + s4.r;
-            }
+            f2 x0 = ld2(B), x1 = ld2(B + m), x2 = ld2(B + 2 * m), x3 = ld2(B + 3 * m);
+            bfly4<INVERSE>(x0, x1, x2, x3, ld2(tw + k * fstride), ld2(tw + 2 * k * fstride), ld2(tw + 3 * k * fstride));
+            st2(B, x0);
+            st2(B + m, x1);
+            st2(B + 2 * m, x2);
+            st2(B + 3 * m, x3);
         }
         __syncthreads();
     }
@@ -261,6 +323,48 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The same kissfft-order transform as fft_lds, executed by ONE wavefront (64 lanes, lane = threadIdx & 63) on one
+// array of N points: only wave-level synchronisation, stage geometry resolved at compile time, the butterflies of a
+// lane issued as batches (all loads, all arithmetic, all stores).
+template <int N, int M, bool INVERSE>
+__device__ __forceinline__ void fft_wave_stage(cpx* F, const cpx* tw, int lane)
+{
+    constexpr int FS = N / (4 * M);
+    constexpr int PER_LANE = (N / 4 + 63) / 64;
+    constexpr int U = PER_LANE < 4 ? PER_LANE : 4;
+#pragma unroll
+    for (int r0 = 0; r0 < N / 4; r0 += 64 * U) {
+        f2 x[U][4], w[U][3];
+        int base[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 64 * u + lane;
+            const int g = r / M, k = r % M;
+            base[u] = g * 4 * M + k;
+            w[u][0] = ld2(tw + k * FS);
+            w[u][1] = ld2(tw + 2 * k * FS);
+            w[u][2] = ld2(tw + 3 * k * FS);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[u][q] = ld2(F + base[u] + q * M);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) bfly4<INVERSE>(x[u][0], x[u][1], x[u][2], x[u][3], w[u][0], w[u][1], w[u][2]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st2(F + base[u] + q * M, x[u][q]);
+        }
+    }
+    wave_sync();
+    if constexpr (4 * M < N) fft_wave_stage<N, 4 * M, INVERSE>(F, tw, lane);
+}
+
+template <int N, bool INVERSE, int M0 = 1>   // M0 = 2: N = 2 * 4^k and the caller stored the radix-2 leaf outputs
+__device__ __forceinline__ void fft_wave(cpx* F, const cpx* tw, int lane)
+{
+    fft_wave_stage<N, M0, INVERSE>(F, tw, lane);
 }
 
 // Divisor applied to sample i of the "new" half for a gain curve: the running-product ramp of

@@ -123,28 +123,26 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
 // the 48 taps are wave-uniform scalars. Accumulation order per output is tap 0..23, multiply then add
 // (no contraction), exactly as qmf.h:54-63.
 __device__ __forceinline__ void qmf4(const float* __restrict__ xb /* LDS, 16-byte aligned pair base */,
-                                     const float (&W)[48] /* taps, wave-uniform (scalar registers) */,
+                                     const f2 (&Wp)[24] /* tap pairs (W[2i], W[2i+1]), wave-uniform (scalar registers) */,
                                      float (&lower)[4], float (&upper)[4])
 {
-    float x[56];
+    // sample pairs (x[2k], x[2k+1]) stay in the register pairs the 16-byte loads deliver; one packed multiply forms
+    // (W[2i] x[2k+1], W[2i+1] x[2k]) - the half swap is an operand modifier - and one packed add extends the two
+    // ordered sums of qmf.h:59-66 together.
+    f2 xp[28];
 #pragma unroll
     for (int q = 0; q < 14; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(xb + 4 * q);
-        x[4 * q + 0] = v.x;
-        x[4 * q + 1] = v.y;
-        x[4 * q + 2] = v.z;
-        x[4 * q + 3] = v.w;
+        xp[2 * q] = mk2(v.x, v.y);
+        xp[2 * q + 1] = mk2(v.z, v.w);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float lo = 0.0f, hi = 0.0f;
+        f2 acc = mk2(0.0f, 0.0f);
 #pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            lo += W[2 * i] * x[2 * (r + 23 - i) + 1];
-            hi += W[2 * i + 1] * x[2 * (r + 23 - i)];
-        }
-        lower[r] = lo + hi;
-        upper[r] = lo - hi;
+        for (int i = 0; i < 24; ++i) acc = acc + Wp[i] * xp[r + 23 - i].yx;
+        lower[r] = acc.x + acc.y;
+        upper[r] = acc.x - acc.y;
     }
 }
 
@@ -180,9 +178,11 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
     int fb = fa + p.frames_per_wg;
     if (fb > p.n_blocks) fb = p.n_blocks;
     const int n_out = p.n_blocks - p.f0;
-    float W[48];   // the 48 taps live in scalar registers for the whole run
+    f2 Wp[24];   // the 48 taps live in scalar register pairs for the whole run
 #pragma unroll
-    for (int i = 0; i < 48; ++i) W[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T->qmf_win[i])));
+    for (int i = 0; i < 24; ++i)
+        Wp[i] = mk2(__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T->qmf_win[2 * i]))),
+                    __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T->qmf_win[2 * i + 1]))));
     const float2* pcm2 = reinterpret_cast<const float2*>(p.pcm) + (size_t)s * p.n_blocks * 1024;
     const float2* hist2 = reinterpret_cast<const float2*>(p.hist) + (size_t)s * kHist;
 
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
         float lo = 0.0f, hi = 0.0f;
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
-            lo += W[2 * i] * x[47 - 2 * i];
-            hi += W[2 * i + 1] * x[46 - 2 * i];
+            lo += Wp[i].x * x[47 - 2 * i];
+            hi += Wp[i].y * x[46 - 2 * i];
         }
         s_lo[ch * kS1Ring + mm] = lo + hi;
         s_hi[ch * kS1Ring + mm] = lo - hi;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
         {
             const int ch = tid >> 7, g = tid & 127;
             float lw[4], up[4];
-            qmf4(s_pcm + ch * kPcmRing + 8 * g, W, lw, up);
+            qmf4(s_pcm + ch * kPcmRing + 8 * g, Wp, lw, up);
             float4 a, bq;
             a.x = lw[0]; a.y = lw[1]; a.z = lw[2]; a.w = lw[3];
             bq.x = up[0]; bq.y = up[1]; bq.z = up[2]; bq.w = up[3];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
         {
             const int ch = tid >> 7, which = (tid >> 6) & 1, g = tid & 63;
             float lw[4], up[4];
-            qmf4((which ? s_hi : s_lo) + ch * kS1Ring + 8 * g, W, lw, up);
+            qmf4((which ? s_hi : s_lo) + ch * kS1Ring + 8 * g, Wp, lw, up);
             float4 a, bq;
             a.x = lw[0]; a.y = lw[1]; a.z = lw[2]; a.w = lw[3];
             bq.x = up[0]; bq.y = up[1]; bq.z = up[2]; bq.w = up[3];
@@ -405,16 +405,14 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
             // 128-point FFT of this combo by its 32 lanes: radix-2 leaves, then three radix-4 passes
             cpx* F = s_fft + c * 128;
             {
-                const cpx w = s_tw[0];
+                const f2 w = ld2(s_tw);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     cpx* a = F + 2 * (lane + 32 * q);
-                    const cpx a0 = a[0], a1 = a[1];
-                    const cpx t = cmul(a1, w);
-                    cpx o0, o1;
-                    o1.r = a0.r - t.r; o1.i = a0.i - t.i;
-                    o0.r = a0.r + t.r; o0.i = a0.i + t.i;
-                    a[0] = o0; a[1] = o1;
+                    f2 a0 = ld2(a), a1 = ld2(a + 1);
+                    bfly2(a0, a1, w);
+                    st2(a, a0);
+                    st2(a + 1, a1);
                 }
             }
             wave_sync();
@@ -423,20 +421,12 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
                 const int fstride = 128 / (4 * m);
                 const int g = lane / m, k = lane % m;
                 cpx* B = F + g * 4 * m + k;
-                const cpx s0 = cmul(B[m], s_tw[k * fstride]);
-                const cpx s1 = cmul(B[2 * m], s_tw[2 * k * fstride]);
-                const cpx s2 = cmul(B[3 * m], s_tw[3 * k * fstride]);
-                cpx s5, s3, s4, f0 = B[0];
-                s5.r = f0.r - s1.r; s5.i = f0.i - s1.i;
-                f0.r += s1.r; f0.i += s1.i;
-                s3.r = s0.r + s2.r; s3.i = s0.i + s2.i;
-                s4.r = s0.r - s2.r; s4.i = s0.i - s2.i;
-                cpx o2, o1, o3;
-                o2.r = f0.r - s3.r; o2.i = f0.i - s3.i;
-                f0.r += s3.r; f0.i += s3.i;
-                o1.r = s5.r + s4.i; o1.i = s5.i - s4.r;
-                o3.r = s5.r - s4.i; o3.i = s5.i + s4.r;
-                B[0] = f0; B[m] = o1; B[2 * m] = o2; B[3 * m] = o3;
+                f2 x0 = ld2(B), x1 = ld2(B + m), x2 = ld2(B + 2 * m), x3 = ld2(B + 3 * m);
+                bfly4<false>(x0, x1, x2, x3, ld2(s_tw + k * fstride), ld2(s_tw + 2 * k * fstride), ld2(s_tw + 3 * k * fstride));
+                st2(B, x0);
+                st2(B + m, x1);
+                st2(B + 2 * m, x2);
+                st2(B + 3 * m, x3);
                 wave_sync();
             }
             // post-rotation (mdct.h:92-101) in place: read this lane's four bins, then scatter the 256 lines

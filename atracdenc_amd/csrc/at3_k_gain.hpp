@@ -24,6 +24,7 @@ struct GainParams {
     int n_blocks;
     int f0;
     int js;
+    int n_streams;
 };
 
 constexpr int kLowCutBin = 38;  // ceil(800 * 512 / 11025)
@@ -80,27 +81,33 @@ __device__ inline float curve_target(const float* in, const float* filtered)
     return usePlateau ? plateau : in[31];
 }
 
-// One workgroup per (stream, frame, channel, band<3).
-//
-// Wave roles: the 256-point core of the forward real FFT is done by wavefront 0 alone with wave-level
-// synchronisation while the other three clear the 2048-point buffer; the five radix-4 passes of the inverse
-// transform use all 256 work-items; afterwards the strictly ordered sums run side by side on different
-// wavefronts (wave 0: the two f64 energy chains of the high-frequency ratio, wave 1: the 32 sub-frame RMS
-// chains and the plateau target) while every work-item produces one 8-sample micro-chunk RMS.
+// One WAVEFRONT per (stream, frame, channel, band<3) item, four independent items per 256-thread workgroup:
+// no workgroup barrier anywhere. Every pass of the two FFTs gives each lane several independent butterflies
+// (8 per lane in the 2048-point inverse transform), which is what hides the LDS latency; the few strictly ordered
+// sums (two f64 energy chains of 257 terms, 32 sub-frame RMS chains of 64 terms) run on the lanes they need.
+struct GainLds {
+    cpx f[2048];        // rfft-512 core in f[0..255], then the irfft-4096 core / 4096 upsampled samples
+    cpx freq[304];      // 257 bins; later reused as 300 f64 energies (257 + zero padding)
+    float micro[256];
+    float gain[32];
+    float filt[32];
+    float minv[32];
+    double hsum[2];
+};
+
 __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Tables* T)
 {
-    __shared__ __attribute__((aligned(16))) cpx s_f[2048];   // irfft-4096 core, then the 4096 upsampled samples
-    __shared__ __attribute__((aligned(16))) cpx s_g[256];    // rfft-512 core
-    __shared__ cpx s_freq[257];
-    __shared__ double s_e[257];
-    __shared__ __attribute__((aligned(16))) float s_micro[256];
-    __shared__ float s_gain[32];
-    __shared__ float s_filt[32];
-    __shared__ float s_minv[32];
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    __shared__ __attribute__((aligned(16))) GainLds s_item[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    GainLds& L = s_item[wave];
     const int nfr = p.n_blocks - p.f0;
-    int wg = blockIdx.x;
+    const int n_items = (int)gridDim.x * 4;   // the launch rounds the item count up to a multiple of 4
+    int item = blockIdx.x * 4 + wave;
+    (void)n_items;
+    const int total = p.n_streams * nfr * 6;
+    const bool valid = item < total;
+    if (!valid) item = total - 1;             // keep the wave alive (uniform code), results are discarded
+    int wg = item;
     const int band = wg % 3; wg /= 3;
     const int ch = wg % 2; wg /= 2;
     const int f = p.f0 + wg % nfr;
@@ -111,11 +118,13 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
     const float* sb1 = p.sub + ((size_t)s * 8 + 1 * 4 + band) * sublen + (size_t)(cb + 2) * 256 - 128;
     GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
 
-    // 1. window and pack as 256 complex points in FFT leaf order
-    {
-        float2 a = *reinterpret_cast<const float2*>(sb0 + 2 * tid);
+    // 1. window and pack as 256 complex points in FFT leaf order (4 points per lane)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        float2 a = *reinterpret_cast<const float2*>(sb0 + 2 * i);
         if (p.js) {
-            const float2 b = *reinterpret_cast<const float2*>(sb1 + 2 * tid);
+            const float2 b = *reinterpret_cast<const float2*>(sb1 + 2 * i);
             if (ch == 0) {
                 a.x = (a.x + b.x) * 0.5f;
                 a.y = (a.y + b.y) * 0.5f;
@@ -124,163 +133,160 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
                 a.y = (a.y - b.y) * 0.5f;
             }
         } else if (ch == 1) {
-            a = *reinterpret_cast<const float2*>(sb1 + 2 * tid);
+            a = *reinterpret_cast<const float2*>(sb1 + 2 * i);
         }
         cpx z;
-        z.r = a.x * T->planck[2 * tid];
-        z.i = a.y * T->planck[2 * tid + 1];
-        s_g[fft_leaf_pos<256>(tid)] = z;
+        z.r = a.x * T->planck[2 * i];
+        z.i = a.y * T->planck[2 * i + 1];
+        L.f[fft_leaf_pos<256>(i)] = z;
     }
-    __syncthreads();
-    if (wave == 0) {
-        // 256-point forward FFT: four radix-4 passes, one butterfly per lane, wave-level sync only
-#pragma unroll
-        for (int m = 1; m < 256; m <<= 2) {
-            const int fstride = 256 / (4 * m);
-            const int g = lane / m, k = lane % m;
-            cpx* B = s_g + g * 4 * m + k;
-            const cpx s0 = cmul(B[m], T->tw256[k * fstride]);
-            const cpx s1 = cmul(B[2 * m], T->tw256[2 * k * fstride]);
-            const cpx s2 = cmul(B[3 * m], T->tw256[3 * k * fstride]);
-            cpx s5, s3, s4, f0 = B[0];
-            s5.r = f0.r - s1.r; s5.i = f0.i - s1.i;
-            f0.r += s1.r; f0.i += s1.i;
-            s3.r = s0.r + s2.r; s3.i = s0.i + s2.i;
-            s4.r = s0.r - s2.r; s4.i = s0.i - s2.i;
-            cpx o1, o2, o3;
-            o2.r = f0.r - s3.r; o2.i = f0.i - s3.i;
-            f0.r += s3.r; f0.i += s3.i;
-            o1.r = s5.r + s4.i; o1.i = s5.i - s4.r;
-            o3.r = s5.r - s4.i; o3.i = s5.i + s4.r;
-            B[0] = f0; B[m] = o1; B[2 * m] = o2; B[3 * m] = o3;
-            wave_sync();
-        }
-        // 2. kiss_fftr post-processing -> 257 bins (k = lane+1 and lane+65)
-        if (lane == 0) {
-            const float tr = s_g[0].r, ti = s_g[0].i;
-            cpx a, b;
-            a.r = tr + ti; a.i = 0.0f;
-            b.r = tr - ti; b.i = 0.0f;
-            s_freq[0] = a;
-            s_freq[256] = b;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int k = lane + 1 + 64 * q;
-            const cpx fpk = s_g[k];
-            cpx fpnk;
-            fpnk.r = s_g[256 - k].r;
-            fpnk.i = -s_g[256 - k].i;
-            cpx f1k, f2k;
-            f1k.r = fpk.r + fpnk.r; f1k.i = fpk.i + fpnk.i;
-            f2k.r = fpk.r - fpnk.r; f2k.i = fpk.i - fpnk.i;
-            const cpx tw = cmul(f2k, T->stw256[k - 1]);
-            cpx a, b;
-            a.r = (f1k.r + tw.r) * 0.5f; a.i = (f1k.i + tw.i) * 0.5f;
-            b.r = (f1k.r - tw.r) * 0.5f; b.i = (tw.i - f1k.i) * 0.5f;
-            if (k != 128) s_freq[k] = a;   // k == 128: the second store wins in the reference
-            s_freq[256 - k] = b;
-        }
-    } else {
-        cpx zero;
-        zero.r = 0.0f;
-        zero.i = 0.0f;
-        for (int k = tid - 64; k < 2048; k += 192) s_f[k] = zero;
+    wave_sync();
+    fft_wave<256, false>(L.f, T->tw256, lane);
+    // 2. kiss_fftr post-processing -> 257 bins (k = lane+1 and lane+65)
+    if (lane == 0) {
+        const float tr = L.f[0].r, ti = L.f[0].i;
+        cpx a, b;
+        a.r = tr + ti; a.i = 0.0f;
+        b.r = tr - ti; b.i = 0.0f;
+        L.freq[0] = a;
+        L.freq[256] = b;
     }
-    __syncthreads();
-
-    // 3. per-bin energies (f64) for the high-frequency ratio; kiss_fftri input. Only bins 38..256 survive the
-    //    high-pass, so tmpbuf is non-zero at k in [38,256] and [1792,2010]; each of those meets an exact zero in
-    //    its radix-2 leaf butterfly (x +- 0*w), whose two outputs are therefore stored directly.
-    for (int k = tid; k <= 256; k += 256) s_e[k] = (double)s_freq[k].r * s_freq[k].r + (double)s_freq[k].i * s_freq[k].i;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = lane + 1 + 64 * q;
+        const cpx fpk = L.f[k];
+        cpx fpnk;
+        fpnk.r = L.f[256 - k].r;
+        fpnk.i = -L.f[256 - k].i;
+        cpx f1k, f2k;
+        f1k.r = fpk.r + fpnk.r; f1k.i = fpk.i + fpnk.i;
+        f2k.r = fpk.r - fpnk.r; f2k.i = fpk.i - fpnk.i;
+        const cpx tw = cmul(f2k, T->stw256[k - 1]);
+        cpx a, b;
+        a.r = (f1k.r + tw.r) * 0.5f; a.i = (f1k.i + tw.i) * 0.5f;
+        b.r = (f1k.r - tw.r) * 0.5f; b.i = (tw.i - f1k.i) * 0.5f;
+        if (k != 128) L.freq[k] = a;   // k == 128: the second store wins in the reference
+        L.freq[256 - k] = b;
+    }
+    wave_sync();
+    // 3. kiss_fftri input. Only bins 38..256 survive the high-pass, so tmpbuf is non-zero at k in [38,256] and
+    //    [1792,2010]; each of those meets an exact zero in its radix-2 leaf butterfly (x +- 0*w), whose two outputs
+    //    are therefore stored directly.
     {
-        const int k = kLowCutBin + tid;
-        if (k <= 256) {
-            cpx fk;
-            const float scale = 8.0f;
-            if (k == 256) {
-                fk.r = s_freq[256].r * scale * 0.5f;
-                fk.i = 0.0f;
-            } else if (k >= kLowCutBin + 2) {
-                fk.r = s_freq[k].r * scale;
-                fk.i = s_freq[k].i * scale;
-            } else {
-                const float w = T->hpf_w[k - kLowCutBin + 1];
-                fk.r = s_freq[k].r * scale * w;
-                fk.i = s_freq[k].i * scale * w;
+        float4* z4 = reinterpret_cast<float4*>(L.f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) z4[lane + 64 * k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    wave_sync();
+    for (int k = kLowCutBin + lane; k <= 256; k += 64) {
+        cpx fk;
+        const float scale = 8.0f;
+        if (k == 256) {
+            fk.r = L.freq[256].r * scale * 0.5f;
+            fk.i = 0.0f;
+        } else if (k >= kLowCutBin + 2) {
+            fk.r = L.freq[k].r * scale;
+            fk.i = L.freq[k].i * scale;
+        } else {
+            const float w = T->hpf_w[k - kLowCutBin + 1];
+            fk.r = L.freq[k].r * scale * w;
+            fk.i = L.freq[k].i * scale * w;
+        }
+        // fnkc = conj(freq[2048 - k]) = (0, -0): fek = fk, tmp = fk
+        const cpx fok = cmul(fk, T->stw2048[k - 1]);
+        cpx a, b, nb;
+        a.r = fk.r + fok.r; a.i = fk.i + fok.i;
+        b.r = fk.r - fok.r; b.i = -(fk.i - fok.i);
+        nb.r = 0.0f - b.r; nb.i = 0.0f - b.i;
+        const int pa = fft_leaf_pos<2048>(k);          // even slot: partner input k + 1024 is zero
+        L.f[pa] = a;
+        L.f[pa + 1] = a;
+        const int pb = fft_leaf_pos<2048>(2048 - k);   // odd slot: partner input 1024 - k is zero
+        L.f[pb - 1] = b;
+        L.f[pb] = nb;
+    }
+    // highFreqRatio (transient_spectral_upsampler.cpp:99-118): two ordered f64 sums over the 257 bin energies, the second
+    // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on). The energies are formed by
+    // all lanes and parked (as f64) over the spectrum, which the inverse transform no longer needs; lane 0 then adds
+    // e[0..256] and lane 1 its two weighted terms followed by e[40..256] - the skipped terms of the reference are
+    // exact zeros and the padding read past bin 256 is zero.
+    {
+        double e[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int k = lane + 64 * t;
+            const cpx z = L.freq[k < 257 ? k : 256];
+            e[t] = (k < 257) ? (double)z.r * z.r + (double)z.i * z.i : 0.0;
+        }
+        wave_sync();
+        double* E = reinterpret_cast<double*>(L.freq);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int k = lane + 64 * t;
+            if (k < 300) E[k] = e[t];
+        }
+        wave_sync();
+        if (lane < 2) {
+            const double h1 = (double)T->hpf_w[1], h2 = (double)T->hpf_w[2];
+            double acc = 0.0;
+            if (lane == 1) {
+                acc += E[kLowCutBin] * h1 * h1;
+                acc += E[kLowCutBin + 1] * h2 * h2;
             }
-            // fnkc = conj(freq[2048 - k]) = (0, -0): fek = fk, tmp = fk
-            const cpx fok = cmul(fk, T->stw2048[k - 1]);
-            cpx a, b, nb;
-            a.r = fk.r + fok.r; a.i = fk.i + fok.i;
-            b.r = fk.r - fok.r; b.i = -(fk.i - fok.i);
-            nb.r = 0.0f - b.r; nb.i = 0.0f - b.i;
-            const int pa = fft_leaf_pos<2048>(k);          // even slot: partner input k + 1024 is zero
-            s_f[pa] = a;
-            s_f[pa + 1] = a;
-            const int pb = fft_leaf_pos<2048>(2048 - k);   // odd slot: partner input 1024 - k is zero
-            s_f[pb - 1] = b;
-            s_f[pb] = nb;
+            const double* src = E + (lane ? kLowCutBin + 2 : 0);
+            for (int k0 = 0; k0 < 256; k0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = src[k0 + i];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc += v[i];
+            }
+            acc += src[256];
+            L.hsum[lane] = acc;
         }
     }
-    __syncthreads();
-    fft_lds<2048, true, true>(s_f, 2048, 1, T->tw2048, tid, 256);
+    wave_sync();
+    fft_wave<2048, true, 2>(L.f, T->tw2048, lane);
 
-    // 4. ordered sums on separate wavefronts + one micro-chunk RMS per work-item
-    const float* sig = reinterpret_cast<const float*>(s_f);
+    // 4. AnalyzeGain over the upsampled samples [1024, 3072): 256 micro-chunks of 8 (4 per lane), 32 sub-frames of 64
+    const float* sig = reinterpret_cast<const float*>(L.f);
     const float norm = 1.0f / 4096.0f;
-    {
-        const float4* x4 = reinterpret_cast<const float4*>(sig + 1024 + tid * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+        const float4* x4 = reinterpret_cast<const float4*>(sig + 1024 + c * 8);
         const float4 a = x4[0], b = x4[1];
         const float v[8] = {a.x * norm, a.y * norm, a.z * norm, a.w * norm, b.x * norm, b.y * norm, b.z * norm, b.w * norm};
         float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc += v[i] * v[i];
         acc /= 8;
-        s_micro[tid] = sqrtf(acc);
+        L.micro[c] = sqrtf(acc);
     }
-    if (wave == 0 && lane < 2) {
-        // highFreqRatio (transient_spectral_upsampler.cpp:99-118): totalE on lane 0, filtered energy on lane 1
-        double acc = 0.0;
-        if (lane == 0) {
-            for (int k = 0; k <= 256; ++k) acc += s_e[k];
-        } else {
-            const double h1 = (double)T->hpf_w[1], h2 = (double)T->hpf_w[2];
-            for (int k = 0; k < kLowCutBin; ++k) acc += s_e[k] * 0.0 * 0.0;
-            acc += s_e[kLowCutBin] * h1 * h1;
-            acc += s_e[kLowCutBin + 1] * h2 * h2;
-            for (int k = kLowCutBin + 2; k <= 256; ++k) acc += s_e[k];
-        }
-        s_e[lane] = acc;   // bins 0 and 1 are not needed any more by the other lane: both loops are done
-    }
-    if (wave == 1 && lane < 32) {
+    if (lane < 32) {
         const float4* x4 = reinterpret_cast<const float4*>(sig + 1024 + lane * 64);
+        float4 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = x4[i];
         float acc = 0.0f;
-        float4 cur = x4[0];
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
-            float4 nxt = cur;
-            if (i + 1 < 16) nxt = x4[i + 1];
-            const float v0 = cur.x * norm, v1 = cur.y * norm, v2 = cur.z * norm, v3 = cur.w * norm;
+            const float v0 = x[i].x * norm, v1 = x[i].y * norm, v2 = x[i].z * norm, v3 = x[i].w * norm;
             acc += v0 * v0;
             acc += v1 * v1;
             acc += v2 * v2;
             acc += v3 * v3;
-            cur = nxt;
         }
         acc /= 64;
-        s_gain[lane] = sqrtf(acc);
+        L.gain[lane] = sqrtf(acc);
     }
-    __syncthreads();
-    if (wave == 0 && lane == 0) {
-        const double totalE = s_e[0], filtE = s_e[1];
-        rec->hfr = (totalE > 0.0) ? (float)(filtE / totalE) : 0.0f;
-    }
-    if (wave == 1) {
+    wave_sync();
+    {
         const int j = lane & 31;
-        const float in_j = s_gain[j];
+        const float in_j = L.gain[j];
         // quartiles of the 8 micro-chunk RMS values (transient_detector.cpp:113-133)
         {
-            const float4 a = *reinterpret_cast<const float4*>(s_micro + j * 8), b = *reinterpret_cast<const float4*>(s_micro + j * 8 + 4);
+            const float4 a = *reinterpret_cast<const float4*>(L.micro + j * 8), b = *reinterpret_cast<const float4*>(L.micro + j * 8 + 4);
             float m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int i = 1; i < 8; ++i) {   // insertion sort, ascending (static indices)
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
                     m[k] = hi;
                 }
             }
-            if (lane < 32) {
+            if (valid && lane < 32) {
                 rec->gain[j] = in_j;
                 rec->lo[j] = m[2];
                 rec->hi[j] = m[6];
@@ -300,22 +306,22 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         // plateau target of CalcCurve (transient_detector.cpp:178-238, 284-297) with ballots
         float filt_j;
         {
-            const float a = s_gain[j > 0 ? j - 1 : 0], c = s_gain[j < 31 ? j + 1 : 31];
+            const float a = L.gain[j > 0 ? j - 1 : 0], c = L.gain[j < 31 ? j + 1 : 31];
             if (j == 0) filt_j = fmaxf(in_j, c);
             else if (j == 31) filt_j = fmaxf(a, in_j);
             else filt_j = fmaxf(fminf(a, in_j), fminf(fmaxf(a, in_j), c));
         }
-        if (lane < 32) s_filt[j] = filt_j;
+        if (lane < 32) L.filt[j] = filt_j;
         wave_sync();
-        if (lane < 32) s_minv[j] = (j <= 29) ? fminf(fminf(filt_j, s_filt[j < 30 ? j + 1 : 31]), s_filt[j < 30 ? j + 2 : 31]) : -1.0f;
+        if (lane < 32) L.minv[j] = (j <= 29) ? fminf(fminf(filt_j, L.filt[j < 30 ? j + 1 : 31]), L.filt[j < 30 ? j + 2 : 31]) : -1.0f;
         wave_sync();
         float maxRaw = 0.0f, sum = 0.0f, bestLevel = 0.0f;
         int bestEnd = -1;
         for (int k = 0; k < 32; ++k) {
-            const float g = s_gain[k];
+            const float g = L.gain[k];
             maxRaw = fmaxf(maxRaw, g);
             sum += g;
-            const float mv = s_minv[k];
+            const float mv = L.minv[k];
             if (k <= 29 && mv > bestLevel) {
                 bestLevel = mv;
                 bestEnd = k + 2;
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         }
         const uint32_t ge = (uint32_t)__ballot(lane < 32 && filt_j >= bestLevel);
         const uint32_t high = (uint32_t)__ballot(lane < 32 && in_j >= bestLevel * 0.7f);
-        const float last = s_gain[31];
+        const float last = L.gain[31];
         float plateau = 0.0f;
         bool release = false;
         if (!(bestLevel < 1e-6f)) {
@@ -336,7 +342,9 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
             }
         }
         const bool usePlateau = plateau > 1e-6f && !release && plateau >= maxRaw * 0.4f;
-        if (lane == 0) {
+        if (valid && lane == 0) {
+            const double totalE = L.hsum[0], filtE = L.hsum[1];
+            rec->hfr = (totalE > 0.0) ? (float)(filtE / totalE) : 0.0f;
             rec->cur_hpf = sum / 32.0f;
             rec->target = usePlateau ? plateau : last;
         }

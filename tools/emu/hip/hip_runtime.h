@@ -7,6 +7,7 @@
 // Model: one workgroup at a time; each work-item is a ucontext fiber; __syncthreads() yields to a
 // round-robin scheduler. __shared__ becomes `static` (one workgroup alive at a time).
 #pragma once
+#define AT3_EMU_HOST 1
 #include <ucontext.h>
 
 #include <cmath>
@@ -29,6 +30,8 @@ struct float2 {
 struct float4 {
     float x, y, z, w;
 };
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
 struct uint2 {
     unsigned x, y;
 };

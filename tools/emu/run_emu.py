@@ -11,7 +11,7 @@ from atracdenc_amd.binding import At3Hip
 EMU = os.path.join(ROOT, "tools", "emu", "libat3hip_emu.so")
 
 def build():
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
+    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
                            "-I", os.path.join(ROOT, "tools", "emu"), "-o", EMU,
                            os.path.join(ROOT, "atracdenc_amd/csrc/at3hip.hip"),
                            os.path.join(ROOT, "atracdenc_amd/csrc/at3_tables.cpp"),
