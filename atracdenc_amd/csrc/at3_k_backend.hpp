@@ -647,6 +647,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     __shared__ __attribute__((aligned(16))) uint8_t s_si[7 * kEaLines];   // per unit: candidates ordered by |delta|
     __shared__ __attribute__((aligned(16))) float s_ct[4][128 + 4];       // per wave: value * mul of the listed candidates
     __shared__ __attribute__((aligned(16))) uint8_t s_ci[4][128 + 4];     // per wave: their lines inside the BFU
+    __shared__ uint8_t s_code[7 * (kEaLines / 4)];   // 2 bits per (wordlen, line): 1 = re-roundable when e2 < e1, 2 = when e2 > e1
     __shared__ uint8_t s_nc[91];
     __shared__ uint8_t s_tie[91];
     __shared__ float s_e1[32];
@@ -677,12 +678,29 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         float4 o;
         o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
         *reinterpret_cast<float4*>(s_val + i0) = o;
+        // The energy-adaptive pass (atrac_scale.cpp:66-126) may re-round a line of BFU > 18 only when it is close to a
+        // rounding boundary (|delta| < 0.25) AND lies on the side the pass moves: rounded towards zero and below the
+        // top code (pass taken when e2 < e1) or rounded away from zero (e2 > e1). Which pass runs is known only after
+        // the ordered sums of phase B, so both possibilities are recorded here, where value * mul is in a register anyway.
+        const bool ea = i0 >= kEaLine0;
 #pragma unroll
         for (int wl = 1; wl <= 7; ++wl) {
             const float mul = max_quant(wl);
-            const uint32_t pk = ((uint32_t)(uint8_t)__float2int_rn(v[0] * mul)) | ((uint32_t)(uint8_t)__float2int_rn(v[1] * mul) << 8) |
-                                ((uint32_t)(uint8_t)__float2int_rn(v[2] * mul) << 16) | ((uint32_t)(uint8_t)__float2int_rn(v[3] * mul) << 24);
+            uint32_t pk = 0, code = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = v[k] * mul;
+                const int m = __float2int_rn(t);
+                pk |= (uint32_t)(uint8_t)m << (8 * k);
+                if (ea) {
+                    const float am = fabsf((float)m), at = fabsf(t);
+                    const float delta = t - (truncf(t) + 0.5f);
+                    const uint32_t c = (am < at && am < (mul - 1)) ? 1u : (am > at) ? 2u : 0u;
+                    code |= (fabsf(delta) < 0.25f ? c : 0u) << (2 * k);
+                }
+            }
             *reinterpret_cast<uint32_t*>(s_mant + (wl - 1) * 1024 + i0) = pk;
+            if (ea) s_code[(wl - 1) * (kEaLines / 4) + ((i0 - kEaLine0) >> 2)] = (uint8_t)code;
         }
     }
     __syncthreads();
@@ -741,54 +759,56 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
         const float mul = max_quant(wl);
         const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
-        const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
+        const uint32_t want = (e2 < e1) ? 1u : (e2 > e1) ? 2u : 3u;   // 3: equal energies, no pass
         float* ct = s_ct[wave];
         uint8_t* ci = s_ci[wave];
+        const uint8_t* codes = s_code + (wl - 1) * (kEaLines / 4);
         int nc = 0;
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
-            bool flag = false;
-            float t = 0.0f;
-            if (j < n && dir != 0) {
-                t = s_val[start + j] * mul;
-                const float delta = t - (truncf(t) + 0.5f);
-                const int m0 = __float2int_rn(t);
-                const float am = (float)(m0 < 0 ? -m0 : m0);
-                const bool side = (dir > 0) ? (am < fabsf(t) && am < (mul - 1)) : (am > fabsf(t));
-                flag = fabsf(delta) < 0.25f && side;
-            }
+            const int line = start - kEaLine0 + j;
+            const bool flag = j < n && ((codes[line >> 2] >> (2 * (line & 3))) & 3u) == want;
             const unsigned long long mask = __ballot(flag);
             if (flag) {
                 const int pos = nc + __popcll(mask & ((1ull << lane) - 1ull));
+                const float t = s_val[start + j] * mul;
                 ci[pos] = (uint8_t)j;
-                ct[pos] = t;
+                ct[pos] = fabsf(t - (truncf(t) + 0.5f));   // sort key |delta|
             }
             nc += __popcll(mask);
         }
-        if (lane < 4) ct[nc + lane] = __builtin_huge_valf();   // pad: the key of +inf is NaN and never counted
+        if (lane < 4) ct[nc + lane] = __builtin_huge_valf();   // pad: never below a key
         wave_sync();
-        // rank of candidate k among the unit's candidates (one lane each, two passes when nc > 64)
+        // rank of candidate k = number of listed keys below its own (one lane per candidate, two passes when nc > 64).
+        // Equal keys collide on a slot; the losing lane sees it when it reads the slot back and the unit is redone
+        // by the exact-order path (C3).
         uint8_t* sorted = s_si + (wl - 1) * kEaLines + (start - kEaLine0);
-        bool tie = false;
-        for (int k0 = 0; k0 < nc; k0 += 64) {
-            const int k = k0 + lane;
+        int rank[2] = {0, 0};
+        uint8_t mine[2] = {0, 0};
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int k = 64 * ps + lane;
             if (k < nc) {
-                const float tk = ct[k];
-                const float key = fabsf(tk - (truncf(tk) + 0.5f));
-                int rank = 0, eq = 0;
+                const float key = ct[k];
+                int r = 0;
                 const float4* t4 = reinterpret_cast<const float4*>(ct);
                 for (int q = 0; q < nc; q += 4) {
                     const float4 cur = t4[q >> 2];
-                    const float k0f = fabsf(cur.x - (truncf(cur.x) + 0.5f)), k1f = fabsf(cur.y - (truncf(cur.y) + 0.5f));
-                    const float k2f = fabsf(cur.z - (truncf(cur.z) + 0.5f)), k3f = fabsf(cur.w - (truncf(cur.w) + 0.5f));
-                    rank += (k0f < key) + (k1f < key) + (k2f < key) + (k3f < key);
-                    rank += (k0f == key && q + 0 < k) + (k1f == key && q + 1 < k) + (k2f == key && q + 2 < k) + (k3f == key && q + 3 < k);
-                    eq += (k0f == key) + (k1f == key) + (k2f == key) + (k3f == key);
+                    r += (cur.x < key);
+                    r += (cur.y < key);
+                    r += (cur.z < key);
+                    r += (cur.w < key);
                 }
-                tie = tie || eq > 1;
-                sorted[rank] = ci[k];
+                rank[ps] = r;
+                mine[ps] = ci[k];
+                sorted[r] = mine[ps];
             }
         }
+        wave_sync();
+        bool tie = false;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+            if (64 * ps + lane < nc) tie = tie || sorted[rank[ps]] != mine[ps];
         const bool any_tie = __ballot(tie) != 0ull;
         if (lane < 4 && nc + lane < ((nc + 3) & ~3)) sorted[nc + lane] = 0;   // pad to a multiple of four
         if (lane == 0) {
