@@ -31,89 +31,8 @@ struct FrontParams {
     int f0;                  // first frame index to emit (1 on the first call of a stream, else 0)
     int frames_per_wg;
     int js;
+    int sub_blocks_per_wg;   // k_qmf_sub only
 };
-
-// LDS carve (floats). Region A is the QMF working set; the MDCT staging buffer aliases it.
-constexpr int kPcmLen = 1168;   // t = -138 .. 1023 -> idx t + 138 (1162 used)
-constexpr int kS1Len = 560;     // m = -46 .. 511  -> idx m + 46  (558 used)
-constexpr int kRegionA = 2 * kPcmLen + 4 * kS1Len;  // 4576 floats >= 8*512
-static_assert(kRegionA >= 8 * 512, "MDCT staging must fit in the QMF region");
-
-__device__ __forceinline__ void load_pcm_tile(const FrontParams& p, int s, int b, float* s_pcm, int tid)
-{
-    const float2* pcm2 = reinterpret_cast<const float2*>(p.pcm) + (size_t)s * p.n_blocks * 1024;
-    const float2* hist2 = reinterpret_cast<const float2*>(p.hist) + (size_t)s * kHist;
-    for (int k = tid; k < 1162; k += 256) {
-        const int g = b * 1024 + k - 138;
-        const float2 v = (g >= 0) ? pcm2[g] : hist2[kHist + g];
-        s_pcm[k] = v.x * 0.25f;            // data / 4.0 (exact)
-        s_pcm[kPcmLen + k] = v.y * 0.25f;
-    }
-}
-
-// Both QMF stages for one block of both channels. In: s_pcm. Out: s_sub[2][4][256].
-__device__ __forceinline__ void qmf_block(const float* s_qw, const float* s_pcm, float* s_lo, float* s_hi,
-                                          float* s_sub, int tid)
-{
-    // stage 1 (Qmf1): 558 (lo,hi) pairs per channel, m = -46..511
-    for (int idx = tid; idx < 2 * 558; idx += 256) {
-        const int ch = idx / 558, mm = idx - ch * 558;
-        const float* x = s_pcm + ch * kPcmLen + 2 * mm;
-        float lo = 0.0f, hi = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            lo += s_qw[2 * i] * x[47 - 2 * i];
-            hi += s_qw[2 * i + 1] * x[46 - 2 * i];
-        }
-        s_lo[ch * kS1Len + mm] = lo + hi;   // lower
-        s_hi[ch * kS1Len + mm] = lo - hi;   // upper
-    }
-    __syncthreads();
-    // stage 2: Qmf2 on the lower half -> bands 0 (lower), 1 (upper); Qmf3 on the upper half -> bands 3, 2
-    for (int idx = tid; idx < 2 * 2 * 256; idx += 256) {
-        const int ch = idx >> 9, which = (idx >> 8) & 1, j = idx & 255;
-        const float* x = (which ? s_hi : s_lo) + ch * kS1Len + 2 * j;
-        float lo = 0.0f, hi = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            lo += s_qw[2 * i] * x[47 - 2 * i];
-            hi += s_qw[2 * i + 1] * x[46 - 2 * i];
-        }
-        float* out = s_sub + ch * 1024;
-        if (which == 0) {
-            out[0 * 256 + j] = lo + hi;
-            out[1 * 256 + j] = lo - hi;
-        } else {
-            out[3 * 256 + j] = lo + hi;
-            out[2 * 256 + j] = lo - hi;
-        }
-    }
-    __syncthreads();
-}
-
-// Subband analysis only (feeds the gain-control kernels): raw L/R subbands of blocks -2 .. n_blocks-1.
-__global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
-{
-    __shared__ float s_a[kRegionA];
-    __shared__ float s_sub[2 * 4 * 256];
-    __shared__ float s_qw[48];
-    const int tid = threadIdx.x;
-    const int nb2 = p.n_blocks + 2;
-    const int s = blockIdx.x / nb2;
-    const int b = (int)(blockIdx.x % nb2) - 2;
-    float* s_pcm = s_a;
-    float* s_lo = s_a + 2 * kPcmLen;
-    float* s_hi = s_lo + 2 * kS1Len;
-    if (tid < 48) s_qw[tid] = T->qmf_win[tid];
-    load_pcm_tile(p, s, b, s_pcm, tid);
-    __syncthreads();
-    qmf_block(s_qw, s_pcm, s_lo, s_hi, s_sub, tid);
-    const size_t sublen = (size_t)nb2 * 256;
-    for (int idx = tid; idx < 2048; idx += 256) {
-        const int cb = idx >> 8, j = idx & 255;  // cb = ch*4 + band
-        p.sub[((size_t)s * 8 + cb) * sublen + (size_t)(b + 2) * 256 + j] = s_sub[idx];
-    }
-}
 
 // ---- fused QMF + gain modulation + windowed MDCT-512 ------------------------------------------------------
 //
@@ -148,6 +67,112 @@ __device__ __forceinline__ void qmf4(const float* __restrict__ xb /* LDS, 16-byt
 
 constexpr int kPcmRing = 1072;  // [46 history | 1024 new] per channel (+2 pad keeps 16-byte alignment)
 constexpr int kS1Ring = 560;    // [46 history | 512 new] per channel and half (+2 pad)
+
+// Subband analysis only (feeds the gain-control kernels): raw L/R subbands of blocks -2 .. n_blocks-1, the same ring
+// scheme as the fused kernel below. One workgroup walks `sub_blocks_per_wg` consecutive blocks of one stream; the
+// four subbands leave stage 2 in registers and go to HBM as 16-byte stores.
+__global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
+{
+    __shared__ __attribute__((aligned(16))) float s_pcm[2 * kPcmRing];
+    __shared__ __attribute__((aligned(16))) float s_lo[2 * kS1Ring];
+    __shared__ __attribute__((aligned(16))) float s_hi[2 * kS1Ring];
+    const int tid = threadIdx.x;
+    const int nb2 = p.n_blocks + 2;
+    const int nchunks = (nb2 + p.sub_blocks_per_wg - 1) / p.sub_blocks_per_wg;
+    const int s = blockIdx.x / nchunks;
+    const int chunk = blockIdx.x % nchunks;
+    const int ba = -2 + chunk * p.sub_blocks_per_wg;
+    int bb = ba + p.sub_blocks_per_wg;
+    if (bb > p.n_blocks) bb = p.n_blocks;
+    f2 Wp[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i)
+        Wp[i] = mk2(__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T->qmf_win[2 * i]))),
+                    __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T->qmf_win[2 * i + 1]))));
+    const float2* pcm2 = reinterpret_cast<const float2*>(p.pcm) + (size_t)s * p.n_blocks * 1024;
+    const float2* hist2 = reinterpret_cast<const float2*>(p.hist) + (size_t)s * kHist;
+
+    // prologue: stage-1 outputs m = -46..-1 of the first block from samples -138..-1
+    for (int k = tid; k < 138; k += 256) {
+        const int g = ba * 1024 - 138 + k;
+        const float2 v = (g >= 0) ? pcm2[g] : hist2[kHist + g];
+        s_pcm[k] = v.x * 0.25f;
+        s_pcm[kPcmRing + k] = v.y * 0.25f;
+    }
+    __syncthreads();
+    float keep = 0.0f;
+    if (tid < 92) {
+        const int ch = tid / 46, mm = tid % 46;
+        const float* x = s_pcm + ch * kPcmRing + 2 * mm;
+        float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            lo += Wp[i].x * x[47 - 2 * i];
+            hi += Wp[i].y * x[46 - 2 * i];
+        }
+        s_lo[ch * kS1Ring + mm] = lo + hi;
+        s_hi[ch * kS1Ring + mm] = lo - hi;
+        keep = s_pcm[ch * kPcmRing + 92 + mm];
+    }
+    __syncthreads();
+    if (tid < 92) s_pcm[(tid / 46) * kPcmRing + (tid % 46)] = keep;
+
+    float2 nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int g = ba * 1024 + tid + 256 * q;
+        nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
+    }
+    const size_t sublen = (size_t)nb2 * 256;
+    for (int b = ba; b < bb; ++b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = tid + 256 * q;
+            s_pcm[46 + k] = nxt[q].x * 0.25f;       // data / 4.0 (exact)
+            s_pcm[kPcmRing + 46 + k] = nxt[q].y * 0.25f;
+        }
+        if (b + 1 < bb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = (b + 1) * 1024 + tid + 256 * q;
+                nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
+            }
+        }
+        __syncthreads();
+        {   // stage 1 (Qmf1)
+            const int ch = tid >> 7, g = tid & 127;
+            float lw[4], up[4];
+            qmf4(s_pcm + ch * kPcmRing + 8 * g, Wp, lw, up);
+            float2* dl = reinterpret_cast<float2*>(s_lo + ch * kS1Ring + 46 + 4 * g);
+            float2* dh = reinterpret_cast<float2*>(s_hi + ch * kS1Ring + 46 + 4 * g);
+            float2 t0, t1;
+            t0.x = lw[0]; t0.y = lw[1]; t1.x = lw[2]; t1.y = lw[3];
+            dl[0] = t0; dl[1] = t1;
+            t0.x = up[0]; t0.y = up[1]; t1.x = up[2]; t1.y = up[3];
+            dh[0] = t0; dh[1] = t1;
+        }
+        __syncthreads();
+        if (tid < 92) keep = s_pcm[(tid / 46) * kPcmRing + 1024 + (tid % 46)];
+        {   // stage 2: Qmf2 on the lower half -> bands 0, 1; Qmf3 on the upper half -> bands 3, 2
+            const int ch = tid >> 7, which = (tid >> 6) & 1, g = tid & 63;
+            float lw[4], up[4];
+            qmf4((which ? s_hi : s_lo) + ch * kS1Ring + 8 * g, Wp, lw, up);
+            float4 a, bq;
+            a.x = lw[0]; a.y = lw[1]; a.z = lw[2]; a.w = lw[3];
+            bq.x = up[0]; bq.y = up[1]; bq.z = up[2]; bq.w = up[3];
+            float* out = p.sub + ((size_t)s * 8 + ch * 4) * sublen + (size_t)(b + 2) * 256 + 4 * g;
+            *reinterpret_cast<float4*>(out + (which ? 3 : 0) * sublen) = a;
+            *reinterpret_cast<float4*>(out + (which ? 2 : 1) * sublen) = bq;
+        }
+        if (tid < 92) s_pcm[(tid / 46) * kPcmRing + (tid % 46)] = keep;
+        __syncthreads();
+        if (tid < 184) {   // stage-1 history for the next block
+            const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
+            float* ring = (hlf ? s_hi : s_lo) + ch * kS1Ring;
+            ring[k] = ring[512 + k];
+        }
+    }
+}
 
 template <bool GAIN>
 __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T)

@@ -81,25 +81,117 @@ __device__ inline float curve_target(const float* in, const float* filtered)
     return usePlateau ? plateau : in[31];
 }
 
+// ---- 2048-point inverse kissfft core of the irfft-4096, one wavefront, points in LDS -----------------------------
+// Logical slot i lives at i + i/32: one pad entry per 32 keeps every access pattern below free of bank conflicts.
+// The five radix-4 passes of kissfft (m = 2, 8, 32, 128, 512; the radix-2 leaves are stored by the caller) run as
+// register-resident pairs: a work unit loads 16 points, applies the four butterflies of pass m and the four of
+// pass 4m that combine exactly those points, and stores them - same butterflies, same operands, half the LDS traffic.
+__device__ __forceinline__ int irfft_pad(int i) { return i + (i >> 5); }
+
+template <int KAPPA>   // passes m = 2 and m = 8: unit = (32-block G = lane, parity KAPPA), points 32 G + KAPPA + 2 i
+__device__ __forceinline__ void irfft_pass_2_8(cpx* F, const cpx* tw, int lane)
+{
+    cpx* B = F + 33 * lane + KAPPA;
+    f2 x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = ld2(B + 2 * i);
+    const f2 a1 = ld2(tw + 256 * KAPPA), a2 = ld2(tw + 512 * KAPPA), a3 = ld2(tw + 768 * KAPPA);   // k = KAPPA, fstride 256
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bfly4<true>(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], a1, a2, a3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = KAPPA + 2 * j;   // fstride 64
+        bfly4<true>(x[j], x[j + 4], x[j + 8], x[j + 12], ld2(tw + 64 * k), ld2(tw + 128 * k), ld2(tw + 192 * k));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st2(B + 2 * i, x[i]);
+}
+
+// passes m = 32 and m = 128: unit v = (512-block G2 = v / 32, k = v % 32), points 512 G2 + k + 32 i
+__device__ __forceinline__ void irfft_pass_32_128(cpx* F, const cpx* tw, int v)
+{
+    const int k = v & 31, G2 = v >> 5;
+    cpx* B = F + 528 * G2 + k;
+    f2 x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = ld2(B + 33 * i);
+    const f2 a1 = ld2(tw + 16 * k), a2 = ld2(tw + 32 * k), a3 = ld2(tw + 48 * k);   // fstride 16
+    f2 w[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kk = k + 32 * j;   // fstride 4
+        w[j][0] = ld2(tw + 4 * kk);
+        w[j][1] = ld2(tw + 8 * kk);
+        w[j][2] = ld2(tw + 12 * kk);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bfly4<true>(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], a1, a2, a3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfly4<true>(x[j], x[j + 4], x[j + 8], x[j + 12], w[j][0], w[j][1], w[j][2]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st2(B + 33 * i, x[i]);
+}
+
+// pass m = 512: butterfly k = lane + 64 u on points k + 512 q, four butterflies per batch
+__device__ __forceinline__ void irfft_pass_512(cpx* F, const cpx* tw, int lane)
+{
+#pragma unroll
+    for (int u0 = 0; u0 < 8; u0 += 4) {
+        f2 x[4][4], w[4][3];
+        cpx* B[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = lane + 64 * (u0 + u);
+            B[u] = F + irfft_pad(k);
+            w[u][0] = ld2(tw + k);
+            w[u][1] = ld2(tw + 2 * k);
+            w[u][2] = ld2(tw + 3 * k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[u][q] = ld2(B[u] + 528 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bfly4<true>(x[u][0], x[u][1], x[u][2], x[u][3], w[u][0], w[u][1], w[u][2]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st2(B[u] + 528 * q, x[u][q]);
+        }
+    }
+}
+
+__device__ __forceinline__ void irfft_core_2048(cpx* F, const cpx* tw, int lane)
+{
+    irfft_pass_2_8<0>(F, tw, lane);
+    irfft_pass_2_8<1>(F, tw, lane);
+    wave_sync();
+    irfft_pass_32_128(F, tw, lane);
+    irfft_pass_32_128(F, tw, lane + 64);
+    wave_sync();
+    irfft_pass_512(F, tw, lane);
+    wave_sync();
+}
+
 // One WAVEFRONT per (stream, frame, channel, band<3) item, four independent items per 256-thread workgroup:
 // no workgroup barrier anywhere. Every pass of the two FFTs gives each lane several independent butterflies
 // (8 per lane in the 2048-point inverse transform), which is what hides the LDS latency; the few strictly ordered
 // sums (two f64 energy chains of 257 terms, 32 sub-frame RMS chains of 64 terms) run on the lanes they need.
 struct GainLds {
-    cpx f[2048];        // rfft-512 core in f[0..255], then the irfft-4096 core / 4096 upsampled samples
-    cpx freq[304];      // 257 bins; later reused as 300 f64 energies (257 + zero padding)
-    float micro[256];
-    float gain[32];
-    float filt[32];
-    float minv[32];
+    cpx f[2048 + 64];   // rfft-512 core in f[0..255]; then the irfft-4096 core / upsampled samples, padded (irfft_pad)
+    cpx freq[304];      // 257 bins, then 300 f64 energies (257 + zero padding), then the AnalyzeGain scratch below
     double hsum[2];
 };
+// AnalyzeGain scratch inside `freq` (dead once the two energy sums are done): float offsets
+constexpr int kGaMicro = 0, kGaGain = 256, kGaFilt = 288, kGaMinv = 320;
 
 __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) GainLds s_item[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     GainLds& L = s_item[wave];
+    float* s_micro = reinterpret_cast<float*>(L.freq) + kGaMicro;
+    float* s_gain = reinterpret_cast<float*>(L.freq) + kGaGain;
+    float* s_filt = reinterpret_cast<float*>(L.freq) + kGaFilt;
+    float* s_minv = reinterpret_cast<float*>(L.freq) + kGaMinv;
     const int nfr = p.n_blocks - p.f0;
     const int n_items = (int)gridDim.x * 4;   // the launch rounds the item count up to a multiple of 4
     int item = blockIdx.x * 4 + wave;
@@ -175,7 +267,8 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
     {
         float4* z4 = reinterpret_cast<float4*>(L.f);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) z4[lane + 64 * k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < 17; ++k)
+            if (lane + 64 * k < (2048 + 64) / 2) z4[lane + 64 * k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     wave_sync();
     for (int k = kLowCutBin + lane; k <= 256; k += 64) {
@@ -199,11 +292,11 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         b.r = fk.r - fok.r; b.i = -(fk.i - fok.i);
         nb.r = 0.0f - b.r; nb.i = 0.0f - b.i;
         const int pa = fft_leaf_pos<2048>(k);          // even slot: partner input k + 1024 is zero
-        L.f[pa] = a;
-        L.f[pa + 1] = a;
+        L.f[irfft_pad(pa)] = a;
+        L.f[irfft_pad(pa) + 1] = a;
         const int pb = fft_leaf_pos<2048>(2048 - k);   // odd slot: partner input 1024 - k is zero
-        L.f[pb - 1] = b;
-        L.f[pb] = nb;
+        L.f[irfft_pad(pb) - 1] = b;
+        L.f[irfft_pad(pb)] = nb;
     }
     // highFreqRatio (transient_spectral_upsampler.cpp:99-118): two ordered f64 sums over the 257 bin energies, the second
     // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on). The energies are formed by
@@ -246,47 +339,49 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         }
     }
     wave_sync();
-    fft_wave<2048, true, 2>(L.f, T->tw2048, lane);
+    irfft_core_2048(L.f, T->tw2048, lane);
 
     // 4. AnalyzeGain over the upsampled samples [1024, 3072): 256 micro-chunks of 8 (4 per lane), 32 sub-frames of 64
-    const float* sig = reinterpret_cast<const float*>(L.f);
+    // complex output j holds the real samples 2j, 2j+1; sample 1024 is complex slot 512 = padded slot 528
     const float norm = 1.0f / 4096.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = lane + 64 * q;
-        const float4* x4 = reinterpret_cast<const float4*>(sig + 1024 + c * 8);
-        const float4 a = x4[0], b = x4[1];
-        const float v[8] = {a.x * norm, a.y * norm, a.z * norm, a.w * norm, b.x * norm, b.y * norm, b.z * norm, b.w * norm};
+        const cpx* src = L.f + 528 + 4 * c + (c >> 3);
         float acc = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc += v[i] * v[i];
+        for (int i = 0; i < 4; ++i) {
+            const f2 v = ld2(src + i) * norm;
+            const f2 sq = v * v;
+            acc += sq.x;
+            acc += sq.y;
+        }
         acc /= 8;
-        L.micro[c] = sqrtf(acc);
+        s_micro[c] = sqrtf(acc);
     }
     if (lane < 32) {
-        const float4* x4 = reinterpret_cast<const float4*>(sig + 1024 + lane * 64);
-        float4 x[16];
+        const cpx* src = L.f + 528 + 33 * lane;
+        f2 x[32];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = x4[i];
+        for (int i = 0; i < 32; ++i) x[i] = ld2(src + i);
         float acc = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v0 = x[i].x * norm, v1 = x[i].y * norm, v2 = x[i].z * norm, v3 = x[i].w * norm;
-            acc += v0 * v0;
-            acc += v1 * v1;
-            acc += v2 * v2;
-            acc += v3 * v3;
+        for (int i = 0; i < 32; ++i) {
+            const f2 v = x[i] * norm;
+            const f2 sq = v * v;
+            acc += sq.x;
+            acc += sq.y;
         }
         acc /= 64;
-        L.gain[lane] = sqrtf(acc);
+        s_gain[lane] = sqrtf(acc);
     }
     wave_sync();
     {
         const int j = lane & 31;
-        const float in_j = L.gain[j];
+        const float in_j = s_gain[j];
         // quartiles of the 8 micro-chunk RMS values (transient_detector.cpp:113-133)
         {
-            const float4 a = *reinterpret_cast<const float4*>(L.micro + j * 8), b = *reinterpret_cast<const float4*>(L.micro + j * 8 + 4);
+            const float4 a = *reinterpret_cast<const float4*>(s_micro + j * 8), b = *reinterpret_cast<const float4*>(s_micro + j * 8 + 4);
             float m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int i = 1; i < 8; ++i) {   // insertion sort, ascending (static indices)
@@ -306,22 +401,22 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         // plateau target of CalcCurve (transient_detector.cpp:178-238, 284-297) with ballots
         float filt_j;
         {
-            const float a = L.gain[j > 0 ? j - 1 : 0], c = L.gain[j < 31 ? j + 1 : 31];
+            const float a = s_gain[j > 0 ? j - 1 : 0], c = s_gain[j < 31 ? j + 1 : 31];
             if (j == 0) filt_j = fmaxf(in_j, c);
             else if (j == 31) filt_j = fmaxf(a, in_j);
             else filt_j = fmaxf(fminf(a, in_j), fminf(fmaxf(a, in_j), c));
         }
-        if (lane < 32) L.filt[j] = filt_j;
+        if (lane < 32) s_filt[j] = filt_j;
         wave_sync();
-        if (lane < 32) L.minv[j] = (j <= 29) ? fminf(fminf(filt_j, L.filt[j < 30 ? j + 1 : 31]), L.filt[j < 30 ? j + 2 : 31]) : -1.0f;
+        if (lane < 32) s_minv[j] = (j <= 29) ? fminf(fminf(filt_j, s_filt[j < 30 ? j + 1 : 31]), s_filt[j < 30 ? j + 2 : 31]) : -1.0f;
         wave_sync();
         float maxRaw = 0.0f, sum = 0.0f, bestLevel = 0.0f;
         int bestEnd = -1;
         for (int k = 0; k < 32; ++k) {
-            const float g = L.gain[k];
+            const float g = s_gain[k];
             maxRaw = fmaxf(maxRaw, g);
             sum += g;
-            const float mv = L.minv[k];
+            const float mv = s_minv[k];
             if (k <= 29 && mv > bestLevel) {
                 bestLevel = mv;
                 bestEnd = k + 2;
@@ -329,7 +424,7 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         }
         const uint32_t ge = (uint32_t)__ballot(lane < 32 && filt_j >= bestLevel);
         const uint32_t high = (uint32_t)__ballot(lane < 32 && in_j >= bestLevel * 0.7f);
-        const float last = L.gain[31];
+        const float last = s_gain[31];
         float plateau = 0.0f;
         bool release = false;
         if (!(bestLevel < 1e-6f)) {

@@ -288,7 +288,16 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.f0 = f0;
             gp.js = c->js;
             gp.n_streams = S;
-            hipLaunchKernelGGL(k_qmf_sub, dim3(S * (n_blocks + 2)), dim3(256), 0, st, fp, c->d_tables);
+            {   // one round of workgroups over the chip, like the fused kernel
+                const int slots = c->n_cus * 3;
+                int runs = slots / S;
+                if (runs < 1) runs = 1;
+                int bpw = (n_blocks + 2 + runs - 1) / runs;
+                if (bpw < 1) bpw = 1;
+                fp.sub_blocks_per_wg = bpw;
+                const int nch = (n_blocks + 2 + bpw - 1) / bpw;
+                hipLaunchKernelGGL(k_qmf_sub, dim3(S * nch), dim3(256), 0, st, fp, c->d_tables);
+            }
             HIPCHK(c, hipEventRecord(c->ev[1], st));
             hipLaunchKernelGGL(k_gain_analysis, dim3((S * n_out * 6 + 3) / 4), dim3(256), 0, st, gp, c->d_tables);
             HIPCHK(c, hipEventRecord(c->ev[2], st));
