@@ -368,20 +368,24 @@ __device__ __forceinline__ void fft_wave(cpx* F, const cpx* tw, int lane)
 }
 
 // Divisor applied to sample i of the "new" half for a gain curve: the running-product ramp of
+// GainLevel[l] = 2^(4 - l) (atrac3.h:192-194): exact powers of two, formed from the exponent field.
+__device__ __forceinline__ float gain_level_of(int l) { return __uint_as_float((uint32_t)(127 + 4 - l) << 23); }
+
 // TGainProcessor::Modulate (gain_processor.h:93-112) / BuildSampleDivisors (atrac3denc.cpp:154-173).
 // Returns 1.0f for samples the curve does not touch (x / 1.0f == x, so dividing is a no-op there).
-__device__ __forceinline__ float curve_divisor(const Tables* T, const Curve& c, int i)
+// gain_interp: the 31-entry GainInterpolation table, preferably staged in LDS by the caller.
+__device__ __forceinline__ float curve_divisor(const float* gain_interp, const Curve& c, int i)
 {
     int pos = 0;
     for (int p = 0; p < c.n; ++p) {
         const int lastPos = (int)c.loc[p] << 3;
-        float level = T->gain_level[c.level[p]];
+        float level = gain_level_of(c.level[p]);
         if (i >= pos && i < lastPos) return level;
         if (lastPos > pos) pos = lastPos;
         if (pos < lastPos + 8) {
             if (i >= pos && i < lastPos + 8) {
                 const int incPos = ((p + 1) < c.n ? (int)c.level[p + 1] : 4) - (int)c.level[p] + 15;
-                const float inc = T->gain_interp[incPos];
+                const float inc = gain_interp[incPos];
                 for (int q = pos; q < i; ++q) level *= inc;
                 return level;
             }

@@ -451,30 +451,34 @@ __device__ __attribute__((noinline)) void std_sort_abs(SortItem* a, int n)
 __device__ inline float ea_greedy(const float* in, const uint8_t* sidx, int nc, float mul, float inv2, float e1, float e2,
                                   int8_t* mant)
 {
+    // Only |mantissa| enters the energy bookkeeping: the re-rounded code is |m0| + 1 (e2 < e1; a zero becomes +-1) or
+    // |m0| - 1 (e2 > e1), atrac_scale.cpp:86-118. The ordered part per candidate is ex = (e2 - d0) + d1 and the test.
     const bool grow = e2 < e1;
+    float dist = fabsf(e2 - e1);
     for (int c0 = 0; c0 < nc; c0 += 4) {
         const uint32_t i4 = *reinterpret_cast<const uint32_t*>(sidx + c0);
-        const float tt[4] = {in[i4 & 0xff] * mul, in[(i4 >> 8) & 0xff] * mul, in[(i4 >> 16) & 0xff] * mul, in[i4 >> 24] * mul};
+        int m0s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m0s[k] = mant[(i4 >> (8 * k)) & 0xff];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (c0 + k < nc) {
-                const float t = tt[k];
-                const int m0 = __float2int_rn(t);
-                int m = m0;
-                if (grow) {
-                    if (m > 0) m++;
-                    if (m < 0) m--;
-                    if (m == 0) m = t > 0 ? 1 : -1;
-                } else {
-                    if (m > 0) m--;
-                    else if (m < 0) m++;
-                }
+                const int m0 = m0s[k];
+                const int a0 = m0 < 0 ? -m0 : m0;
+                const int a1 = grow ? a0 + 1 : (a0 > 0 ? a0 - 1 : 0);
                 float ex = e2;
-                ex -= (float)(m0 * m0) * inv2;
-                ex += (float)(m * m) * inv2;
-                if (fabsf(ex - e1) < fabsf(e2 - e1)) {
-                    mant[(i4 >> (8 * k)) & 0xff] = (int8_t)m;
+                ex -= (float)(a0 * a0) * inv2;
+                ex += (float)(a1 * a1) * inv2;
+                const float nd = fabsf(ex - e1);
+                if (nd < dist) {
+                    const int idx = (i4 >> (8 * k)) & 0xff;
+                    int m;
+                    if (m0 > 0) m = a1;
+                    else if (m0 < 0) m = -a1;
+                    else m = (in[idx] * mul > 0) ? 1 : -1;   // only reached when growing
+                    mant[idx] = (int8_t)m;
                     e2 = ex;
+                    dist = nd;
                 }
             }
         }
@@ -645,8 +649,10 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     __shared__ __attribute__((aligned(16))) float s_val[1024];
     __shared__ __attribute__((aligned(16))) int8_t s_mant[7 * 1024];
     __shared__ __attribute__((aligned(16))) uint8_t s_si[7 * kEaLines];   // per unit: candidates ordered by |delta|
-    __shared__ __attribute__((aligned(16))) float s_ct[4][128 + 4];       // per wave: value * mul of the listed candidates
-    __shared__ __attribute__((aligned(16))) uint8_t s_ci[4][128 + 4];     // per wave: their lines inside the BFU
+    __shared__ __attribute__((aligned(16))) float s_uk[kEaLines + 4];     // per wordlen plane: sort keys listed per unit (+inf padded)
+    __shared__ float s_pk[kEaLines];                                      // plane-wide candidate list: key ...
+    __shared__ uint16_t s_pu[kEaLines];                                   // ... and (unit in plane) << 7 | line inside the BFU
+    __shared__ int s_cnt[2][16];                                          // [0..12] candidates per unit, [13] per plane (double buffered)
     __shared__ uint8_t s_code[7 * (kEaLines / 4)];   // 2 bits per (wordlen, line): 1 = re-roundable when e2 < e1, 2 = when e2 > e1
     __shared__ uint8_t s_nc[91];
     __shared__ uint8_t s_tie[91];
@@ -750,48 +756,77 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     __syncthreads();
     if (p.debug_stop == 2) return;
 
-    // ---- (C) energy-adaptive units (bfu > 18): unit u = (wl - 1) * 13 + (bfu - 19), wave-local processing ----
+    // ---- (C) energy-adaptive units (bfu > 18), one wordlen plane (13 units, 736 lines) at a time ----
     // A candidate (|delta| < 0.25) can only ever be re-rounded when it passes the side test of the pass that will
     // run (e2 < e1: rounded down and below the top code; e2 > e1: rounded up; equal: nothing runs), and a skipped
-    // candidate changes no state - so only those are listed, in scan order (atrac_scale.cpp:66-126).
-    for (int u = wave; u < 91; u += 4) {
-        const int wl = 1 + u / 13, bfu = 19 + u % 13;
-        const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
+    // candidate changes no state - so only those are listed (atrac_scale.cpp:66-126). The pass visits them by
+    // ascending |delta|: the position of a candidate is the number of keys of its unit below its own, which needs
+    // the unit's keys as a set only - the lists are filled in arrival order through LDS atomics.
+    //   step 1: 64-line chunks -> flag, compact into the unit's key list and into a plane-wide (key, unit, line) list
+    //   step 2: one work-item per listed candidate counts the smaller keys of its unit and stores its line at that rank
+    //   step 3: equal keys collide on a rank; the loser notices on read-back and the unit goes to the exact path (C3)
+    for (int i = tid; i < kEaLines + 4; i += kQuantThreads) s_uk[i] = __builtin_huge_valf();
+    if (tid < 32) (&s_cnt[0][0])[tid] = 0;
+    if (tid < 91) s_tie[tid] = 0;
+    __syncthreads();
+    for (int wl = 1; wl <= 7; ++wl) {
         const float mul = max_quant(wl);
-        const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
-        const uint32_t want = (e2 < e1) ? 1u : (e2 > e1) ? 2u : 3u;   // 3: equal energies, no pass
-        float* ct = s_ct[wave];
-        uint8_t* ci = s_ci[wave];
+        int* cnt = s_cnt[wl & 1];
         const uint8_t* codes = s_code + (wl - 1) * (kEaLines / 4);
-        int nc = 0;
-        for (int j0 = 0; j0 < n; j0 += 64) {
-            const int j = j0 + lane;
-            const int line = start - kEaLine0 + j;
-            const bool flag = j < n && ((codes[line >> 2] >> (2 * (line & 3))) & 3u) == want;
-            const unsigned long long mask = __ballot(flag);
-            if (flag) {
-                const int pos = nc + __popcll(mask & ((1ull << lane) - 1ull));
-                const float t = s_val[start + j] * mul;
-                ci[pos] = (uint8_t)j;
-                ct[pos] = fabsf(t - (truncf(t) + 0.5f));   // sort key |delta|
+        uint8_t* plane_sorted = s_si + (wl - 1) * kEaLines;
+        for (int c = wave; c < 12; c += 4) {
+            const int hi = lane >> 5;
+            int bfu, start;   // of this lane's half of the chunk
+            if (c < 4) { bfu = 18 + 2 * c + hi; start = 256 + 64 * c + 32 * hi; }
+            else if (c < 8) { bfu = 22 + c; start = 256 + 64 * c; }
+            else { bfu = 30 + ((c - 8) >> 1); start = 768 + 128 * ((c - 8) >> 1); }
+            const int line = 256 + 64 * c + lane;
+            bool flag = false;
+            if (bfu > 18) {
+                const float e1 = s_e1[bfu], e2 = s_err[wl * 32 + bfu];
+                const uint32_t want = (e2 < e1) ? 1u : (e2 > e1) ? 2u : 3u;   // 3: equal energies, no pass
+                flag = ((codes[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;
             }
-            nc += __popcll(mask);
+            const unsigned long long mask = __ballot(flag);
+            const uint32_t half = hi ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+            const int below = __popc(half & ((1u << (lane & 31)) - 1u));
+            int base_u = 0, base_p = 0;
+            if ((lane & 31) == 0) {
+                const int n_half = __popc(half);
+                if (n_half) {
+                    base_u = atomicAdd(&cnt[bfu - 19], n_half);
+                    base_p = atomicAdd(&cnt[13], n_half);
+                }
+            }
+            {
+                const int u0 = __builtin_amdgcn_readlane(base_u, 0), u1 = __builtin_amdgcn_readlane(base_u, 32);
+                const int p0 = __builtin_amdgcn_readlane(base_p, 0), p1 = __builtin_amdgcn_readlane(base_p, 32);
+                base_u = hi ? u1 : u0;
+                base_p = hi ? p1 : p0;
+            }
+            if (flag) {
+                const float t = s_val[line] * mul;
+                const float key = fabsf(t - (truncf(t) + 0.5f));   // sort key |delta|
+                s_uk[start - kEaLine0 + base_u + below] = key;
+                s_pk[base_p + below] = key;
+                s_pu[base_p + below] = (uint16_t)(((bfu - 19) << 7) | (line - start));
+            }
         }
-        if (lane < 4) ct[nc + lane] = __builtin_huge_valf();   // pad: never below a key
-        wave_sync();
-        // rank of candidate k = number of listed keys below its own (one lane per candidate, two passes when nc > 64).
-        // Equal keys collide on a slot; the losing lane sees it when it reads the slot back and the unit is redone
-        // by the exact-order path (C3).
-        uint8_t* sorted = s_si + (wl - 1) * kEaLines + (start - kEaLine0);
-        int rank[2] = {0, 0};
-        uint8_t mine[2] = {0, 0};
+        __syncthreads();
+        const int total = cnt[13];
+        int rank[3] = {0, 0, 0};
+        int where[3] = {0, 0, 0};   // unit << 7 | line
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int k = 64 * ps + lane;
-            if (k < nc) {
-                const float key = ct[k];
+        for (int rd = 0; rd < 3; ++rd) {
+            const int t = rd * kQuantThreads + tid;
+            if (t < total) {
+                const float key = s_pk[t];
+                const int pu = s_pu[t];
+                const int ub = pu >> 7;
+                const int ustart = ub < 7 ? 32 * ub : ub < 11 ? 64 * ub - 224 : 128 * ub - 928;
+                const int nc = cnt[ub];
+                const float4* t4 = reinterpret_cast<const float4*>(s_uk + ustart);
                 int r = 0;
-                const float4* t4 = reinterpret_cast<const float4*>(ct);
                 for (int q = 0; q < nc; q += 4) {
                     const float4 cur = t4[q >> 2];
                     r += (cur.x < key);
@@ -799,24 +834,29 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                     r += (cur.z < key);
                     r += (cur.w < key);
                 }
-                rank[ps] = r;
-                mine[ps] = ci[k];
-                sorted[r] = mine[ps];
+                plane_sorted[ustart + r] = (uint8_t)(pu & 127);
+                rank[rd] = ustart + r;
+                where[rd] = pu;
             }
         }
-        wave_sync();
-        bool tie = false;
+        __syncthreads();
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps)
-            if (64 * ps + lane < nc) tie = tie || sorted[rank[ps]] != mine[ps];
-        const bool any_tie = __ballot(tie) != 0ull;
-        if (lane < 4 && nc + lane < ((nc + 3) & ~3)) sorted[nc + lane] = 0;   // pad to a multiple of four
-        if (lane == 0) {
-            s_nc[u] = (uint8_t)nc;
-            s_tie[u] = any_tie;
-            if (any_tie) s_anytie = 1;
+        for (int rd = 0; rd < 3; ++rd) {
+            if (rd * kQuantThreads + tid < total && plane_sorted[rank[rd]] != (uint8_t)(where[rd] & 127)) {
+                s_tie[(wl - 1) * 13 + (where[rd] >> 7)] = 1;
+                s_anytie = 1;
+            }
         }
-        wave_sync();   // scratch is reused by the next unit
+        if (tid < 13) {
+            const int nc = cnt[tid];
+            const int ustart = tid < 7 ? 32 * tid : tid < 11 ? 64 * tid - 224 : 128 * tid - 928;
+            s_nc[(wl - 1) * 13 + tid] = (uint8_t)nc;
+            for (int k = nc; k < ((nc + 3) & ~3); ++k) plane_sorted[ustart + k] = 0;   // pad to a multiple of four
+        }
+        // next plane: fresh key lists and counters (the other counter buffer was cleared one plane ago)
+        for (int i = tid; i < kEaLines; i += kQuantThreads) s_uk[i] = __builtin_huge_valf();
+        if (tid < 16) s_cnt[(wl + 1) & 1][tid] = 0;
+        __syncthreads();
     }
     __syncthreads();
     if (p.debug_stop == 3) return;
@@ -858,9 +898,12 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
         __syncthreads();
     }
     // (C4) sequential re-rounding pass, one lane per unit
-    if (tid < 91) {
-        const int u = tid;
-        const int wl = 1 + u / 13, bfu = 19 + u % 13;
+    //      Wide BFUs (long candidate lists) share wavefront 0, the 32-line BFUs wavefront 1: a wavefront runs as long
+    //      as its longest list.
+    if (tid < 42 || (tid >= 64 && tid < 113)) {
+        const int wl = (tid < 42) ? 1 + tid / 6 : 1 + (tid - 64) / 7;
+        const int bfu = (tid < 42) ? 26 + tid % 6 : 19 + (tid - 64) % 7;
+        const int u = (wl - 1) * 13 + (bfu - 19);
         const int start = bfu_start(bfu);
         const int nc = s_nc[u];
         if (nc > 0) {

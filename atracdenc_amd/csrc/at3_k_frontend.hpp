@@ -32,6 +32,7 @@ struct FrontParams {
     int frames_per_wg;
     int js;
     int sub_blocks_per_wg;   // k_qmf_sub only
+    int debug;               // profiling aid (env AT3HIP_DEBUG_FRONT): 1 = skip the energy-scale chains, 2 = ignore curves
 };
 
 // ---- fused QMF + gain modulation + windowed MDCT-512 ------------------------------------------------------
@@ -41,7 +42,8 @@ struct FrontParams {
 // that are fetched from LDS with seven 16-byte reads and then stay in registers for all 192 multiply-adds;
 // the 48 taps are wave-uniform scalars. Accumulation order per output is tap 0..23, multiply then add
 // (no contraction), exactly as qmf.h:54-63.
-__device__ __forceinline__ void qmf4(const float* __restrict__ xb /* LDS, 16-byte aligned pair base */,
+template <int H>
+__device__ __forceinline__ void qmf4(const float4* __restrict__ xb /* LDS ring + work-item index g, in 16-byte slots */,
                                      const f2 (&Wp)[24] /* tap pairs (W[2i], W[2i+1]), wave-uniform (scalar registers) */,
                                      float (&lower)[4], float (&upper)[4])
 {
@@ -51,7 +53,7 @@ __device__ __forceinline__ void qmf4(const float* __restrict__ xb /* LDS, 16-byt
     f2 xp[28];
 #pragma unroll
     for (int q = 0; q < 14; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(xb + 4 * q);
+        const float4 v = xb[(q >> 1) + (q & 1) * H];
         xp[2 * q] = mk2(v.x, v.y);
         xp[2 * q + 1] = mk2(v.z, v.w);
     }
@@ -65,8 +67,20 @@ __device__ __forceinline__ void qmf4(const float* __restrict__ xb /* LDS, 16-byt
     }
 }
 
-constexpr int kPcmRing = 1072;  // [46 history | 1024 new] per channel (+2 pad keeps 16-byte alignment)
-constexpr int kS1Ring = 560;    // [46 history | 512 new] per channel and half (+2 pad)
+// Ring storage order. Work-item g of a QMF stage reads the 16-byte groups 2g .. 2g+13 of its ring; with the groups in
+// natural order neighbouring work-items are 32 bytes apart and every 16-byte LDS read is a two-way bank conflict.
+// The rings therefore keep even groups in their first half and odd groups in the second (H groups each, H = 8 mod 16
+// so that the halves are 128 bytes out of phase): group j lives in slot (j >> 1) + (j & 1) * H, and a stage reads slot
+// g + (q >> 1) + (q & 1) * H for q = 0..13 - consecutive work-items, consecutive slots.
+constexpr int kPcmH = 136, kS1H = 72;   // slots per half: logical floats [46 history | 1024 new] resp. [46 | 512]
+constexpr int kPcmRing = 8 * kPcmH;     // 1088 floats per channel
+constexpr int kS1Ring = 8 * kS1H;       // 576 floats per channel and half
+template <int H>
+__device__ __forceinline__ int ring_at(int e)   // physical float index of logical ring element e
+{
+    const int j = e >> 2;
+    return (((j >> 1) + (j & 1) * H) << 2) | (e & 3);
+}
 
 // Subband analysis only (feeds the gain-control kernels): raw L/R subbands of blocks -2 .. n_blocks-1, the same ring
 // scheme as the fused kernel below. One workgroup walks `sub_blocks_per_wg` consecutive blocks of one stream; the
@@ -110,12 +124,12 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
             lo += Wp[i].x * x[47 - 2 * i];
             hi += Wp[i].y * x[46 - 2 * i];
         }
-        s_lo[ch * kS1Ring + mm] = lo + hi;
-        s_hi[ch * kS1Ring + mm] = lo - hi;
+        s_lo[ch * kS1Ring + ring_at<kS1H>(mm)] = lo + hi;
+        s_hi[ch * kS1Ring + ring_at<kS1H>(mm)] = lo - hi;
         keep = s_pcm[ch * kPcmRing + 92 + mm];
     }
     __syncthreads();
-    if (tid < 92) s_pcm[(tid / 46) * kPcmRing + (tid % 46)] = keep;
+    if (tid < 92) s_pcm[(tid / 46) * kPcmRing + ring_at<kPcmH>(tid % 46)] = keep;
 
     float2 nxt[4];
 #pragma unroll
@@ -128,8 +142,8 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = tid + 256 * q;
-            s_pcm[46 + k] = nxt[q].x * 0.25f;       // data / 4.0 (exact)
-            s_pcm[kPcmRing + 46 + k] = nxt[q].y * 0.25f;
+            s_pcm[ring_at<kPcmH>(46 + k)] = nxt[q].x * 0.25f;       // data / 4.0 (exact)
+            s_pcm[kPcmRing + ring_at<kPcmH>(46 + k)] = nxt[q].y * 0.25f;
         }
         if (b + 1 < bb) {
 #pragma unroll
@@ -142,21 +156,23 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
         {   // stage 1 (Qmf1)
             const int ch = tid >> 7, g = tid & 127;
             float lw[4], up[4];
-            qmf4(s_pcm + ch * kPcmRing + 8 * g, Wp, lw, up);
-            float2* dl = reinterpret_cast<float2*>(s_lo + ch * kS1Ring + 46 + 4 * g);
-            float2* dh = reinterpret_cast<float2*>(s_hi + ch * kS1Ring + 46 + 4 * g);
+            qmf4<kPcmH>(reinterpret_cast<const float4*>(s_pcm + ch * kPcmRing) + g, Wp, lw, up);
+            // ring element of output m is 46 + m: 8-byte aligned pairs, (46 + 4g, +1) and (48 + 4g, +1) sit in two groups
+            float* rl = s_lo + ch * kS1Ring;
+            float* rh = s_hi + ch * kS1Ring;
+            const int e0 = ring_at<kS1H>(46 + 4 * g), e1 = ring_at<kS1H>(48 + 4 * g);
             float2 t0, t1;
             t0.x = lw[0]; t0.y = lw[1]; t1.x = lw[2]; t1.y = lw[3];
-            dl[0] = t0; dl[1] = t1;
+            *reinterpret_cast<float2*>(rl + e0) = t0; *reinterpret_cast<float2*>(rl + e1) = t1;
             t0.x = up[0]; t0.y = up[1]; t1.x = up[2]; t1.y = up[3];
-            dh[0] = t0; dh[1] = t1;
+            *reinterpret_cast<float2*>(rh + e0) = t0; *reinterpret_cast<float2*>(rh + e1) = t1;
         }
         __syncthreads();
-        if (tid < 92) keep = s_pcm[(tid / 46) * kPcmRing + 1024 + (tid % 46)];
+        if (tid < 92) keep = s_pcm[(tid / 46) * kPcmRing + ring_at<kPcmH>(1024 + tid % 46)];
         {   // stage 2: Qmf2 on the lower half -> bands 0, 1; Qmf3 on the upper half -> bands 3, 2
             const int ch = tid >> 7, which = (tid >> 6) & 1, g = tid & 63;
             float lw[4], up[4];
-            qmf4((which ? s_hi : s_lo) + ch * kS1Ring + 8 * g, Wp, lw, up);
+            qmf4<kS1H>(reinterpret_cast<const float4*>((which ? s_hi : s_lo) + ch * kS1Ring) + g, Wp, lw, up);
             float4 a, bq;
             a.x = lw[0]; a.y = lw[1]; a.z = lw[2]; a.w = lw[3];
             bq.x = up[0]; bq.y = up[1]; bq.z = up[2]; bq.w = up[3];
@@ -164,32 +180,36 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
             *reinterpret_cast<float4*>(out + (which ? 3 : 0) * sublen) = a;
             *reinterpret_cast<float4*>(out + (which ? 2 : 1) * sublen) = bq;
         }
-        if (tid < 92) s_pcm[(tid / 46) * kPcmRing + (tid % 46)] = keep;
+        if (tid < 92) s_pcm[(tid / 46) * kPcmRing + ring_at<kPcmH>(tid % 46)] = keep;
         __syncthreads();
         if (tid < 184) {   // stage-1 history for the next block
             const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
             float* ring = (hlf ? s_hi : s_lo) + ch * kS1Ring;
-            ring[k] = ring[512 + k];
+            ring[ring_at<kS1H>(k)] = ring[ring_at<kS1H>(512 + k)];
         }
     }
 }
 
 template <bool GAIN>
-__global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T)
+__global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) float s_pcm[2 * kPcmRing];
-    __shared__ __attribute__((aligned(16))) float s_lo[2 * kS1Ring];
-    __shared__ __attribute__((aligned(16))) float s_hi[2 * kS1Ring];
+    __shared__ __attribute__((aligned(16))) float s_s1[4 * kS1Ring];      // stage-1 rings: lower halves of both channels, then upper
     __shared__ __attribute__((aligned(16))) float s_sub[2 * 4 * 256];     // current block's subbands [ch][band][256]
     __shared__ __attribute__((aligned(16))) float s_prevw[2 * 4 * 256];   // overlap half carried to the next frame
-    __shared__ __attribute__((aligned(16))) cpx s_fft[8 * 128];
+    float* s_lo = s_s1;
+    float* s_hi = s_s1 + 2 * kS1Ring;
+    // The stage-1 rings are dead between stage 2 and the next block's stage 1 (their 46-sample histories wait in
+    // registers meanwhile), so the eight 128-point FFT buffers of the MDCT phase live in the same storage.
+    static_assert(4 * kS1Ring * sizeof(float) >= 8 * 128 * sizeof(cpx), "FFT buffers must fit in the stage-1 rings");
+    cpx* s_fft = reinterpret_cast<cpx*>(s_s1);
     __shared__ __attribute__((aligned(16))) float s_win[256];
     __shared__ float s_cs[256];
     __shared__ cpx s_tw[128];
     __shared__ Curve s_curve[8];
+    __shared__ float s_gi[32];               // GainInterpolation
     __shared__ float s_nextscale[8];         // NextOverlapScale of the block just processed
     __shared__ float s_sum[8][5];
-    __shared__ Curve s_curves_all[GAIN ? 33 * 8 : 1];   // curves of frames fa-1 .. fb-1 (frames_per_wg <= 32)
     // Gain-path scratch aliases buffers that are dead between stage 2 and the MDCT fold of the same block:
     // the per-sample divisors live in the FFT buffer (written by the fold afterwards), the energy-term staging in
     // each channel's PCM ring behind the 46-sample history (rewritten by the next block's tile load).
@@ -215,13 +235,15 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
     s_cs[tid] = T->mdct_sincos[tid];
     if (tid < 128) s_tw[tid] = T->tw128[tid];
     if (tid < 8) s_nextscale[tid] = 1.0f;
+    if (GAIN && tid < 32) s_gi[tid] = T->gain_interp[tid];
     for (int i = tid; i < 2048; i += 256) s_prevw[i] = 0.0f;
-    if (GAIN) {
-        // gain curves of every frame this run touches (frame fa-1 only shapes the carried overlap)
-        for (int i = tid; i < (fb - fa + 1) * 8; i += 256) {
-            const int f = fa - 1 + i / 8, cb = i % 8;
-            s_curves_all[i] = (f < 0) ? p.state[(size_t)s * 8 + cb].prev_curve : p.curves[((size_t)s * p.n_blocks + f) * 8 + cb];
-        }
+    // gain curve of the frame about to be processed, fetched one block ahead by work-items 0..7 (frame fa-1 only
+    // shapes the carried overlap; frame -1 is the curve carried in the stream state)
+    Curve ncv;
+    ncv.n = 0;
+    if (GAIN && tid < 8) {
+        const int f = fa - 1;
+        ncv = (f < 0) ? p.state[(size_t)s * 8 + tid].prev_curve : p.curves[((size_t)s * p.n_blocks + f) * 8 + tid];
     }
 
     // ---- prologue: FIR histories of the first block (b0 = fa - 2) ----
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
         s_pcm[kPcmRing + k] = v.y * 0.25f;
     }
     __syncthreads();
-    float keep = 0.0f;
+    float keep = 0.0f, keep1 = 0.0f;
     if (tid < 92) {
         const int ch = tid / 46, mm = tid % 46;   // output m = mm - 46, pair base = 2 * mm in the temp layout
         const float* x = s_pcm + ch * kPcmRing + 2 * mm;
@@ -244,12 +266,12 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
             lo += Wp[i].x * x[47 - 2 * i];
             hi += Wp[i].y * x[46 - 2 * i];
         }
-        s_lo[ch * kS1Ring + mm] = lo + hi;
-        s_hi[ch * kS1Ring + mm] = lo - hi;
+        s_lo[ch * kS1Ring + ring_at<kS1H>(mm)] = lo + hi;
+        s_hi[ch * kS1Ring + ring_at<kS1H>(mm)] = lo - hi;
         keep = s_pcm[ch * kPcmRing + 92 + mm];    // samples -46..-1 move to the front of the ring
     }
     __syncthreads();
-    if (tid < 92) s_pcm[(tid / 46) * kPcmRing + (tid % 46)] = keep;
+    if (tid < 92) s_pcm[(tid / 46) * kPcmRing + ring_at<kPcmH>(tid % 46)] = keep;
 
     const int c = tid >> 5;      // (channel, band) combo owning this thread in the MDCT phase; a wave owns 2
     const int lane = tid & 31;
@@ -268,8 +290,8 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = tid + 256 * q;
-            s_pcm[46 + k] = nxt[q].x * 0.25f;
-            s_pcm[kPcmRing + 46 + k] = nxt[q].y * 0.25f;
+            s_pcm[ring_at<kPcmH>(46 + k)] = nxt[q].x * 0.25f;
+            s_pcm[kPcmRing + ring_at<kPcmH>(46 + k)] = nxt[q].y * 0.25f;
         }
         if (b + 1 <= fb - 2) {   // issue the next block's coalesced float2 loads now; they land during this block's math
 #pragma unroll
@@ -278,36 +300,48 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
                 nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
             }
         }
-        if (GAIN && tid < 8) s_curve[tid] = s_curves_all[(f - (fa - 1)) * 8 + tid];
+        if (GAIN && tid < 8) {
+            s_curve[tid] = ncv;
+            if (b + 1 <= fb - 2) ncv = p.curves[((size_t)s * p.n_blocks + f + 1) * 8 + tid];
+        }
+        if (tid < 184 && b > b0) {   // stage-1 histories return to the rings (they shared storage with the FFT buffers)
+            const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
+            ((hlf ? s_hi : s_lo) + ch * kS1Ring)[ring_at<kS1H>(k)] = keep1;
+        }
         __syncthreads();
         // ---- stage 1 (Qmf1): 2 channels x 128 tasks x 4 outputs ----
         {
             const int ch = tid >> 7, g = tid & 127;
             float lw[4], up[4];
-            qmf4(s_pcm + ch * kPcmRing + 8 * g, Wp, lw, up);
+            qmf4<kPcmH>(reinterpret_cast<const float4*>(s_pcm + ch * kPcmRing) + g, Wp, lw, up);
             float4 a, bq;
             a.x = lw[0]; a.y = lw[1]; a.z = lw[2]; a.w = lw[3];
             bq.x = up[0]; bq.y = up[1]; bq.z = up[2]; bq.w = up[3];
-            // ring index of output m is 46 + m: 8-byte aligned only -> two float2 stores
-            float2* dl = reinterpret_cast<float2*>(s_lo + ch * kS1Ring + 46 + 4 * g);
-            float2* dh = reinterpret_cast<float2*>(s_hi + ch * kS1Ring + 46 + 4 * g);
+            // ring element of output m is 46 + m: 8-byte aligned pairs, (46 + 4g, +1) and (48 + 4g, +1) sit in two groups
+            float* rl = s_lo + ch * kS1Ring;
+            float* rh = s_hi + ch * kS1Ring;
+            const int e0 = ring_at<kS1H>(46 + 4 * g), e1 = ring_at<kS1H>(48 + 4 * g);
             float2 t0, t1;
             t0.x = a.x; t0.y = a.y; t1.x = a.z; t1.y = a.w;
-            dl[0] = t0; dl[1] = t1;
+            *reinterpret_cast<float2*>(rl + e0) = t0; *reinterpret_cast<float2*>(rl + e1) = t1;
             t0.x = bq.x; t0.y = bq.y; t1.x = bq.z; t1.y = bq.w;
-            dh[0] = t0; dh[1] = t1;
+            *reinterpret_cast<float2*>(rh + e0) = t0; *reinterpret_cast<float2*>(rh + e1) = t1;
         }
         __syncthreads();
         // PCM history for the next block (stage 1 is done with the ring)
         if (tid < 92) {
             const int ch = tid / 46, k = tid % 46;
-            keep = s_pcm[ch * kPcmRing + 1024 + k];
+            keep = s_pcm[ch * kPcmRing + ring_at<kPcmH>(1024 + k)];
+        }
+        if (tid < 184) {   // stage-1 history for the next block, parked in a register across the MDCT phase
+            const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
+            keep1 = ((hlf ? s_hi : s_lo) + ch * kS1Ring)[ring_at<kS1H>(512 + k)];
         }
         // ---- stage 2: Qmf2 on the lower half -> bands 0, 1; Qmf3 on the upper half -> bands 3, 2 ----
         {
             const int ch = tid >> 7, which = (tid >> 6) & 1, g = tid & 63;
             float lw[4], up[4];
-            qmf4((which ? s_hi : s_lo) + ch * kS1Ring + 8 * g, Wp, lw, up);
+            qmf4<kS1H>(reinterpret_cast<const float4*>((which ? s_hi : s_lo) + ch * kS1Ring) + g, Wp, lw, up);
             float4 a, bq;
             a.x = lw[0]; a.y = lw[1]; a.z = lw[2]; a.w = lw[3];
             bq.x = up[0]; bq.y = up[1]; bq.z = up[2]; bq.w = up[3];
@@ -315,14 +349,8 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
             *reinterpret_cast<float4*>(out + (which ? 3 : 0) * 256 + 4 * g) = a;
             *reinterpret_cast<float4*>(out + (which ? 2 : 1) * 256 + 4 * g) = bq;
         }
-        if (tid < 92) s_pcm[(tid / 46) * kPcmRing + (tid % 46)] = keep;
+        if (tid < 92) s_pcm[(tid / 46) * kPcmRing + ring_at<kPcmH>(tid % 46)] = keep;
         __syncthreads();
-        // stage-1 history for the next block (stage 2 is done with the rings)
-        if (tid < 184) {
-            const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
-            float* ring = (hlf ? s_hi : s_lo) + ch * kS1Ring;
-            ring[k] = ring[512 + k];
-        }
         if (p.js) {  // M/S matrixing in the subband domain
             for (int idx = tid; idx < 1024; idx += 256) {
                 const float l = s_sub[idx], r = s_sub[1024 + idx];
@@ -339,17 +367,19 @@ __global__ __launch_bounds__(256) void k_qmf_mdct(FrontParams p, const Tables* T
         float scale = 1.0f;
         if (GAIN) {
             const float prev_scale = s_nextscale[c];
-            has_curve = s_curve[c].n > 0;
+            has_curve = s_curve[c].n > 0 && p.debug != 2;
             if (has_curve) {
-                scale = T->gain_level[s_curve[c].level[0]];
-                for (int i = lane; i < 256; i += 32) s_div[c * 256 + i] = curve_divisor(T, s_curve[c], i);
+                scale = gain_level_of(s_curve[c].level[0]);
+                for (int i = lane; i < 256; i += 32) s_div[c * 256 + i] = curve_divisor(s_gi, s_curve[c], i);
             }
             wave_sync();
             // CalcGainEnergyScale (atrac3denc.cpp:189-216): five strictly ordered 256-term sums. The terms are
             // produced 32 at a time by all lanes of the combo; lanes 0..4 then extend one chain each.
-            const bool need = has_curve || prev_scale != 1.0f;
+            const bool need = (has_curve || prev_scale != 1.0f) && p.debug != 1;
             if (__ballot(need) != 0ull) {   // wave-uniform: both combos of the wavefront walk the chunks together
-                float* terms = s_pcm + (c >> 2) * kPcmRing + 64 + (c & 3) * 160;   // [5][32], in the dead part of the PCM ring
+                // [5][32] per combo in the dead part of the channel's PCM ring: the 46-sample history occupies the first 24
+                // floats of each half (ring_at), the rest is rewritten by the next block's tile store
+                float* terms = s_pcm + (c >> 2) * kPcmRing + ((c & 3) < 3 ? 32 + (c & 3) * 160 : 4 * kPcmH + 32);
                 float acc = 0.0f;
                 for (int base = 0; base < 256; base += 32) {
                     const int i = base + lane;
@@ -517,14 +547,14 @@ __global__ __launch_bounds__(128) void k_mdct_items(MdctItemsParams p, const Tab
     s_tw[tid] = T->tw128[tid];
     __syncthreads();
     const bool has_curve = s_curve[c].n > 0;
-    const float scale = has_curve ? T->gain_level[s_curve[c].level[0]] : 1.0f;
+    const float scale = has_curve ? gain_level_of(s_curve[c].level[0]) : 1.0f;
     float* tmp = s_tmp + c * 512;
     for (int i = lane; i < 256; i += 32) {
         float ov = band[i];
         float v = band[256 + i];
         if (has_curve) {
             ov = ov / scale;
-            const float d = curve_divisor(T, s_curve[c], i);
+            const float d = curve_divisor(T->gain_interp, s_curve[c], i);
             v = v / d;
             band[256 + i] = v;
         }

@@ -582,7 +582,7 @@ __device__ __forceinline__ float early_mismatch_score_grp(const Tables* T, float
         c.loc[i] = (uint8_t)cp.loc[i];
     }
     float dsum = 0.0f;
-    for (int k = 0; k < 8; ++k) dsum += curve_divisor(T, c, j * 8 + k);
+    for (int k = 0; k < 8; ++k) dsum += curve_divisor(T->gain_interp, c, j * 8 + k);
     const float div = dsum / 8.0f;
     int maxLoc = 0;
 #pragma unroll
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
             if (sf < nBefore) sum += v;
         }
         if (pts.n > 0 && pts.loc[0] > 0) {
-            hpfRmsNextMod = (sum / (float)nBefore) / T->gain_level[pts.level[0]];
+            hpfRmsNextMod = (sum / (float)nBefore) / gain_level_of(pts.level[0]);
             validMod = true;
         } else if (pts.n == 0) {
             hpfRmsNextMod = sum / 32;
@@ -824,9 +824,9 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
         bool keepByBoundary = false;
         if (p0ok) {
             const float x = prevTarget / hpfRmsNextMod;
-            const float desired = fminf(fmaxf(x, T->gain_level[15]), T->gain_level[0]);
-            const float scaleBefore = T->gain_level[before.n == 0 ? 4 : before.level[0]];
-            const float scaleAfter = T->gain_level[pts.n == 0 ? 4 : pts.level[0]];
+            const float desired = fminf(fmaxf(x, gain_level_of(15)), gain_level_of(0));
+            const float scaleBefore = gain_level_of(before.n == 0 ? 4 : before.level[0]);
+            const float scaleAfter = gain_level_of(pts.n == 0 ? 4 : pts.level[0]);
             const float eps = 1e-9f;
             const float errBefore = fabsf(at3_log2f(T, fmaxf(scaleBefore, eps) / fmaxf(desired, eps)));
             const float errAfter = fabsf(at3_log2f(T, fmaxf(scaleAfter, eps) / fmaxf(desired, eps)));

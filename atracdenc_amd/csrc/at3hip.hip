@@ -92,13 +92,13 @@ int dev_alloc(at3hip_ctx* c, Tp** p, size_t count)
 }
 
 // Frames per workgroup run of the fused kernel: long runs amortise the one-block prologue, short runs keep
-// every CU busy on small batches (three workgroups are resident per CU).
+// every CU busy on small batches (four workgroups are resident per CU).
 int pick_frames_per_wg(const at3hip_ctx* c, int n_out)
 {
     if (c->frames_per_wg > 0) return c->frames_per_wg;
-    // three workgroups of the fused kernel are resident per CU: cut every stream into as many runs as fit in ONE
+    // four workgroups of the fused kernel are resident per CU: cut every stream into as many runs as fit in ONE
     // round of the grid (a partial second round would double the kernel time on small batches)
-    const long long slots = (long long)c->n_cus * 3;
+    const long long slots = (long long)c->n_cus * 4;
     long long runs_per_stream = slots / c->cfg.n_streams;
     if (runs_per_stream < 1) runs_per_stream = 1;
     long long f = (n_out + runs_per_stream - 1) / runs_per_stream;
@@ -277,6 +277,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         fp.n_blocks = n_blocks;
         fp.f0 = f0;
         fp.frames_per_wg = pick_frames_per_wg(c, n_out);
+        fp.debug = getenv("AT3HIP_DEBUG_FRONT") ? atoi(getenv("AT3HIP_DEBUG_FRONT")) : 0;
         fp.js = c->js;
         if (gain) {
             GainParams gp;
@@ -456,6 +457,8 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
     fp.specs = specs;
     fp.ges = nullptr;
     fp.sub = nullptr;
+    fp.sub_blocks_per_wg = 0;
+    fp.debug = 0;
     fp.n_blocks = n_blocks;
     fp.f0 = 1;
     const int n_out = n_blocks - 1;

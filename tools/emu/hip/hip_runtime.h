@@ -96,6 +96,7 @@ void emu_wave_barrier();
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
