@@ -47,9 +47,9 @@ __device__ __forceinline__ void qmf4(const float4* __restrict__ xb /* LDS ring +
                                      const f2 (&Wp)[24] /* tap pairs (W[2i], W[2i+1]), wave-uniform (scalar registers) */,
                                      float (&lower)[4], float (&upper)[4])
 {
-    // sample pairs (x[2k], x[2k+1]) stay in the register pairs the 16-byte loads deliver; one packed multiply forms
-    // (W[2i] x[2k+1], W[2i+1] x[2k]) - the half swap is an operand modifier - and one packed add extends the two
-    // ordered sums of qmf.h:59-66 together.
+    // sample pairs arrive as (x[2k+1], x[2k]) in the register pairs the 16-byte loads deliver (see ring_at); one
+    // packed multiply forms (W[2i] x[2k+1], W[2i+1] x[2k]) and one packed add extends the two ordered sums of
+    // qmf.h:59-66 together.
     f2 xp[28];
 #pragma unroll
     for (int q = 0; q < 14; ++q) {
@@ -61,7 +61,7 @@ __device__ __forceinline__ void qmf4(const float4* __restrict__ xb /* LDS ring +
     for (int r = 0; r < 4; ++r) {
         f2 acc = mk2(0.0f, 0.0f);
 #pragma unroll
-        for (int i = 0; i < 24; ++i) acc = acc + Wp[i] * xp[r + 23 - i].yx;
+        for (int i = 0; i < 24; ++i) acc = acc + Wp[i] * xp[r + 23 - i];
         lower[r] = acc.x + acc.y;
         upper[r] = acc.x - acc.y;
     }
@@ -75,11 +75,13 @@ __device__ __forceinline__ void qmf4(const float4* __restrict__ xb /* LDS ring +
 constexpr int kPcmH = 136, kS1H = 72;   // slots per half: logical floats [46 history | 1024 new] resp. [46 | 512]
 constexpr int kPcmRing = 8 * kPcmH;     // 1088 floats per channel
 constexpr int kS1Ring = 8 * kS1H;       // 576 floats per channel and half
+// Inside a group the two floats of a sample pair are stored swapped, (x[2k+1], x[2k]): that is the operand order of the
+// packed tap product (W[2i] x[2k+1], W[2i+1] x[2k]), so the FIR consumes the loaded register pairs as they are.
 template <int H>
 __device__ __forceinline__ int ring_at(int e)   // physical float index of logical ring element e
 {
     const int j = e >> 2;
-    return (((j >> 1) + (j & 1) * H) << 2) | (e & 3);
+    return (((j >> 1) + (j & 1) * H) << 2) | ((e & 3) ^ 1);
 }
 
 // Subband analysis only (feeds the gain-control kernels): raw L/R subbands of blocks -2 .. n_blocks-1, the same ring
@@ -160,11 +162,11 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
             // ring element of output m is 46 + m: 8-byte aligned pairs, (46 + 4g, +1) and (48 + 4g, +1) sit in two groups
             float* rl = s_lo + ch * kS1Ring;
             float* rh = s_hi + ch * kS1Ring;
-            const int e0 = ring_at<kS1H>(46 + 4 * g), e1 = ring_at<kS1H>(48 + 4 * g);
+            const int e0 = ring_at<kS1H>(47 + 4 * g), e1 = ring_at<kS1H>(49 + 4 * g);   // pair bases: the odd element comes first
             float2 t0, t1;
-            t0.x = lw[0]; t0.y = lw[1]; t1.x = lw[2]; t1.y = lw[3];
+            t0.x = lw[1]; t0.y = lw[0]; t1.x = lw[3]; t1.y = lw[2];
             *reinterpret_cast<float2*>(rl + e0) = t0; *reinterpret_cast<float2*>(rl + e1) = t1;
-            t0.x = up[0]; t0.y = up[1]; t1.x = up[2]; t1.y = up[3];
+            t0.x = up[1]; t0.y = up[0]; t1.x = up[3]; t1.y = up[2];
             *reinterpret_cast<float2*>(rh + e0) = t0; *reinterpret_cast<float2*>(rh + e1) = t1;
         }
         __syncthreads();
@@ -211,9 +213,9 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
     __shared__ float s_nextscale[8];         // NextOverlapScale of the block just processed
     __shared__ float s_sum[8][5];
     // Gain-path scratch aliases buffers that are dead between stage 2 and the MDCT fold of the same block:
-    // the per-sample divisors live in the FFT buffer (written by the fold afterwards), the energy-term staging in
+    // the modulated samples live in the FFT buffer (written by the fold afterwards), the energy-term staging in
     // each channel's PCM ring behind the 46-sample history (rewritten by the next block's tile load).
-    float* s_div = reinterpret_cast<float*>(s_fft);          // [8][256]
+    float* s_mod = reinterpret_cast<float*>(s_fft);          // [8][256]
 
     const int tid = threadIdx.x;
     const int nchunks = (p.n_blocks - p.f0 + p.frames_per_wg - 1) / p.frames_per_wg;
@@ -320,11 +322,11 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
             // ring element of output m is 46 + m: 8-byte aligned pairs, (46 + 4g, +1) and (48 + 4g, +1) sit in two groups
             float* rl = s_lo + ch * kS1Ring;
             float* rh = s_hi + ch * kS1Ring;
-            const int e0 = ring_at<kS1H>(46 + 4 * g), e1 = ring_at<kS1H>(48 + 4 * g);
+            const int e0 = ring_at<kS1H>(47 + 4 * g), e1 = ring_at<kS1H>(49 + 4 * g);   // pair bases: the odd element comes first
             float2 t0, t1;
-            t0.x = a.x; t0.y = a.y; t1.x = a.z; t1.y = a.w;
+            t0.x = a.y; t0.y = a.x; t1.x = a.w; t1.y = a.z;
             *reinterpret_cast<float2*>(rl + e0) = t0; *reinterpret_cast<float2*>(rl + e1) = t1;
-            t0.x = bq.x; t0.y = bq.y; t1.x = bq.z; t1.y = bq.w;
+            t0.x = bq.y; t0.y = bq.x; t1.x = bq.w; t1.y = bq.z;
             *reinterpret_cast<float2*>(rh + e0) = t0; *reinterpret_cast<float2*>(rh + e1) = t1;
         }
         __syncthreads();
@@ -369,8 +371,51 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
             const float prev_scale = s_nextscale[c];
             has_curve = s_curve[c].n > 0 && p.debug != 2;
             if (has_curve) {
-                scale = gain_level_of(s_curve[c].level[0]);
-                for (int i = lane; i < 256; i += 32) s_div[c * 256 + i] = curve_divisor(s_gi, s_curve[c], i);
+                // Modulated new half (gain_processor.h:93-112): lane j owns samples 8j .. 8j+7. Level boundaries and
+                // the 8-sample ramps are aligned to these cells, so a cell is untouched, divided by one level (a
+                // power of two: multiplying by its reciprocal is the same rounding) or by one running-product ramp.
+                const Curve cv = s_curve[c];
+                scale = gain_level_of(cv.level[0]);
+                const int cell = 8 * lane;
+                int kind = 0;   // 0 untouched, 1 constant level, 2 ramp
+                float lvl = 1.0f, inc = 1.0f, inv = 1.0f;
+                int pos = 0;
+                for (int q = 0; q < cv.n; ++q) {
+                    const int lastPos = (int)cv.loc[q] << 3;
+                    if (cell >= pos && cell < lastPos) {
+                        kind = 1;
+                        inv = __uint_as_float((uint32_t)(127 - 4 + cv.level[q]) << 23);   // 1 / GainLevel
+                        break;
+                    }
+                    if (lastPos > pos) pos = lastPos;
+                    if (pos < lastPos + 8) {
+                        if (cell >= pos && cell < lastPos + 8) {
+                            kind = 2;
+                            lvl = gain_level_of(cv.level[q]);
+                            inc = s_gi[((q + 1) < cv.n ? (int)cv.level[q + 1] : 4) - (int)cv.level[q] + 15];
+                            break;
+                        }
+                        pos = lastPos + 8;
+                    }
+                }
+                const float4 xa = *reinterpret_cast<const float4*>(xs + cell), xb = *reinterpret_cast<const float4*>(xs + cell + 4);
+                float v[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                if (kind == 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = v[k] * inv;
+                } else if (kind == 2) {
+                    float d = lvl;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        v[k] = v[k] / d;
+                        d *= inc;
+                    }
+                }
+                float4 oa, ob;
+                oa.x = v[0]; oa.y = v[1]; oa.z = v[2]; oa.w = v[3];
+                ob.x = v[4]; ob.y = v[5]; ob.z = v[6]; ob.w = v[7];
+                *reinterpret_cast<float4*>(s_mod + c * 256 + cell) = oa;
+                *reinterpret_cast<float4*>(s_mod + c * 256 + cell + 4) = ob;
             }
             wave_sync();
             // CalcGainEnergyScale (atrac3denc.cpp:189-216): five strictly ordered 256-term sums. The terms are
@@ -384,7 +429,7 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
                 for (int base = 0; base < 256; base += 32) {
                     const int i = base + lane;
                     const float x = xs[i];
-                    const float mod = has_curve ? x / s_div[c * 256 + i] : x;
+                    const float mod = has_curve ? s_mod[c * 256 + i] : x;
                     const float wc = s_win[255 - i], wn = s_win[i];
                     const float pv = pw[i];
                     const float cw = x * wc, mw = mod * wc, nw = x * wn, mnw = mod * wn;
@@ -426,9 +471,10 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
                 if (is_frame) p.ges[((size_t)s * p.n_blocks + f) * 8 + c] = frame_scale;
             }
             if (has_curve) {   // Modulate (gain_processor.h:87-121): new half / ramp, overlap half / first level
+                const float inv_scale = 1.0f / scale;   // scale is a power of two
                 for (int i = lane; i < 256; i += 32) {
-                    xs[i] = xs[i] / s_div[c * 256 + i];
-                    pw[i] = pw[i] / scale;
+                    xs[i] = s_mod[c * 256 + i];
+                    pw[i] = pw[i] * inv_scale;
                 }
             }
             wave_sync();
