@@ -50,20 +50,31 @@ __device__ __forceinline__ void qmf4(const float4* __restrict__ xb /* LDS ring +
     // sample pairs arrive as (x[2k+1], x[2k]) in the register pairs the 16-byte loads deliver (see ring_at); one
     // packed multiply forms (W[2i] x[2k+1], W[2i+1] x[2k]) and one packed add extends the two ordered sums of
     // qmf.h:59-66 together.
-    f2 xp[28];
+    // Pair k feeds tap i = r + 23 - k of output r: walking k downwards extends every sum in tap order while each
+    // 16-byte group is needed only around its own two steps - the loads trail the arithmetic instead of filling 56
+    // registers up front.
+    f2 acc[4];
 #pragma unroll
-    for (int q = 0; q < 14; ++q) {
+    for (int r = 0; r < 4; ++r) acc[r] = mk2(0.0f, 0.0f);
+#pragma unroll
+    for (int q = 13; q >= 0; --q) {
         const float4 v = xb[(q >> 1) + (q & 1) * H];
-        xp[2 * q] = mk2(v.x, v.y);
-        xp[2 * q + 1] = mk2(v.z, v.w);
+        const f2 hi = mk2(v.z, v.w), lo = mk2(v.x, v.y);   // pairs 2q+1, 2q
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = r + 23 - (2 * q + 1);
+            if (i >= 0 && i < 24) acc[r] = acc[r] + Wp[i] * hi;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = r + 23 - 2 * q;
+            if (i >= 0 && i < 24) acc[r] = acc[r] + Wp[i] * lo;
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        f2 acc = mk2(0.0f, 0.0f);
-#pragma unroll
-        for (int i = 0; i < 24; ++i) acc = acc + Wp[i] * xp[r + 23 - i];
-        lower[r] = acc.x + acc.y;
-        upper[r] = acc.x - acc.y;
+        lower[r] = acc[r].x + acc[r].y;
+        upper[r] = acc[r].x - acc[r].y;
     }
 }
 
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
 }
 
 template <bool GAIN>
-__global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables* T)
+__global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) float s_pcm[2 * kPcmRing];
     __shared__ __attribute__((aligned(16))) float s_s1[4 * kS1Ring];      // stage-1 rings: lower halves of both channels, then upper
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
     __shared__ __attribute__((aligned(16))) float s_win[256];
     __shared__ float s_cs[256];
     __shared__ cpx s_tw[128];
-    __shared__ Curve s_curve[8];
+    __shared__ __attribute__((aligned(16))) Curve s_curve[8];
     __shared__ float s_gi[32];               // GainInterpolation
     __shared__ float s_nextscale[8];         // NextOverlapScale of the block just processed
     __shared__ float s_sum[8][5];
@@ -241,11 +252,11 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
     for (int i = tid; i < 2048; i += 256) s_prevw[i] = 0.0f;
     // gain curve of the frame about to be processed, fetched one block ahead by work-items 0..7 (frame fa-1 only
     // shapes the carried overlap; frame -1 is the curve carried in the stream state)
-    Curve ncv;
-    ncv.n = 0;
+    uint4 ncv = {0u, 0u, 0u, 0u};   // one Curve, as the 16 bytes it is
     if (GAIN && tid < 8) {
         const int f = fa - 1;
-        ncv = (f < 0) ? p.state[(size_t)s * 8 + tid].prev_curve : p.curves[((size_t)s * p.n_blocks + f) * 8 + tid];
+        ncv = *reinterpret_cast<const uint4*>((f < 0) ? &p.state[(size_t)s * 8 + tid].prev_curve
+                                                      : &p.curves[((size_t)s * p.n_blocks + f) * 8 + tid]);
     }
 
     // ---- prologue: FIR histories of the first block (b0 = fa - 2) ----
@@ -303,8 +314,8 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
             }
         }
         if (GAIN && tid < 8) {
-            s_curve[tid] = ncv;
-            if (b + 1 <= fb - 2) ncv = p.curves[((size_t)s * p.n_blocks + f + 1) * 8 + tid];
+            *reinterpret_cast<uint4*>(&s_curve[tid]) = ncv;
+            if (b + 1 <= fb - 2) ncv = *reinterpret_cast<const uint4*>(&p.curves[((size_t)s * p.n_blocks + f + 1) * 8 + tid]);
         }
         if (tid < 184 && b > b0) {   // stage-1 histories return to the rings (they shared storage with the FFT buffers)
             const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
                 // Modulated new half (gain_processor.h:93-112): lane j owns samples 8j .. 8j+7. Level boundaries and
                 // the 8-sample ramps are aligned to these cells, so a cell is untouched, divided by one level (a
                 // power of two: multiplying by its reciprocal is the same rounding) or by one running-product ramp.
-                const Curve cv = s_curve[c];
+                const Curve& cv = s_curve[c];   // read in place: a private copy indexed in a loop would live in scratch
                 scale = gain_level_of(cv.level[0]);
                 const int cell = 8 * lane;
                 int kind = 0;   // 0 untouched, 1 constant level, 2 ramp

@@ -44,6 +44,7 @@ struct at3hip_ctx {
     long long blocks_fed = 0;   // per stream
     int frames_per_wg = 0;
     int n_cus = 256;
+    int wgs_per_cu = 3;   // resident workgroups of the fused front-end kernel per CU
 
     Tables* d_tables = nullptr;
     float* d_pcm_in = nullptr;       // staging for host PCM [S][max_blocks][1024][2]
@@ -96,9 +97,9 @@ int dev_alloc(at3hip_ctx* c, Tp** p, size_t count)
 int pick_frames_per_wg(const at3hip_ctx* c, int n_out)
 {
     if (c->frames_per_wg > 0) return c->frames_per_wg;
-    // four workgroups of the fused kernel are resident per CU: cut every stream into as many runs as fit in ONE
-    // round of the grid (a partial second round would double the kernel time on small batches)
-    const long long slots = (long long)c->n_cus * 4;
+    // cut every stream into as many runs as fit in ONE round of the grid (a partial second round would double the
+    // kernel time on small batches); wgs_per_cu is the occupancy the runtime reports for the fused kernel
+    const long long slots = (long long)c->n_cus * c->wgs_per_cu;
     long long runs_per_stream = slots / c->cfg.n_streams;
     if (runs_per_stream < 1) runs_per_stream = 1;
     long long f = (n_out + runs_per_stream - 1) / runs_per_stream;
@@ -197,6 +198,13 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if (c->frames_per_wg > 32) c->frames_per_wg = 32;
     hipDeviceProp_t prop;
     c->n_cus = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    {
+        int nb = 0;
+        const bool gain = !c->cfg.no_gain_control;
+        const hipError_t e = gain ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_mdct<true>, 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_mdct<false>, 256, 0);
+        c->wgs_per_cu = (e == hipSuccess && nb > 0) ? nb : 3;
+    }
     *out = c;
     return AT3HIP_OK;
 }
@@ -290,7 +298,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.js = c->js;
             gp.n_streams = S;
             {   // one round of workgroups over the chip, like the fused kernel
-                const int slots = c->n_cus * 3;
+                const int slots = c->n_cus * c->wgs_per_cu;
                 int runs = slots / S;
                 if (runs < 1) runs = 1;
                 int bpw = (n_blocks + 2 + runs - 1) / runs;

@@ -59,6 +59,7 @@ template <typename T, typename U> static inline T atomicAdd(T* p, U v) { T o = *
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 
 typedef int hipError_t;
+template <typename F> static inline int hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 3; return 0; }
 enum { hipSuccess = 0, hipErrorUnknown = 1 };
 typedef void* hipStream_t;
 typedef struct emu_event* hipEvent_t;

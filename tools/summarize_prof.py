@@ -32,3 +32,30 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
              "group by kernel_name, counter_name order by kernel_name, counter_name")
         for k, c, v, n in db.execute(q):
             print(f"{short(k):48s} {c:24s} avg={v:.6g} (n={n})")
+
+# ---- HBM traffic of the fused QMF+MDCT kernel -> k1_traffic.json (read by bench.py for roofline.traffic) ----
+import json
+
+def avg_counter(sub, counter, like):
+    for f in dbs(sub):
+        db = sqlite3.connect(f)
+        row = db.execute("select kernel_name, avg(value) from counters_collection where counter_name=? and kernel_name like ? "
+                         "group by kernel_name", (counter, like)).fetchone()
+        if row:
+            return row[0], row[1]
+    return None, None
+
+kn, fetch = avg_counter("pmc_fetch", "FETCH_SIZE", "%k_qmf_mdct%")
+_, write = avg_counter("pmc_write", "WRITE_SIZE", "%k_qmf_mdct%")
+if fetch is not None and write is not None:
+    algo = 16384 * 4096
+    total = (2.0 * fetch + write) * 1024.0
+    out = {
+        "kernel": short(kn), "workload": "64 streams x 64 frames (4096 frames/launch), frames_per_wg auto",
+        "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
+        "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)",
+        "bytes_per_launch": total, "algorithmic_bytes_per_launch": algo, "ratio": total / algo,
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/profile_gpu.sh)",
+    }
+    json.dump(out, open(os.path.join(root, "k1_traffic.json"), "w"), indent=1)
+    print("== k1 traffic ==", json.dumps(out))
