@@ -339,6 +339,16 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         }
     }
     wave_sync();
+    {
+        // below 5 % high-band energy the reference drops the band before the upsampler output is looked at
+        // (atrac3denc.cpp:319-327): nothing downstream reads the other fields of such a record
+        const double totalE = L.hsum[0], filtE = L.hsum[1];
+        const float hfr = (totalE > 0.0) ? (float)(filtE / totalE) : 0.0f;
+        if (hfr < 0.05f) {
+            if (valid && lane == 0) rec->hfr = hfr;
+            return;
+        }
+    }
     irfft_core_2048(L.f, T->tw2048, lane);
 
     // 4. AnalyzeGain over the upsampled samples [1024, 3072): 256 micro-chunks of 8 (4 per lane), 32 sub-frames of 64
@@ -669,6 +679,22 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
 
     // ---- CalcCurve (transient_detector.cpp:299-482) ----
     const bool active = valid && !(hfr < 0.05f) && !(target < 1e-6f) && !(savedLastLevel < 1e-6f);
+    // An item without curve points after CalcCurve ends as "no_curve" whatever the later stages say
+    // (atrac3denc.cpp:395-400), and most items are like that: a wavefront whose two items are both out stops here.
+    if (__ballot(active) == 0ull) {
+        if (valid && j == 0) {
+            Curve out;
+            out.pad = 0;
+            out.n = 0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                out.level[i] = 0;
+                out.loc[i] = 0;
+            }
+            *dst = out;
+        }
+        return;
+    }
     const float intraRatio = maxGain / fmaxf(target, 1e-9f);
     float interRatio = 1.0f;
     if (prevTarget > 1e-6f) interRatio = fmaxf(prevTarget, target) / fmaxf(fminf(prevTarget, target), 1e-9f);
@@ -686,11 +712,22 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
         minIdx = idxLo < idxHi ? idxLo : idxHi;
         maxIdx = idxLo < idxHi ? idxHi : idxLo;
     }
+    // sticky quantisation chain (:360-383): L[j] = f_j(L[j-1]) with f_j(x) = x when sub-frame j may stick to its left
+    // neighbour's level, raw[j] otherwise. Solved by relaxation from L = raw: every round re-evaluates all sub-frames
+    // against the current left neighbour; a round without change is the forward-substitution result.
     int L = raw;
-    for (int jj = 1; jj < 32; ++jj) {   // sticky quantisation chain (:360-383)
-        const int prev = grp_readlane_i(L, jj - 1, half);
-        const int d = raw - prev;
-        if (j == jj && sticky && maxIdx - minIdx <= 1 && (d == 1 || d == -1) && prev >= minIdx && prev <= maxIdx) L = prev;
+    {
+        const bool may_stick = j > 0 && sticky && maxIdx - minIdx <= 1;
+        if (__ballot(may_stick) != 0ull) {
+            for (int round = 0; round < 32; ++round) {
+                const int prev = __builtin_amdgcn_update_dpp(0, L, 0x138, 0xf, 0xf, false);   // wave_shr:1 = lane j-1
+                const int d = raw - prev;
+                const int nl = (may_stick && (d == 1 || d == -1) && prev >= minIdx && prev <= maxIdx) ? prev : raw;
+                const bool moved = nl != L;
+                L = nl;
+                if (__ballot(moved) == 0ull) break;
+            }
+        }
     }
     const unsigned long long nzm = __ballot(active && j <= 30 && L != 4);
     const uint32_t gm = (uint32_t)(nzm >> (32 * half));
@@ -704,14 +741,21 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
         const float eps = 1e-9f;
         bs = fmaxf((rightMax + eps) / (leftMax + eps), (leftMax + eps) / (rightMax + eps));
     }
-    // right-to-left transition scan (:404-450)
+    // right-to-left transition scan (:404-450). Sub-frames whose level equals the running `prev` are no-ops, so the
+    // scan jumps from one differing sub-frame to the next lower one (ballot + find-first-set) instead of visiting all 31.
     int nt = 0;
     {
         int prev = 4;
-        for (int sf = 30; sf >= 0; --sf) {
-            const int lev = grp_readlane_i(L, sf, half);
-            const float sc = grp_readlane_f(bs, sf + 1, half);
-            if (sf < targetSf && lev != prev) {
+        uint32_t remaining = targetSf >= 31 ? 0x7fffffffu : ((1u << targetSf) - 1u);   // sf < targetSf, sf <= 30
+        for (int it = 0; it < 32; ++it) {
+            const unsigned long long m = __ballot(L != prev);
+            const uint32_t cand = (uint32_t)(m >> (32 * half)) & remaining;
+            const bool done = cand == 0u;
+            if (__ballot(!done) == 0ull) break;
+            const int sf = done ? 0 : 31 - __builtin_clz(cand);
+            const int lev = __builtin_amdgcn_ds_bpermute(4 * (32 * half + sf), L);
+            const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (32 * half + sf + 1), (int)__float_as_uint(bs)));
+            if (!done) {
                 const int loc = sf + 1;
                 const int delta = lev > prev ? lev - prev : prev - lev;
                 const bool keep = (loc == targetSf) || (delta >= 2) || (sc >= minScore);
@@ -724,6 +768,7 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
                     ++nt;
                     prev = lev;
                 }
+                remaining &= (1u << sf) - 1u;
             }
         }
     }
@@ -768,6 +813,20 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
         pts.loc[i] = (i < pts.n) ? s_tloc[grp][i] : 0;
     }
     const bool have = pts.n > 0;   // else "skip: no_curve" (atrac3denc.cpp:395-400)
+    if (__ballot(have) == 0ull) {
+        if (valid && j == 0) {
+            Curve out;
+            out.pad = 0;
+            out.n = 0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                out.level[i] = 0;
+                out.loc[i] = 0;
+            }
+            *dst = out;
+        }
+        return;
+    }
 
     // ---- CreateSubbandInfo tail (atrac3denc.cpp:410-577), band < 3 ----
     if (maxGain < 1e-4f) pts.n = 0;

@@ -89,6 +89,8 @@ unsigned emu_wave_exchange(unsigned value, unsigned* all64);   // deposit `value
 unsigned long long emu_ballot(bool pred);
 static inline unsigned long long __ballot(bool pred) { return emu_ballot(pred); }
 int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl);
+int emu_bpermute(int addr, int v);
+#define __builtin_amdgcn_ds_bpermute(addr, v) emu_bpermute((int)(addr), (int)(v))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
 int emu_readlane(int v, int lane);
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((int)(v), (lane))
