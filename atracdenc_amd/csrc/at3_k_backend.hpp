@@ -455,11 +455,20 @@ __device__ inline float ea_greedy(const float* in, const uint8_t* sidx, int nc, 
     // |m0| - 1 (e2 > e1), atrac_scale.cpp:86-118. The ordered part per candidate is ex = (e2 - d0) + d1 and the test.
     const bool grow = e2 < e1;
     float dist = fabsf(e2 - e1);
-    for (int c0 = 0; c0 < nc; c0 += 4) {
-        const uint32_t i4 = *reinterpret_cast<const uint32_t*>(sidx + c0);
-        int m0s[4];
+    // the list and the mantissas of the next four candidates are fetched while the current four run through the
+    // ordered test (their lines are distinct, so the stores of accepted candidates cannot touch them)
+    uint32_t i4 = *reinterpret_cast<const uint32_t*>(sidx);
+    int m0s[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m0s[k] = mant[(i4 >> (8 * k)) & 0xff];
+    for (int k = 0; k < 4; ++k) m0s[k] = mant[(i4 >> (8 * k)) & 0xff];
+    for (int c0 = 0; c0 < nc; c0 += 4) {
+        uint32_t i4n = 0;
+        int m0n[4] = {0, 0, 0, 0};
+        if (c0 + 4 < nc) {
+            i4n = *reinterpret_cast<const uint32_t*>(sidx + c0 + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m0n[k] = mant[(i4n >> (8 * k)) & 0xff];
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (c0 + k < nc) {
@@ -482,6 +491,9 @@ __device__ inline float ea_greedy(const float* in, const uint8_t* sidx, int nc, 
                 }
             }
         }
+        i4 = i4n;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m0s[k] = m0n[k];
     }
     return e2;
 }
@@ -762,8 +774,11 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     // candidate changes no state - so only those are listed (atrac_scale.cpp:66-126). The pass visits them by
     // ascending |delta|: the position of a candidate is the number of keys of its unit below its own, which needs
     // the unit's keys as a set only - the lists are filled in arrival order through LDS atomics.
-    //   step 1: 64-line chunks -> flag, compact into the unit's key list and into a plane-wide (key, unit, line) list
-    //   step 2: one work-item per listed candidate counts the smaller keys of its unit and stores its line at that rank
+    //   step 1: 64-line chunks -> flag, compact into the unit's key list and into the candidate list of the unit's
+    //           size class (128-, 64- and 32-line BFUs: lists at 0, 256, 512 of s_pk / s_pu)
+    //   step 2: wavefront k owns size class k: one lane per listed candidate counts the smaller keys of its unit and
+    //           stores its line at that rank. Lists of one class have similar lengths, so the lanes of a wavefront run
+    //           the same number of steps; a unit is handled entirely inside one wavefront.
     //   step 3: equal keys collide on a rank; the loser notices on read-back and the unit goes to the exact path (C3)
     for (int i = tid; i < kEaLines + 4; i += kQuantThreads) s_uk[i] = __builtin_huge_valf();
     if (tid < 32) (&s_cnt[0][0])[tid] = 0;
@@ -780,6 +795,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
             if (c < 4) { bfu = 18 + 2 * c + hi; start = 256 + 64 * c + 32 * hi; }
             else if (c < 8) { bfu = 22 + c; start = 256 + 64 * c; }
             else { bfu = 30 + ((c - 8) >> 1); start = 768 + 128 * ((c - 8) >> 1); }
+            const int cls = c < 4 ? 2 : c < 8 ? 1 : 0;
             const int line = 256 + 64 * c + lane;
             bool flag = false;
             if (bfu > 18) {
@@ -795,14 +811,14 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                 const int n_half = __popc(half);
                 if (n_half) {
                     base_u = atomicAdd(&cnt[bfu - 19], n_half);
-                    base_p = atomicAdd(&cnt[13], n_half);
+                    base_p = atomicAdd(&cnt[13 + cls], n_half);
                 }
             }
             {
                 const int u0 = __builtin_amdgcn_readlane(base_u, 0), u1 = __builtin_amdgcn_readlane(base_u, 32);
                 const int p0 = __builtin_amdgcn_readlane(base_p, 0), p1 = __builtin_amdgcn_readlane(base_p, 32);
                 base_u = hi ? u1 : u0;
-                base_p = hi ? p1 : p0;
+                base_p = (hi ? p1 : p0) + 256 * cls;
             }
             if (flag) {
                 const float t = s_val[line] * mul;
@@ -813,49 +829,57 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
             }
         }
         __syncthreads();
-        const int total = cnt[13];
-        int rank[3] = {0, 0, 0};
-        int where[3] = {0, 0, 0};   // unit << 7 | line
+        if (wave < 3) {
+            const int cls = wave;
+            const int total = cnt[13 + cls];
+            int rank[4] = {0, 0, 0, 0};
+            int where[4] = {0, 0, 0, 0};   // unit << 7 | line
 #pragma unroll
-        for (int rd = 0; rd < 3; ++rd) {
-            const int t = rd * kQuantThreads + tid;
-            if (t < total) {
-                const float key = s_pk[t];
-                const int pu = s_pu[t];
-                const int ub = pu >> 7;
-                const int ustart = ub < 7 ? 32 * ub : ub < 11 ? 64 * ub - 224 : 128 * ub - 928;
-                const int nc = cnt[ub];
-                const float4* t4 = reinterpret_cast<const float4*>(s_uk + ustart);
-                int r = 0;
-                for (int q = 0; q < nc; q += 4) {
-                    const float4 cur = t4[q >> 2];
-                    r += (cur.x < key);
-                    r += (cur.y < key);
-                    r += (cur.z < key);
-                    r += (cur.w < key);
+            for (int rd = 0; rd < 4; ++rd) {
+                const int t = rd * 64 + lane;
+                if (t < total) {
+                    const float key = s_pk[256 * cls + t];
+                    const int pu = s_pu[256 * cls + t];
+                    const int ub = pu >> 7;
+                    const int ustart = ub < 7 ? 32 * ub : ub < 11 ? 64 * ub - 224 : 128 * ub - 928;
+                    const int nc = cnt[ub];
+                    const float4* t4 = reinterpret_cast<const float4*>(s_uk + ustart);
+                    int r = 0;
+                    for (int q = 0; q < nc; q += 4) {
+                        const float4 cur = t4[q >> 2];
+                        r += (cur.x < key);
+                        r += (cur.y < key);
+                        r += (cur.z < key);
+                        r += (cur.w < key);
+                    }
+                    plane_sorted[ustart + r] = (uint8_t)(pu & 127);
+                    rank[rd] = ustart + r;
+                    where[rd] = pu;
                 }
-                plane_sorted[ustart + r] = (uint8_t)(pu & 127);
-                rank[rd] = ustart + r;
-                where[rd] = pu;
             }
-        }
-        __syncthreads();
+            wave_sync();
 #pragma unroll
-        for (int rd = 0; rd < 3; ++rd) {
-            if (rd * kQuantThreads + tid < total && plane_sorted[rank[rd]] != (uint8_t)(where[rd] & 127)) {
-                s_tie[(wl - 1) * 13 + (where[rd] >> 7)] = 1;
-                s_anytie = 1;
+            for (int rd = 0; rd < 4; ++rd) {
+                if (rd * 64 + lane < total && plane_sorted[rank[rd]] != (uint8_t)(where[rd] & 127)) {
+                    s_tie[(wl - 1) * 13 + (where[rd] >> 7)] = 1;
+                    s_anytie = 1;
+                }
             }
+            const int ub0 = cls == 0 ? 11 : cls == 1 ? 7 : 0, ub1 = cls == 0 ? 13 : cls == 1 ? 11 : 7;
+            if (lane < ub1 - ub0) {
+                const int ub = ub0 + lane;
+                const int nc = cnt[ub];
+                const int ustart = ub < 7 ? 32 * ub : ub < 11 ? 64 * ub - 224 : 128 * ub - 928;
+                s_nc[(wl - 1) * 13 + ub] = (uint8_t)nc;
+                for (int k = nc; k < ((nc + 3) & ~3); ++k) plane_sorted[ustart + k] = 0;   // pad to a multiple of four
+            }
+            wave_sync();
+            // next plane: fresh key lists of this class
+            const int k0 = cls == 0 ? 480 : cls == 1 ? 224 : 0, k1 = cls == 0 ? 736 : cls == 1 ? 480 : 224;
+            for (int i = k0 + lane; i < k1; i += 64) s_uk[i] = __builtin_huge_valf();
+        } else if (lane < 16) {
+            s_cnt[(wl + 1) & 1][lane] = 0;   // the other counter buffer: last read one plane ago, next used one plane ahead
         }
-        if (tid < 13) {
-            const int nc = cnt[tid];
-            const int ustart = tid < 7 ? 32 * tid : tid < 11 ? 64 * tid - 224 : 128 * tid - 928;
-            s_nc[(wl - 1) * 13 + tid] = (uint8_t)nc;
-            for (int k = nc; k < ((nc + 3) & ~3); ++k) plane_sorted[ustart + k] = 0;   // pad to a multiple of four
-        }
-        // next plane: fresh key lists and counters (the other counter buffer was cleared one plane ago)
-        for (int i = tid; i < kEaLines; i += kQuantThreads) s_uk[i] = __builtin_huge_valf();
-        if (tid < 16) s_cnt[(wl + 1) & 1][tid] = 0;
         __syncthreads();
     }
     __syncthreads();
