@@ -40,8 +40,22 @@ struct QuantRec {            // per (stream, frame, channel)
     uint32_t cost[7][32];    // CLC bits | VLC bits << 13
 };
 
+// Smallest table index whose scale factor is >= maxAbs, 63 if there is none: std::map::lower_bound on the increasing
+// ScaleTable (atrac_scale.cpp:150-160) as a six-step binary search; `scale_tab` should sit in LDS.
+__device__ __forceinline__ int scale_index(const float* scale_tab, float maxAbs)
+{
+    int lo = 0, hi = 63;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int mid = (lo + hi) >> 1;
+        if (scale_tab[mid] < maxAbs) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
 // atrac_scale.cpp:141-172. Returns sfi; values/energy optional.
-__device__ inline int scale_block(const Tables* T, const float* in, int len, float* values, float* energy)
+__device__ inline int scale_block(const float* scale_tab, const float* in, int len, float* values, float* energy)
 {
     float maxAbs = 0.0f;
     for (int i = 0; i < len; ++i) {
@@ -49,9 +63,8 @@ __device__ inline int scale_block(const Tables* T, const float* in, int len, flo
         if (a > maxAbs) maxAbs = a;
     }
     if (maxAbs > 1.0f) maxAbs = 1.0f;
-    int sfi = 0;
-    while (sfi < 63 && T->scale[sfi] < maxAbs) ++sfi;   // map::lower_bound on the increasing table
-    const float sf = T->scale[sfi];
+    const int sfi = scale_index(scale_tab, maxAbs);
+    const float sf = scale_tab[sfi];
     float e = 0.0f;
     for (int i = 0; i < len; ++i) {
         const float x = in[i];
@@ -78,6 +91,8 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     __shared__ uint16_t s_tv_pos[112];
     __shared__ float s_tv_val[112];
     __shared__ uint8_t s_tv_bfu[112];
+    __shared__ float s_scale[64];          // ScaleTable
+    __shared__ uint32_t s_maxbits[32];     // per BFU: max |x| as its bit pattern (ordered like the value for x >= 0)
     const int tid = threadIdx.x;
     const int n_out = p.n_blocks - p.f0;
     const int ch = blockIdx.x & 1;
@@ -112,7 +127,11 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
             }
         }
     }
-    if (tid < 32) s_run_len[tid] = 0;
+    if (tid < 32) {
+        s_run_len[tid] = 0;
+        s_maxbits[tid] = 0u;
+    }
+    if (tid >= 64 && tid < 128) s_scale[tid - 64] = T->scale[tid - 64];
     __syncthreads();
 
     if (tid == 192) {
@@ -201,7 +220,7 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
             for (int j = 0; j < 7; ++j) tb.values[j] = 0.0f;
             for (int j = 0; j < 3; ++j) tb.pad[j] = 0;
             for (int j = 0; j < 4; ++j) tb.pad2[j] = 0;
-            tb.sfi = (uint8_t)scale_block(T, s_tv_val + startPos, len, tb.values, nullptr);
+            tb.sfi = (uint8_t)scale_block(s_scale, s_tv_val + startPos, len, tb.values, nullptr);
             if (nb < kMaxTonal) rec->tonal[nb] = tb;
             ++nb;
         }
@@ -209,10 +228,32 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     }
     __syncthreads();
 
+    // TScaler::Scale per BFU (atrac_scale.cpp:141-172) on the residual spectrum: the maximum is order-free (all
+    // work-items, LDS atomic max), the scale factor a binary search, the energy an ordered sum (one lane per BFU)
+    {
+        const float4 v = *reinterpret_cast<const float4*>(s_spec + 4 * tid);
+        const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        atomicMax(&s_maxbits[bfu_of_line(4 * tid)], __float_as_uint(m));
+    }
+    __syncthreads();
     if (tid < 32) {
         const int start = bfu_start(tid), len = bfu_start(tid + 1) - start;
-        float e;
-        const int sfi = scale_block(T, s_spec + start, len, nullptr, &e);
+        float maxAbs = __uint_as_float(s_maxbits[tid]);
+        if (maxAbs > 1.0f) maxAbs = 1.0f;
+        const int sfi = scale_index(s_scale, maxAbs);
+        const float4* x4 = reinterpret_cast<const float4*>(s_spec + start);
+        float e = 0.0f;
+        for (int i = 0; i < len / 8; ++i) {
+            const float4 a = x4[2 * i], b = x4[2 * i + 1];
+            e += a.x * a.x;
+            e += a.y * a.y;
+            e += a.z * a.z;
+            e += a.w * a.w;
+            e += b.x * b.x;
+            e += b.y * b.y;
+            e += b.z * b.z;
+            e += b.w * b.w;
+        }
         rec->sfi[tid] = (uint8_t)sfi;
         rec->energy[tid] = e;
     }

@@ -57,6 +57,7 @@ static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); re
 static inline int __float2int_rn(float f) { return (int)lrintf(f); }
 template <typename T, typename U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = o + (T)v; return o; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 
 typedef int hipError_t;
 template <typename F> static inline int hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 3; return 0; }
