@@ -1043,6 +1043,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
     __shared__ uint8_t s_tbits[kMaxTonal * 8];
     __shared__ uint16_t s_huff[130];
     __shared__ int s_misc[4];
+    __shared__ uint32_t s_cost[8 * 32];
 
     const int lane = threadIdx.x;
     const int n_out = p.n_blocks - p.f0;
@@ -1094,12 +1095,13 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
     const int i = lane & 31;   // BFU owned by this lane (lanes 32..63 mirror 0..31 but never contribute)
     float spread;
     {
+        const int my_sfi = rec->sfi[i];   // one load per lane; the ordered sums walk the lanes
         float sum = 0.0f;
-        for (int k = 0; k < 32; ++k) sum += (float)rec->sfi[k];
+        for (int k = 0; k < 32; ++k) sum += (float)__builtin_amdgcn_readlane(my_sfi, k);
         sum /= 32;
         float sigma = 0.0f;
         for (int k = 0; k < 32; ++k) {
-            float t = ((float)rec->sfi[k] - sum);
+            float t = ((float)__builtin_amdgcn_readlane(my_sfi, k) - sum);
             t *= t;
             sigma += t;
         }
@@ -1153,19 +1155,24 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
     }
     // ConsiderEnergyErr as a per-BFU map wl -> wl' (first 10 BFUs, atrac3_bitstream.cpp:241-257, :638-641):
     // BFUs are independent, so iterating the reference's do/while to its fixed point is a closure per BFU.
+    // A wordlen keeps climbing while its energy error is out of range, so the map sends wl to the first k >= wl that
+    // is acceptable (k = 0 and k = 7 always are): a backward scan over the eight entries.
     uint32_t gmap = 0;
+    {
+        int g = 7;
+        gmap = 7u << 21;
 #pragma unroll
-    for (int wl = 0; wl <= 7; ++wl) {
-        int gq = wl;
-        if (i < 10) {
-#pragma unroll
-            for (int it = 0; it < 7; ++it) {
-                const float e = pick8(err, gq);
-                if (gq > 0 && ((e > 0 && e < 0.7f) || e > 1.2f) && gq < 7) ++gq;
-            }
+        for (int k = 6; k >= 0; --k) {
+            const float e = err[k];
+            const bool climbs = i < 10 && k > 0 && ((e > 0 && e < 0.7f) || e > 1.2f);
+            g = climbs ? g : k;
+            gmap |= (uint32_t)g << (3 * k);
         }
-        gmap |= (uint32_t)gq << (3 * wl);
     }
+    // cost table of this lane's BFU in LDS: the rate loop indexes it with a run-time wordlen
+#pragma unroll
+    for (int wl = 0; wl <= 7; ++wl)
+        if (lane < 32) s_cost[wl * 32 + lane] = cost[wl];
     __syncthreads();
 
     // ---- rate loop: TConfigure / TAlloc under the bisection driver (uniform control flow) ----
@@ -1204,7 +1211,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
                 if (bits > 2 && tcount) bits = (bits - tcount > 2) ? bits - tcount : 2;
                 bits = (int)((gmap >> (3 * bits)) & 7u);
             }
-            const uint32_t mine = (lane < num_bfu) ? pick8(cost, bits) : 0u;
+            const uint32_t mine = (lane < num_bfu) ? s_cost[bits * 32 + i] : 0u;
             const uint32_t rsum = row_allreduce_add(mine);
             const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
             const uint32_t clc = acc & 0x1fffu, vlc = (acc >> 13) & 0x3fffu, nz = acc >> 27;
