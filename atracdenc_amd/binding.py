@@ -89,9 +89,10 @@ class At3Hip:
     """n_streams TAtrac3Encoder objects encoded side by side on one GPU."""
 
     def __init__(self, n_streams=1, max_blocks=64, bitrate=LP2, no_gain=False, no_tonal=False, bfu_idx_const=0,
-                 device_id=0, lib_path=None):
+                 device_id=0, lib_path=None, channels=2):
         self.lib = load_library(lib_path)
-        self.cfg = Config(int(bitrate), 2, int(no_gain), int(no_tonal), int(bfu_idx_const), int(n_streams),
+        self.channels = int(channels)
+        self.cfg = Config(int(bitrate), int(channels), int(no_gain), int(no_tonal), int(bfu_idx_const), int(n_streams),
                           int(max_blocks), int(device_id))
         self.ctx = ctypes.c_void_p()
         rc = self.lib.at3hip_create(ctypes.byref(self.cfg), ctypes.byref(self.ctx))
@@ -118,9 +119,9 @@ class At3Hip:
         self._check(self.lib.at3hip_reset(self.ctx), "at3hip_reset")
 
     def encode(self, pcm):
-        """pcm float32 [n_streams, n_blocks, 1024, 2] (host) -> uint8 [n_streams, n_frames, frame_size]."""
+        """pcm float32 [n_streams, n_blocks, 1024, channels] (host) -> uint8 [n_streams, n_frames, frame_size]."""
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
-        assert pcm.ndim == 4 and pcm.shape[0] == self.n_streams and pcm.shape[2:] == (1024, 2), pcm.shape
+        assert pcm.ndim == 4 and pcm.shape[0] == self.n_streams and pcm.shape[2:] == (1024, self.channels), pcm.shape
         nb = pcm.shape[1]
         out = np.zeros((self.n_streams, nb, self.frame_size), dtype=np.uint8)
         nf = ctypes.c_int32()

@@ -1365,6 +1365,19 @@ struct StateParams {
     int n_streams;
 };
 
+// One-channel input: every sample becomes an (L, R) = (x, x) pair in the layout the stereo pipeline reads.
+__global__ __launch_bounds__(256) void k_mono_to_pairs(const float* __restrict__ mono, float* __restrict__ pairs, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float x = mono[i];
+        float2 v;
+        v.x = x;
+        v.y = x;
+        reinterpret_cast<float2*>(pairs)[i] = v;
+    }
+}
+
 __global__ void k_state_update(StateParams p)
 {
     const int s = blockIdx.y;

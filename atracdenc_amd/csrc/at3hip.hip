@@ -48,6 +48,7 @@ struct at3hip_ctx {
 
     Tables* d_tables = nullptr;
     float* d_pcm_in = nullptr;       // staging for host PCM [S][max_blocks][1024][2]
+    float* d_pcm_mono = nullptr;     // one-channel contexts: staging for host PCM [S][max_blocks][1024]
     float* d_hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
     float* d_sub = nullptr;
@@ -136,7 +137,7 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
 {
     if (!cfg || !out) return AT3HIP_EINVAL;
     *out = nullptr;
-    if (cfg->channels != 2 || cfg->n_streams < 1 || cfg->max_blocks < 1 || cfg->bfu_idx_const < 0 ||
+    if ((cfg->channels != 1 && cfg->channels != 2) || cfg->n_streams < 1 || cfg->max_blocks < 1 || cfg->bfu_idx_const < 0 ||
         cfg->bfu_idx_const > 32)
         return AT3HIP_EINVAL;
     int ndev = 0;
@@ -151,6 +152,10 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     while (idx < 7 && kContainer[idx].bitrate < br) ++idx;  // lower_bound, atrac3.cpp:47-53
     c->frame_sz = kContainer[idx].frame_sz;
     c->js = kContainer[idx].js;
+    if (cfg->channels == 1 && c->js) {   // mono joint-stereo frames carry an empty second unit (atrac3denc.cpp:843-849): not built
+        delete c;
+        return AT3HIP_EINVAL;
+    }
 
     int rc = AT3HIP_OK;
     auto bail = [&](int code) {
@@ -176,6 +181,7 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if (rc != AT3HIP_OK) return bail(rc);
 
     if ((rc = dev_alloc(c, &c->d_pcm_in, S * B * 2048)) != AT3HIP_OK) return bail(rc);
+    if (cfg->channels == 1 && (rc = dev_alloc(c, &c->d_pcm_mono, S * B * 1024)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_hist[0], S * kHist * 2)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_hist[1], S * kHist * 2)) != AT3HIP_OK) return bail(rc);
     if (!cfg->no_gain_control) {
@@ -215,7 +221,7 @@ void at3hip_destroy(at3hip_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void* bufs[] = {c->d_tables, c->d_pcm_in, c->d_hist[0], c->d_hist[1], c->d_sub,  c->d_rec,        c->d_state,
-                    c->d_curves, c->d_specs,  c->d_ges,     c->d_psy,     c->d_loud, c->d_loud_state, c->d_out, c->d_quant, c->d_mant};
+                    c->d_curves, c->d_specs,  c->d_ges,     c->d_psy,     c->d_loud, c->d_loud_state, c->d_out, c->d_quant, c->d_mant, c->d_pcm_mono};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : c->ev)
@@ -262,7 +268,19 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     const bool gain = !c->cfg.no_gain_control;
 
     const float* d_pcm = pcm;
-    if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
+    if (c->cfg.channels == 1) {
+        // "No mono mode for atrac3, just make duplicate of first channel" (atrac3_bitstream.cpp:836-843): the one-channel
+        // frame is two identical sound units, i.e. the discrete-stereo frame of L = R (TrackLoudness' 0.02 l equals
+        // 0.01 (l + l) exactly). The samples are duplicated in HBM and the stereo pipeline runs unchanged.
+        const float* d_mono = pcm;
+        const size_t n = (size_t)S * n_blocks * 1024;
+        if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
+            HIPCHK(c, hipMemcpyAsync(c->d_pcm_mono, pcm, n * sizeof(float), hipMemcpyHostToDevice, st));
+            d_mono = c->d_pcm_mono;
+        }
+        hipLaunchKernelGGL(k_mono_to_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_mono, c->d_pcm_in, n);
+        d_pcm = c->d_pcm_in;
+    } else if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
         HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)S * n_blocks * 2048 * sizeof(float), hipMemcpyHostToDevice, st));
         d_pcm = c->d_pcm_in;
     }

@@ -131,7 +131,7 @@ public:
     TAtrac3EncoderBatch& operator=(const TAtrac3EncoderBatch&) = delete;
 
     int FrameSize() const { return FrameSz; }
-    // pcm [nStreams][nBlocks][1024][2] -> frames [nStreams][nFrames][FrameSize()]; returns nFrames per stream.
+    // pcm [nStreams][nBlocks][1024][SourceChannels] -> frames [nStreams][nFrames][FrameSize()]; returns nFrames per stream.
     int Encode(const float* pcm, int nBlocks, std::vector<uint8_t>& frames)
     {
         frames.resize((size_t)NStreams * nBlocks * FrameSz);
@@ -153,10 +153,12 @@ private:
 class TAtrac3Encoder {
 public:
     TAtrac3Encoder(TCompressedOutputPtr&& oma, TAtrac3EncoderSettings&& settings, int batchBlocks = 64, int deviceId = 0)
-        : Oma(std::move(oma)), Params(settings), BatchBlocks(batchBlocks), Batch(settings, 1, batchBlocks, deviceId)
+        : Oma(std::move(oma)), Params(settings), BatchBlocks(batchBlocks), Batch(settings, 1, batchBlocks, deviceId),
+          BlockFloats(1024u * settings.SourceChannels)
     {
-        if (Params.SourceChannels != 2) throw std::runtime_error("TAtrac3Encoder(hip): stereo input only");
-        Pending.reserve((size_t)BatchBlocks * 2048);
+        // one input channel is accepted for the discrete-stereo bitrates (the frame holds the unit twice,
+        // atrac3_bitstream.cpp:836-843); at3hip_create refuses the other combinations
+        Pending.reserve((size_t)BatchBlocks * BlockFloats);
     }
     ~TAtrac3Encoder()
     {
@@ -169,10 +171,10 @@ public:
     TProcessLambda GetLambda()
     {
         return [this](float* data, const ProcessMeta& meta) {
-            if (meta.Channels != 2) throw std::runtime_error("TAtrac3Encoder(hip): stereo input only");
-            Pending.insert(Pending.end(), data, data + 2048);
+            if (meta.Channels != Params.SourceChannels) throw std::runtime_error("TAtrac3Encoder(hip): channel count changed");
+            Pending.insert(Pending.end(), data, data + BlockFloats);
             const bool first = (Calls++ == 0);
-            if ((int)(Pending.size() / 2048) == BatchBlocks) Flush();
+            if ((int)(Pending.size() / BlockFloats) == BatchBlocks) Flush();
             return first ? EProcessResult::LOOK_AHEAD : EProcessResult::PROCESSED;   // atrac3denc.cpp:715-718, 865
         };
     }
@@ -180,7 +182,7 @@ public:
     // Encode what is buffered and hand the frames to the sink in order.
     void Flush()
     {
-        const int nb = (int)(Pending.size() / 2048);
+        const int nb = (int)(Pending.size() / BlockFloats);
         if (nb == 0) return;
         std::vector<uint8_t> frames;
         const int nf = Batch.Encode(Pending.data(), nb, frames);
@@ -195,6 +197,7 @@ private:
     const TAtrac3EncoderSettings Params;
     const int BatchBlocks;
     TAtrac3EncoderBatch Batch;
+    const size_t BlockFloats;
     std::vector<float> Pending;
     uint64_t Calls = 0;
 };

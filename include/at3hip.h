@@ -38,7 +38,8 @@ typedef struct at3hip_config {
     int32_t bitrate;          /* bit/s as TAtrac3EncoderSettings takes it; 0 = LP2 (132300). The container
                                  row {Bitrate, FrameSz, Js} is chosen like GetContainerParamsForBitrate
                                  (atrac3.cpp:47-53): 66150 -> LP4 192 B joint stereo, 132300 -> LP2 384 B. */
-    int32_t channels;         /* SourceChannels; 2 (stereo). */
+    int32_t channels;         /* SourceChannels: 2, or 1 with a discrete-stereo bitrate (the frame then holds the one
+                               * sound unit twice, atrac3_bitstream.cpp:836-843). Mono joint-stereo bitrates are refused. */
     int32_t no_gain_control;  /* NoGainControll */
     int32_t no_tonal;         /* NoTonalComponents */
     int32_t bfu_idx_const;    /* BfuIdxConst (0 = automatic) */

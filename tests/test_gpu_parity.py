@@ -155,6 +155,21 @@ def test_full_batch_config_properties(hip, oracle):
         assert np.array_equal(got[i], oracle.encode(pcm[i], LP2)[0]), i
 
 
+def test_mono_input_lp2(hip, oracle):
+    # SourceChannels = 1 (atrac3.h:260-277): [stream][block][1024][1] in, the one sound unit twice per frame out
+    nb = 24
+    names = ["burst", "mix", "tones", "noise"]
+    pcm = np.stack([np.ascontiguousarray(SIGNALS[n](nb)[:, :, :1]) for n in names])
+    enc = hip.At3Hip(n_streams=len(names), max_blocks=nb, bitrate=LP2, channels=1)
+    got = enc.encode(pcm)
+    enc.close()
+    exp = np.stack([oracle.encode(pcm[i], LP2)[0] for i in range(len(names))])
+    assert np.array_equal(got, exp)
+    assert np.array_equal(got[:, :, :192], got[:, :, 192:])
+    with pytest.raises(hip.At3HipError):   # mono joint stereo needs the empty second unit: refused, not approximated
+        hip.At3Hip(n_streams=1, bitrate=LP4, channels=1)
+
+
 def test_error_handling(hip):
     with pytest.raises(hip.At3HipError):
         hip.At3Hip(n_streams=0)

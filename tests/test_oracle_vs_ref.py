@@ -27,6 +27,19 @@ def test_frames_and_taps(oracle, name, br):
             assert np.array_equal(bits(to[k]), bits(tr[k])), k
 
 
+@pytest.mark.parametrize("name", ["burst", "mix", "tones"])
+def test_mono_lp2(oracle, name):
+    """One input channel, discrete-stereo container: one sound unit, stored twice (atrac3_bitstream.cpp:836-843).
+    The oracle restates that path; the duplicated-channel stereo encode must give the same frame bytes, which is
+    what the GPU boundary relies on."""
+    pcm = SIGNALS[name](30)
+    mono = np.ascontiguousarray(pcm[:, :, :1])
+    fo = oracle.encode(mono, LP2)[0]
+    assert np.array_equal(fo, ref().encode(mono, LP2)[0])
+    assert np.array_equal(fo[:, :192], fo[:, 192:])
+    assert np.array_equal(fo, oracle.encode(np.repeat(mono, 2, axis=2), LP2)[0])
+
+
 def test_long_noise_soak(oracle):
     pcm = SIGNALS["noise"](400, seed=21)
     for br in (LP2, LP4):
