@@ -32,6 +32,10 @@
 #include "transient_detector.h"
 #include "transient_spectral_upsampler.h"
 #include "qmf/qmf.h"
+#include "pcmengin.h"
+#include "oma.h"
+#include "at3.h"
+#include "raw.h"
 
 using namespace NAtracDEnc;
 using namespace NAtrac3;
@@ -247,6 +251,71 @@ void ref_mdct512(const float* in512, float* out256)
     static NMDCT::TMDCT<512> m(1);
     const auto& r = m(in512);
     memcpy(out256, r.data(), 256 * 4);
+}
+
+
+// ---- callers and data formats either side of the path -------------------------------------------
+
+// The reference's container writers fed with `n_frames` frames of `frame_sz` bytes. kind: 0 OMA, 1 RIFF, 2 raw.
+int at3ref_write_container(int kind, const char* path, const uint8_t* frames, int n_frames, int frame_sz, int js,
+                           int num_frames_hint, int nch)
+{
+    try {
+        TCompressedOutputPtr out;
+        if (kind == 1) out = CreateAt3Output(path, 2, (uint32_t)num_frames_hint, (uint32_t)frame_sz, js != 0);
+        else if (kind == 2) out = CreateRawOutput(path, (size_t)nch);
+        else out.reset(new TOma(path, "test", (size_t)nch, (uint32_t)num_frames_hint, OMAC_ID_ATRAC3, (uint32_t)frame_sz, js != 0));
+        for (int i = 0; i < n_frames; ++i)
+            out->WriteFrame(std::vector<char>(frames + (size_t)i * frame_sz, frames + (size_t)(i + 1) * frame_sz));
+    } catch (const std::exception&) {
+        return -1;
+    }
+    return 0;
+}
+
+// TPCMEngine::ApplyProcess driven like main.cpp:697-705 by a reader that delivers `total_samples` frames of a ramp
+// (sample value = 1 + frame index, every channel) with the short-read / end-of-data behaviour of TWav::GetPCMReader
+// (wav.cpp:46-61). The lambda answers LOOK_AHEAD once, then PROCESSED, and logs the first and last frame value of every
+// call, plus - when `tail` is given - the whole 1024 x nch block of the LAST call. Returns the number of lambda calls (or -1 if the engine threw TNoDataToRead), *processed_out = final count.
+int at3ref_engine_trace(uint64_t total_samples, int nch, float* first_vals, float* last_vals, int max_calls, uint64_t* processed_out,
+                        float* tail)
+{
+    struct TRampReader : public IPCMReader {
+        mutable uint64_t Pos = 0;
+        uint64_t Total;
+        explicit TRampReader(uint64_t total) : Total(total) {}
+        bool Read(TPCMBuffer& data, const uint32_t size) const override
+        {
+            uint64_t n = Total - Pos;
+            if (n > size) n = size;
+            if (!n) return false;
+            for (uint64_t i = 0; i < n; ++i)
+                for (int c = 0; c < data.Channels(); ++c) data[i][c] = (float)(Pos + i + 1);
+            if (n != size) data.Zero(n, size - n);   // exactly what TWav::GetPCMReader does with a short read
+            Pos += n;
+            return true;
+        }
+    };
+    TPCMEngine engine(4096, (size_t)nch, TPCMEngine::TReaderPtr(new TRampReader(total_samples)));
+    int calls = 0;
+    auto lambda = [&](float* data, const TPCMEngine::ProcessMeta& meta) {
+        if (calls < max_calls) {
+            first_vals[calls] = data[0];
+            last_vals[calls] = data[1023 * meta.Channels];
+        }
+        if (tail) memcpy(tail, data, sizeof(float) * 1024 * meta.Channels);
+        return (calls++ == 0) ? TPCMEngine::EProcessResult::LOOK_AHEAD : TPCMEngine::EProcessResult::PROCESSED;
+    };
+    uint64_t processed = 0;
+    try {
+        while (total_samples > (processed = engine.ApplyProcess(1024, lambda))) {
+        }
+    } catch (const TNoDataToRead&) {
+        *processed_out = processed;
+        return -1;
+    }
+    *processed_out = processed;
+    return calls;
 }
 
 } // extern "C"

@@ -193,3 +193,54 @@ def test_host_cpp_shim(hip, oracle, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "HOST SHIM TEST OK" in out.stdout
+
+
+@pytest.mark.parametrize("nsamp,ext,opts", [(20000, "oma", []), (12288, "at3", ["--bitrate", "64"]), (9000, "raw", ["--nogaincontrol"]),
+                                            (8192, "oma", ["--notonal", "--batch", "3"])])
+def test_cli_file_parity(oracle, tmp_path, nsamp, ext, opts):
+    """at3hipenc (WAV -> container) against: the reference's container writer (oracle/_ref) fed with the oracle's
+    frames for the block sequence the reference's frame schedule produces (look-ahead call, short-read tail, drain call)."""
+    import ctypes
+    import os
+    import struct
+    import subprocess
+    from at3_testlib import REF_SO, have_ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "atracdenc_amd", "at3hipenc")
+    if not os.path.exists(exe):
+        pytest.skip("at3hipenc not built")
+    s16 = (SIGNALS["mix"]((nsamp + 1023) // 1024 + 1, seed=11)[: (nsamp + 1023) // 1024 + 1].reshape(-1, 2)[:nsamp] * 32768).astype("<i2")
+    body = s16.tobytes()
+    wav = str(tmp_path / "in.wav")
+    fmt = struct.pack("<HHIIHH", 1, 2, 44100, 44100 * 4, 4, 16)
+    open(wav, "wb").write(b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt +
+                          b"data" + struct.pack("<I", len(body)) + body)
+    out = str(tmp_path / ("out." + ext))
+    r = subprocess.run([exe, "-e", "atrac3", "-i", wav, "-o", out, "--nostdout"] + opts, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = open(out, "rb").read()
+
+    # expected: the engine's block sequence (host IO layer, pinned against TPCMEngine in tests/test_host_io.py) ...
+    so = str(tmp_path / "libhostio.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", os.path.join(root, "include"), "-o", so,
+                           os.path.join(root, "tests", "host", "host_io_capi.cpp")])
+    host = ctypes.CDLL(so)
+    blocks = np.zeros((64, 1024, 2), np.float32)
+    info = (ctypes.c_uint64 * 3)()
+    nb = host.at3host_wav_blocks(wav.encode(), blocks.ctypes.data_as(ctypes.c_void_p), 64, info)
+    assert nb >= 2 and info[2] == nsamp
+    br = 65536 if "--bitrate" in opts else 0
+    frames = oracle.encode(blocks[:nb], br if br else LP2, int("--nogaincontrol" in opts), int("--notonal" in opts))[0]
+    assert frames.shape[0] == nb - 1
+    fsz = frames.shape[1]
+    js = int(fsz == 192)
+    kind = {"oma": 0, "at3": 1, "raw": 2}[ext]
+    if have_ref():   # ... wrapped by the reference's own container code
+        ref = ctypes.CDLL(REF_SO)
+        exp_path = str(tmp_path / "exp.bin")
+        buf = np.ascontiguousarray(frames)
+        assert ref.at3ref_write_container(kind, exp_path.encode(), buf.ctypes.data_as(ctypes.c_void_p), buf.shape[0], fsz, js, nsamp // 1024, 2) == 0
+        exp = open(exp_path, "rb").read()
+        assert got == exp
+    else:
+        assert got[-frames.size:] == frames.tobytes()
