@@ -132,16 +132,17 @@ __device__ __forceinline__ void irfft_pass_32_128(cpx* F, const cpx* tw, int v)
     for (int i = 0; i < 16; ++i) st2(B + 33 * i, x[i]);
 }
 
-// pass m = 512: butterfly k = lane + 64 u on points k + 512 q, four butterflies per batch
-__device__ __forceinline__ void irfft_pass_512(cpx* F, const cpx* tw, int lane)
+// pass m = 512: butterfly k = tid + NT u on points k + 512 q, four butterflies per batch (NT work-items share the pass)
+template <int NT>
+__device__ __forceinline__ void irfft_pass_512(cpx* F, const cpx* tw, int tid)
 {
 #pragma unroll
-    for (int u0 = 0; u0 < 8; u0 += 4) {
+    for (int u0 = 0; u0 < 512 / NT; u0 += 4) {
         f2 x[4][4], w[4][3];
         cpx* B[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = lane + 64 * (u0 + u);
+            const int k = tid + NT * (u0 + u);
             B[u] = F + irfft_pad(k);
             w[u][0] = ld2(tw + k);
             w[u][1] = ld2(tw + 2 * k);
@@ -159,22 +160,10 @@ __device__ __forceinline__ void irfft_pass_512(cpx* F, const cpx* tw, int lane)
     }
 }
 
-__device__ __forceinline__ void irfft_core_2048(cpx* F, const cpx* tw, int lane)
-{
-    irfft_pass_2_8<0>(F, tw, lane);
-    irfft_pass_2_8<1>(F, tw, lane);
-    wave_sync();
-    irfft_pass_32_128(F, tw, lane);
-    irfft_pass_32_128(F, tw, lane + 64);
-    wave_sync();
-    irfft_pass_512(F, tw, lane);
-    wave_sync();
-}
-
-// One WAVEFRONT per (stream, frame, channel, band<3) item, four independent items per 256-thread workgroup:
-// no workgroup barrier anywhere. Every pass of the two FFTs gives each lane several independent butterflies
-// (8 per lane in the 2048-point inverse transform), which is what hides the LDS latency; the few strictly ordered
-// sums (two f64 energy chains of 257 terms, 32 sub-frame RMS chains of 64 terms) run on the lanes they need.
+// One 128-thread workgroup (two wavefronts) per (stream, frame, channel, band<3) item. Every pass of the inverse
+// transform gives each work-item one register-resident radix-16 unit or four butterflies; the 19 KB working set allows
+// eight items = 16 wavefronts per CU. The strictly ordered sums (two f64 energy chains of 257 terms, 32 sub-frame RMS
+// chains of 64 terms) and the small forward transform run on wavefront 0 while wavefront 1 waits at the barrier.
 struct GainLds {
     cpx f[2048 + 64];   // rfft-512 core in f[0..255]; then the irfft-4096 core / upsampled samples, padded (irfft_pad)
     cpx freq[304];      // 257 bins, then 300 f64 energies (257 + zero padding), then the AnalyzeGain scratch below
@@ -183,23 +172,18 @@ struct GainLds {
 // AnalyzeGain scratch inside `freq` (dead once the two energy sums are done): float offsets
 constexpr int kGaMicro = 0, kGaGain = 256, kGaFilt = 288, kGaMinv = 320;
 
-__global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Tables* T)
+__global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Tables* T)
 {
-    __shared__ __attribute__((aligned(16))) GainLds s_item[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    GainLds& L = s_item[wave];
+    __shared__ __attribute__((aligned(16))) GainLds s_item[1];
+    const int tid = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    GainLds& L = s_item[0];
     float* s_micro = reinterpret_cast<float*>(L.freq) + kGaMicro;
     float* s_gain = reinterpret_cast<float*>(L.freq) + kGaGain;
     float* s_filt = reinterpret_cast<float*>(L.freq) + kGaFilt;
     float* s_minv = reinterpret_cast<float*>(L.freq) + kGaMinv;
     const int nfr = p.n_blocks - p.f0;
-    const int n_items = (int)gridDim.x * 4;   // the launch rounds the item count up to a multiple of 4
-    int item = blockIdx.x * 4 + wave;
-    (void)n_items;
-    const int total = p.n_streams * nfr * 6;
-    const bool valid = item < total;
-    if (!valid) item = total - 1;             // keep the wave alive (uniform code), results are discarded
-    int wg = item;
+    const bool valid = true;
+    int wg = blockIdx.x;
     const int band = wg % 3; wg /= 3;
     const int ch = wg % 2; wg /= 2;
     const int f = p.f0 + wg % nfr;
@@ -210,10 +194,10 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
     const float* sb1 = p.sub + ((size_t)s * 8 + 1 * 4 + band) * sublen + (size_t)(cb + 2) * 256 - 128;
     GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
 
-    // 1. window and pack as 256 complex points in FFT leaf order (4 points per lane)
+    // 1. window and pack as 256 complex points in FFT leaf order (2 points per work-item)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = lane + 64 * q;
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + 128 * q;
         float2 a = *reinterpret_cast<const float2*>(sb0 + 2 * i);
         if (p.js) {
             const float2 b = *reinterpret_cast<const float2*>(sb1 + 2 * i);
@@ -232,10 +216,11 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         z.i = a.y * T->planck[2 * i + 1];
         L.f[fft_leaf_pos<256>(i)] = z;
     }
-    wave_sync();
-    fft_wave<256, false>(L.f, T->tw256, lane);
-    // 2. kiss_fftr post-processing -> 257 bins (k = lane+1 and lane+65)
-    if (lane == 0) {
+    __syncthreads();
+    if (wave == 0) fft_wave<256, false>(L.f, T->tw256, lane);
+    __syncthreads();
+    // 2. kiss_fftr post-processing -> 257 bins (k = tid + 1)
+    if (tid == 0) {
         const float tr = L.f[0].r, ti = L.f[0].i;
         cpx a, b;
         a.r = tr + ti; a.i = 0.0f;
@@ -243,9 +228,8 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         L.freq[0] = a;
         L.freq[256] = b;
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int k = lane + 1 + 64 * q;
+    {
+        const int k = tid + 1;
         const cpx fpk = L.f[k];
         cpx fpnk;
         fpnk.r = L.f[256 - k].r;
@@ -260,18 +244,18 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         if (k != 128) L.freq[k] = a;   // k == 128: the second store wins in the reference
         L.freq[256 - k] = b;
     }
-    wave_sync();
+    __syncthreads();
     // 3. kiss_fftri input. Only bins 38..256 survive the high-pass, so tmpbuf is non-zero at k in [38,256] and
     //    [1792,2010]; each of those meets an exact zero in its radix-2 leaf butterfly (x +- 0*w), whose two outputs
     //    are therefore stored directly.
     {
         float4* z4 = reinterpret_cast<float4*>(L.f);
 #pragma unroll
-        for (int k = 0; k < 17; ++k)
-            if (lane + 64 * k < (2048 + 64) / 2) z4[lane + 64 * k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < 9; ++k)
+            if (tid + 128 * k < (2048 + 64) / 2) z4[tid + 128 * k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    wave_sync();
-    for (int k = kLowCutBin + lane; k <= 256; k += 64) {
+    __syncthreads();
+    for (int k = kLowCutBin + tid; k <= 256; k += 128) {
         cpx fk;
         const float scale = 8.0f;
         if (k == 256) {
@@ -304,22 +288,22 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
     // e[0..256] and lane 1 its two weighted terms followed by e[40..256] - the skipped terms of the reference are
     // exact zeros and the padding read past bin 256 is zero.
     {
-        double e[5];
+        double e[3];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const int k = lane + 64 * t;
+        for (int t = 0; t < 3; ++t) {
+            const int k = tid + 128 * t;
             const cpx z = L.freq[k < 257 ? k : 256];
             e[t] = (k < 257) ? (double)z.r * z.r + (double)z.i * z.i : 0.0;
         }
-        wave_sync();
+        __syncthreads();
         double* E = reinterpret_cast<double*>(L.freq);
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const int k = lane + 64 * t;
+        for (int t = 0; t < 3; ++t) {
+            const int k = tid + 128 * t;
             if (k < 300) E[k] = e[t];
         }
-        wave_sync();
-        if (lane < 2) {
+        __syncthreads();
+        if (tid < 2) {
             const double h1 = (double)T->hpf_w[1], h2 = (double)T->hpf_w[2];
             double acc = 0.0;
             if (lane == 1) {
@@ -338,25 +322,32 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
             L.hsum[lane] = acc;
         }
     }
-    wave_sync();
+    __syncthreads();
     {
         // below 5 % high-band energy the reference drops the band before the upsampler output is looked at
         // (atrac3denc.cpp:319-327): nothing downstream reads the other fields of such a record
         const double totalE = L.hsum[0], filtE = L.hsum[1];
         const float hfr = (totalE > 0.0) ? (float)(filtE / totalE) : 0.0f;
         if (hfr < 0.05f) {
-            if (valid && lane == 0) rec->hfr = hfr;
+            if (valid && tid == 0) rec->hfr = hfr;
             return;
         }
     }
-    irfft_core_2048(L.f, T->tw2048, lane);
+    // inverse transform: 128 radix-16 units per pass pair, one per work-item
+    if (wave == 0) irfft_pass_2_8<0>(L.f, T->tw2048, lane);
+    else irfft_pass_2_8<1>(L.f, T->tw2048, lane);
+    __syncthreads();
+    irfft_pass_32_128(L.f, T->tw2048, tid);
+    __syncthreads();
+    irfft_pass_512<128>(L.f, T->tw2048, tid);
+    __syncthreads();
 
     // 4. AnalyzeGain over the upsampled samples [1024, 3072): 256 micro-chunks of 8 (4 per lane), 32 sub-frames of 64
     // complex output j holds the real samples 2j, 2j+1; sample 1024 is complex slot 512 = padded slot 528
     const float norm = 1.0f / 4096.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c = lane + 64 * q;
+    for (int q = 0; q < 2; ++q) {
+        const int c = tid + 128 * q;
         const cpx* src = L.f + 528 + 4 * c + (c >> 3);
         float acc = 0.0f;
 #pragma unroll
@@ -369,7 +360,7 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         acc /= 8;
         s_micro[c] = sqrtf(acc);
     }
-    if (lane < 32) {
+    if (tid < 32) {
         const cpx* src = L.f + 528 + 33 * lane;
         f2 x[32];
 #pragma unroll
@@ -385,8 +376,8 @@ __global__ __launch_bounds__(256) void k_gain_analysis(GainParams p, const Table
         acc /= 64;
         s_gain[lane] = sqrtf(acc);
     }
-    wave_sync();
-    {
+    __syncthreads();
+    if (wave == 0) {
         const int j = lane & 31;
         const float in_j = s_gain[j];
         // quartiles of the 8 micro-chunk RMS values (transient_detector.cpp:113-133)

@@ -326,7 +326,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
                 hipLaunchKernelGGL(k_qmf_sub, dim3(S * nch), dim3(256), 0, st, fp, c->d_tables);
             }
             HIPCHK(c, hipEventRecord(c->ev[1], st));
-            hipLaunchKernelGGL(k_gain_analysis, dim3((S * n_out * 6 + 3) / 4), dim3(256), 0, st, gp, c->d_tables);
+            hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), 0, st, gp, c->d_tables);
             HIPCHK(c, hipEventRecord(c->ev[2], st));
             hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), 0, st, gp, S);
             hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), 0, st, gp, c->d_tables, S);
