@@ -107,55 +107,82 @@ __device__ __forceinline__ void irfft_pass_2_8(cpx* F, const cpx* tw, int lane)
     for (int i = 0; i < 16; ++i) st2(B + 2 * i, x[i]);
 }
 
-// passes m = 32 and m = 128: unit v = (512-block G2 = v / 32, k = v % 32), points 512 G2 + k + 32 i
-__device__ __forceinline__ void irfft_pass_32_128(cpx* F, const cpx* tw, int v)
+// passes m = 32 and m = 128: unit v = (512-block G2 = v / 32, k = v % 32), points 512 G2 + k + 32 i.
+// The 15 twiddles of a unit depend on v only; they are fetched long before the pass runs (a dependent global load
+// costs a microsecond, the passes themselves a few hundred cycles).
+struct Tw32_128 {
+    f2 a[3];
+    f2 w[4][3];
+};
+__device__ __forceinline__ Tw32_128 irfft_tw_32_128(const cpx* tw, int v)
+{
+    const int k = v & 31;
+    Tw32_128 t;
+    t.a[0] = ld2(tw + 16 * k);   // fstride 16
+    t.a[1] = ld2(tw + 32 * k);
+    t.a[2] = ld2(tw + 48 * k);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kk = k + 32 * j;   // fstride 4
+        t.w[j][0] = ld2(tw + 4 * kk);
+        t.w[j][1] = ld2(tw + 8 * kk);
+        t.w[j][2] = ld2(tw + 12 * kk);
+    }
+    return t;
+}
+__device__ __forceinline__ void irfft_pass_32_128(cpx* F, const Tw32_128& t, int v)
 {
     const int k = v & 31, G2 = v >> 5;
     cpx* B = F + 528 * G2 + k;
     f2 x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = ld2(B + 33 * i);
-    const f2 a1 = ld2(tw + 16 * k), a2 = ld2(tw + 32 * k), a3 = ld2(tw + 48 * k);   // fstride 16
-    f2 w[4][3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int kk = k + 32 * j;   // fstride 4
-        w[j][0] = ld2(tw + 4 * kk);
-        w[j][1] = ld2(tw + 8 * kk);
-        w[j][2] = ld2(tw + 12 * kk);
-    }
+    for (int g = 0; g < 4; ++g) bfly4<true>(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], t.a[0], t.a[1], t.a[2]);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bfly4<true>(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], a1, a2, a3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bfly4<true>(x[j], x[j + 4], x[j + 8], x[j + 12], w[j][0], w[j][1], w[j][2]);
+    for (int j = 0; j < 4; ++j) bfly4<true>(x[j], x[j + 4], x[j + 8], x[j + 12], t.w[j][0], t.w[j][1], t.w[j][2]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) st2(B + 33 * i, x[i]);
 }
 
-// pass m = 512: butterfly k = tid + NT u on points k + 512 q, four butterflies per batch (NT work-items share the pass)
+// pass m = 512: butterfly k = tid + NT u on points k + 512 q (NT work-items share the pass); twiddles prefetched
 template <int NT>
-__device__ __forceinline__ void irfft_pass_512(cpx* F, const cpx* tw, int tid)
+struct Tw512 {
+    f2 w[512 / NT][3];
+};
+template <int NT>
+__device__ __forceinline__ Tw512<NT> irfft_tw_512(const cpx* tw, int tid)
+{
+    Tw512<NT> t;
+#pragma unroll
+    for (int u = 0; u < 512 / NT; ++u) {
+        const int k = tid + NT * u;
+        t.w[u][0] = ld2(tw + k);
+        t.w[u][1] = ld2(tw + 2 * k);
+        t.w[u][2] = ld2(tw + 3 * k);
+    }
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ void irfft_pass_512(cpx* F, const Tw512<NT>& t, int tid)
 {
 #pragma unroll
     for (int u0 = 0; u0 < 512 / NT; u0 += 4) {
-        f2 x[4][4], w[4][3];
+        f2 x[4][4];
         cpx* B[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = tid + NT * (u0 + u);
-            B[u] = F + irfft_pad(k);
-            w[u][0] = ld2(tw + k);
-            w[u][1] = ld2(tw + 2 * k);
-            w[u][2] = ld2(tw + 3 * k);
+            B[u] = F + irfft_pad(tid + NT * (u0 + u));
 #pragma unroll
             for (int q = 0; q < 4; ++q) x[u][q] = ld2(B[u] + 528 * q);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bfly4<true>(x[u][0], x[u][1], x[u][2], x[u][3], w[u][0], w[u][1], w[u][2]);
+        for (int u = 0; u < 4; ++u) bfly4<true>(x[u][0], x[u][1], x[u][2], x[u][3], t.w[u0 + u][0], t.w[u0 + u][1], t.w[u0 + u][2]);
+        // only the middle half of the upsampled frame is analysed (samples 1024..3071 = outputs k + 512, k + 1024)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) st2(B[u] + 528 * q, x[u][q]);
+            st2(B[u] + 528, x[u][1]);
+            st2(B[u] + 1056, x[u][2]);
         }
     }
 }
@@ -194,6 +221,20 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     const float* sb1 = p.sub + ((size_t)s * 8 + 1 * 4 + band) * sublen + (size_t)(cb + 2) * 256 - 128;
     GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
 
+    // Table entries this work-item will need depend on its index only: all fetched now, so that the kernel pays one
+    // global-memory latency instead of one per pass.
+    f2 tw_a[4][3];                     // forward 256-point core: pass m = 4^st, k = lane % m, fstride 64 / m
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int m = 1 << (2 * st), k = lane % m, fs = 64 / m;
+        tw_a[st][0] = ld2(T->tw256 + k * fs);
+        tw_a[st][1] = ld2(T->tw256 + 2 * k * fs);
+        tw_a[st][2] = ld2(T->tw256 + 3 * k * fs);
+    }
+    const cpx stw_post = T->stw256[tid];                                         // bin k = tid + 1
+    const cpx stw_in0 = T->stw2048[kLowCutBin + tid - 1];                        // bins k = 38 + tid, 166 + tid
+    const cpx stw_in1 = T->stw2048[kLowCutBin + 128 + tid - 1 < 1024 ? kLowCutBin + 128 + tid - 1 : 1023];
+    const float hpf1 = T->hpf_w[1], hpf2 = T->hpf_w[2];
     // 1. window and pack as 256 complex points in FFT leaf order (2 points per work-item)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -217,7 +258,20 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         L.f[fft_leaf_pos<256>(i)] = z;
     }
     __syncthreads();
-    if (wave == 0) fft_wave<256, false>(L.f, T->tw256, lane);
+    if (wave == 0) {   // 256-point forward core, one butterfly per lane and pass, twiddles fetched at kernel entry
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int m = 1 << (2 * st);
+            cpx* B = L.f + (lane / m) * 4 * m + lane % m;
+            f2 x0 = ld2(B), x1 = ld2(B + m), x2 = ld2(B + 2 * m), x3 = ld2(B + 3 * m);
+            bfly4<false>(x0, x1, x2, x3, tw_a[st][0], tw_a[st][1], tw_a[st][2]);
+            st2(B, x0);
+            st2(B + m, x1);
+            st2(B + 2 * m, x2);
+            st2(B + 3 * m, x3);
+            wave_sync();
+        }
+    }
     __syncthreads();
     // 2. kiss_fftr post-processing -> 257 bins (k = tid + 1)
     if (tid == 0) {
@@ -237,7 +291,7 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         cpx f1k, f2k;
         f1k.r = fpk.r + fpnk.r; f1k.i = fpk.i + fpnk.i;
         f2k.r = fpk.r - fpnk.r; f2k.i = fpk.i - fpnk.i;
-        const cpx tw = cmul(f2k, T->stw256[k - 1]);
+        const cpx tw = cmul(f2k, stw_post);
         cpx a, b;
         a.r = (f1k.r + tw.r) * 0.5f; a.i = (f1k.i + tw.i) * 0.5f;
         b.r = (f1k.r - tw.r) * 0.5f; b.i = (tw.i - f1k.i) * 0.5f;
@@ -265,12 +319,12 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
             fk.r = L.freq[k].r * scale;
             fk.i = L.freq[k].i * scale;
         } else {
-            const float w = T->hpf_w[k - kLowCutBin + 1];
+            const float w = (k == kLowCutBin) ? hpf1 : hpf2;
             fk.r = L.freq[k].r * scale * w;
             fk.i = L.freq[k].i * scale * w;
         }
         // fnkc = conj(freq[2048 - k]) = (0, -0): fek = fk, tmp = fk
-        const cpx fok = cmul(fk, T->stw2048[k - 1]);
+        const cpx fok = cmul(fk, (k < kLowCutBin + 128) ? stw_in0 : stw_in1);
         cpx a, b, nb;
         a.r = fk.r + fok.r; a.i = fk.i + fok.i;
         b.r = fk.r - fok.r; b.i = -(fk.i - fok.i);
@@ -282,6 +336,9 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         L.f[irfft_pad(pb) - 1] = b;
         L.f[irfft_pad(pb)] = nb;
     }
+    // twiddles of the last three inverse passes: issued here, consumed after the energy sums below
+    const Tw32_128 tw_b = irfft_tw_32_128(T->tw2048, tid);
+    const Tw512<128> tw_c = irfft_tw_512<128>(T->tw2048, tid);
     // highFreqRatio (transient_spectral_upsampler.cpp:99-118): two ordered f64 sums over the 257 bin energies, the second
     // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on). The energies are formed by
     // all lanes and parked (as f64) over the spectrum, which the inverse transform no longer needs; lane 0 then adds
@@ -304,7 +361,7 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         }
         __syncthreads();
         if (tid < 2) {
-            const double h1 = (double)T->hpf_w[1], h2 = (double)T->hpf_w[2];
+            const double h1 = (double)hpf1, h2 = (double)hpf2;
             double acc = 0.0;
             if (lane == 1) {
                 acc += E[kLowCutBin] * h1 * h1;
@@ -337,9 +394,9 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     if (wave == 0) irfft_pass_2_8<0>(L.f, T->tw2048, lane);
     else irfft_pass_2_8<1>(L.f, T->tw2048, lane);
     __syncthreads();
-    irfft_pass_32_128(L.f, T->tw2048, tid);
+    irfft_pass_32_128(L.f, tw_b, tid);
     __syncthreads();
-    irfft_pass_512<128>(L.f, T->tw2048, tid);
+    irfft_pass_512<128>(L.f, tw_c, tid);
     __syncthreads();
 
     // 4. AnalyzeGain over the upsampled samples [1024, 3072): 256 micro-chunks of 8 (4 per lane), 32 sub-frames of 64
