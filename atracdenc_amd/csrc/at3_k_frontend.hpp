@@ -35,6 +35,169 @@ struct FrontParams {
     int debug;               // profiling aid (env AT3HIP_DEBUG_FRONT): 1 = skip the energy-scale chains, 2 = ignore curves
 };
 
+// Modulated new half of one band (TGainProcessor::Modulate, gain_processor.h:93-112) for the eight samples of cell
+// `cell / 8`. Level boundaries and the 8-sample ramps are aligned to these cells, so a cell is untouched, divided by
+// one level (a power of two: multiplying by its reciprocal is the same rounding) or by one running-product ramp.
+// `cv` should be read in place (LDS / global): a private copy indexed in a loop would live in scratch.
+__device__ __forceinline__ void modulate_cell(const Curve& cv, const float* gain_interp, int cell, float (&v)[8])
+{
+    int kind = 0;   // 0 untouched, 1 constant level, 2 ramp
+    float lvl = 1.0f, inc = 1.0f, inv = 1.0f;
+    int pos = 0;
+    for (int q = 0; q < cv.n; ++q) {
+        const int lastPos = (int)cv.loc[q] << 3;
+        if (cell >= pos && cell < lastPos) {
+            kind = 1;
+            inv = __uint_as_float((uint32_t)(127 - 4 + cv.level[q]) << 23);   // 1 / GainLevel
+            break;
+        }
+        if (lastPos > pos) pos = lastPos;
+        if (pos < lastPos + 8) {
+            if (cell >= pos && cell < lastPos + 8) {
+                kind = 2;
+                lvl = gain_level_of(cv.level[q]);
+                inc = gain_interp[((q + 1) < cv.n ? (int)cv.level[q + 1] : 4) - (int)cv.level[q] + 15];
+                break;
+            }
+            pos = lastPos + 8;
+        }
+    }
+    if (kind == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] * inv;
+    } else if (kind == 2) {
+        float d = lvl;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = v[k] / d;
+            d *= inc;
+        }
+    }
+}
+
+// CalcGainEnergyScale (atrac3denc.cpp:175-224), the `Frame` value the psychoacoustics and the allocator use: ratio of
+// the frame's energy without and with gain modulation. One wavefront per (stream, frame), eight bands. The value is
+// 1 unless this block's or the previous block's curve is non-empty, which is the case for a few per cent of the bands;
+// those compute five strictly ordered 256-term sums: three over this block (carried overlap, windowed original,
+// windowed modulated) and two over the previous one (its "next overlap" scale, which the reference carries forward as
+// PrevOverlapGainScale). Lanes 0..31 own the eight-sample cells of the current block, lanes 32..63 those of the
+// previous block; lanes 0..4 then add the staged terms in order.
+__global__ __launch_bounds__(256) void k_gain_energy_scale(FrontParams p, const Tables* T, int n_frames_total)
+{
+    __shared__ __attribute__((aligned(16))) float s_terms[4][5][256];
+    __shared__ __attribute__((aligned(16))) Curve s_cv[4][8][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int sf = blockIdx.x * 4 + wave;             // (stream, frame): the wavefront looks at its eight bands together
+    if (sf >= n_frames_total) return;
+    const int nfr = p.n_blocks - p.f0;
+    const int f = p.f0 + sf % nfr;
+    const int s = sf / nfr;
+    const int b = f - 1;   // the block this frame's new half comes from
+    // lanes 0..7: the band's two curves as 16-byte words; their point lists are later walked from LDS
+    uint4 w_cur = {0u, 0u, 0u, 0u}, w_prev = {0u, 0u, 0u, 0u};
+    if (lane < 8) {
+        w_cur = *reinterpret_cast<const uint4*>(p.curves + ((size_t)s * p.n_blocks + f) * 8 + lane);
+        w_prev = *reinterpret_cast<const uint4*>((f - 1 < 0) ? &p.state[(size_t)s * 8 + lane].prev_curve
+                                                             : p.curves + ((size_t)s * p.n_blocks + (f - 1)) * 8 + lane);
+        *reinterpret_cast<uint4*>(&s_cv[wave][lane][0]) = w_cur;
+        *reinterpret_cast<uint4*>(&s_cv[wave][lane][1]) = w_prev;
+    }
+    const bool active = lane < 8 && (((w_cur.x | w_prev.x) & 0xffu) != 0u);   // Curve::n is the first byte
+    uint32_t todo = (uint32_t)__ballot(active);
+    float* out8 = p.ges + ((size_t)s * p.n_blocks + f) * 8;
+    if (lane < 8 && !active) out8[lane] = 1.0f;       // no modulation on either side: every ratio is exactly 1
+    wave_sync();
+    const int mine = lane >> 5;                       // 0: current block, 1: previous block
+    const int cell = 8 * (lane & 31);
+    const size_t sublen = (size_t)(p.n_blocks + 2) * 256;
+    const size_t at = (size_t)(b - mine + 2) * 256 + cell;
+    float wc[8], wn[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        wc[k] = T->enc_win[255 - (cell + k)];
+        wn[k] = T->enc_win[cell + k];
+    }
+    while (todo) {
+        const int c = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const Curve& cv_cur = s_cv[wave][c][0];
+        const Curve& cv_prev = s_cv[wave][c][1];
+        const bool has_cur = cv_cur.n > 0, has_prev = cv_prev.n > 0;
+        // raw subband samples of this lane's cell (M/S matrixed for joint stereo, atrac3denc.cpp:665-677)
+        const int ch = c >> 2, band = c & 3;
+        const float* sb0 = p.sub + ((size_t)s * 8 + band) * sublen + at;
+        const float* sb1 = p.sub + ((size_t)s * 8 + 4 + band) * sublen + at;
+        float x[8];
+        {
+            const float4 a0 = *reinterpret_cast<const float4*>(ch ? sb1 : sb0), a1 = *reinterpret_cast<const float4*>((ch ? sb1 : sb0) + 4);
+            x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+            if (p.js) {
+                const float4 l0 = *reinterpret_cast<const float4*>(sb0), l1 = *reinterpret_cast<const float4*>(sb0 + 4);
+                const float4 r0 = *reinterpret_cast<const float4*>(sb1), r1 = *reinterpret_cast<const float4*>(sb1 + 4);
+                const float l[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w}, r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = ch ? (l[k] - r[k]) * 0.5f : (l[k] + r[k]) * 0.5f;
+            }
+        }
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = x[k];
+        if (mine ? has_prev : has_cur) modulate_cell(mine ? cv_prev : cv_cur, T->gain_interp, cell, m);
+        float (*terms)[256] = s_terms[wave];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = cell + k;
+            if (mine == 0) {
+                const float cw = x[k] * wc[k], mw = m[k] * wc[k];
+                terms[1][i] = cw * cw;
+                terms[2][i] = mw * mw;
+            } else {
+                const float pv = wn[k] * m[k];              // the overlap this block inherited: EncodeWindow[i] * modulated sample
+                const float nw = x[k] * wn[k], mnw = m[k] * wn[k];
+                terms[0][i] = pv * pv;
+                terms[3][i] = nw * nw;
+                terms[4][i] = mnw * mnw;
+            }
+        }
+        wave_sync();
+        float acc = 0.0f;
+        if (lane < 5) {
+            const float4* t4 = reinterpret_cast<const float4*>(terms[lane]);
+            for (int q0 = 0; q0 < 64; q0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = t4[q0 + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    acc += v[q].x;
+                    acc += v[q].y;
+                    acc += v[q].z;
+                    acc += v[q].w;
+                }
+            }
+        }
+        const float s0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 0));
+        const float s1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 1));
+        const float s2 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 2));
+        const float s3 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 3));
+        const float s4 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 4));
+        if (lane == 0) {
+            // PrevOverlapGainScale: the previous block's NextOverlapScale, 1 when that block had no curve (equal sums)
+            float ps = has_prev ? safe_energy_scale(s3, s4) : 1.0f;
+            float frame_scale = 1.0f;
+            if (has_cur || ps != 1.0f) {
+                if (!isfinite(ps) || ps <= 0.0f) ps = 1.0f;
+                const float prevDiv = has_cur ? gain_level_of(cv_cur.level[0]) : 1.0f;
+                const float prevOrig = s0 * ps;
+                const float prevMod = s0 / (prevDiv * prevDiv);
+                frame_scale = safe_energy_scale(prevOrig + s1, prevMod + s2);
+            }
+            out8[c] = frame_scale;
+        }
+        wave_sync();   // the term buffer is reused by the next band
+    }
+}
+
 // ---- fused QMF + gain modulation + windowed MDCT-512 ------------------------------------------------------
 //
 // Register-blocked FIR: one work-item produces four consecutive (lower, upper) output pairs of one two-band
@@ -221,8 +384,6 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
     __shared__ cpx s_tw[128];
     __shared__ __attribute__((aligned(16))) Curve s_curve[8];
     __shared__ float s_gi[32];               // GainInterpolation
-    __shared__ float s_nextscale[8];         // NextOverlapScale of the block just processed
-    __shared__ float s_sum[8][5];
     // Gain-path scratch aliases buffers that are dead between stage 2 and the MDCT fold of the same block:
     // the modulated samples live in the FFT buffer (written by the fold afterwards), the energy-term staging in
     // each channel's PCM ring behind the 46-sample history (rewritten by the next block's tile load).
@@ -247,7 +408,6 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
     s_win[tid] = T->enc_win[tid];
     s_cs[tid] = T->mdct_sincos[tid];
     if (tid < 128) s_tw[tid] = T->tw128[tid];
-    if (tid < 8) s_nextscale[tid] = 1.0f;
     if (GAIN && tid < 32) s_gi[tid] = T->gain_interp[tid];
     for (int i = tid; i < 2048; i += 256) s_prevw[i] = 0.0f;
     // gain curve of the frame about to be processed, fetched one block ahead by work-items 0..7 (frame fa-1 only
@@ -379,49 +539,15 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
         bool has_curve = false;
         float scale = 1.0f;
         if (GAIN) {
-            const float prev_scale = s_nextscale[c];
             has_curve = s_curve[c].n > 0 && p.debug != 2;
             if (has_curve) {
-                // Modulated new half (gain_processor.h:93-112): lane j owns samples 8j .. 8j+7. Level boundaries and
-                // the 8-sample ramps are aligned to these cells, so a cell is untouched, divided by one level (a
-                // power of two: multiplying by its reciprocal is the same rounding) or by one running-product ramp.
-                const Curve& cv = s_curve[c];   // read in place: a private copy indexed in a loop would live in scratch
+                // lane j owns samples 8j .. 8j+7 of the modulated new half (modulate_cell)
+                const Curve& cv = s_curve[c];
                 scale = gain_level_of(cv.level[0]);
                 const int cell = 8 * lane;
-                int kind = 0;   // 0 untouched, 1 constant level, 2 ramp
-                float lvl = 1.0f, inc = 1.0f, inv = 1.0f;
-                int pos = 0;
-                for (int q = 0; q < cv.n; ++q) {
-                    const int lastPos = (int)cv.loc[q] << 3;
-                    if (cell >= pos && cell < lastPos) {
-                        kind = 1;
-                        inv = __uint_as_float((uint32_t)(127 - 4 + cv.level[q]) << 23);   // 1 / GainLevel
-                        break;
-                    }
-                    if (lastPos > pos) pos = lastPos;
-                    if (pos < lastPos + 8) {
-                        if (cell >= pos && cell < lastPos + 8) {
-                            kind = 2;
-                            lvl = gain_level_of(cv.level[q]);
-                            inc = s_gi[((q + 1) < cv.n ? (int)cv.level[q + 1] : 4) - (int)cv.level[q] + 15];
-                            break;
-                        }
-                        pos = lastPos + 8;
-                    }
-                }
                 const float4 xa = *reinterpret_cast<const float4*>(xs + cell), xb = *reinterpret_cast<const float4*>(xs + cell + 4);
                 float v[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                if (kind == 1) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = v[k] * inv;
-                } else if (kind == 2) {
-                    float d = lvl;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        v[k] = v[k] / d;
-                        d *= inc;
-                    }
-                }
+                modulate_cell(cv, s_gi, cell, v);
                 float4 oa, ob;
                 oa.x = v[0]; oa.y = v[1]; oa.z = v[2]; oa.w = v[3];
                 ob.x = v[4]; ob.y = v[5]; ob.z = v[6]; ob.w = v[7];
@@ -429,58 +555,7 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
                 *reinterpret_cast<float4*>(s_mod + c * 256 + cell + 4) = ob;
             }
             wave_sync();
-            // CalcGainEnergyScale (atrac3denc.cpp:189-216): five strictly ordered 256-term sums. The terms are
-            // produced 32 at a time by all lanes of the combo; lanes 0..4 then extend one chain each.
-            const bool need = (has_curve || prev_scale != 1.0f) && p.debug != 1;
-            if (__ballot(need) != 0ull) {   // wave-uniform: both combos of the wavefront walk the chunks together
-                // [5][32] per combo in the dead part of the channel's PCM ring: the 46-sample history occupies the first 24
-                // floats of each half (ring_at), the rest is rewritten by the next block's tile store
-                float* terms = s_pcm + (c >> 2) * kPcmRing + ((c & 3) < 3 ? 32 + (c & 3) * 160 : 4 * kPcmH + 32);
-                float acc = 0.0f;
-                for (int base = 0; base < 256; base += 32) {
-                    const int i = base + lane;
-                    const float x = xs[i];
-                    const float mod = has_curve ? s_mod[c * 256 + i] : x;
-                    const float wc = s_win[255 - i], wn = s_win[i];
-                    const float pv = pw[i];
-                    const float cw = x * wc, mw = mod * wc, nw = x * wn, mnw = mod * wn;
-                    terms[0 * 32 + lane] = pv * pv;
-                    terms[1 * 32 + lane] = cw * cw;
-                    terms[2 * 32 + lane] = mw * mw;
-                    terms[3 * 32 + lane] = nw * nw;
-                    terms[4 * 32 + lane] = mnw * mnw;
-                    wave_sync();
-                    if (lane < 5) {
-                        const float4* t4 = reinterpret_cast<const float4*>(terms + lane * 32);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const float4 v = t4[q];
-                            acc += v.x;
-                            acc += v.y;
-                            acc += v.z;
-                            acc += v.w;
-                        }
-                    }
-                    wave_sync();
-                }
-                if (need && lane < 5) s_sum[c][lane] = acc;
-            }
-            wave_sync();
-            if (lane == 0) {
-                float frame_scale = 1.0f, next_scale = 1.0f;
-                if (need) {
-                    float ps = prev_scale;
-                    if (!isfinite(ps) || ps <= 0.0f) ps = 1.0f;
-                    const float prevDiv = has_curve ? scale : 1.0f;
-                    const float prevStored = s_sum[c][0];
-                    const float prevOrig = prevStored * ps;
-                    const float prevMod = prevStored / (prevDiv * prevDiv);
-                    frame_scale = safe_energy_scale(prevOrig + s_sum[c][1], prevMod + s_sum[c][2]);
-                    next_scale = safe_energy_scale(s_sum[c][3], s_sum[c][4]);
-                }
-                s_nextscale[c] = next_scale;
-                if (is_frame) p.ges[((size_t)s * p.n_blocks + f) * 8 + c] = frame_scale;
-            }
+            // (CalcGainEnergyScale runs in k_gain_energy_scale, from the same subbands and curves)
             if (has_curve) {   // Modulate (gain_processor.h:87-121): new half / ramp, overlap half / first level
                 const float inv_scale = 1.0f / scale;   // scale is a power of two
                 for (int i = lane; i < 256; i += 32) {
