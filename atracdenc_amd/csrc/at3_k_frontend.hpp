@@ -455,24 +455,33 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
         const int g = b0 * 1024 + tid + 256 * q;
         nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
     }
+    // The PCM tile of a block is stored while the previous block is between its two QMF stages (the ring's sample
+    // area is only read by stage 1), so a block needs three workgroup barriers, not four. Work-items 210..255 hold
+    // the last 46 samples of the tile they store: these become the FIR history once stage 1 is done with the ring.
+    float2 hv = {0.0f, 0.0f};
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = tid + 256 * q;
+            s_pcm[ring_at<kPcmH>(46 + k)] = nxt[q].x * 0.25f;                 // data / 4.0 (exact)
+            s_pcm[kPcmRing + ring_at<kPcmH>(46 + k)] = nxt[q].y * 0.25f;
+        }
+        hv.x = nxt[3].x * 0.25f;
+        hv.y = nxt[3].y * 0.25f;
+    };
+    store_tile();
+    if (b0 + 1 <= fb - 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int g = (b0 + 1) * 1024 + tid + 256 * q;
+            nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
+        }
+    }
+    __syncthreads();
     // block b carries frame f = b + 1; the block before the first frame only primes the overlap.
     for (int b = b0; b <= fb - 2; ++b) {
         const int f = b + 1;
         const bool is_frame = (f >= fa);
-        // ---- PCM tile: 1024 new stereo samples (fetched one block ahead into registers), /4.0 ----
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = tid + 256 * q;
-            s_pcm[ring_at<kPcmH>(46 + k)] = nxt[q].x * 0.25f;
-            s_pcm[kPcmRing + ring_at<kPcmH>(46 + k)] = nxt[q].y * 0.25f;
-        }
-        if (b + 1 <= fb - 2) {   // issue the next block's coalesced float2 loads now; they land during this block's math
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int g = (b + 1) * 1024 + tid + 256 * q;
-                nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
-            }
-        }
         if (GAIN && tid < 8) {
             *reinterpret_cast<uint4*>(&s_curve[tid]) = ncv;
             if (b + 1 <= fb - 2) ncv = *reinterpret_cast<const uint4*>(&p.curves[((size_t)s * p.n_blocks + f + 1) * 8 + tid]);
@@ -481,7 +490,6 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
             const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
             ((hlf ? s_hi : s_lo) + ch * kS1Ring)[ring_at<kS1H>(k)] = keep1;
         }
-        __syncthreads();
         // ---- stage 1 (Qmf1): 2 channels x 128 tasks x 4 outputs ----
         {
             const int ch = tid >> 7, g = tid & 127;
@@ -501,10 +509,21 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
             *reinterpret_cast<float2*>(rh + e0) = t0; *reinterpret_cast<float2*>(rh + e1) = t1;
         }
         __syncthreads();
-        // PCM history for the next block (stage 1 is done with the ring)
-        if (tid < 92) {
-            const int ch = tid / 46, k = tid % 46;
-            keep = s_pcm[ch * kPcmRing + ring_at<kPcmH>(1024 + k)];
+        // PCM history for the next block (stage 1 is done with the ring), then the next block's tile and the
+        // coalesced float2 loads of the block after it: they land during this block's remaining math
+        if (tid >= 210) {
+            s_pcm[ring_at<kPcmH>(tid - 210)] = hv.x;
+            s_pcm[kPcmRing + ring_at<kPcmH>(tid - 210)] = hv.y;
+        }
+        if (b + 1 <= fb - 2) {
+            store_tile();
+            if (b + 2 <= fb - 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = (b + 2) * 1024 + tid + 256 * q;
+                    nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
+                }
+            }
         }
         if (tid < 184) {   // stage-1 history for the next block, parked in a register across the MDCT phase
             const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
@@ -522,7 +541,6 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
             *reinterpret_cast<float4*>(out + (which ? 3 : 0) * 256 + 4 * g) = a;
             *reinterpret_cast<float4*>(out + (which ? 2 : 1) * 256 + 4 * g) = bq;
         }
-        if (tid < 92) s_pcm[(tid / 46) * kPcmRing + ring_at<kPcmH>(tid % 46)] = keep;
         __syncthreads();
         if (p.js) {  // M/S matrixing in the subband domain
             for (int idx = tid; idx < 1024; idx += 256) {
