@@ -1,5 +1,6 @@
 // Shared device-side definitions of the ATRAC3 encode kernels (gfx950).
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -200,7 +201,13 @@ __device__ __forceinline__ void bfly2(f2& x0, f2& x1, f2 w)
 }
 
 // log2f with the exact operation sequence of glibc 2.35's FMA build (see at3_tables.cpp); x > 0, finite.
-__device__ __forceinline__ float at3_log2f(const Tables* T, float x)
+// L: the 36 doubles {log2f_tab[16][2], log2f_poly[4]} (Tables layout), preferably staged in LDS by the caller.
+struct Log2fTab {
+    double tab[16][2];
+    double poly[4];
+};
+static_assert(offsetof(Tables, log2f_poly) - offsetof(Tables, log2f_tab) == sizeof(double) * 32, "Tables keeps tab and poly together");
+__device__ __forceinline__ float at3_log2f(const Log2fTab* L, float x)
 {
     uint32_t ix = __float_as_uint(x);
     if (ix == 0x3f800000u) return 0.0f;
@@ -214,14 +221,18 @@ __device__ __forceinline__ float at3_log2f(const Tables* T, float x)
     const uint32_t iz = ix - top;
     const int k = (int32_t)tmp >> 23;
     const double z = (double)__uint_as_float(iz);
-    const double r = fma(z, T->log2f_tab[i][0], -1.0);
-    const double y0 = T->log2f_tab[i][1] + (double)k;
+    const double r = fma(z, L->tab[i][0], -1.0);
+    const double y0 = L->tab[i][1] + (double)k;
     const double r2 = r * r;
-    double y = fma(T->log2f_poly[1], r, T->log2f_poly[2]);
-    y = fma(T->log2f_poly[0], r2, y);
-    const double p = fma(T->log2f_poly[3], r, y0);
+    double y = fma(L->poly[1], r, L->poly[2]);
+    y = fma(L->poly[0], r2, y);
+    const double p = fma(L->poly[3], r, y0);
     y = fma(y, r2, p);
     return (float)y;
+}
+__device__ __forceinline__ float at3_log2f(const Tables* T, float x)   // tables straight from global memory
+{
+    return at3_log2f(reinterpret_cast<const Log2fTab*>(&T->log2f_tab[0][0]), x);
 }
 
 // ---- kissfft-order in-LDS FFT -------------------------------------------------------------------

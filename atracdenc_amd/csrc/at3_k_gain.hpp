@@ -25,6 +25,7 @@ struct GainParams {
     int f0;
     int js;
     int n_streams;
+    int debug;   // profiling aid (env AT3HIP_DEBUG_GAIN): k_gain_curve returns early at stage N
 };
 
 constexpr int kLowCutBin = 38;  // ceil(800 * 512 / 11025)
@@ -629,18 +630,56 @@ struct CurvePts {   // register-resident curve (redundant in every lane of the i
 };
 
 // CalcCurveEarlyMismatchScore (atrac3denc.cpp:228-297); in_j / in_next are this lane's gain[j], gain[j+1].
-__device__ __forceinline__ float early_mismatch_score_grp(const Tables* T, float in_j, float in_next, float target,
-                                                          const CurvePts& cp, float* s_tmp, int j, int half)
+__device__ __forceinline__ float early_mismatch_score_grp(const Log2fTab* L2, const float* gain_interp, float in_j, float in_next, float target,
+                                                          const CurvePts& cp, float* s_tmp, uint8_t* s_pts, int j, int half)
 {
-    Curve c;
-    c.n = (uint8_t)cp.n;
+    // BuildSampleDivisors restricted to sub-frame j (samples 8j .. 8j+7): level boundaries and ramps are aligned to
+    // these cells, so the eight divisors are all 1, all one level, or one running-product ramp (same values as
+    // curve_divisor sample by sample). The points are walked from LDS: indexing a register-resident list with a
+    // run-time index costs a select chain per access, which made this the longest path of the kernel.
+    if (j < 7) {
+        int lv = 0, lc = 0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        c.level[i] = (uint8_t)cp.level[i];
-        c.loc[i] = (uint8_t)cp.loc[i];
+        for (int i = 0; i < 7; ++i) {
+            lv = (j == i) ? cp.level[i] : lv;
+            lc = (j == i) ? cp.loc[i] : lc;
+        }
+        s_pts[j] = (uint8_t)lv;
+        s_pts[8 + j] = (uint8_t)lc;
     }
+    wave_sync();
     float dsum = 0.0f;
-    for (int k = 0; k < 8; ++k) dsum += curve_divisor(T->gain_interp, c, j * 8 + k);
+    {
+        const int cell = 8 * j;
+        int kind = 0;
+        float lvl = 1.0f, inc = 1.0f;
+        int pos = 0;
+        for (int q = 0; q < cp.n; ++q) {
+            const int lastPos = (int)s_pts[8 + q] << 3;
+            if (cell >= pos && cell < lastPos) {
+                kind = 1;
+                lvl = gain_level_of(s_pts[q]);
+                break;
+            }
+            if (lastPos > pos) pos = lastPos;
+            if (pos < lastPos + 8) {
+                if (cell >= pos && cell < lastPos + 8) {
+                    kind = 2;
+                    lvl = gain_level_of(s_pts[q]);
+                    inc = gain_interp[((q + 1) < cp.n ? (int)s_pts[q + 1] : 4) - (int)s_pts[q] + 15];
+                    break;
+                }
+                pos = lastPos + 8;
+            }
+        }
+        float d = (kind == 0) ? 1.0f : lvl;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            dsum += d;
+            if (kind == 2) d *= inc;
+        }
+    }
+    wave_sync();   // s_pts is rewritten by the next call
     const float div = dsum / 8.0f;
     int maxLoc = 0;
 #pragma unroll
@@ -650,9 +689,9 @@ __device__ __forceinline__ float early_mismatch_score_grp(const Tables* T, float
     if (evalSf > 32) evalSf = 32;
     const float eps = 1e-9f;
     const float mod = in_j / fmaxf(div, eps);
-    const float e = at3_log2f(T, fmaxf(mod, eps) / fmaxf(target, eps));
+    const float e = at3_log2f(L2, fmaxf(mod, eps) / fmaxf(target, eps));
     const float sq = e * e;
-    const float a = at3_log2f(T, fmaxf(div, eps));
+    const float a = at3_log2f(L2, fmaxf(div, eps));
     s_tmp[j] = a;
     wave_sync();
     const float a_next = s_tmp[j < 31 ? j + 1 : 31];
@@ -660,17 +699,39 @@ __device__ __forceinline__ float early_mismatch_score_grp(const Tables* T, float
     const float d = a_next - a;
     const float w = 0.5f * (in_j + in_next);
     const float lterm = d * d * w;
+    // three ordered 32-term sums: the terms go through LDS and every lane adds them up in order (wide broadcast reads)
+    float* st = s_tmp + 32;   // [3][32] behind the first 32 floats of the item's scratch
+    st[j] = sq;
+    st[32 + j] = lterm;
+    st[64 + j] = w;
+    wave_sync();
     float fit = 0.0f, leak = 0.0f, wsum = 0.0f;
-    for (int sf = 0; sf < 32; ++sf) {   // ordered sums
-        const float v = grp_readlane_f(sq, sf, half);
-        const float lt = grp_readlane_f(lterm, sf, half);
-        const float ww = grp_readlane_f(w, sf, half);
-        if (sf < evalSf) fit += v;
-        if (sf + 1 < evalSf) {
-            leak += lt;
-            wsum += ww;
+    {
+        const float4* a4 = reinterpret_cast<const float4*>(st);
+        float4 va[8], vl[8], vw[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            va[q] = a4[q];
+            vl[q] = a4[8 + q];
+            vw[q] = a4[16 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float v[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
+            const float lt[4] = {vl[q].x, vl[q].y, vl[q].z, vl[q].w};
+            const float ww[4] = {vw[q].x, vw[q].y, vw[q].z, vw[q].w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sf = 4 * q + t;
+                if (sf < evalSf) fit += v[t];
+                if (sf + 1 < evalSf) {
+                    leak += lt[t];
+                    wsum += ww[t];
+                }
+            }
         }
     }
+    wave_sync();   // the scratch is rewritten by the next call
     fit /= (float)evalSf;
     if (wsum > eps) leak /= wsum;
     const float score = fit + 0.25f * leak;
@@ -682,12 +743,22 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
 {
     __shared__ float s_in[8][32];
     __shared__ float s_filt[8][32];
-    __shared__ float s_tmp[8][32];
+    __shared__ __attribute__((aligned(16))) float s_tmp[8][128];   // per item: 32 floats + three 32-term lists of the early-mismatch score
     __shared__ int s_tloc[8][32];
     __shared__ int s_tdelta[8][32];
     __shared__ int s_tlev[8][32];
+    __shared__ uint8_t s_pts[8][16];  // per item: levels [0..6], locations [8..14] of the curve being scored
+    __shared__ Log2fTab s_l2[4];      // per wavefront: the log2f tables and GainInterpolation, so that the rare long
+    __shared__ float s_gi4[4][32];    // path (a few items with curves set the kernel's duration) has no dependent global loads
     const int tid = threadIdx.x;
     const int grp = tid >> 5, j = tid & 31, half = grp & 1;
+    {
+        const int wv = tid >> 6, ln = tid & 63;
+        if (ln < 36) reinterpret_cast<double*>(&s_l2[wv])[ln] = (&T->log2f_tab[0][0])[ln];
+        if (ln < 32) s_gi4[wv][ln] = T->gain_interp[ln < 31 ? ln : 30];
+    }
+    const Log2fTab* L2 = &s_l2[tid >> 6];
+    const float* gi = s_gi4[tid >> 6];
     const int nfr = p.n_blocks - p.f0;
     const int n_items = n_streams * nfr * 6;
     int item = blockIdx.x * 8 + grp;
@@ -727,6 +798,7 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
 
     // ---- CalcCurve (transient_detector.cpp:299-482) ----
     const bool active = valid && !(hfr < 0.05f) && !(target < 1e-6f) && !(savedLastLevel < 1e-6f);
+    if (p.debug == 1) return;
     // An item without curve points after CalcCurve ends as "no_curve" whatever the later stages say
     // (atrac3denc.cpp:395-400), and most items are like that: a wavefront whose two items are both out stops here.
     if (__ballot(active) == 0ull) {
@@ -861,6 +933,7 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
         pts.loc[i] = (i < pts.n) ? s_tloc[grp][i] : 0;
     }
     const bool have = pts.n > 0;   // else "skip: no_curve" (atrac3denc.cpp:395-400)
+    if (p.debug == 2) return;
     if (__ballot(have) == 0ull) {
         if (valid && j == 0) {
             Curve out;
@@ -924,9 +997,12 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
             changed = true;
         }
     }
+    if (p.debug == 3) return;
     // both scores are evaluated unconditionally (wave-uniform control flow); used only when `changed`
-    const float scoreBefore = early_mismatch_score_grp(T, in_j, in_next, target, before, s_tmp[grp], j, half);
-    const float scoreAfter = early_mismatch_score_grp(T, in_j, in_next, target, pts, s_tmp[grp], j, half);
+    const float scoreBefore = early_mismatch_score_grp(L2, gi, in_j, in_next, target, before, s_tmp[grp], s_pts[grp], j, half);
+    if (p.debug == 4) { if (scoreBefore == 12345.0f) *dst = Curve(); return; }
+    const float scoreAfter = early_mismatch_score_grp(L2, gi, in_j, in_next, target, pts, s_tmp[grp], s_pts[grp], j, half);
+    if (p.debug == 5) { if (scoreBefore + scoreAfter == 12345.0f) *dst = Curve(); return; }
     if (changed) {
         bool keepByBoundary = false;
         if (p0ok) {
@@ -935,8 +1011,8 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
             const float scaleBefore = gain_level_of(before.n == 0 ? 4 : before.level[0]);
             const float scaleAfter = gain_level_of(pts.n == 0 ? 4 : pts.level[0]);
             const float eps = 1e-9f;
-            const float errBefore = fabsf(at3_log2f(T, fmaxf(scaleBefore, eps) / fmaxf(desired, eps)));
-            const float errAfter = fabsf(at3_log2f(T, fmaxf(scaleAfter, eps) / fmaxf(desired, eps)));
+            const float errBefore = fabsf(at3_log2f(L2, fmaxf(scaleBefore, eps) / fmaxf(desired, eps)));
+            const float errAfter = fabsf(at3_log2f(L2, fmaxf(scaleAfter, eps) / fmaxf(desired, eps)));
             keepByBoundary = (errAfter + 0.20f < errBefore);
         }
         if (!keepByBoundary && scoreAfter > scoreBefore * (1.0f + 0.02f)) pts = before;

@@ -315,6 +315,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.f0 = f0;
             gp.js = c->js;
             gp.n_streams = S;
+            gp.debug = getenv("AT3HIP_DEBUG_GAIN") ? atoi(getenv("AT3HIP_DEBUG_GAIN")) : 0;
             {   // one round of workgroups over the chip, like the fused kernel
                 const int slots = c->n_cus * c->wgs_per_cu;
                 int runs = slots / S;
