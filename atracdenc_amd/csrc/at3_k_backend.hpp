@@ -1175,6 +1175,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
         if (lane < 32) s_cost[wl * 32 + lane] = cost[wl];
     __syncthreads();
 
+    if (p.debug_stop == 11) return;
     // ---- rate loop: TConfigure / TAlloc under the bisection driver (uniform control flow) ----
     int num_bfu = p.bfu_idx_const ? p.bfu_idx_const : 32;
     if (target < 101) {
@@ -1252,6 +1253,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
     if (lane < 32) s_alloc[lane] = bits;
     __syncthreads();
 
+    if (p.debug_stop == 12) return;
     // ---- emission (WriteSoundUnit header, EncodeSpecs) ----
     int pos = 0;
     if (lane == 0) {
@@ -1285,6 +1287,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
     }
     __syncthreads();
     pos = s_misc[1];
+    if (p.debug_stop == 13) return;
     const unsigned long long nzmask = __ballot(lane < num_bfu && bits != 0);
     if (lane < num_bfu) put_bits(s_words, pos + 3 * lane, (uint32_t)bits, 3);
     pos += 3 * num_bfu;
