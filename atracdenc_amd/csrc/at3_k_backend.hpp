@@ -703,8 +703,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     __shared__ __attribute__((aligned(16))) int8_t s_mant[7 * 1024];
     __shared__ __attribute__((aligned(16))) uint8_t s_si[7 * kEaLines];   // per unit: candidates ordered by |delta|
     __shared__ __attribute__((aligned(16))) float s_uk[kEaLines + 4];     // per wordlen plane: sort keys listed per unit (+inf padded)
-    __shared__ float s_pk[kEaLines];                                      // plane-wide candidate list: key ...
-    __shared__ uint16_t s_pu[kEaLines];                                   // ... and (unit in plane) << 7 | line inside the BFU
+    __shared__ uint32_t s_pu[kEaLines];                                   // candidate lists per size class: unit << 14 | slot in the unit's key list << 7 | line inside the BFU
     __shared__ int s_cnt[2][16];                                          // [0..12] candidates per unit, [13] per plane (double buffered)
     __shared__ uint8_t s_code[7 * (kEaLines / 4)];   // 2 bits per (wordlen, line): 1 = re-roundable when e2 < e1, 2 = when e2 > e1
     __shared__ uint8_t s_nc[91];
@@ -713,7 +712,6 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     __shared__ float s_err[8 * 32];            // e2 during phases B/C, then e1 / e2
     __shared__ uint32_t s_vlc[8 * 32];
     __shared__ uint16_t s_huff[130];
-    __shared__ SortItem s_items[128];          // scratch of the rare tie-order sort
     __shared__ int s_anytie;
 
     const int tid = threadIdx.x;
@@ -816,7 +814,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     // ascending |delta|: the position of a candidate is the number of keys of its unit below its own, which needs
     // the unit's keys as a set only - the lists are filled in arrival order through LDS atomics.
     //   step 1: 64-line chunks -> flag, compact into the unit's key list and into the candidate list of the unit's
-    //           size class (128-, 64- and 32-line BFUs: lists at 0, 256, 512 of s_pk / s_pu)
+    //           size class (128-, 64- and 32-line BFUs: lists at 0, 256, 512 of s_pu)
     //   step 2: wavefront k owns size class k: one lane per listed candidate counts the smaller keys of its unit and
     //           stores its line at that rank. Lists of one class have similar lengths, so the lanes of a wavefront run
     //           the same number of steps; a unit is handled entirely inside one wavefront.
@@ -865,8 +863,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                 const float t = s_val[line] * mul;
                 const float key = fabsf(t - (truncf(t) + 0.5f));   // sort key |delta|
                 s_uk[start - kEaLine0 + base_u + below] = key;
-                s_pk[base_p + below] = key;
-                s_pu[base_p + below] = (uint16_t)(((bfu - 19) << 7) | (line - start));
+                s_pu[base_p + below] = ((uint32_t)(bfu - 19) << 14) | ((uint32_t)(base_u + below) << 7) | (uint32_t)(line - start);
             }
         }
         __syncthreads();
@@ -874,15 +871,15 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
             const int cls = wave;
             const int total = cnt[13 + cls];
             int rank[4] = {0, 0, 0, 0};
-            int where[4] = {0, 0, 0, 0};   // unit << 7 | line
+            int where[4] = {0, 0, 0, 0};   // the list entry (unit, slot, line)
 #pragma unroll
             for (int rd = 0; rd < 4; ++rd) {
                 const int t = rd * 64 + lane;
                 if (t < total) {
-                    const float key = s_pk[256 * cls + t];
-                    const int pu = s_pu[256 * cls + t];
-                    const int ub = pu >> 7;
+                    const int pu = (int)s_pu[256 * cls + t];
+                    const int ub = pu >> 14;
                     const int ustart = ub < 7 ? 32 * ub : ub < 11 ? 64 * ub - 224 : 128 * ub - 928;
+                    const float key = s_uk[ustart + ((pu >> 7) & 127)];
                     const int nc = cnt[ub];
                     const float4* t4 = reinterpret_cast<const float4*>(s_uk + ustart);
                     int r = 0;
@@ -902,7 +899,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
 #pragma unroll
             for (int rd = 0; rd < 4; ++rd) {
                 if (rd * 64 + lane < total && plane_sorted[rank[rd]] != (uint8_t)(where[rd] & 127)) {
-                    s_tie[(wl - 1) * 13 + (where[rd] >> 7)] = 1;
+                    s_tie[(wl - 1) * 13 + (where[rd] >> 14)] = 1;
                     s_anytie = 1;
                 }
             }
@@ -929,6 +926,8 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     //      elements depends on the whole array the reference sorts, so the full |delta| < 0.25 list is rebuilt,
     //      sorted with the restated algorithm and then filtered.
     if (s_anytie) {
+        SortItem* s_items = reinterpret_cast<SortItem*>(s_uk);   // scratch of the rare tie-order sort: the key lists are dead now
+        static_assert(sizeof(SortItem) * 128 <= sizeof(float) * (kEaLines + 4), "tie-sort scratch must fit in the key lists");
         if (tid == 0) {
             for (int u = 0; u < 91; ++u) {
                 if (!s_tie[u]) continue;
