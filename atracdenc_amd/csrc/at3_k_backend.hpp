@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     __syncthreads();
 
     if (tid == 192) {
-        // loudness: strictly sequential 1024-term sum, on its own wavefront
+        // loudness: strictly sequential 1024-term sum, on its own wavefront, at raised issue priority: the workgroup's
+        // lifetime is this chain, and a dependent add that has to queue behind seven other wavefronts costs 8x
+        __builtin_amdgcn_s_setprio(3);
         const float4* t4 = reinterpret_cast<const float4*>(s_term);
         float l = 0.0f;
         float4 cur = t4[0];
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
             cur = nxt;
         }
         rec->loud_ch = l;
+        __builtin_amdgcn_s_setprio(0);
     }
 
     if (!p.no_tonal && tid >= 8 && tid < 29) {
@@ -766,6 +769,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     // ---- (B) ordered sums on wavefront 0: lane -> `per` chains of `len` lines, chain c = (bfu, kind),
     //      kind 0 = e1 (sum of value^2), kind 1..7 = e2 of that wordlen (sum of mantissa^2 / mul^2) ----
     if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);   // the other three wavefronts wait for these chains
         int len, first_chain, bfu_top;
         if (lane < 16) { len = 128; first_chain = lane; bfu_top = 31; }
         else if (lane < 32) { len = 64; first_chain = (lane - 16) * 2; bfu_top = 29; }
@@ -803,6 +807,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                 else s_err[kind * 32 + bfu] = acc;
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     if (p.debug_stop == 2) return;
@@ -964,6 +969,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
     // (C4) sequential re-rounding pass, one lane per unit
     //      Wide BFUs (long candidate lists) share wavefront 0, the 32-line BFUs wavefront 1: a wavefront runs as long
     //      as its longest list.
+    if (tid < 128) __builtin_amdgcn_s_setprio(3);   // two wavefronts run the ordered passes, two wait
     if (tid < 42 || (tid >= 64 && tid < 113)) {
         const int wl = (tid < 42) ? 1 + tid / 6 : 1 + (tid - 64) / 7;
         const int bfu = (tid < 42) ? 26 + tid % 6 : 19 + (tid - 64) % 7;
@@ -977,6 +983,7 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
                                              s_err[wl * 32 + bfu], s_mant + (wl - 1) * 1024 + start);
         }
     }
+    if (tid < 128) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (p.debug_stop == 4) return;
 

@@ -99,6 +99,7 @@ void emu_wave_barrier();
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 
