@@ -85,7 +85,6 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     __shared__ __attribute__((aligned(16))) float s_spec[1024];
     __shared__ __attribute__((aligned(16))) float s_e[1024];
     __shared__ __attribute__((aligned(16))) float s_term[1024];
-    __shared__ double s_log[768];
     __shared__ int s_run_start[32];
     __shared__ int s_run_len[32];
     __shared__ uint16_t s_tv_pos[112];
@@ -117,15 +116,6 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
         *reinterpret_cast<float4*>(s_spec + 4 * tid) = x4;
         *reinterpret_cast<float4*>(s_e + 4 * tid) = e4;
         *reinterpret_cast<float4*>(s_term + 4 * tid) = t4;
-        if (!p.no_tonal && 4 * tid >= 64 && 4 * tid < 768) {
-            const double floor_ = (double)1e-12f;
-            const float ev[4] = {e4.x, e4.y, e4.z, e4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double e = (double)fmaxf(0.0f, ev[k]);
-                s_log[4 * tid + k] = log(e > floor_ ? e : floor_);
-            }
-        }
     }
     if (tid < 32) {
         s_run_len[tid] = 0;
@@ -157,13 +147,29 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     if (!p.no_tonal && tid >= 8 && tid < 29) {
         const int b = tid;
         const int start = bfu_start(b), end = bfu_start(b + 1), len = end - start;
-        double arith = 0.0, meanLog = 0.0;
-        for (int i = start; i < end; ++i) {
-            arith += (double)fmaxf(0.0f, s_e[i]);
-            meanLog += s_log[i];
+        // CalcSpectralFlatnessPerBfu (atrac_psy_common.cpp:158-199) needs mean(log(max(e, floor))). The logarithm of a
+        // product is the sum of the logarithms: the lines' f64 mantissas are multiplied (8 .. 64 factors in [0.5, 1),
+        // no underflow), their exponents added, and ONE log per BFU closes the sum - instead of one f64 log per
+        // spectral line, which was a third of this kernel. The result differs from the reference's sum of rounded
+        // logs by a few 1e-16 relative; it is narrowed to f32 and only compared with 0.01.
+        double arith = 0.0, prod = 1.0;
+        int esum = 0;
+        const double floor_ = (double)1e-12f;
+        for (int i0 = start; i0 < end; i0 += 8) {
+            const float4 ea = *reinterpret_cast<const float4*>(s_e + i0), eb = *reinterpret_cast<const float4*>(s_e + i0 + 4);
+            const float ev[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double e = (double)fmaxf(0.0f, ev[k]);
+                arith += e;
+                const double d = e > floor_ ? e : floor_;
+                const uint64_t bits = (uint64_t)__double_as_longlong(d);
+                esum += (int)((bits >> 52) & 0x7ffu) - 1022;
+                prod *= __longlong_as_double((long long)((bits & 0x800fffffffffffffull) | 0x3fe0000000000000ull));
+            }
         }
         arith /= (double)len;
-        meanLog /= (double)len;
+        const double meanLog = (log(prod) + (double)esum * 0.69314718055994530942) / (double)len;
         float flat = 1.0f;
         if (!(arith <= (double)1e-12f)) {
             const double ratio = exp(meanLog) / arith;

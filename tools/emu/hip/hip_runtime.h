@@ -55,6 +55,8 @@ void emu_syncthreads();
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __float2int_rn(float f) { return (int)lrintf(f); }
+static inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
+static inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 template <typename T, typename U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = o + (T)v; return o; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
