@@ -155,6 +155,25 @@ def test_full_batch_config_properties(hip, oracle):
         assert np.array_equal(got[i], oracle.encode(pcm[i], LP2)[0]), i
 
 
+@pytest.mark.parametrize("br", [LP2, LP4])
+def test_config3_shard_properties(hip, oracle, br):
+    """The per-GPU shard of BASELINE configs[2]/[3] (1M frames on 8 GPUs): 1024 streams x 128 frames, LP2 and LP4.
+    Long workgroup runs (32 frames), many grid rounds; checked through size-independent properties and spot streams."""
+    S, nb = 1024, 129
+    base = [SIGNALS["noise"](nb, seed=7), SIGNALS["mix"](nb, seed=8), SIGNALS["burst"](nb), SIGNALS["tones"](nb),
+            SIGNALS["noise"](nb, seed=11), SIGNALS["mix"](nb, seed=12), SIGNALS["silence"](nb), SIGNALS["burst"](nb, period=2500, phase=700)]
+    pcm = np.stack([base[i % 8] for i in range(S)])
+    enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=br)
+    got = enc.encode(pcm)
+    enc.close()
+    fsz = 384 if br == LP2 else 192
+    assert got.shape == (S, 128, fsz)
+    for i in range(8, S, 37):
+        assert np.array_equal(got[i], got[i % 8]), i           # identical streams -> identical frames, wherever they run
+    for i in (1, 2, 3):                                        # spot streams against the oracle (burst: multi-point curves)
+        assert np.array_equal(got[i], oracle.encode(pcm[i], br)[0]), i
+
+
 def test_mono_input_lp2(hip, oracle):
     # SourceChannels = 1 (atrac3.h:260-277): [stream][block][1024][1] in, the one sound unit twice per frame out
     nb = 24
