@@ -76,18 +76,21 @@ __device__ __forceinline__ void modulate_cell(const Curve& cv, const float* gain
 }
 
 // CalcGainEnergyScale (atrac3denc.cpp:175-224), the `Frame` value the psychoacoustics and the allocator use: ratio of
-// the frame's energy without and with gain modulation. One wavefront per (stream, frame), eight bands. The value is
-// 1 unless this block's or the previous block's curve is non-empty, which is the case for a few per cent of the bands;
-// those compute five strictly ordered 256-term sums: three over this block (carried overlap, windowed original,
-// windowed modulated) and two over the previous one (its "next overlap" scale, which the reference carries forward as
-// PrevOverlapGainScale). Lanes 0..31 own the eight-sample cells of the current block, lanes 32..63 those of the
-// previous block; lanes 0..4 then add the staged terms in order.
-__global__ __launch_bounds__(256) void k_gain_energy_scale(FrontParams p, const Tables* T, int n_frames_total)
+// the frame's energy without and with gain modulation. One wavefront per (stream, frame), all eight bands at once. The
+// value is 1 unless this block's or the previous block's curve is non-empty, which is the case for a few per cent of
+// the bands (but then often for several bands of the same frame); those need five strictly ordered 256-term sums: three
+// over this block (carried overlap, windowed original, windowed modulated) and two over the previous one (its "next
+// overlap" scale, which the reference carries forward as PrevOverlapGainScale).
+// Lane (band = lane / 8, slot = lane % 8) produces, in four rounds of 64 samples, the terms of cell 8 round + slot of
+// its band for both blocks; lanes 0..39 = (band, sum) then extend the 40 ordered sums by 64 terms each.
+__global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const Tables* T, int n_frames_total)
 {
-    __shared__ __attribute__((aligned(16))) float s_terms[4][5][256];
-    __shared__ __attribute__((aligned(16))) Curve s_cv[4][8][2];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sf = blockIdx.x * 4 + wave;             // (stream, frame): the wavefront looks at its eight bands together
+    __shared__ __attribute__((aligned(16))) float s_terms[1][8][5][64];   // one wavefront per workgroup: 10 KB, so that
+    __shared__ __attribute__((aligned(16))) Curve s_cv[1][8][2];           // every frame of a 4096-frame batch is resident at once
+    __shared__ __attribute__((aligned(16))) float s_win[256];
+    const int wave = 0, lane = threadIdx.x;
+    *reinterpret_cast<float4*>(s_win + 4 * lane) = *reinterpret_cast<const float4*>(T->enc_win + 4 * lane);
+    const int sf = blockIdx.x;
     if (sf >= n_frames_total) return;
     const int nfr = p.n_blocks - p.f0;
     const int f = p.f0 + sf % nfr;
@@ -102,99 +105,112 @@ __global__ __launch_bounds__(256) void k_gain_energy_scale(FrontParams p, const 
         *reinterpret_cast<uint4*>(&s_cv[wave][lane][0]) = w_cur;
         *reinterpret_cast<uint4*>(&s_cv[wave][lane][1]) = w_prev;
     }
-    const bool active = lane < 8 && (((w_cur.x | w_prev.x) & 0xffu) != 0u);   // Curve::n is the first byte
-    uint32_t todo = (uint32_t)__ballot(active);
+    const uint32_t active = (uint32_t)__ballot(lane < 8 && (((w_cur.x | w_prev.x) & 0xffu) != 0u));   // Curve::n is the first byte
     float* out8 = p.ges + ((size_t)s * p.n_blocks + f) * 8;
-    if (lane < 8 && !active) out8[lane] = 1.0f;       // no modulation on either side: every ratio is exactly 1
+    if (lane < 8 && !((active >> lane) & 1u)) out8[lane] = 1.0f;   // no modulation on either side: every ratio is exactly 1
+    if (active == 0u || p.debug == 3) return;
     wave_sync();
-    const int mine = lane >> 5;                       // 0: current block, 1: previous block
-    const int cell = 8 * (lane & 31);
+    const int c = lane >> 3, slot = lane & 7;
+    const bool on = (active >> c) & 1u;
+    const Curve& cv_cur = s_cv[wave][c][0];
+    const Curve& cv_prev = s_cv[wave][c][1];
+    const bool has_cur = cv_cur.n > 0, has_prev = cv_prev.n > 0;
+    const int ch = c >> 2, band = c & 3;
     const size_t sublen = (size_t)(p.n_blocks + 2) * 256;
-    const size_t at = (size_t)(b - mine + 2) * 256 + cell;
-    float wc[8], wn[8];
+    const float* sb0 = p.sub + ((size_t)s * 8 + band) * sublen + (size_t)(b + 2) * 256;       // left / own channel, current block
+    const float* sb1 = p.sub + ((size_t)s * 8 + 4 + band) * sublen + (size_t)(b + 2) * 256;   // right
+    float acc = 0.0f;
+    const int cc = lane / 5, kk = lane % 5;   // chain lanes: band cc, sum kk
+    const bool chain = lane < 40 && ((active >> cc) & 1u);
+    // all samples this lane will need (four cells of the current and of the previous block), fetched up front
+    float xc[4][8], xp[4][8];
+    if (on) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        wc[k] = T->enc_win[255 - (cell + k)];
-        wn[k] = T->enc_win[cell + k];
-    }
-    while (todo) {
-        const int c = __builtin_ctz(todo);
-        todo &= todo - 1;
-        const Curve& cv_cur = s_cv[wave][c][0];
-        const Curve& cv_prev = s_cv[wave][c][1];
-        const bool has_cur = cv_cur.n > 0, has_prev = cv_prev.n > 0;
-        // raw subband samples of this lane's cell (M/S matrixed for joint stereo, atrac3denc.cpp:665-677)
-        const int ch = c >> 2, band = c & 3;
-        const float* sb0 = p.sub + ((size_t)s * 8 + band) * sublen + at;
-        const float* sb1 = p.sub + ((size_t)s * 8 + 4 + band) * sublen + at;
-        float x[8];
-        {
-            const float4 a0 = *reinterpret_cast<const float4*>(ch ? sb1 : sb0), a1 = *reinterpret_cast<const float4*>((ch ? sb1 : sb0) + 4);
-            x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
-            if (p.js) {
-                const float4 l0 = *reinterpret_cast<const float4*>(sb0), l1 = *reinterpret_cast<const float4*>(sb0 + 4);
-                const float4 r0 = *reinterpret_cast<const float4*>(sb1), r1 = *reinterpret_cast<const float4*>(sb1 + 4);
-                const float l[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w}, r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        for (int rd = 0; rd < 4; ++rd) {
+            const int cell = 8 * (8 * rd + slot);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) x[k] = ch ? (l[k] - r[k]) * 0.5f : (l[k] + r[k]) * 0.5f;
+            for (int h = 0; h < 2; ++h) {
+                const float* q0 = sb0 + cell + 4 * h;
+                const float* q1 = sb1 + cell + 4 * h;
+                float4 l = *reinterpret_cast<const float4*>(ch ? q1 : q0), lp = *reinterpret_cast<const float4*>((ch ? q1 : q0) - 256);
+                if (p.js) {   // M/S matrixing (atrac3denc.cpp:665-677)
+                    const float4 a0 = *reinterpret_cast<const float4*>(q0), a1 = *reinterpret_cast<const float4*>(q1);
+                    const float4 b0 = *reinterpret_cast<const float4*>(q0 - 256), b1 = *reinterpret_cast<const float4*>(q1 - 256);
+                    if (ch) {
+                        l.x = (a0.x - a1.x) * 0.5f; l.y = (a0.y - a1.y) * 0.5f; l.z = (a0.z - a1.z) * 0.5f; l.w = (a0.w - a1.w) * 0.5f;
+                        lp.x = (b0.x - b1.x) * 0.5f; lp.y = (b0.y - b1.y) * 0.5f; lp.z = (b0.z - b1.z) * 0.5f; lp.w = (b0.w - b1.w) * 0.5f;
+                    } else {
+                        l.x = (a0.x + a1.x) * 0.5f; l.y = (a0.y + a1.y) * 0.5f; l.z = (a0.z + a1.z) * 0.5f; l.w = (a0.w + a1.w) * 0.5f;
+                        lp.x = (b0.x + b1.x) * 0.5f; lp.y = (b0.y + b1.y) * 0.5f; lp.z = (b0.z + b1.z) * 0.5f; lp.w = (b0.w + b1.w) * 0.5f;
+                    }
+                }
+                xc[rd][4 * h] = l.x; xc[rd][4 * h + 1] = l.y; xc[rd][4 * h + 2] = l.z; xc[rd][4 * h + 3] = l.w;
+                xp[rd][4 * h] = lp.x; xp[rd][4 * h + 1] = lp.y; xp[rd][4 * h + 2] = lp.z; xp[rd][4 * h + 3] = lp.w;
             }
         }
-        float m[8];
+    }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) m[k] = x[k];
-        if (mine ? has_prev : has_cur) modulate_cell(mine ? cv_prev : cv_cur, T->gain_interp, cell, m);
-        float (*terms)[256] = s_terms[wave];
+    for (int rd = 0; rd < 4; ++rd) {
+        if (on) {
+            const int cell = 8 * (8 * rd + slot);
+            float mc[8], mp[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = cell + k;
-            if (mine == 0) {
-                const float cw = x[k] * wc[k], mw = m[k] * wc[k];
-                terms[1][i] = cw * cw;
-                terms[2][i] = mw * mw;
-            } else {
-                const float pv = wn[k] * m[k];              // the overlap this block inherited: EncodeWindow[i] * modulated sample
-                const float nw = x[k] * wn[k], mnw = m[k] * wn[k];
-                terms[0][i] = pv * pv;
-                terms[3][i] = nw * nw;
-                terms[4][i] = mnw * mnw;
+            for (int k = 0; k < 8; ++k) {
+                mc[k] = xc[rd][k];
+                mp[k] = xp[rd][k];
+            }
+            if (has_cur) modulate_cell(cv_cur, T->gain_interp, cell, mc);
+            if (has_prev) modulate_cell(cv_prev, T->gain_interp, cell, mp);
+            float (*terms)[64] = s_terms[wave][c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = cell + k, o = 8 * slot + k;
+                const float wc = s_win[255 - i], wn = s_win[i];
+                const float pv = wn * mp[k];                // the overlap this block inherited: EncodeWindow[i] * modulated sample
+                const float cw = xc[rd][k] * wc, mw = mc[k] * wc, nw = xp[rd][k] * wn, mnw = mp[k] * wn;
+                terms[0][o] = pv * pv;
+                terms[1][o] = cw * cw;
+                terms[2][o] = mw * mw;
+                terms[3][o] = nw * nw;
+                terms[4][o] = mnw * mnw;
             }
         }
         wave_sync();
-        float acc = 0.0f;
-        if (lane < 5) {
-            const float4* t4 = reinterpret_cast<const float4*>(terms[lane]);
-            for (int q0 = 0; q0 < 64; q0 += 8) {
-                float4 v[8];
+        if (chain) {
+            const float4* t4 = reinterpret_cast<const float4*>(s_terms[wave][cc][kk]);
+            float4 v[16];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = t4[q0 + q];
+            for (int q = 0; q < 16; ++q) v[q] = t4[q];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    acc += v[q].x;
-                    acc += v[q].y;
-                    acc += v[q].z;
-                    acc += v[q].w;
-                }
+            for (int q = 0; q < 16; ++q) {
+                acc += v[q].x;
+                acc += v[q].y;
+                acc += v[q].z;
+                acc += v[q].w;
             }
         }
-        const float s0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 0));
-        const float s1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 1));
-        const float s2 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 2));
-        const float s3 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 3));
-        const float s4 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc), 4));
-        if (lane == 0) {
-            // PrevOverlapGainScale: the previous block's NextOverlapScale, 1 when that block had no curve (equal sums)
-            float ps = has_prev ? safe_energy_scale(s3, s4) : 1.0f;
-            float frame_scale = 1.0f;
-            if (has_cur || ps != 1.0f) {
-                if (!isfinite(ps) || ps <= 0.0f) ps = 1.0f;
-                const float prevDiv = has_cur ? gain_level_of(cv_cur.level[0]) : 1.0f;
-                const float prevOrig = s0 * ps;
-                const float prevMod = s0 / (prevDiv * prevDiv);
-                frame_scale = safe_energy_scale(prevOrig + s1, prevMod + s2);
-            }
-            out8[c] = frame_scale;
+        wave_sync();   // the term buffers are rewritten by the next round
+    }
+    // the five sums of band cc sit in lanes 5 cc .. 5 cc + 4; the first of them closes the formula
+    const float s1 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 1), (int)__float_as_uint(acc)));
+    const float s2 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 2), (int)__float_as_uint(acc)));
+    const float s3 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 3), (int)__float_as_uint(acc)));
+    const float s4 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 4), (int)__float_as_uint(acc)));
+    if (chain && kk == 0) {
+        const Curve& q_cur = s_cv[wave][cc][0];
+        const bool h_cur = q_cur.n > 0, h_prev = s_cv[wave][cc][1].n > 0;
+        const float s0 = acc;
+        // PrevOverlapGainScale: the previous block's NextOverlapScale, 1 when that block had no curve (equal sums)
+        float ps = h_prev ? safe_energy_scale(s3, s4) : 1.0f;
+        float frame_scale = 1.0f;
+        if (h_cur || ps != 1.0f) {
+            if (!isfinite(ps) || ps <= 0.0f) ps = 1.0f;
+            const float prevDiv = h_cur ? gain_level_of(q_cur.level[0]) : 1.0f;
+            const float prevOrig = s0 * ps;
+            const float prevMod = s0 / (prevDiv * prevDiv);
+            frame_scale = safe_energy_scale(prevOrig + s1, prevMod + s2);
         }
-        wave_sync();   // the term buffer is reused by the next band
+        out8[cc] = frame_scale;
     }
 }
 

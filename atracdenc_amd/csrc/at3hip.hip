@@ -331,7 +331,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             HIPCHK(c, hipEventRecord(c->ev[2], st));
             hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), 0, st, gp, S);
             hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), 0, st, gp, c->d_tables, S);
-            hipLaunchKernelGGL(k_gain_energy_scale, dim3((S * n_out + 3) / 4), dim3(256), 0, st, fp, c->d_tables, S * n_out);
+            hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), 0, st, fp, c->d_tables, S * n_out);
         } else {
             HIPCHK(c, hipEventRecord(c->ev[1], st));
             HIPCHK(c, hipEventRecord(c->ev[2], st));
