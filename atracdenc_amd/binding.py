@@ -11,6 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 
 AT3HIP_PCM_ON_DEVICE = 1
 AT3HIP_OUT_ON_DEVICE = 2
+AT3HIP_ASYNC = 4
 LP2 = 132300
 LP4 = 66150
 
@@ -31,7 +32,7 @@ class Timings(ctypes.Structure):
 
 SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint_stereo", "at3hip_last_error",
            "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
-           "at3hip_set_stream", "at3hip_version"]
+           "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago"]
 
 
 def build_library(verbose=False):
@@ -76,6 +77,8 @@ def load_library(path=None):
     lib.at3hip_qmf_mdct.argtypes = [vp, vp, i32, vp, ctypes.c_uint32]
     lib.at3hip_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
     lib.at3hip_set_stream.argtypes = [vp, vp]
+    lib.at3hip_sync.argtypes = [vp]
+    lib.at3hip_get_timings_ago.argtypes = [vp, i32, ctypes.POINTER(Timings)]
     lib.at3hip_version.restype = ctypes.c_uint32
     _lib_cache[path] = lib
     return lib
@@ -130,13 +133,22 @@ class At3Hip:
         return np.ascontiguousarray(out.reshape(-1)[: self.n_streams * n * self.frame_size].reshape(
             self.n_streams, n, self.frame_size))
 
-    def encode_device(self, pcm_ptr, n_blocks, out_ptr):
-        """Device-resident PCM/out (raw pointers, e.g. torch tensor .data_ptr()). Returns frames per stream."""
+    def encode_device(self, pcm_ptr, n_blocks, out_ptr, asynchronous=False):
+        """Device-resident PCM/out (raw pointers, e.g. torch tensor .data_ptr()). Returns frames per stream.
+        asynchronous=True only queues the work (AT3HIP_ASYNC): call sync() before the frames are read."""
         nf = ctypes.c_int32()
+        flags = AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE | (AT3HIP_ASYNC if asynchronous else 0)
         self._check(self.lib.at3hip_encode(self.ctx, ctypes.c_void_p(pcm_ptr), n_blocks, ctypes.c_void_p(out_ptr),
-                                           ctypes.byref(nf), AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE),
-                    "at3hip_encode")
+                                           ctypes.byref(nf), flags), "at3hip_encode")
         return nf.value
+
+    def sync(self):
+        self._check(self.lib.at3hip_sync(self.ctx), "at3hip_sync")
+
+    def timings_ago(self, ago):
+        t = Timings()
+        self._check(self.lib.at3hip_get_timings_ago(self.ctx, int(ago), ctypes.byref(t)), "at3hip_get_timings_ago")
+        return {n: getattr(t, n) for n, _ in Timings._fields_}
 
     def qmf_mdct_device(self, pcm_ptr, n_blocks, specs_ptr):
         self._check(self.lib.at3hip_qmf_mdct(self.ctx, ctypes.c_void_p(pcm_ptr), n_blocks, ctypes.c_void_p(specs_ptr),

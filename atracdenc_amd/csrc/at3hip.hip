@@ -38,8 +38,18 @@ struct at3hip_ctx {
     int js = 0;
     int device = 0;
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipStream_t stream = nullptr;        // front half: QMF, gain control, fused QMF+MDCT, carried state
+    hipStream_t back_stream = nullptr;   // back half: psychoacoustics, quantisation, rate loop, packing
+    // The back half of call N only consumes what the front half of call N produced (spectra, curves, energy scales),
+    // and the front half of call N+1 only depends on the front half of call N (carried state): the two halves run on
+    // two HIP streams, buffers that cross between them are double-buffered by call parity, and consecutive calls overlap.
+    static constexpr int kSlots = 32;    // timing history (events per call)
+    hipEvent_t ev[kSlots][8] = {};
+    hipEvent_t ev_back_done[2] = {};     // back half finished with the parity's cross buffers
+    bool back_done_valid[2] = {false, false};
+    long long enc_calls = 0;             // at3hip_encode calls so far
+    int last_slot = -1;                  // slot of the most recent call that produced frames
+    bool slot_has_frames[kSlots] = {};
     char err[256] = {0};
     long long blocks_fed = 0;   // per stream
     int frames_per_wg = 0;
@@ -54,9 +64,9 @@ struct at3hip_ctx {
     float* d_sub = nullptr;
     GainRec* d_rec = nullptr;
     BandState* d_state = nullptr;
-    Curve* d_curves = nullptr;
-    float* d_specs = nullptr;
-    float* d_ges = nullptr;
+    Curve* d_curves[2] = {nullptr, nullptr};   // by call parity
+    float* d_specs[2] = {nullptr, nullptr};
+    float* d_ges[2] = {nullptr, nullptr};
     PsyRec* d_psy = nullptr;
     float* d_loud = nullptr;
     float* d_loud_state = nullptr;
@@ -91,6 +101,31 @@ int dev_alloc(at3hip_ctx* c, Tp** p, size_t count)
     if (e != hipSuccess) return fail(c, AT3HIP_ENOMEM, "hipMalloc", e);
     *p = (Tp*)q;
     return AT3HIP_OK;
+}
+
+// Waits for everything this context has queued on its two streams.
+int drain(at3hip_ctx* c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->back_stream));
+    return AT3HIP_OK;
+}
+
+// Stage timings of the call recorded in `slot` (its events must have completed).
+void read_timings(const at3hip_ctx* c, int slot, at3hip_timings* tm)
+{
+    memset(tm, 0, sizeof(*tm));
+    if (slot < 0 || !c->slot_has_frames[slot]) return;
+    hipEvent_t const* ev = c->ev[slot];
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, ev[0], ev[1]); tm->qmf_ms = ms;
+    (void)hipEventElapsedTime(&ms, ev[1], ev[2]); tm->gain_ms = ms;
+    (void)hipEventElapsedTime(&ms, ev[2], ev[3]); tm->curve_ms = ms;
+    (void)hipEventElapsedTime(&ms, ev[3], ev[4]); tm->qmf_mdct_ms = ms;
+    (void)hipEventElapsedTime(&ms, ev[5], ev[6]); tm->psy_ms = ms;
+    (void)hipEventElapsedTime(&ms, ev[6], ev[7]); tm->alloc_ms = ms;
+    (void)hipEventElapsedTime(&ms, ev[0], ev[7]); tm->total_ms = ms;   // first front-half kernel to last back-half kernel
+    tm->qmf_mdct_launches = 1;
 }
 
 // Frames per workgroup run of the fused kernel: long runs amortise the one-block prologue, short runs keep
@@ -163,10 +198,20 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
         return code;
     };
     if (hipSetDevice(c->device) != hipSuccess) return bail(AT3HIP_EDEVICE);
-    if (hipStreamCreate(&c->own_stream) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    {
+        // the front half is short, latency-bound kernels; it gets the higher stream priority so that its workgroups are
+        // placed ahead of the back half's long throughput kernels when both streams have work
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // lo = numerically greatest = lowest priority
+        if (hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(AT3HIP_EDEVICE);
+        if (hipStreamCreateWithPriority(&c->back_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    }
     c->stream = c->own_stream;
-    for (auto& e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    for (auto& row : c->ev)
+        for (auto& e : row)
+            if (hipEventCreate(&e) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    for (auto& e : c->ev_back_done)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
 
     const size_t S = cfg->n_streams, B = cfg->max_blocks;
     Tables* host_tables = new (std::nothrow) Tables();
@@ -187,11 +232,14 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if (!cfg->no_gain_control) {
         if ((rc = dev_alloc(c, &c->d_sub, S * 8 * (B + 2) * 256)) != AT3HIP_OK) return bail(rc);
         if ((rc = dev_alloc(c, &c->d_rec, S * B * 6)) != AT3HIP_OK) return bail(rc);
-        if ((rc = dev_alloc(c, &c->d_ges, S * B * 8)) != AT3HIP_OK) return bail(rc);
+        for (int q = 0; q < 2; ++q)
+            if ((rc = dev_alloc(c, &c->d_ges[q], S * B * 8)) != AT3HIP_OK) return bail(rc);
     }
     if ((rc = dev_alloc(c, &c->d_state, S * 8)) != AT3HIP_OK) return bail(rc);
-    if ((rc = dev_alloc(c, &c->d_curves, S * B * 8)) != AT3HIP_OK) return bail(rc);
-    if ((rc = dev_alloc(c, &c->d_specs, S * B * 2048)) != AT3HIP_OK) return bail(rc);
+    for (int q = 0; q < 2; ++q) {
+        if ((rc = dev_alloc(c, &c->d_curves[q], S * B * 8)) != AT3HIP_OK) return bail(rc);
+        if ((rc = dev_alloc(c, &c->d_specs[q], S * B * 2048)) != AT3HIP_OK) return bail(rc);
+    }
     if ((rc = dev_alloc(c, &c->d_psy, S * B * 2)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_loud, S * B)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_loud_state, S)) != AT3HIP_OK) return bail(rc);
@@ -219,14 +267,21 @@ void at3hip_destroy(at3hip_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void* bufs[] = {c->d_tables, c->d_pcm_in, c->d_hist[0], c->d_hist[1], c->d_sub,  c->d_rec,        c->d_state,
-                    c->d_curves, c->d_specs,  c->d_ges,     c->d_psy,     c->d_loud, c->d_loud_state, c->d_out, c->d_quant, c->d_mant, c->d_pcm_mono};
+    if (c->back_stream) (void)hipStreamSynchronize(c->back_stream);
+    void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
+                    c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
+                    c->d_out,       c->d_quant,     c->d_mant,     c->d_pcm_mono};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
-    for (auto& e : c->ev)
+    for (auto& row : c->ev)
+        for (auto& e : row)
+            if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_back_done)
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->back_stream) (void)hipStreamDestroy(c->back_stream);
     delete c;
 }
 
@@ -237,6 +292,9 @@ const char* at3hip_last_error(const at3hip_ctx* c) { return c ? c->err : "null c
 int at3hip_set_stream(at3hip_ctx* c, void* hip_stream)
 {
     if (!c) return AT3HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = drain(c);
+    if (rc != AT3HIP_OK) return rc;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return AT3HIP_OK;
 }
@@ -245,6 +303,8 @@ int at3hip_reset(at3hip_ctx* c)
 {
     if (!c) return AT3HIP_EINVAL;
     HIPCHK(c, hipSetDevice(c->device));
+    const int rc = drain(c);
+    if (rc != AT3HIP_OK) return rc;
     return reset_state(c);
 }
 
@@ -287,18 +347,27 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     uint8_t* d_out = (flags & AT3HIP_OUT_ON_DEVICE) ? out_frames : c->d_out;
     const float* hist = c->d_hist[c->hist_cur];
     float* hist_next = c->d_hist[c->hist_cur ^ 1];
-    memset(&c->tm, 0, sizeof(c->tm));
+    hipStream_t bk = c->back_stream;
+    const int par = (int)(c->enc_calls & 1);
+    const int slot = (int)(c->enc_calls % at3hip_ctx::kSlots);
+    hipEvent_t* ev = c->ev[slot];
+    Curve* d_curves = c->d_curves[par];
+    float* d_specs = c->d_specs[par];
+    float* d_ges = c->d_ges[par];
+    c->slot_has_frames[slot] = false;
 
-    HIPCHK(c, hipEventRecord(c->ev[0], st));
-    HIPCHK(c, hipMemsetAsync(c->d_curves, 0, (size_t)S * n_blocks * 8 * sizeof(Curve), st));
+    // the back half of the call before the previous one must be done with this parity's spectra / curves / scales
+    if (c->back_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_back_done[par], 0));
+    HIPCHK(c, hipEventRecord(ev[0], st));
+    HIPCHK(c, hipMemsetAsync(d_curves, 0, (size_t)S * n_blocks * 8 * sizeof(Curve), st));
     if (n_out > 0) {
         FrontParams fp;
         fp.pcm = d_pcm;
         fp.hist = hist;
-        fp.curves = c->d_curves;
+        fp.curves = d_curves;
         fp.state = c->d_state;
-        fp.specs = c->d_specs;
-        fp.ges = c->d_ges;
+        fp.specs = d_specs;
+        fp.ges = d_ges;
         fp.sub = c->d_sub;
         fp.n_blocks = n_blocks;
         fp.f0 = f0;
@@ -310,7 +379,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.sub = c->d_sub;
             gp.rec = c->d_rec;
             gp.state = c->d_state;
-            gp.curves = c->d_curves;
+            gp.curves = d_curves;
             gp.n_blocks = n_blocks;
             gp.f0 = f0;
             gp.js = c->js;
@@ -326,26 +395,42 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
                 const int nch = (n_blocks + 2 + bpw - 1) / bpw;
                 hipLaunchKernelGGL(k_qmf_sub, dim3(S * nch), dim3(256), 0, st, fp, c->d_tables);
             }
-            HIPCHK(c, hipEventRecord(c->ev[1], st));
+            HIPCHK(c, hipEventRecord(ev[1], st));
             hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), 0, st, gp, c->d_tables);
-            HIPCHK(c, hipEventRecord(c->ev[2], st));
+            HIPCHK(c, hipEventRecord(ev[2], st));
             hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), 0, st, gp, S);
             hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), 0, st, gp, c->d_tables, S);
             hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), 0, st, fp, c->d_tables, S * n_out);
         } else {
-            HIPCHK(c, hipEventRecord(c->ev[1], st));
-            HIPCHK(c, hipEventRecord(c->ev[2], st));
+            fp.sub_blocks_per_wg = 0;
+            HIPCHK(c, hipEventRecord(ev[1], st));
+            HIPCHK(c, hipEventRecord(ev[2], st));
         }
-        HIPCHK(c, hipEventRecord(c->ev[3], st));
+        HIPCHK(c, hipEventRecord(ev[3], st));
         const int nchunks = (n_out + fp.frames_per_wg - 1) / fp.frames_per_wg;
         if (gain) hipLaunchKernelGGL(k_qmf_mdct<true>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
         else hipLaunchKernelGGL(k_qmf_mdct<false>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
-        HIPCHK(c, hipEventRecord(c->ev[4], st));
-
+        HIPCHK(c, hipEventRecord(ev[4], st));
+    }
+    {
+        StateParams sp;
+        sp.pcm = d_pcm;
+        sp.hist_in = hist;
+        sp.hist_out = hist_next;
+        sp.curves = d_curves;
+        sp.state = c->d_state;
+        sp.n_blocks = n_blocks;
+        sp.n_streams = S;
+        hipLaunchKernelGGL(k_state_update, dim3((kHist + 255) / 256, S), dim3(256), 0, st, sp);
+    }
+    if (n_out > 0) {
+        // ---- back half, on its own stream, after the fused kernel of THIS call ----
+        HIPCHK(c, hipStreamWaitEvent(bk, ev[4], 0));
+        HIPCHK(c, hipEventRecord(ev[5], bk));
         BackParams bp;
-        bp.specs = c->d_specs;
-        bp.ges = gain ? c->d_ges : nullptr;
-        bp.curves = c->d_curves;
+        bp.specs = d_specs;
+        bp.ges = gain ? d_ges : nullptr;
+        bp.curves = d_curves;
         bp.psy = c->d_psy;
         bp.loud = c->d_loud;
         bp.loud_state = c->d_loud_state;
@@ -360,43 +445,49 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.debug_stop = getenv("AT3HIP_DEBUG_STOP") ? atoi(getenv("AT3HIP_DEBUG_STOP")) : 0;
         bp.quant = c->d_quant;
         bp.mant = c->d_mant;
-        hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
-        HIPCHK(c, hipEventRecord(c->ev[5], st));
-        hipLaunchKernelGGL(k_loudness, dim3(S), dim3(64), 0, st, bp);
-        hipLaunchKernelGGL(k_quant, dim3(S * n_out * 2), dim3(256), 0, st, bp, c->d_tables);
-        hipLaunchKernelGGL(k_rate_pack, dim3(S * n_out * 2), dim3(64), 0, st, bp, c->d_tables);
-        HIPCHK(c, hipEventRecord(c->ev[6], st));
+        hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, bk, bp, c->d_tables);
+        HIPCHK(c, hipEventRecord(ev[6], bk));
+        hipLaunchKernelGGL(k_loudness, dim3(S), dim3(64), 0, bk, bp);
+        hipLaunchKernelGGL(k_quant, dim3(S * n_out * 2), dim3(256), 0, bk, bp, c->d_tables);
+        hipLaunchKernelGGL(k_rate_pack, dim3(S * n_out * 2), dim3(64), 0, bk, bp, c->d_tables);
+        HIPCHK(c, hipEventRecord(ev[7], bk));
+        if (!(flags & AT3HIP_OUT_ON_DEVICE))
+            HIPCHK(c, hipMemcpyAsync(out_frames, c->d_out, (size_t)S * n_out * c->frame_sz, hipMemcpyDeviceToHost, bk));
+        HIPCHK(c, hipEventRecord(c->ev_back_done[par], bk));
+        c->back_done_valid[par] = true;
+        c->slot_has_frames[slot] = true;
+        c->last_slot = slot;
     }
-    {
-        StateParams sp;
-        sp.pcm = d_pcm;
-        sp.hist_in = hist;
-        sp.hist_out = hist_next;
-        sp.curves = c->d_curves;
-        sp.state = c->d_state;
-        sp.n_blocks = n_blocks;
-        sp.n_streams = S;
-        hipLaunchKernelGGL(k_state_update, dim3((kHist + 255) / 256, S), dim3(256), 0, st, sp);
-    }
-    HIPCHK(c, hipEventRecord(c->ev[7], st));
     HIPCHK(c, hipGetLastError());
-    if (n_out > 0 && !(flags & AT3HIP_OUT_ON_DEVICE))
-        HIPCHK(c, hipMemcpyAsync(out_frames, c->d_out, (size_t)S * n_out * c->frame_sz, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
     c->hist_cur ^= 1;
     c->blocks_fed += n_blocks;
+    c->enc_calls++;
     if (n_frames_out) *n_frames_out = n_out;
-    if (n_out > 0) {
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->tm.qmf_ms = ms;
-        (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->tm.gain_ms = ms;
-        (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->tm.curve_ms = ms;
-        (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->tm.qmf_mdct_ms = ms;
-        (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); c->tm.psy_ms = ms;
-        (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->tm.alloc_ms = ms;
-        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[7]); c->tm.total_ms = ms;
-        c->tm.qmf_mdct_launches = 1;
+    if (!(flags & AT3HIP_ASYNC)) {
+        const int rc = drain(c);
+        if (rc != AT3HIP_OK) return rc;
+        if (n_out > 0) read_timings(c, slot, &c->tm);
     }
+    return AT3HIP_OK;
+}
+
+int at3hip_sync(at3hip_ctx* c)
+{
+    if (!c) return AT3HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = drain(c);
+    if (rc != AT3HIP_OK) return rc;
+    read_timings(c, c->last_slot, &c->tm);
+    return AT3HIP_OK;
+}
+
+int at3hip_get_timings_ago(at3hip_ctx* c, int32_t ago, at3hip_timings* out)
+{
+    if (!c || !out || ago < 0 || ago >= at3hip_ctx::kSlots || ago >= c->enc_calls) return AT3HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = drain(c);
+    if (rc != AT3HIP_OK) return rc;
+    read_timings(c, (int)((c->enc_calls - 1 - ago) % at3hip_ctx::kSlots), out);
     return AT3HIP_OK;
 }
 
@@ -472,6 +563,10 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
     if ((flags & (AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE)) != (AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE))
         return fail(c, AT3HIP_EINVAL, "qmf_mdct needs device pointers");
     HIPCHK(c, hipSetDevice(c->device));
+    {
+        const int rc = drain(c);
+        if (rc != AT3HIP_OK) return rc;
+    }
     hipStream_t st = c->stream;
     const int S = c->cfg.n_streams;
     // start-of-stream history: an all-zero buffer (the spare history buffer is kept zeroed for this)
@@ -493,14 +588,14 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
     fp.frames_per_wg = pick_frames_per_wg(c, n_out);
     fp.js = c->js;
     const int nchunks = (n_out + fp.frames_per_wg - 1) / fp.frames_per_wg;
-    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    HIPCHK(c, hipEventRecord(c->ev[0][0], st));
     hipLaunchKernelGGL(k_qmf_mdct<false>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
-    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipEventRecord(c->ev[0][1], st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
     memset(&c->tm, 0, sizeof(c->tm));
     float ms = 0.0f;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&ms, c->ev[0][0], c->ev[0][1]);
     c->tm.qmf_mdct_ms = ms;
     c->tm.total_ms = ms;
     c->tm.qmf_mdct_launches = 1;

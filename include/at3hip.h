@@ -30,6 +30,10 @@ extern "C" {
 /* at3hip_encode / at3hip_mdct / at3hip_qmf_mdct flags */
 #define AT3HIP_PCM_ON_DEVICE 1u  /* input pointer is device memory (already resident in HBM) */
 #define AT3HIP_OUT_ON_DEVICE 2u  /* output pointer is device memory */
+#define AT3HIP_ASYNC 4u          /* at3hip_encode only queues the work and returns; pcm must stay valid and out_frames
+                                  * must not be read until at3hip_sync(). Consecutive asynchronous calls overlap: the
+                                  * front half (QMF, gain control, MDCT) of call N+1 runs beside the back half
+                                  * (psychoacoustics, quantisation, rate loop, packing) of call N. */
 
 typedef struct at3hip_ctx at3hip_ctx;
 
@@ -48,8 +52,9 @@ typedef struct at3hip_config {
     int32_t device_id;        /* HIP device ordinal */
 } at3hip_config;
 
-/* Per-call device timings in milliseconds (HIP events on the ctx stream), filled by the last
- * at3hip_encode / at3hip_qmf_mdct call. */
+/* Per-call device timings in milliseconds (HIP events on the ctx's two streams), filled by the last
+ * at3hip_encode / at3hip_qmf_mdct call. total_ms spans the first front-half kernel to the last back-half kernel of ONE
+ * call (its latency); with AT3HIP_ASYNC consecutive calls overlap, so throughput is not 1 / total_ms. */
 typedef struct at3hip_timings {
     float total_ms;
     float qmf_ms;        /* subband analysis for the gain path */
@@ -107,8 +112,16 @@ int at3hip_mdct(at3hip_ctx* ctx, float* bands, float* specs, const int32_t* n_po
  * Both pointers must be device memory (flags must contain AT3HIP_PCM_ON_DEVICE|AT3HIP_OUT_ON_DEVICE). */
 int at3hip_qmf_mdct(at3hip_ctx* ctx, const float* pcm, int32_t n_blocks, float* specs, uint32_t flags);
 
-/* Timings of the last at3hip_encode / at3hip_qmf_mdct call. */
+/* Timings of the last at3hip_encode / at3hip_qmf_mdct call (after at3hip_sync() for asynchronous calls). */
 int at3hip_get_timings(const at3hip_ctx* ctx, at3hip_timings* out);
+
+/* Waits for all queued work of this ctx (the completion point of AT3HIP_ASYNC calls; what a host shim calls before it
+ * hands frames to ICompressedOutput::WriteFrame). */
+int at3hip_sync(at3hip_ctx* ctx);
+
+/* Timings of the at3hip_encode call `ago` calls back (0 = the most recent one, at most 31); waits for queued work.
+ * Zeroed for calls that produced no frames (the LOOK_AHEAD call). */
+int at3hip_get_timings_ago(at3hip_ctx* ctx, int32_t ago, at3hip_timings* out);
 
 /* Bind all work of this ctx to a caller-provided hipStream_t (NULL = the ctx's own stream). */
 int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);

@@ -174,6 +174,34 @@ def test_config3_shard_properties(hip, oracle, br):
         assert np.array_equal(got[i], oracle.encode(pcm[i], br)[0]), i
 
 
+@pytest.mark.parametrize("br", [LP2, LP4])
+def test_async_pipelined_calls(hip, oracle, br):
+    """AT3HIP_ASYNC: calls are only queued; the front half of a call runs beside the back half of the previous one on a
+    second stream, with double-buffered spectra / curves / energy scales. Every call writes its own output buffer;
+    after at3hip_sync() the concatenation must be what the synchronous path (and the oracle) produces."""
+    import torch
+    nb, piece = 49, 6
+    names = ["burst", "mix", "tones", "noise"]
+    pcm = np.stack([SIGNALS[n](nb) for n in names])
+    enc = hip.At3Hip(n_streams=len(names), max_blocks=piece, bitrate=br)
+    d_in, d_out, counts = [], [], []
+    for pos in range(0, nb, piece):
+        x = torch.from_numpy(np.ascontiguousarray(pcm[:, pos:pos + piece])).cuda()
+        y = torch.zeros((len(names), piece, enc.frame_size), dtype=torch.uint8, device="cuda")
+        d_in.append(x)
+        d_out.append(y)
+    torch.cuda.synchronize()
+    for x, y in zip(d_in, d_out):
+        counts.append(enc.encode_device(x.data_ptr(), x.shape[1], y.data_ptr(), asynchronous=True))
+    enc.sync()
+    fs, S = enc.frame_size, len(names)
+    got = np.concatenate([y.cpu().numpy().reshape(-1)[: S * n * fs].reshape(S, n, fs) for y, n in zip(d_out, counts)], axis=1)   # [S][n][fs], compact
+    tm = enc.timings_ago(0)
+    enc.close()
+    assert sum(counts) == nb - 1 and tm["qmf_mdct_ms"] > 0
+    assert np.array_equal(got, oracle_frames(oracle, pcm, br))
+
+
 def test_mono_input_lp2(hip, oracle):
     # SourceChannels = 1 (atrac3.h:260-277): [stream][block][1024][1] in, the one sound unit twice per frame out
     nb = 24
