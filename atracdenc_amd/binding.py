@@ -12,6 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 AT3HIP_PCM_ON_DEVICE = 1
 AT3HIP_OUT_ON_DEVICE = 2
 AT3HIP_ASYNC = 4
+TAP_SPECTRA, TAP_CURVES, TAP_ENERGY_SCALE, TAP_PSY, TAP_LOUDNESS, TAP_QUANT = 1, 2, 3, 4, 5, 6
 LP2 = 132300
 LP4 = 66150
 
@@ -32,7 +33,7 @@ class Timings(ctypes.Structure):
 
 SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint_stereo", "at3hip_last_error",
            "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
-           "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago"]
+           "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago", "at3hip_read_tap"]
 
 
 def build_library(verbose=False):
@@ -78,6 +79,7 @@ def load_library(path=None):
     lib.at3hip_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
     lib.at3hip_set_stream.argtypes = [vp, vp]
     lib.at3hip_sync.argtypes = [vp]
+    lib.at3hip_read_tap.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.at3hip_get_timings_ago.argtypes = [vp, i32, ctypes.POINTER(Timings)]
     lib.at3hip_version.restype = ctypes.c_uint32
     _lib_cache[path] = lib
@@ -141,6 +143,17 @@ class At3Hip:
         self._check(self.lib.at3hip_encode(self.ctx, ctypes.c_void_p(pcm_ptr), n_blocks, ctypes.c_void_p(out_ptr),
                                            ctypes.byref(nf), flags), "at3hip_encode")
         return nf.value
+
+    PSY_DTYPE = np.dtype([("loud_ch", "<f4"), ("n_tonal", "<i4"), ("sfi", "u1", 32), ("energy", "<f4", 32),
+                          ("tonal", [("pos", "<u2"), ("bfu", "u1"), ("len", "u1"), ("sfi", "u1"), ("pad", "u1", 3),
+                                     ("values", "<f4", 7), ("pad2", "u1", 4)], 24)])
+    QUANT_DTYPE = np.dtype([("err", "<f4", (7, 32)), ("cost", "<u4", (7, 32))])
+
+    def read_tap(self, kind, dtype, shape):
+        """Stage tap of the most recent encode call (AT3HIP_TAP_*), as a numpy array of `dtype` and `shape`."""
+        out = np.zeros(shape, dtype=dtype)
+        self._check(self.lib.at3hip_read_tap(self.ctx, int(kind), _vp(out), out.nbytes), "at3hip_read_tap")
+        return out
 
     def sync(self):
         self._check(self.lib.at3hip_sync(self.ctx), "at3hip_sync")

@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
 #pragma unroll
         for (int wl = 1; wl <= 7; ++wl) {
             err[wl] = q->err[wl - 1][i];
-            cost[wl] = q->cost[wl - 1][i] | (1u << 27);
+            cost[wl] = q->cost[wl - 1][i];
         }
     }
     // ConsiderEnergyErr as a per-BFU map wl -> wl' (first 10 BFUs, atrac3_bitstream.cpp:241-257, :638-641):
@@ -1227,7 +1227,10 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
             const uint32_t mine = (lane < num_bfu) ? s_cost[bits * 32 + i] : 0u;
             const uint32_t rsum = row_allreduce_add(mine);
             const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
-            const uint32_t clc = acc & 0x1fffu, vlc = (acc >> 13) & 0x3fffu, nz = acc >> 27;
+            // the count of non-zero BFUs comes from a ballot: summed as a third field it would need six bits at
+            // 32 of 32 (and silently wrapped to zero when every BFU of the frame was coded)
+            const uint32_t clc = acc & 0x1fffu, vlc = (acc >> 13) & 0x3fffu;
+            const uint32_t nz = (uint32_t)__popcll(__ballot(lane < num_bfu && bits != 0));
             mode = clc <= vlc ? 1 : 0;
             const uint32_t spec_bits = (uint32_t)num_bfu * 3 + 6 * nz + (mode ? clc : vlc);
             uint32_t tonal_bits = 5;

@@ -481,6 +481,31 @@ int at3hip_sync(at3hip_ctx* c)
     return AT3HIP_OK;
 }
 
+int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
+{
+    if (!c || !dst) return AT3HIP_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = drain(c);
+    if (rc != AT3HIP_OK) return rc;
+    if (c->enc_calls == 0) return fail(c, AT3HIP_EINVAL, "no encode call yet");
+    const int par = (int)((c->enc_calls - 1) & 1);
+    const size_t S = c->cfg.n_streams, B = c->cfg.max_blocks;
+    const void* src = nullptr;
+    size_t cap = 0;
+    switch (kind) {
+        case AT3HIP_TAP_SPECTRA: src = c->d_specs[par]; cap = S * B * 2048 * sizeof(float); break;
+        case AT3HIP_TAP_CURVES: src = c->d_curves[par]; cap = S * B * 8 * sizeof(Curve); break;
+        case AT3HIP_TAP_ENERGY_SCALE: src = c->d_ges[par]; cap = c->d_ges[par] ? S * B * 8 * sizeof(float) : 0; break;
+        case AT3HIP_TAP_PSY: src = c->d_psy; cap = S * B * 2 * sizeof(PsyRec); break;
+        case AT3HIP_TAP_LOUDNESS: src = c->d_loud; cap = S * B * sizeof(float); break;
+        case AT3HIP_TAP_QUANT: src = c->d_quant; cap = S * B * 2 * sizeof(QuantRec); break;
+        default: return fail(c, AT3HIP_EINVAL, "unknown tap");
+    }
+    if (!src || bytes > cap) return fail(c, AT3HIP_EINVAL, "tap not available or request too large");
+    HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return AT3HIP_OK;
+}
+
 int at3hip_get_timings_ago(at3hip_ctx* c, int32_t ago, at3hip_timings* out)
 {
     if (!c || !out || ago < 0 || ago >= at3hip_ctx::kSlots || ago >= c->enc_calls) return AT3HIP_EINVAL;

@@ -119,6 +119,24 @@ int at3hip_get_timings(const at3hip_ctx* ctx, at3hip_timings* out);
  * hands frames to ICompressedOutput::WriteFrame). */
 int at3hip_sync(at3hip_ctx* ctx);
 
+/* Stage taps of the most recent at3hip_encode call (the tap points SURVEY.md 8(c) lists; test and diagnosis aid):
+ * copies the first `bytes` bytes of an intermediate buffer to host memory. Layouts, with n = blocks of that call,
+ * F = frames it produced (frame index f0 .. n-1, f0 = 1 on the first call of a stream else 0):
+ *   SPECTRA       float [n_streams][F][2][1024]   spectra after Mdct, tonal lines zeroed        (T3)
+ *   CURVES        16-byte records [n_streams][n][2][4]: n, level[7], loc[7], pad - by frame index (T2)
+ *   ENERGY_SCALE  float [n_streams][n][2][4] GainEnergyScale.Frame by frame index (gain control only)
+ *   PSY           1128-byte records [n_streams][F][2]: float loud_ch, int32 n_tonal, u8 sfi[32], float energy[32],
+ *                 tonal blocks 24 x {u16 pos, u8 bfu, len, sfi, pad[3], float values[7], pad[4]}    (T4, T5, T6)
+ *   LOUDNESS      float [n_streams][F] tracked loudness                                             (T6)
+ *   QUANT         1792-byte records [n_streams][F][2]: float err[7][32] (e1/e2), u32 cost[7][32] (CLC | VLC << 13) */
+#define AT3HIP_TAP_SPECTRA 1
+#define AT3HIP_TAP_CURVES 2
+#define AT3HIP_TAP_ENERGY_SCALE 3
+#define AT3HIP_TAP_PSY 4
+#define AT3HIP_TAP_LOUDNESS 5
+#define AT3HIP_TAP_QUANT 6
+int at3hip_read_tap(at3hip_ctx* ctx, int32_t kind, void* dst, size_t bytes);
+
 /* Timings of the at3hip_encode call `ago` calls back (0 = the most recent one, at most 31); waits for queued work.
  * Zeroed for calls that produced no frames (the LOOK_AHEAD call). */
 int at3hip_get_timings_ago(at3hip_ctx* ctx, int32_t ago, at3hip_timings* out);

@@ -260,6 +260,52 @@ def pcm_mix(nblocks, seed=7):
     return _quant16(bed + tone + hit).reshape(nblocks, 1024, 2)
 
 
+def pcm_stress(nblocks, seed=3):
+    """Corner cases of the arithmetic, one after another in 4-block segments: full-scale noise (scale-factor clamp at
+    1.0 and the +-0.99999 clip), full-scale square wave, isolated unit impulses, DC with a tiny dither (denormal-range
+    energies), a linear chirp to Nyquist, hard-gated full-scale tone bursts (largest gain-curve swings), one silent
+    channel, and sign-alternating full scale."""
+    rng = np.random.RandomState(seed)
+    n = nblocks * 1024
+    out = np.zeros((n, 2), dtype=np.float64)
+    seg = 4 * 1024
+    t = np.arange(n, dtype=np.float64)
+    for k in range(0, n, seg):
+        sl = slice(k, min(n, k + seg))
+        m = sl.stop - sl.start
+        kind = (k // seg) % 8
+        if kind == 0:
+            out[sl] = rng.randint(-32768, 32768, size=(m, 2)) / 32768.0
+        elif kind == 1:
+            sq = np.where((t[sl] // 37) % 2 == 0, 32767, -32768) / 32768.0
+            out[sl, 0] = sq
+            out[sl, 1] = -sq
+        elif kind == 2:
+            imp = np.zeros(m)
+            imp[::701] = 1.0 - 1.0 / 32768.0
+            out[sl, 0] = imp
+            out[sl, 1] = -imp[::-1]
+        elif kind == 3:
+            out[sl, 0] = 0.25 + rng.randint(-1, 2, size=m) / 32768.0
+            out[sl, 1] = rng.randint(-1, 2, size=m) / 32768.0
+        elif kind == 4:
+            ph = np.pi * (np.arange(m) ** 2) / (2.0 * m)       # 0 .. fs/2
+            out[sl, 0] = 0.9 * np.sin(ph)
+            out[sl, 1] = 0.9 * np.cos(ph)
+        elif kind == 5:
+            gate = ((np.arange(m) // 300) % 3 == 0).astype(np.float64)
+            out[sl, 0] = gate * np.sin(2 * np.pi * 5000.0 * t[sl] / 44100.0) * (32767 / 32768.0)
+            out[sl, 1] = (1 - gate) * np.sin(2 * np.pi * 900.0 * t[sl] / 44100.0) * 0.7
+        elif kind == 6:
+            out[sl, 0] = rng.randint(-20000, 20000, size=m) / 32768.0
+        else:
+            alt = np.where(np.arange(m) % 2 == 0, 32767, -32768) / 32768.0
+            out[sl, 0] = alt
+            out[sl, 1] = alt
+    s16 = np.clip(np.round(out * 32768.0), -32768, 32767)
+    return (s16.astype(np.float32) / np.float32(32768.0)).reshape(nblocks, 1024, 2).astype(np.float32)
+
+
 SIGNALS = {
     "noise": pcm_noise,
     "burst": pcm_burst,

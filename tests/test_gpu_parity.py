@@ -5,7 +5,7 @@ too (the kernels keep the reference's fp32 operation order, contraction off), wh
 import numpy as np
 import pytest
 
-from at3_testlib import LP2, LP4, SIGNALS
+from at3_testlib import LP2, LP4, SIGNALS, pcm_stress
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,54 @@ def test_frames_all_signals(hip, oracle, br, opts):
     assert got.shape == exp.shape
     bad = np.argwhere((got != exp).any(axis=2))
     assert bad.size == 0, f"mismatching (stream, frame): {bad[:10].tolist()} of {names}"
+
+
+@pytest.mark.parametrize("br", [LP2, LP4])
+def test_stress_signal(hip, oracle, br):
+    """Full-scale noise and square waves (scale-factor clamp, +-0.99999 clip), impulses, DC with denormal-range
+    energies, a chirp to Nyquist, hard-gated bursts (largest gain-curve swings), one silent channel."""
+    nb = 66
+    pcm = np.stack([pcm_stress(nb, seed=3), pcm_stress(nb, seed=4)[::-1].copy()])
+    for ng, nt in ((0, 0), (1, 1)):
+        enc = hip.At3Hip(n_streams=2, max_blocks=nb, bitrate=br, no_gain=ng, no_tonal=nt)
+        got = enc.encode(pcm)
+        enc.close()
+        exp = oracle_frames(oracle, pcm, br, ng, nt)
+        bad = np.argwhere((got != exp).any(axis=2))
+        assert bad.size == 0, f"mismatching (stream, frame): {bad[:10].tolist()}"
+
+
+@pytest.mark.parametrize("br", [LP2, LP4])
+def test_stage_taps(hip, oracle, br):
+    """Stage outputs through at3hip_read_tap against the oracle's taps: gain curves, energy
+    scales, scale-factor indices, BFU energies, per-channel and tracked loudness, tonal blocks - bit patterns."""
+    from atracdenc_amd import binding as B
+    nb = 30
+    names = ["burst", "mix", "tones"]
+    pcm = np.stack([SIGNALS[n](nb) for n in names])
+    S, F = len(names), nb - 1
+    enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=br)
+    enc.encode(pcm)
+    psy = enc.read_tap(B.TAP_PSY, B.At3Hip.PSY_DTYPE, (S, F, 2))
+    loud = enc.read_tap(B.TAP_LOUDNESS, np.float32, (S, F))
+    curves = enc.read_tap(B.TAP_CURVES, np.uint8, (S, nb, 2, 4, 16))
+    ges = enc.read_tap(B.TAP_ENERGY_SCALE, np.float32, (S, nb, 2, 4))
+    enc.close()
+    u32 = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    for i in range(S):
+        _, tap = oracle.encode(pcm[i], br, taps=True)
+        assert np.array_equal(psy[i]["sfi"], tap["sfi"].astype(np.uint8))
+        assert np.array_equal(u32(psy[i]["energy"]), u32(tap["energy"]))
+        assert np.array_equal(u32(psy[i]["loud_ch"]), u32(tap["loudness_ch"]))
+        assert np.array_equal(u32(loud[i]), u32(tap["loudness_track"][:, 0] if tap["loudness_track"].ndim > 1 else tap["loudness_track"]))
+        assert np.array_equal(psy[i]["n_tonal"], tap["n_tonal"])
+        assert np.array_equal(curves[i, 1:, :, :, 0], tap["n_points"].astype(np.uint8))          # frame f at index f
+        assert np.array_equal(u32(ges[i, 1:]), u32(tap["ges_frame"]))
+        for f, ch in zip(*np.nonzero(tap["n_points"].sum(axis=2))):
+            for b in range(4):
+                n = int(tap["n_points"][f, ch, b])
+                assert np.array_equal(curves[i, f + 1, ch, b, 1:1 + n], tap["level"][f, ch, b, :n].astype(np.uint8))
+                assert np.array_equal(curves[i, f + 1, ch, b, 8:8 + n], tap["loc"][f, ch, b, :n].astype(np.uint8))
 
 
 @pytest.mark.parametrize("mode", ["lp2", "lp4"])

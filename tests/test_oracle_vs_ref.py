@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from at3_testlib import LP2, LP4, SIGNALS, TAP_DTYPE, have_ref, ref
+from at3_testlib import LP2, LP4, SIGNALS, TAP_DTYPE, have_ref, pcm_stress, ref
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
 
@@ -38,6 +38,21 @@ def test_mono_lp2(oracle, name):
     assert np.array_equal(fo, ref().encode(mono, LP2)[0])
     assert np.array_equal(fo[:, :192], fo[:, 192:])
     assert np.array_equal(fo, oracle.encode(np.repeat(mono, 2, axis=2), LP2)[0])
+
+
+@pytest.mark.parametrize("br", [LP2, LP4])
+def test_stress_signal(oracle, br):
+    """Full-scale, impulsive, DC / denormal-range, chirp and hard-gated material (at3_testlib.pcm_stress)."""
+    r = ref()
+    pcm = pcm_stress(66)
+    for ng, nt in ((0, 0), (1, 1)):
+        fo, to = oracle.encode(pcm, br, ng, nt, taps=True)
+        fr, tr = r.encode(pcm, br, ng, nt, taps=True)
+        assert np.array_equal(fo, fr)
+        for k in TAP_DTYPE.names:
+            if k == "tonal_pos":
+                continue
+            assert np.array_equal(bits(to[k]), bits(tr[k])), k
 
 
 def test_long_noise_soak(oracle):
