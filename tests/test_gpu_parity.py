@@ -84,6 +84,25 @@ def test_stage_taps(hip, oracle, br):
                 assert np.array_equal(curves[i, f + 1, ch, b, 8:8 + n], tap["loc"][f, ch, b, :n].astype(np.uint8))
 
 
+def test_fuzz_slice(hip, oracle):
+    """A slice of tools/fuzz_gpu.py (twelve families of random material from 1-LSB dither to clipped full scale):
+    the long campaign (2.9 M frames, all option sets) is run by hand on the GPU box, this keeps the generator honest."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.RandomState(4242)
+    S, nb = 96, 17
+    pcm = np.stack([fz.gen(rng, nb)[1] for _ in range(S)])
+    for br in (LP2, LP4):
+        enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=br)
+        got = enc.encode(pcm)
+        enc.close()
+        for i in range(S):
+            assert np.array_equal(got[i], oracle.encode(pcm[i], br)[0]), (br, i)
+
+
 @pytest.mark.parametrize("mode", ["lp2", "lp4"])
 @pytest.mark.parametrize("tag", ["full", "nogain", "notonal"])
 def test_golden_frames(hip, golden_encode, mode, tag):
