@@ -336,49 +336,6 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The same kissfft-order transform as fft_lds, executed by ONE wavefront (64 lanes, lane = threadIdx & 63) on one
-// array of N points: only wave-level synchronisation, stage geometry resolved at compile time, the butterflies of a
-// lane issued as batches (all loads, all arithmetic, all stores).
-template <int N, int M, bool INVERSE>
-__device__ __forceinline__ void fft_wave_stage(cpx* F, const cpx* tw, int lane)
-{
-    constexpr int FS = N / (4 * M);
-    constexpr int PER_LANE = (N / 4 + 63) / 64;
-    constexpr int U = PER_LANE < 4 ? PER_LANE : 4;
-#pragma unroll
-    for (int r0 = 0; r0 < N / 4; r0 += 64 * U) {
-        f2 x[U][4], w[U][3];
-        int base[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = r0 + 64 * u + lane;
-            const int g = r / M, k = r % M;
-            base[u] = g * 4 * M + k;
-            w[u][0] = ld2(tw + k * FS);
-            w[u][1] = ld2(tw + 2 * k * FS);
-            w[u][2] = ld2(tw + 3 * k * FS);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[u][q] = ld2(F + base[u] + q * M);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) bfly4<INVERSE>(x[u][0], x[u][1], x[u][2], x[u][3], w[u][0], w[u][1], w[u][2]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) st2(F + base[u] + q * M, x[u][q]);
-        }
-    }
-    wave_sync();
-    if constexpr (4 * M < N) fft_wave_stage<N, 4 * M, INVERSE>(F, tw, lane);
-}
-
-template <int N, bool INVERSE, int M0 = 1>   // M0 = 2: N = 2 * 4^k and the caller stored the radix-2 leaf outputs
-__device__ __forceinline__ void fft_wave(cpx* F, const cpx* tw, int lane)
-{
-    fft_wave_stage<N, M0, INVERSE>(F, tw, lane);
-}
-
-// Divisor applied to sample i of the "new" half for a gain curve: the running-product ramp of
 // GainLevel[l] = 2^(4 - l) (atrac3.h:192-194): exact powers of two, formed from the exponent field.
 __device__ __forceinline__ float gain_level_of(int l) { return __uint_as_float((uint32_t)(127 + 4 - l) << 23); }
 

@@ -1039,15 +1039,6 @@ __global__ __launch_bounds__(kQuantThreads) void k_quant(BackParams p, const Tab
 // Lane i < 32 owns BFU i and keeps its seven (error, cost) pairs and the ConsiderEnergyErr fixed-point map in
 // registers, so one evaluation of CalcBitsAllocation + CalcSpecsBitsConsumption is a handful of VALU ops, a
 // DPP row reduction and two readlanes; no LDS round trip and no barrier sits inside the bisection.
-template <typename Tv>
-__device__ __forceinline__ Tv pick8(const Tv (&a)[8], int idx)
-{
-    Tv r = a[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) r = (idx == k) ? a[k] : r;
-    return r;
-}
-
 __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
 {
     __shared__ uint32_t s_words[kBitWords];

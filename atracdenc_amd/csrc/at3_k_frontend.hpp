@@ -8,12 +8,14 @@
 //   gain_processor.h:87-121  TGainProcessor::Modulate
 //   atrac3denc.cpp:33-58     TAtrac3MDCT::Mdct;  lib/mdct/mdct.h:51-104 TMDCT<512>;  kiss_fft.c (128-pt)
 //
-// Work decomposition: one 256-thread workgroup owns one stream and a run of consecutive frames, both
-// channels. Per block it stages the interleaved PCM tile (+138-sample FIR reach) in LDS with coalesced
-// float2 loads, runs the two QMF stages out of LDS (taps in LDS), and - for frames - modulates, windows
-// and transforms the four subbands of both channels as eight concurrent 128-point FFTs (32 lanes each).
-// The previous block's windowed overlap stays in LDS between frames, so each PCM sample is read from
-// HBM once per workgroup run and spectra are written once: algorithmic traffic is 16 KiB per frame.
+// Work decomposition of the fused kernel: one 256-thread workgroup owns one stream and a run of consecutive frames,
+// both channels. Per block it stores the interleaved PCM tile (prefetched one block ahead into registers with
+// coalesced float2 loads) into LDS rings, runs the two QMF stages out of LDS with the taps in scalar registers and
+// packed fp32 arithmetic, and - for frames - modulates, windows and transforms the four subbands of both channels as
+// eight concurrent 128-point FFTs (32 lanes each). FIR histories and the previous block's windowed overlap stay in
+// LDS between frames, so each PCM sample is read from HBM once per workgroup run (plus the run's two priming blocks)
+// and spectra are written once: algorithmic traffic is 16 KiB per frame. CalcGainEnergyScale is its own kernel
+// (k_gain_energy_scale); k_qmf_sub is the QMF-only variant that feeds the gain-control kernels.
 #pragma once
 #include "at3_common.hpp"
 

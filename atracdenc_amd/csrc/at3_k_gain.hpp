@@ -591,19 +591,6 @@ __device__ inline int relation_to_idx_hdr(float x)
     return 4 - (int)first_set_bit((uint32_t)(int32_t)truncf(x));
 }
 
-// transient_detector.cpp:255-274
-__device__ inline float boundary_score(const float* env, int loc)
-{
-    const int leftStart = loc - 3 > 0 ? loc - 3 : 0;
-    const int rightEnd = loc + 3 < 32 ? loc + 3 : 32;
-    float leftMax = 0.0f, rightMax = 0.0f;
-    for (int i = leftStart; i < loc; ++i) leftMax = fmaxf(leftMax, env[i]);
-    for (int i = loc; i < rightEnd; ++i) rightMax = fmaxf(rightMax, env[i]);
-    const float eps = 1e-9f;
-    const float attack = (rightMax + eps) / (leftMax + eps);
-    const float release = (leftMax + eps) / (rightMax + eps);
-    return fmaxf(attack, release);
-}
 
 // ---- CalcCurve + CreateSubbandInfo tail, 32 lanes per (stream, frame, channel, band<3) item ------------------
 // Lane j of a half-wavefront owns sub-frame j. Everything that is order-free (median filter, level
