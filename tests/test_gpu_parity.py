@@ -310,7 +310,8 @@ def test_host_cpp_shim(hip, oracle, tmp_path):
 
 
 @pytest.mark.parametrize("nsamp,ext,opts", [(20000, "oma", []), (12288, "at3", ["--bitrate", "64"]), (9000, "raw", ["--nogaincontrol"]),
-                                            (8192, "oma", ["--notonal", "--batch", "3"])])
+                                            (8192, "oma", ["--notonal", "--batch", "3"]), (100, "at3", []), (4096, "oma", ["--mono"]),
+                                            (7000, "at3", ["--mono", "--batch", "2"])])
 def test_cli_file_parity(oracle, tmp_path, nsamp, ext, opts):
     """at3hipenc (WAV -> container) against: the reference's container writer (oracle/_ref) fed with the oracle's
     frames for the block sequence the reference's frame schedule produces (look-ahead call, short-read tail, drain call)."""
@@ -323,10 +324,13 @@ def test_cli_file_parity(oracle, tmp_path, nsamp, ext, opts):
     exe = os.path.join(root, "atracdenc_amd", "at3hipenc")
     if not os.path.exists(exe):
         pytest.skip("at3hipenc not built")
-    s16 = (SIGNALS["mix"]((nsamp + 1023) // 1024 + 1, seed=11)[: (nsamp + 1023) // 1024 + 1].reshape(-1, 2)[:nsamp] * 32768).astype("<i2")
-    body = s16.tobytes()
+    mono = "--mono" in opts          # test-only marker: write a one-channel WAV (the tool takes the channel count from the file)
+    opts = [x for x in opts if x != "--mono"]
+    nch = 1 if mono else 2
+    s16 = (SIGNALS["mix"]((nsamp + 1023) // 1024 + 1, seed=11)[: (nsamp + 1023) // 1024 + 1].reshape(-1, 2)[:nsamp, :nch] * 32768).astype("<i2")
+    body = np.ascontiguousarray(s16).tobytes()
     wav = str(tmp_path / "in.wav")
-    fmt = struct.pack("<HHIIHH", 1, 2, 44100, 44100 * 4, 4, 16)
+    fmt = struct.pack("<HHIIHH", 1, nch, 44100, 44100 * 2 * nch, 2 * nch, 16)
     open(wav, "wb").write(b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt +
                           b"data" + struct.pack("<I", len(body)) + body)
     out = str(tmp_path / ("out." + ext))
@@ -339,10 +343,10 @@ def test_cli_file_parity(oracle, tmp_path, nsamp, ext, opts):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", os.path.join(root, "include"), "-o", so,
                            os.path.join(root, "tests", "host", "host_io_capi.cpp")])
     host = ctypes.CDLL(so)
-    blocks = np.zeros((64, 1024, 2), np.float32)
+    blocks = np.zeros((64, 1024, nch), np.float32)
     info = (ctypes.c_uint64 * 3)()
     nb = host.at3host_wav_blocks(wav.encode(), blocks.ctypes.data_as(ctypes.c_void_p), 64, info)
-    assert nb >= 2 and info[2] == nsamp
+    assert nb >= 2 and info[2] == nsamp and info[0] == nch
     br = 65536 if "--bitrate" in opts else 0
     frames = oracle.encode(blocks[:nb], br if br else LP2, int("--nogaincontrol" in opts), int("--notonal" in opts))[0]
     assert frames.shape[0] == nb - 1
@@ -353,7 +357,7 @@ def test_cli_file_parity(oracle, tmp_path, nsamp, ext, opts):
         ref = ctypes.CDLL(REF_SO)
         exp_path = str(tmp_path / "exp.bin")
         buf = np.ascontiguousarray(frames)
-        assert ref.at3ref_write_container(kind, exp_path.encode(), buf.ctypes.data_as(ctypes.c_void_p), buf.shape[0], fsz, js, nsamp // 1024, 2) == 0
+        assert ref.at3ref_write_container(kind, exp_path.encode(), buf.ctypes.data_as(ctypes.c_void_p), buf.shape[0], fsz, js, nsamp // 1024, nch) == 0
         exp = open(exp_path, "rb").read()
         assert got == exp
     else:
