@@ -33,6 +33,8 @@
 #include "transient_spectral_upsampler.h"
 #include "qmf/qmf.h"
 #include "pcmengin.h"
+#include "atrac/at1/atrac1_bitalloc.h"
+#include "atrac1denc.h"
 #include "oma.h"
 #include "at3.h"
 #include "raw.h"
@@ -316,6 +318,45 @@ int at3ref_engine_trace(uint64_t total_samples, int nch, float* first_vals, floa
     }
     *processed_out = processed;
     return calls;
+}
+
+
+// ---- ATRAC1 encoder: the reference's TAtrac1Encoder driven one 512-sample block at a time --------
+namespace {
+struct TCaptureOut : public ICompressedOutput {
+    std::vector<uint8_t>* Dst;
+    size_t Channels;
+    TCaptureOut(std::vector<uint8_t>* dst, size_t ch) : Dst(dst), Channels(ch) {}
+    void WriteFrame(std::vector<char> data) override
+    {
+        data.resize(212);   // the sound unit; the bit writer appends rounding bytes that the AEA container drops (aea.cpp:182)
+        Dst->insert(Dst->end(), data.begin(), data.end());
+    }
+    std::string GetName() const override { return {}; }
+    size_t GetChannelNum() const override { return Channels; }
+};
+}
+
+// pcm [n_blocks][512][nch] -> out [n_blocks][nch][212]; returns bytes written. window_auto = 1: transient detection,
+// else `window_mask` (bit 0 low, 1 mid, 2 high band short) for every frame. bfu_idx_const as TAtrac1EncodeSettings.
+int at1ref_encode(const float* pcm, int nch, int n_blocks, int window_auto, int window_mask, int bfu_idx_const, uint8_t* out)
+{
+    std::vector<uint8_t> bytes;
+    {
+        NAtrac1::TAtrac1EncodeSettings settings((uint32_t)bfu_idx_const,
+            window_auto ? NAtrac1::TAtrac1EncodeSettings::EWindowMode::EWM_AUTO : NAtrac1::TAtrac1EncodeSettings::EWindowMode::EWM_NOTRANSIENT,
+            (uint32_t)window_mask);
+        TAtrac1Encoder enc(TCompressedOutputPtr(new TCaptureOut(&bytes, (size_t)nch)), std::move(settings));
+        auto lambda = enc.GetLambda();
+        std::vector<float> block(512 * (size_t)nch);
+        const TPCMEngine::ProcessMeta meta = {(uint16_t)nch};
+        for (int b = 0; b < n_blocks; ++b) {
+            memcpy(block.data(), pcm + (size_t)b * 512 * nch, sizeof(float) * 512 * nch);
+            lambda(block.data(), meta);
+        }
+    }
+    memcpy(out, bytes.data(), bytes.size());
+    return (int)bytes.size();
 }
 
 } // extern "C"

@@ -313,3 +313,46 @@ SIGNALS = {
     "silence": pcm_silence,
     "mix": pcm_mix,
 }
+
+
+# ----------------------------------------------------------------------------------------------
+# ATRAC1 (SURVEY.md 8(f) row f3): oracle/at1_oracle.c and the reference's TAtrac1Encoder (oracle/_ref)
+# ----------------------------------------------------------------------------------------------
+AT1_FRAME = 212
+AT1_BLOCK = 512
+# (window_auto, window_mask, bfu_idx_const) as TAtrac1EncodeSettings takes them
+AT1_MODES = {"auto": (1, 0, 0), "long": (0, 0, 0), "short": (0, 7, 0), "mask5": (0, 5, 0), "auto_bfu8": (1, 0, 8),
+             "auto_bfu3": (1, 0, 3), "mask2_bfu1": (0, 2, 1)}
+
+
+def at1_blocks(pcm, nch=2):
+    """[nblocks, 1024, 2] ATRAC3-shaped test PCM -> contiguous [2*nblocks, 512, nch]."""
+    return np.ascontiguousarray(pcm.reshape(-1, AT1_BLOCK, 2)[:, :, :nch])
+
+
+def at1_oracle_encode(pcm, mode="auto", taps=False):
+    """pcm [n_blocks, 512, nch] float32 -> sound units [n_blocks, nch, 212] (+ specs, window masks, loudness)."""
+    if not os.path.exists(ORACLE_SO):
+        build_oracle()
+    lib = ctypes.CDLL(ORACLE_SO)
+    nb, _, nch = pcm.shape
+    auto, mask, bfu = AT1_MODES[mode] if isinstance(mode, str) else mode
+    out = np.zeros((nb, nch, AT1_FRAME), np.uint8)
+    specs = np.zeros((nb, nch, 512), np.float32)
+    masks = np.zeros((nb, nch), np.int32)
+    loud = np.zeros((nb,), np.float32)
+    lib.at1o_encode.restype = ctypes.c_int
+    n = lib.at1o_encode(_vp(pcm), nch, nb, auto, mask, bfu, _vp(out), _vp(specs), _vp(masks), _vp(loud))
+    assert n == out.size
+    return (out, specs, masks, loud) if taps else out
+
+
+def at1_ref_encode(pcm, mode="auto"):
+    lib = ctypes.CDLL(REF_SO)
+    nb, _, nch = pcm.shape
+    auto, mask, bfu = AT1_MODES[mode] if isinstance(mode, str) else mode
+    out = np.zeros((nb, nch, AT1_FRAME), np.uint8)
+    lib.at1ref_encode.restype = ctypes.c_int
+    n = lib.at1ref_encode(_vp(pcm), nch, nb, auto, mask, bfu, _vp(out))
+    assert n == out.size
+    return out
