@@ -34,12 +34,24 @@ class Timings(ctypes.Structure):
 SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint_stereo", "at3hip_last_error",
            "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
            "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago", "at3hip_read_tap"]
+# include/at1hip.h
+AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_encode", "at1hip_reset", "at1hip_get_timings",
+               "at1hip_read_tap", "at1hip_host_tables"]
+
+
+class At1Config(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("channels", "window_auto", "window_mask", "bfu_idx_const", "n_streams", "max_blocks",
+                                              "device_id")]
+
+
+class At1Timings(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "front_ms", "scan_ms", "pack_ms")]
 
 
 def build_library(verbose=False):
     """Compile libat3hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-o", LIB_PATH, os.path.join(CSRC, "at3hip.hip"), os.path.join(CSRC, "at3_tables.cpp")]
+           "-o", LIB_PATH, os.path.join(CSRC, "at3hip.hip"), os.path.join(CSRC, "at1hip.hip"), os.path.join(CSRC, "at3_tables.cpp")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -82,6 +94,16 @@ def load_library(path=None):
     lib.at3hip_read_tap.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.at3hip_get_timings_ago.argtypes = [vp, i32, ctypes.POINTER(Timings)]
     lib.at3hip_version.restype = ctypes.c_uint32
+    lib.at1hip_create.argtypes = [ctypes.POINTER(At1Config), ctypes.POINTER(vp)]
+    lib.at1hip_destroy.argtypes = [vp]
+    lib.at1hip_destroy.restype = None
+    lib.at1hip_last_error.argtypes = [vp]
+    lib.at1hip_last_error.restype = ctypes.c_char_p
+    lib.at1hip_encode.argtypes = [vp, vp, i32, vp, ctypes.c_uint32]
+    lib.at1hip_reset.argtypes = [vp]
+    lib.at1hip_get_timings.argtypes = [vp, ctypes.POINTER(At1Timings)]
+    lib.at1hip_read_tap.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    lib.at1hip_host_tables.argtypes = [vp, ctypes.c_size_t]
     _lib_cache[path] = lib
     return lib
 
@@ -186,3 +208,76 @@ class At3Hip:
         t = Timings()
         self._check(self.lib.at3hip_get_timings(self.ctx, ctypes.byref(t)), "at3hip_get_timings")
         return {n: getattr(t, n) for n, _ in Timings._fields_}
+
+
+AT1_TABLES_DTYPE = np.dtype([("qmf_win", "<f4", 48), ("scale", "<f4", 64), ("sine", "<f4", 32), ("sc512", "<f4", 256),
+                             ("sc256", "<f4", 128), ("sc64", "<f4", 32), ("tw128", "<f4", 256), ("tw64", "<f4", 128),
+                             ("tw16", "<f4", 32), ("loud", "<f4", 512), ("ath_bfu", "<f4", 52), ("fir", "<f4", 10),
+                             ("fix_long", "<f4", 52), ("fix_short", "<f4", 52), ("logf", "<f8", 36)])
+assert AT1_TABLES_DTYPE.itemsize == 6904
+
+
+def at1_host_tables(lib_path=None):
+    """The ATRAC1 constant tables as the library builds them on the host (no GPU involved)."""
+    out = np.zeros((), dtype=AT1_TABLES_DTYPE)
+    rc = load_library(lib_path).at1hip_host_tables(_vp(out), out.nbytes)
+    if rc != 0:
+        raise At3HipError(f"at1hip_host_tables failed ({rc})")
+    return out
+
+
+class At1Hip:
+    """n_streams TAtrac1Encoder objects encoded side by side on one GPU (include/at1hip.h)."""
+
+    FRAME = 212
+    TAP_SPECTRA, TAP_MASKS, TAP_LOUDNESS, TAP_TABLES = 1, 2, 3, 4
+
+    def __init__(self, n_streams=1, max_blocks=64, channels=2, window_auto=True, window_mask=0, bfu_idx_const=0, device_id=0,
+                 lib_path=None):
+        self.lib = load_library(lib_path)
+        self.channels, self.n_streams = int(channels), int(n_streams)
+        self.cfg = At1Config(int(channels), int(bool(window_auto)), int(window_mask), int(bfu_idx_const), int(n_streams),
+                             int(max_blocks), int(device_id))
+        self.ctx = ctypes.c_void_p()
+        rc = self.lib.at1hip_create(ctypes.byref(self.cfg), ctypes.byref(self.ctx))
+        if rc != 0:
+            self.ctx = None
+            raise At3HipError(f"at1hip_create failed with {rc} (no usable MI355X / HIP runtime?)")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.at1hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise At3HipError(f"{what} failed ({rc}): {self.lib.at1hip_last_error(self.ctx).decode()}")
+
+    def reset(self):
+        self._check(self.lib.at1hip_reset(self.ctx), "at1hip_reset")
+
+    def encode(self, pcm):
+        """pcm float32 [n_streams, n_blocks, 512, channels] (host) -> uint8 [n_streams, n_blocks, channels, 212]."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        assert pcm.ndim == 4 and pcm.shape[0] == self.n_streams and pcm.shape[2:] == (512, self.channels), pcm.shape
+        nb = pcm.shape[1]
+        out = np.zeros((self.n_streams, nb, self.channels, self.FRAME), dtype=np.uint8)
+        self._check(self.lib.at1hip_encode(self.ctx, _vp(pcm), nb, _vp(out), 0), "at1hip_encode")
+        return out
+
+    def encode_device(self, pcm_ptr, n_blocks, out_ptr):
+        self._check(self.lib.at1hip_encode(self.ctx, ctypes.c_void_p(pcm_ptr), n_blocks, ctypes.c_void_p(out_ptr),
+                                           AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE), "at1hip_encode")
+
+    def read_tap(self, kind, dtype, shape):
+        out = np.zeros(shape, dtype=dtype)
+        self._check(self.lib.at1hip_read_tap(self.ctx, int(kind), _vp(out), out.nbytes), "at1hip_read_tap")
+        return out
+
+    def timings(self):
+        t = At1Timings()
+        self._check(self.lib.at1hip_get_timings(self.ctx, ctypes.byref(t)), "at1hip_get_timings")
+        return {n: getattr(t, n) for n, _ in At1Timings._fields_}

@@ -1,20 +1,27 @@
 // Host-side constant tables (see at3_tables.hpp). Plain C++; compiled with contraction off so the
 // float expressions round exactly like the reference's x86-64 baseline build.
 #include "at3_tables.hpp"
+#include "at1_tables.hpp"
 
 #include <cmath>
 #include <cstring>
 
+// The table builders must CALL libm at run time, like the reference's static initialisers do: at -O3 clang folds
+// sinf / cosf / powf of constant arguments through double precision, which is one ulp off glibc's float routines for
+// some entries (seen on the 64-point MDCT's table once its 16-iteration loop got unrolled).
+#define AT3_RUNTIME_LIBM __attribute__((optnone, noinline))
+
 namespace at3 {
 
-namespace {
-
 // QMF prototype, first half (qmf/qmf.cpp:25-32).
+extern const float kTapHalf[24];
 const float kTapHalf[24] = {
     -0.00001461907,  -0.00009205479, -0.000056157569, 0.00030117269, 0.0002422519,  -0.00085293897,
     -0.0005205574,   0.0020340169,   0.00078333891,   -0.0042153862, -0.00075614988, 0.0078402944,
     -0.000061169922, -0.01344162,    0.0024626821,    0.021736089,   -0.007801671,   -0.034090221,
     0.01880949,      0.054326009,    -0.043596379,    -0.099384367,  0.13207909,     0.46424159};
+
+namespace {
 
 // Threshold in quiet, millibel re 20 uPa, 4 steps per third starting at 10 Hz (Musepack table used by
 // atrac/atrac_psy_common.cpp:43-83).
@@ -30,7 +37,9 @@ const short kAthMilliBel[] = {
 const uint16_t kBfuStart[33] = {0,   8,   16,  24,  32,  40,  48,  56,  64,  80,  96,  112, 128, 144, 160, 176, 192,
                                 224, 256, 288, 320, 352, 384, 416, 448, 480, 512, 576, 640, 704, 768, 896, 1024};
 
-float ath_db(float freq)
+}  // namespace
+
+AT3_RUNTIME_LIBM float ath_db(float freq)
 {
     if (freq < 10.) freq = 10.;
     if (freq > 29853.) freq = 29853.;
@@ -39,7 +48,7 @@ float ath_db(float freq)
     return 0.01 * (kAthMilliBel[idx] * (1 + idx - fl) + kAthMilliBel[idx + 1] * (fl - idx));
 }
 
-void fill_twiddles(cpx* tw, int n, bool inverse)
+AT3_RUNTIME_LIBM void fill_twiddles(cpx* tw, int n, bool inverse)
 {
     const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
     for (int i = 0; i < n; ++i) {
@@ -50,7 +59,9 @@ void fill_twiddles(cpx* tw, int n, bool inverse)
     }
 }
 
-void fill_super_twiddles(cpx* tw, int ncfft, bool inverse)
+namespace {
+
+AT3_RUNTIME_LIBM void fill_super_twiddles(cpx* tw, int ncfft, bool inverse)
 {
     for (int i = 0; i < ncfft / 2; ++i) {
         double phase = -3.14159265358979323846264338327 * ((double)(i + 1) / ncfft + .5);
@@ -62,7 +73,7 @@ void fill_super_twiddles(cpx* tw, int ncfft, bool inverse)
 
 }  // namespace
 
-void build_tables(Tables* t)
+AT3_RUNTIME_LIBM void build_tables(Tables* t)
 {
     memset(t, 0, sizeof(*t));
     for (int i = 0; i < 24; ++i) t->qmf_win[i] = t->qmf_win[47 - i] = kTapHalf[i] * 2.0;
@@ -148,3 +159,91 @@ void build_tables(Tables* t)
 }
 
 }  // namespace at3
+
+// ---- ATRAC1 -----------------------------------------------------------------------------------------------------
+namespace at1 {
+
+namespace {
+
+const uint16_t kSpecsStartLong[kMaxBfus] = {0,   8,   16,  24,  32,  36,  40,  44,  48,  56,  64,  72,  80,  86,  92,  98,  104, 110,
+                                            116, 122, 128, 134, 140, 146, 152, 159, 166, 173, 180, 189, 198, 207, 216, 226, 236, 246,
+                                            256, 268, 280, 292, 304, 316, 328, 340, 352, 372, 392, 412, 432, 452, 472, 492};
+const uint8_t kSpecsPerBlock[kMaxBfus] = {8,  8,  8,  8,  4,  4,  4,  4,  8,  8,  8,  8,  6,  6,  6,  6,  6,  6,
+                                          6,  6,  6,  6,  6,  6,  7,  7,  7,  7,  9,  9,  9,  9,  10, 10, 10, 10,
+                                          12, 12, 12, 12, 12, 12, 12, 12, 20, 20, 20, 20, 20, 20, 20, 20};
+
+// CalcSinCos(n, scale), lib/mdct/mdct.cpp:25-36: float overloads of sqrt / cos / sin are the ones selected
+AT3_RUNTIME_LIBM void mdct_sincos(float* dst, size_t n, float scale)
+{
+    const float alpha = 2.0 * M_PI / (8.0 * n);
+    const float omiga = 2.0 * M_PI / n;
+    scale = sqrtf(scale / n);
+    for (size_t i = 0; i < (n >> 2); ++i) {
+        dst[2 * i + 0] = scale * cosf(omiga * i + alpha);
+        dst[2 * i + 1] = scale * sinf(omiga * i + alpha);
+    }
+}
+
+}  // namespace
+
+AT3_RUNTIME_LIBM void build_tables(Tables* t)
+{
+    memset(t, 0, sizeof(*t));
+    for (int i = 0; i < 24; ++i) t->qmf_win[i] = t->qmf_win[47 - i] = at3::kTapHalf[i] * 2.0;
+    for (uint32_t i = 0; i < 64; ++i) t->scale[i] = pow(2.0, (double)(i / 3.0 - 21.0));
+    for (uint32_t i = 0; i < 32; ++i) t->sine[i] = sin((i + 0.5) * (M_PI / (2.0 * 32.0)));
+    mdct_sincos(t->sc512, 512, 1.0f);
+    mdct_sincos(t->sc256, 256, 0.5f);
+    mdct_sincos(t->sc64, 64, 0.5f);
+    at3::fill_twiddles(t->tw128, 128, false);
+    at3::fill_twiddles(t->tw64, 64, false);
+    at3::fill_twiddles(t->tw16, 16, false);
+    for (size_t i = 0; i < 512; ++i) {
+        float f = (float)(i + 3) * 0.5 * 44100 / (float)512;
+        float v = log10f(f) - 3.5;
+        v = -10 * v * v + 3 - f / 3000;
+        v = pow(10, (0.1 * v));
+        t->loud[i] = v;
+    }
+    {
+        float ath_line[512];
+        const float mf = (float)44100 / 2000.0;
+        for (size_t i = 0; i < 512; ++i) {
+            const float f = (float)(i + 1) * mf / 512;
+            float trh = at3::ath_db(1.e3 * f) - 100;
+            trh -= f * f * 0.015;
+            ath_line[i] = trh;
+        }
+        for (int b = 0; b < kMaxBfus; ++b) {
+            float x = 999;
+            for (int line = kSpecsStartLong[b]; line < kSpecsStartLong[b] + kSpecsPerBlock[b]; ++line) x = fmin(x, ath_line[line]);
+            x = pow(10, 0.1 * x);
+            t->ath_bfu[b] = x;
+        }
+    }
+    static const float fir[10] = {-8.65163e-18 * 2.0, -0.00851586 * 2.0, -6.74764e-18 * 2.0, 0.0209036 * 2.0, -3.36639e-17 * 2.0,
+                                  -0.0438162 * 2.0,   -1.54175e-17 * 2.0, 0.0931738 * 2.0,   -5.52212e-17 * 2.0, -0.313819 * 2.0};
+    memcpy(t->fir, fir, sizeof(fir));
+    static const float fix_long[kMaxBfus] = {7, 7, 7, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5, 5, 5,
+                                             5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 4, 4, 3, 3, 3, 3, 3, 3, 2, 1, 1, 1, 1, 0, 0, 0};
+    static const float fix_short[kMaxBfus] = {6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5,
+                                              5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 4, 4, 4, 4, 4, 4, 4, 0, 0, 0, 0, 0, 0, 0, 0};
+    memcpy(t->fix_long, fix_long, sizeof(fix_long));
+    memcpy(t->fix_short, fix_short, sizeof(fix_short));
+    static const double tab[16][2] = {
+        {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+        {0x1.49539f0f010b0p+0, -0x1.01eae7f513a67p-2}, {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+        {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8ea0p+0, -0x1.1aa2bc79c8100p-3},
+        {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+        {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1.0000000000000p+0, 0x0.0p+0},
+        {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aa0p-1, 0x1.c5e53aa362eb4p-4},
+        {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d224770p-3},
+        {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+    memcpy(t->logf_tab, tab, sizeof(tab));
+    t->logf_ln2 = 0x1.62e42fefa39efp-1;
+    t->logf_poly[0] = -0x1.00ea348b88334p-2;
+    t->logf_poly[1] = 0x1.5575b0be00b6ap-2;
+    t->logf_poly[2] = -0x1.ffffef20a4123p-2;
+}
+
+}  // namespace at1

@@ -75,7 +75,7 @@ static float ath_formula_frank(float freq) /* atrac_psy_common.cpp:33-95 */
 {
     if (freq < 10.) freq = 10.;
     if (freq > 29853.) freq = 29853.;
-    const float freq_log = 40. * log10(0.1 * freq); /* 4 steps per third, starting at 10 Hz */
+    const double freq_log = 40. * log10(0.1 * freq); /* 4 steps per third, starting at 10 Hz */
     const unsigned index = (unsigned)freq_log;
     return 0.01 * (kAthTab[index] * (1 + index - freq_log) + kAthTab[index + 1] * (freq_log - index));
 }
@@ -108,7 +108,7 @@ static void init_tables(void)
         float f = (float)(i + 3) * 0.5 * 44100 / (float)512;
         float t = log10f(f) - 3.5;
         t = -10 * t * t + 3 - f / 3000;
-        t = powf(10, (0.1 * t));
+        t = pow(10, (0.1 * t));
         T.loud[i] = t;
     }
     {   /* CalcATH(512, 44100) (:126-140) then CalcAt1ATH (atrac1_bitalloc.cpp:130-149) */
@@ -514,6 +514,27 @@ static void write_frame(const sblock* blocks, const int log_count[3], float loud
     bw_write(&w, 0, 8);
     bw_write(&w, 0, 8);
     memcpy(out, w.buf, 212);
+}
+
+/* Table dump for the tests: the layout of atracdenc_amd/csrc/at1_tables.hpp up to ath_bfu (all float32). */
+int at1o_tables(float* dst, int n_floats)
+{
+    init_tables();
+    float* p = dst;
+    const int need = 48 + 64 + 32 + 256 + 128 + 32 + 2 * (128 + 64 + 16) + 512 + 52;
+    if (n_floats != need) return -1;
+    memcpy(p, T.qmf_win, sizeof(T.qmf_win)); p += 48;
+    memcpy(p, T.scale, sizeof(T.scale)); p += 64;
+    memcpy(p, T.sine, sizeof(T.sine)); p += 32;
+    memcpy(p, T.sc512, sizeof(T.sc512)); p += 256;
+    memcpy(p, T.sc256, sizeof(T.sc256)); p += 128;
+    memcpy(p, T.sc64, sizeof(T.sc64)); p += 32;
+    memcpy(p, T.tw128, sizeof(T.tw128)); p += 256;
+    memcpy(p, T.tw64, sizeof(T.tw64)); p += 128;
+    memcpy(p, T.tw16, sizeof(T.tw16)); p += 32;
+    memcpy(p, T.loud, sizeof(T.loud)); p += 512;
+    memcpy(p, T.ath_bfu, sizeof(T.ath_bfu)); p += 52;
+    return need;
 }
 
 /* ---- encoder object (atrac1denc.cpp:180-255) ------------------------------------------------------------------- */

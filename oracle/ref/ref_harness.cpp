@@ -337,6 +337,15 @@ struct TCaptureOut : public ICompressedOutput {
 };
 }
 
+// CalcATH(512, 44100) and CreateLoudnessCurve(512) as the ATRAC1 encoder uses them (atrac_psy_common.cpp:126-156)
+void at1ref_psy_tables(float* ath512, float* loud512)
+{
+    const std::vector<float> a = CalcATH(512, 44100);
+    const std::vector<float> l = CreateLoudnessCurve(512);
+    memcpy(ath512, a.data(), 512 * sizeof(float));
+    memcpy(loud512, l.data(), 512 * sizeof(float));
+}
+
 // pcm [n_blocks][512][nch] -> out [n_blocks][nch][212]; returns bytes written. window_auto = 1: transient detection,
 // else `window_mask` (bit 0 low, 1 mid, 2 high band short) for every frame. bfu_idx_const as TAtrac1EncodeSettings.
 int at1ref_encode(const float* pcm, int nch, int n_blocks, int window_auto, int window_mask, int bfu_idx_const, uint8_t* out)

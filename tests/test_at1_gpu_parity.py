@@ -1,0 +1,117 @@
+"""ATRAC1 HIP path (include/at1hip.h) against the oracle and the golden sound units.
+Bit-exact: bytes equal; float taps equal as bit patterns."""
+import os
+
+import numpy as np
+import pytest
+
+from at3_testlib import AT1_MODES, SIGNALS, at1_blocks, at1_oracle_encode, pcm_mix, pcm_stress
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "at1_encode.npz"))
+
+
+def _enc(**kw):
+    from atracdenc_amd import At1Hip
+    return At1Hip(**kw)
+
+
+def _mode_kw(mode):
+    auto, mask, bfu = AT1_MODES[mode]
+    return dict(window_auto=auto, window_mask=mask, bfu_idx_const=bfu)
+
+
+def bits(a):
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+@pytest.mark.parametrize("mode", sorted(AT1_MODES))
+@pytest.mark.parametrize("nch", [1, 2])
+def test_signals_in_pieces_with_taps(oracle, mode, nch):
+    """Five streams side by side, fed in pieces of 7 + 1 + 32 blocks: frames, spectra, window masks and the tracked
+    loudness of every piece equal the oracle's one-shot encode."""
+    from atracdenc_amd import At1Hip
+    names = sorted(SIGNALS)
+    pcm = np.stack([at1_blocks(SIGNALS[n](20), nch) for n in names])
+    exp = [at1_oracle_encode(pcm[i], mode, taps=True) for i in range(len(names))]
+    enc = _enc(n_streams=len(names), max_blocks=32, channels=nch, **_mode_kw(mode))
+    pos = 0
+    for n in (7, 1, 32):
+        got = enc.encode(pcm[:, pos:pos + n])
+        specs = enc.read_tap(At1Hip.TAP_SPECTRA, np.float32, (len(names), n, nch, 512))
+        masks = enc.read_tap(At1Hip.TAP_MASKS, np.int32, (len(names), n, nch))
+        loud = enc.read_tap(At1Hip.TAP_LOUDNESS, np.float32, (len(names), n))
+        for i, name in enumerate(names):
+            f, s, m, l = (e[pos:pos + n] for e in exp[i])
+            assert np.array_equal(masks[i], m), (name, pos)
+            assert np.array_equal(bits(specs[i]), bits(s)), (name, pos)
+            assert np.array_equal(bits(loud[i]), bits(l)), (name, pos)
+            assert np.array_equal(got[i], f), (name, pos)
+        pos += n
+    enc.close()
+
+
+@pytest.mark.parametrize("key", sorted(k for k in GOLD.files if "_ch" in k))
+def test_golden(key):
+    name, ch, mode = key.split("_", 2)
+    nch = int(ch[2:])
+    pcm = (GOLD[f"{name}_pcm_s16"].astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    blocks = at1_blocks(pcm, nch)
+    enc = _enc(n_streams=1, max_blocks=blocks.shape[0], channels=nch, **_mode_kw(mode))
+    got = enc.encode(blocks[None])[0]
+    enc.close()
+    assert np.array_equal(got, GOLD[key])
+
+
+@pytest.mark.parametrize("mode", ["auto", "short", "auto_bfu3"])
+def test_stress_signal(oracle, mode):
+    blocks = at1_blocks(pcm_stress(66))
+    enc = _enc(n_streams=1, max_blocks=blocks.shape[0], **_mode_kw(mode))
+    got = enc.encode(blocks[None])[0]
+    enc.close()
+    assert np.array_equal(got, at1_oracle_encode(blocks, mode))
+
+
+def test_reset_and_device_pointers(oracle):
+    """Device-resident PCM / output (the layout bench-style callers use) and at1hip_reset."""
+    import torch
+    blocks = np.stack([at1_blocks(pcm_mix(16, seed=s)) for s in (1, 2, 3)])
+    exp = np.stack([at1_oracle_encode(b, "auto") for b in blocks])
+    enc = _enc(n_streams=3, max_blocks=32)
+    d_pcm = torch.from_numpy(blocks).cuda()
+    d_out = torch.zeros((3, 32, 2, 212), dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        enc.encode_device(d_pcm.data_ptr(), 32, d_out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), exp)
+        enc.reset()
+    enc.close()
+
+
+def test_wide_batch(oracle):
+    """96 streams x 64 blocks (the batch shape of BASELINE configs[1], in ATRAC1 sound units): every stream equals the
+    oracle's encode of that stream alone - no cross-stream leakage, grid-size independent results."""
+    S, nb = 96, 64
+    blocks = np.stack([at1_blocks(pcm_mix(nb // 2, seed=100 + s)) for s in range(S)])
+    enc = _enc(n_streams=S, max_blocks=nb)
+    got = enc.encode(blocks)
+    enc.close()
+    for s in range(0, S, 7):
+        assert np.array_equal(got[s], at1_oracle_encode(blocks[s], "auto")), s
+    # determinism / size-independent property over all streams: a second context gives the same bytes
+    enc = _enc(n_streams=S, max_blocks=nb)
+    assert np.array_equal(enc.encode(blocks), got)
+    enc.close()
+
+
+def test_bad_arguments():
+    from atracdenc_amd import At3HipError
+    with pytest.raises(At3HipError):
+        _enc(n_streams=1, channels=3)
+    with pytest.raises(At3HipError):
+        _enc(n_streams=1, bfu_idx_const=9)
+    enc = _enc(n_streams=1, max_blocks=4)
+    with pytest.raises(At3HipError):
+        enc.encode(np.zeros((1, 5, 512, 2), np.float32))
+    enc.close()

@@ -56,3 +56,42 @@ def test_vs_reference(oracle, mode, nch):
     for name, gen in gens.items():
         blocks = at1_blocks(gen(66 if name == "stress" else 40), nch)
         assert np.array_equal(at1_oracle_encode(blocks, mode), at1_ref_encode(blocks, mode)), name
+
+
+def test_product_host_tables_equal_oracle_tables(oracle):
+    """The constant tables the library builds on the host (at1hip_host_tables, no GPU) are, bit for bit, the oracle's
+    restatement of the reference's static initialisers."""
+    import ctypes
+    import atracdenc_amd
+    from atracdenc_amd.binding import at1_host_tables
+    from at3_testlib import ORACLE_SO, _vp
+    if not os.path.exists(atracdenc_amd.LIB_PATH):
+        atracdenc_amd.build_library()
+    t = at1_host_tables()
+    names = ["qmf_win", "scale", "sine", "sc512", "sc256", "sc64", "tw128", "tw64", "tw16", "loud", "ath_bfu"]
+    n = sum(t[k].size for k in names)
+    ref = np.zeros(n, np.float32)
+    assert ctypes.CDLL(ORACLE_SO).at1o_tables(_vp(ref), n) == n
+    got = np.concatenate([t[k].ravel() for k in names])
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+def test_psy_tables_vs_reference(oracle):
+    """Loudness curve and the per-BFU threshold in quiet against the reference's CalcATH / CreateLoudnessCurve; the
+    frame bytes are not sensitive enough to pin these (a float/double slip in the ATH formula went unnoticed by them)."""
+    import ctypes
+    from at3_testlib import ORACLE_SO, REF_SO, _vp
+    n = 48 + 64 + 32 + 256 + 128 + 32 + 2 * (128 + 64 + 16) + 512 + 52
+    tab = np.zeros(n, np.float32)
+    assert ctypes.CDLL(ORACLE_SO).at1o_tables(_vp(tab), n) == n
+    ath = np.zeros(512, np.float32)
+    loud = np.zeros(512, np.float32)
+    ctypes.CDLL(REF_SO).at1ref_psy_tables(_vp(ath), _vp(loud))
+    assert np.array_equal(tab[n - 52 - 512:n - 52].view(np.uint32), loud.view(np.uint32))
+    start = [0, 8, 16, 24, 32, 36, 40, 44, 48, 56, 64, 72, 80, 86, 92, 98, 104, 110, 116, 122, 128, 134, 140, 146, 152, 159, 166,
+             173, 180, 189, 198, 207, 216, 226, 236, 246, 256, 268, 280, 292, 304, 316, 328, 340, 352, 372, 392, 412, 432, 452,
+             472, 492, 512]
+    # CalcAt1ATH (atrac1_bitalloc.cpp:118-135): pow(10, 0.1 * min over the BFU's lines), double pow, float result
+    want = np.array([np.float32(np.power(10.0, 0.1 * np.float64(ath[start[b]:start[b + 1]].min()))) for b in range(52)], np.float32)
+    assert np.array_equal(tab[n - 52:].view(np.uint32), want.view(np.uint32))

@@ -14,6 +14,7 @@ def build():
     subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
                            "-I", os.path.join(ROOT, "tools", "emu"), "-o", EMU,
                            os.path.join(ROOT, "atracdenc_amd/csrc/at3hip.hip"),
+                           os.path.join(ROOT, "atracdenc_amd/csrc/at1hip.hip"),
                            os.path.join(ROOT, "atracdenc_amd/csrc/at3_tables.cpp"),
                            os.path.join(ROOT, "tools/emu/emu_runtime.cpp")])
 
