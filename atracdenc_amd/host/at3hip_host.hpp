@@ -25,6 +25,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/at1hip.h"
 #include "../../include/at3hip.h"
 
 namespace NAtracDEncHip {
@@ -200,6 +201,85 @@ private:
     const size_t BlockFloats;
     std::vector<float> Pending;
     uint64_t Calls = 0;
+};
+
+// ---- ATRAC1 -----------------------------------------------------------------------
+// NAtrac1::TAtrac1EncodeSettings (atrac/at1/atrac1.h:33-54)
+struct TAtrac1EncodeSettings {
+    enum class EWindowMode { EWM_NOTRANSIENT, EWM_AUTO };
+    uint32_t BfuIdxConst = 0;
+    EWindowMode WindowMode = EWindowMode::EWM_AUTO;
+    uint32_t WindowMask = 0;
+    TAtrac1EncodeSettings() = default;
+    TAtrac1EncodeSettings(uint32_t bfuIdxConst, EWindowMode windowMode, uint32_t windowMask)
+        : BfuIdxConst(bfuIdxConst), WindowMode(windowMode), WindowMask(windowMask)
+    {
+    }
+};
+
+inline void Check1(int rc, at1hip_ctx* ctx, const char* what)
+{
+    if (rc != AT3HIP_OK) throw std::runtime_error(std::string(what) + ": " + (ctx ? at1hip_last_error(ctx) : "error " + std::to_string(rc)));
+}
+
+// TAtrac1Encoder (atrac1denc.h:56-110): lambda in - one call per 512-sample block - and one WriteFrame per channel
+// and block out, channel 0 first (atrac1denc.cpp:249-251). The channel count comes from the sink, as in the reference.
+// Calls are buffered `batchBlocks` at a time like TAtrac3Encoder above; there is no look-ahead call in this codec.
+class TAtrac1Encoder {
+public:
+    TAtrac1Encoder(TCompressedOutputPtr&& aea, TAtrac1EncodeSettings&& settings, int batchBlocks = 512, int deviceId = 0)
+        : Aea(std::move(aea)), Settings(settings), BatchBlocks(batchBlocks), Channels(Aea->GetChannelNum()), BlockFloats(512u * Channels)
+    {
+        at1hip_config cfg{};
+        cfg.channels = (int32_t)Channels;
+        cfg.window_auto = Settings.WindowMode == TAtrac1EncodeSettings::EWindowMode::EWM_AUTO;
+        cfg.window_mask = (int32_t)Settings.WindowMask;
+        cfg.bfu_idx_const = (int32_t)Settings.BfuIdxConst;
+        cfg.n_streams = 1;
+        cfg.max_blocks = batchBlocks;
+        cfg.device_id = deviceId;
+        Check1(at1hip_create(&cfg, &Ctx), nullptr, "at1hip_create");
+        Pending.reserve((size_t)BatchBlocks * BlockFloats);
+    }
+    ~TAtrac1Encoder()
+    {
+        try {
+            Flush();
+        } catch (...) {
+        }
+        at1hip_destroy(Ctx);
+    }
+    TAtrac1Encoder(const TAtrac1Encoder&) = delete;
+    TAtrac1Encoder& operator=(const TAtrac1Encoder&) = delete;
+
+    TProcessLambda GetLambda()
+    {
+        return [this](float* data, const ProcessMeta&) {
+            Pending.insert(Pending.end(), data, data + BlockFloats);
+            if ((int)(Pending.size() / BlockFloats) == BatchBlocks) Flush();
+            return EProcessResult::PROCESSED;
+        };
+    }
+
+    void Flush()
+    {
+        const int nb = (int)(Pending.size() / BlockFloats);
+        if (nb == 0) return;
+        std::vector<uint8_t> units((size_t)nb * Channels * AT1HIP_FRAME_SIZE);
+        Check1(at1hip_encode(Ctx, Pending.data(), nb, units.data(), 0), Ctx, "at1hip_encode");
+        Pending.clear();
+        for (size_t i = 0; i < (size_t)nb * Channels; ++i)
+            Aea->WriteFrame(std::vector<char>(units.begin() + i * AT1HIP_FRAME_SIZE, units.begin() + (i + 1) * AT1HIP_FRAME_SIZE));
+    }
+
+private:
+    TCompressedOutputPtr Aea;
+    const TAtrac1EncodeSettings Settings;
+    const int BatchBlocks;
+    const size_t Channels;
+    const size_t BlockFloats;
+    at1hip_ctx* Ctx = nullptr;
+    std::vector<float> Pending;
 };
 
 }  // namespace NAtracDEncHip

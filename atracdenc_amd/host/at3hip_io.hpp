@@ -11,6 +11,7 @@
 //   TAt3RiffOutput      ATRAC3-in-WAV container (at3.cpp:38-262: 76-byte header, lengths back-filled on close)
 //   TRawOutput          bare frames (raw.cpp:27-57)
 //   SelectAtrac3Container  extension rule of main.cpp:207-220
+//   TAeaOutput          ATRAC1's AEA container (aea.cpp:120-189); SelectAtrac1Container main.cpp:196-205
 //
 // RealMedia output (rm.cpp) is not built. Everything here is plain host C++ over at3hip_host.hpp.
 #pragma once
@@ -180,7 +181,7 @@ private:
 };
 
 // ---- containers -------------------------------------------------------------------------------------------------
-enum class EContainer { OMA, RIFF, RAW };
+enum class EContainer { OMA, RIFF, RAW, AEA };
 
 inline EContainer SelectAtrac3Container(const std::string& outFile)   // main.cpp:207-220 (AUTO)
 {
@@ -326,6 +327,59 @@ inline TCompressedOutputPtr CreateAtrac3Output(EContainer c, const std::string& 
         case EContainer::RAW: return TCompressedOutputPtr(new TRawOutput(outFile, numChannels));
         default: return TCompressedOutputPtr(new TOmaOutput(outFile, frameSize, jointStereo));
     }
+}
+
+// ---- ATRAC1 -----------------------------------------------------------------------------------------------------
+inline EContainer SelectAtrac1Container(const std::string& outFile)   // main.cpp:196-205 (AUTO)
+{
+    std::string ext;
+    const size_t dot = outFile.find_last_of('.');
+    if (dot != std::string::npos) ext = outFile.substr(dot + 1);
+    for (char& ch : ext)
+        if (ch >= 'A' && ch <= 'Z') ch = (char)(ch - 'A' + 'a');
+    if (ext == "raw" || ext == "dat") return EContainer::RAW;
+    return EContainer::AEA;
+}
+
+// 2048-byte header: 00 08 00 00, title (at most 15 characters kept) at 4, little-endian frame count at 260, channel
+// count at 264; then one all-zero 212-byte unit. The FIRST WriteFrame call is swallowed (aea.cpp:176-181): the file
+// carries the dummy unit in its place, every later unit follows resized to 212 bytes.
+class TAeaOutput : public TFileOutput {
+public:
+    TAeaOutput(const std::string& filename, const std::string& title, size_t numChannels, uint32_t numFrames)
+        : TFileOutput(filename, numChannels), Title(title)
+    {
+        uint8_t h[2048];
+        memset(h, 0, sizeof(h));
+        h[1] = 0x08;
+        strncpy(reinterpret_cast<char*>(h) + 4, title.c_str(), 16);
+        h[19] = 0;
+        Le32(h + 260, numFrames);
+        h[264] = (uint8_t)numChannels;
+        Put(h, sizeof(h), "Can't write AEA header");
+        static const char dummy[212] = {0};
+        Put(dummy, sizeof(dummy), "Can't write dummy frame");
+    }
+    void WriteFrame(std::vector<char> data) override
+    {
+        if (FirstWrite) {
+            FirstWrite = false;
+            return;
+        }
+        data.resize(212);
+        Put(data.data(), data.size(), "Can't write AEA frame");
+    }
+    std::string GetName() const override { return Title.substr(0, 15); }
+
+private:
+    std::string Title;
+    bool FirstWrite = true;
+};
+
+inline TCompressedOutputPtr CreateAtrac1Output(EContainer c, const std::string& outFile, size_t numChannels, uint32_t numFrames)   // main.cpp:320-326
+{
+    if (c == EContainer::RAW) return TCompressedOutputPtr(new TRawOutput(outFile, numChannels, 212));
+    return TCompressedOutputPtr(new TAeaOutput(outFile, "test", numChannels, numFrames));
 }
 
 }  // namespace NAtracDEncHip

@@ -38,6 +38,7 @@
 #include "oma.h"
 #include "at3.h"
 #include "raw.h"
+#include "aea.h"
 
 using namespace NAtracDEnc;
 using namespace NAtrac3;
@@ -266,6 +267,8 @@ int at3ref_write_container(int kind, const char* path, const uint8_t* frames, in
         TCompressedOutputPtr out;
         if (kind == 1) out = CreateAt3Output(path, 2, (uint32_t)num_frames_hint, (uint32_t)frame_sz, js != 0);
         else if (kind == 2) out = CreateRawOutput(path, (size_t)nch);
+        else if (kind == 3) out = CreateAeaOutput(path, "test", (size_t)nch, (uint32_t)num_frames_hint);
+        else if (kind == 4) out = CreateRawOutput(path, (size_t)nch, (uint32_t)frame_sz);   // ATRAC1 raw, main.cpp:323
         else out.reset(new TOma(path, "test", (size_t)nch, (uint32_t)num_frames_hint, OMAC_ID_ATRAC3, (uint32_t)frame_sz, js != 0));
         for (int i = 0; i < n_frames; ++i)
             out->WriteFrame(std::vector<char>(frames + (size_t)i * frame_sz, frames + (size_t)(i + 1) * frame_sz));
@@ -279,8 +282,8 @@ int at3ref_write_container(int kind, const char* path, const uint8_t* frames, in
 // (sample value = 1 + frame index, every channel) with the short-read / end-of-data behaviour of TWav::GetPCMReader
 // (wav.cpp:46-61). The lambda answers LOOK_AHEAD once, then PROCESSED, and logs the first and last frame value of every
 // call, plus - when `tail` is given - the whole 1024 x nch block of the LAST call. Returns the number of lambda calls (or -1 if the engine threw TNoDataToRead), *processed_out = final count.
-int at3ref_engine_trace(uint64_t total_samples, int nch, float* first_vals, float* last_vals, int max_calls, uint64_t* processed_out,
-                        float* tail)
+int at3ref_engine_trace_step(uint64_t total_samples, int nch, int step, int look_ahead, float* first_vals, float* last_vals, int max_calls,
+                             uint64_t* processed_out, float* tail)
 {
     struct TRampReader : public IPCMReader {
         mutable uint64_t Pos = 0;
@@ -303,14 +306,14 @@ int at3ref_engine_trace(uint64_t total_samples, int nch, float* first_vals, floa
     auto lambda = [&](float* data, const TPCMEngine::ProcessMeta& meta) {
         if (calls < max_calls) {
             first_vals[calls] = data[0];
-            last_vals[calls] = data[1023 * meta.Channels];
+            last_vals[calls] = data[(size_t)(step - 1) * meta.Channels];
         }
-        if (tail) memcpy(tail, data, sizeof(float) * 1024 * meta.Channels);
-        return (calls++ == 0) ? TPCMEngine::EProcessResult::LOOK_AHEAD : TPCMEngine::EProcessResult::PROCESSED;
+        if (tail) memcpy(tail, data, sizeof(float) * step * meta.Channels);
+        return (calls++ == 0 && look_ahead) ? TPCMEngine::EProcessResult::LOOK_AHEAD : TPCMEngine::EProcessResult::PROCESSED;
     };
     uint64_t processed = 0;
     try {
-        while (total_samples > (processed = engine.ApplyProcess(1024, lambda))) {
+        while (total_samples > (processed = engine.ApplyProcess((size_t)step, lambda))) {
         }
     } catch (const TNoDataToRead&) {
         *processed_out = processed;
@@ -320,6 +323,12 @@ int at3ref_engine_trace(uint64_t total_samples, int nch, float* first_vals, floa
     return calls;
 }
 
+
+int at3ref_engine_trace(uint64_t total_samples, int nch, float* first_vals, float* last_vals, int max_calls, uint64_t* processed_out,
+                        float* tail)
+{
+    return at3ref_engine_trace_step(total_samples, nch, 1024, 1, first_vals, last_vals, max_calls, processed_out, tail);
+}
 
 // ---- ATRAC1 encoder: the reference's TAtrac1Encoder driven one 512-sample block at a time --------
 namespace {

@@ -14,7 +14,8 @@ int at3host_write_container(int kind, const char* path, const uint8_t* frames, i
                             int num_frames_hint, int nch)
 {
     try {
-        TCompressedOutputPtr out = CreateAtrac3Output(kind == 1 ? EContainer::RIFF : kind == 2 ? EContainer::RAW : EContainer::OMA, path,
+        TCompressedOutputPtr out = kind >= 3 ? CreateAtrac1Output(kind == 3 ? EContainer::AEA : EContainer::RAW, path, (size_t)nch, (uint32_t)num_frames_hint)
+                                             : CreateAtrac3Output(kind == 1 ? EContainer::RIFF : kind == 2 ? EContainer::RAW : EContainer::OMA, path,
                                                       (size_t)nch, (uint32_t)num_frames_hint, (uint32_t)frame_sz, js != 0);
         for (int i = 0; i < n_frames; ++i)
             out->WriteFrame(std::vector<char>(frames + (size_t)i * frame_sz, frames + (size_t)(i + 1) * frame_sz));
@@ -33,9 +34,9 @@ int at3host_select_container(const char* out_file)
     }
 }
 
-// Same contract as at3ref_engine_trace in oracle/ref/ref_harness.cpp.
-int at3host_engine_trace(uint64_t total_samples, int nch, float* first_vals, float* last_vals, int max_calls, uint64_t* processed_out,
-                         float* tail)
+// Same contract as at3ref_engine_trace_step in oracle/ref/ref_harness.cpp.
+int at3host_engine_trace_step(uint64_t total_samples, int nch, int step, int look_ahead, float* first_vals, float* last_vals, int max_calls,
+                              uint64_t* processed_out, float* tail)
 {
     uint64_t pos = 0;
     TPCMEngine engine(4096, (size_t)nch, [&](float* dst, size_t frames) -> size_t {
@@ -50,14 +51,14 @@ int at3host_engine_trace(uint64_t total_samples, int nch, float* first_vals, flo
     TProcessLambda lambda = [&](float* data, const ProcessMeta& meta) {
         if (calls < max_calls) {
             first_vals[calls] = data[0];
-            last_vals[calls] = data[1023 * meta.Channels];
+            last_vals[calls] = data[(size_t)(step - 1) * meta.Channels];
         }
-        if (tail) memcpy(tail, data, sizeof(float) * 1024 * meta.Channels);
-        return (calls++ == 0) ? EProcessResult::LOOK_AHEAD : EProcessResult::PROCESSED;
+        if (tail) memcpy(tail, data, sizeof(float) * step * meta.Channels);
+        return (calls++ == 0 && look_ahead) ? EProcessResult::LOOK_AHEAD : EProcessResult::PROCESSED;
     };
     uint64_t processed = 0;
     try {
-        while (total_samples > (processed = engine.ApplyProcess(1024, lambda))) {
+        while (total_samples > (processed = engine.ApplyProcess((size_t)step, lambda))) {
         }
     } catch (const TNoDataToRead&) {
         *processed_out = processed;
@@ -67,9 +68,15 @@ int at3host_engine_trace(uint64_t total_samples, int nch, float* first_vals, flo
     return calls;
 }
 
+int at3host_engine_trace(uint64_t total_samples, int nch, float* first_vals, float* last_vals, int max_calls, uint64_t* processed_out,
+                         float* tail)
+{
+    return at3host_engine_trace_step(total_samples, nch, 1024, 1, first_vals, last_vals, max_calls, processed_out, tail);
+}
+
 // Reads a WAV file through TWavSource + TPCMEngine exactly as at3hipenc does and returns every block handed to the
-// encoder lambda: blocks [max_blocks][1024][channels]. Returns the number of blocks, info = {channels, rate, total}.
-int at3host_wav_blocks(const char* path, float* blocks, int max_blocks, uint64_t* info)
+// encoder lambda: blocks [max_blocks][step][channels]. Returns the number of blocks, info = {channels, rate, total}.
+int at3host_wav_blocks_step(const char* path, float* blocks, int max_blocks, uint64_t* info, int step, int look_ahead)
 {
     try {
         TWavSource wav(path);
@@ -80,12 +87,12 @@ int at3host_wav_blocks(const char* path, float* blocks, int max_blocks, uint64_t
         TPCMEngine engine(4096, nch, [&wav](float* dst, size_t frames) { return wav.Read(dst, frames); });
         int calls = 0;
         TProcessLambda lambda = [&](float* data, const ProcessMeta& meta) {
-            if (calls < max_blocks) memcpy(blocks + (size_t)calls * 1024 * meta.Channels, data, sizeof(float) * 1024 * meta.Channels);
-            return (calls++ == 0) ? EProcessResult::LOOK_AHEAD : EProcessResult::PROCESSED;
+            if (calls < max_blocks) memcpy(blocks + (size_t)calls * step * meta.Channels, data, sizeof(float) * step * meta.Channels);
+            return (calls++ == 0 && look_ahead) ? EProcessResult::LOOK_AHEAD : EProcessResult::PROCESSED;
         };
         const uint64_t total = wav.GetTotalSamples();
         try {
-            while (total > engine.ApplyProcess(1024, lambda)) {
+            while (total > engine.ApplyProcess((size_t)step, lambda)) {
             }
         } catch (const TNoDataToRead&) {
         }
@@ -93,6 +100,11 @@ int at3host_wav_blocks(const char* path, float* blocks, int max_blocks, uint64_t
     } catch (const std::exception&) {
         return -1;
     }
+}
+
+int at3host_wav_blocks(const char* path, float* blocks, int max_blocks, uint64_t* info)
+{
+    return at3host_wav_blocks_step(path, blocks, max_blocks, info, 1024, 1);
 }
 
 }  // extern "C"

@@ -138,3 +138,40 @@ def test_wav_reader(host, tmp_path, case):
     assert not tail[:nz].any()
     stale = flat[:4096].reshape(-1)[904 * nch + nz:]
     assert np.array_equal(tail[nz:], stale)
+
+
+# ---- ATRAC1 side: AEA container, 512-sample schedule without a look-ahead call ------------------
+@pytest.mark.parametrize("kind", [3, 4])
+@pytest.mark.parametrize("nch", [1, 2])
+@pytest.mark.parametrize("n,hint", [(9, 9), (1, 1), (0, 4), (5, 70000)])
+def test_aea_container_bytes(host, reflib, tmp_path, kind, nch, n, hint):
+    """TAeaOutput (2048-byte header, dummy unit, first WriteFrame swallowed) and ATRAC1's raw output."""
+    frames = np.random.RandomState(kind * 10 + n).randint(0, 256, size=(n, 212)).astype(np.uint8)
+    a = _write(reflib, "at3ref_write_container", kind, str(tmp_path / "ref.bin"), frames, 212, 0, hint, nch)
+    b = _write(host, "at3host_write_container", kind, str(tmp_path / "own.bin"), frames, 212, 0, hint, nch)
+    assert a == b
+    assert len(a) == (2048 + 212 + max(n - 1, 0) * 212 if kind == 3 else n * 212)
+
+
+def _trace_step(lib, fn, total, nch, step, look_ahead):
+    n = 96
+    first = np.zeros(n, np.float32)
+    last = np.zeros(n, np.float32)
+    tail = np.zeros(step * nch, np.float32)
+    processed = ctypes.c_uint64()
+    f = getattr(lib, fn)
+    f.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                  ctypes.c_void_p, ctypes.c_void_p]
+    calls = f(total, nch, step, look_ahead, first.ctypes.data, last.ctypes.data, n, ctypes.byref(processed), tail.ctypes.data)
+    return calls, processed.value, first, last, tail
+
+
+@pytest.mark.parametrize("nch", [1, 2])
+@pytest.mark.parametrize("total", [1, 511, 512, 513, 4095, 4096, 4097, 6000, 8192, 12800, 20001])
+def test_frame_schedule_atrac1(host, reflib, total, nch):
+    """ApplyProcess(512, ...) with a lambda that always answers PROCESSED (main.cpp:646, atrac1denc.cpp:253)."""
+    a = _trace_step(reflib, "at3ref_engine_trace_step", total, nch, 512, 0)
+    b = _trace_step(host, "at3host_engine_trace_step", total, nch, 512, 0)
+    assert a[0] == b[0] and a[1] == b[1]
+    for i in (2, 3, 4):
+        assert np.array_equal(a[i].view(np.uint32), b[i].view(np.uint32))
