@@ -96,32 +96,48 @@ struct FrontParams {
     float* loud_ch;      // [S][F][nch]
 };
 
-// TQmf<N>::Analysis (qmf/qmf.h:47-64) for one output pair; b points at in[j] of the reference's loop (j = 2 m)
-__device__ __forceinline__ void qmf_pair(const float* W, const float* b, float& lower, float& upper)
+// TQmf<N>::Analysis (qmf/qmf.h:47-64) for one output pair; b points at in[j] of the reference's loop (j = 2 m), 8-byte
+// aligned. The two 24-tap running sums are independent, so they ride in the two halves of packed fp32 operations:
+// Wp[i] = (QmfWindow[2i+1], QmfWindow[2i]) against the naturally ordered sample pair (in[j-2i], in[j-2i+1]).
+__device__ __forceinline__ void qmf_pair(const f2* Wp, const float* b, float& lower, float& upper)
 {
-    float lo = 0.0f, hi = 0.0f;
+    f2 acc = at3::mk2(0.0f, 0.0f);   // (upper-tap sum, lower-tap sum)
 #pragma unroll
-    for (int i = 0; i < 24; ++i) {
-        lo += W[2 * i] * b[1 - 2 * i];
-        hi += W[2 * i + 1] * b[-2 * i];
-    }
-    upper = lo - hi;
-    lower = lo + hi;
+    for (int i = 0; i < 24; ++i) acc += Wp[i] * *reinterpret_cast<const f2*>(b - 2 * i);
+    upper = acc.y - acc.x;
+    lower = acc.y + acc.x;
+}
+
+// The windowed MDCT input buffer of TAtrac1MDCT::Mdct (atrac1denc.cpp:83-90) at offset o: src = the band's samples with
+// index 0 at the unit's first one (the previous unit's tail at negative indices), B = 128 / 256 samples per unit,
+// k = short block number. Long: [zeros | sine-rising overlap (32) | B samples, the last 32 sine-falling | zeros].
+__device__ __forceinline__ float mdct_in(const float* src, const float* sine, int B, bool sh, int k, int o)
+{
+    if (sh) return o < 32 ? sine[o] * src[32 * (k - 1) + o] : sine[63 - o] * src[32 * k + o - 32];
+    const int i = o - (B == 256 ? 112 : 48) - 32;
+    if (i < -32 || i >= B) return 0.0f;
+    const float v = src[i];
+    if (i < 0) return sine[i + 32] * v;
+    if (i >= B - 32) return sine[B - 1 - i] * v;
+    return v;
 }
 
 __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
 {
     // window of band signals kept per workgroup, indices relative to the sound unit's first sample of each rate
     __shared__ __attribute__((aligned(16))) float s_pcm[800];   // t  in [-288, 512)
-    __shared__ float s_lo1[376];                                // m  in [-118, 256)   first-stage lower band
+    __shared__ __attribute__((aligned(16))) float s_lo1[376];                             // m  in [-118, 256)   first-stage lower band
     __shared__ float s_up1[332];                                // m  in [-75, 256)    first-stage upper band; hi[i] = up1[i - 39]
-    __shared__ float s_low[164], s_mid[164];                    // q  in [-36, 128)
+    __shared__ float s_low[166], s_mid[164];                    // q  in [-36, 128); s_low[164] = 0 for the detector
+    __shared__ float s_dmid[166], s_dhi[294];                   // InvertSpectr'ed mid [-36,128] / high [-36,256] band, last = 0
     __shared__ float s_filt[560];                               // detector high-pass output: low/mid [-16,128), hi [-16,256)
     __shared__ float s_rms[3][17];
-    __shared__ __attribute__((aligned(16))) float s_tmp[1024];  // MDCT input buffers; later e * LoudnessCurve
+    __shared__ __attribute__((aligned(16))) float s_tmp[512];   // e * LoudnessCurve
     __shared__ __attribute__((aligned(16))) at3::cpx s_f[256];
     __shared__ __attribute__((aligned(16))) float s_specs[512];
-    __shared__ float s_win[48], s_scale[64], s_sine[32], s_fir[10];
+    __shared__ __attribute__((aligned(16))) f2 s_win[24];
+    __shared__ float s_scale[64], s_sine[32];
+    __shared__ __attribute__((aligned(8))) float s_fir[10];
     __shared__ LogfTab s_logf;
     __shared__ int s_mask;
 
@@ -135,12 +151,17 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         const int t = 512 * f - 288 + j;
         s_pcm[j] = t >= 0 ? p.pcm[((size_t)s * p.n_frames * 512 + t) * nch + ch] : p.hist[((size_t)s * 512 + (512 + t)) * nch + ch];
     }
-    if (tid < 48) s_win[tid] = T->qmf_win[tid];
+    if (tid < 48) reinterpret_cast<float*>(s_win)[tid] = T->qmf_win[tid ^ 1];
     else if (tid < 112) s_scale[tid - 48] = T->scale[tid - 48];
     else if (tid < 144) s_sine[tid - 112] = T->sine[tid - 112];
     else if (tid < 154) s_fir[tid - 144] = T->fir[tid - 144];
     else if (tid < 154 + 36) (&s_logf.tab[0][0])[tid - 154] = (&T->logf_tab[0][0])[tid - 154];
-    if (tid == 255) s_mask = 0;
+    if (tid == 255) {
+        s_mask = 0;
+        s_low[164] = 0.0f;   // HPFBuffer[BlockSz + 20] is never written: the sample after the block reads as 0
+        s_dmid[164] = 0.0f;
+        s_dhi[292] = 0.0f;
+    }
     __syncthreads();
 
     // Atrac1AnalysisFilterBank::Analysis (atrac/at1/atrac1_qmf.h:37-43): Qmf1 over the PCM ...
@@ -149,7 +170,10 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         float lo, up;
         qmf_pair(s_win, s_pcm + (2 * m + 288), lo, up);
         s_lo1[j] = lo;
-        if (m >= -75) s_up1[m + 75] = up;
+        if (m >= -75) {
+            s_up1[m + 75] = up;
+            if (m < 217) s_dhi[m + 75] = (m & 1) ? -up : up;   // hi[i] = up1[i - 39]: i even <=> m odd (InvertSpectr, util.h:51-63)
+        }
     }
     __syncthreads();
     // ... Qmf2 over its lower half; the upper half is delayed by 39 samples
@@ -159,32 +183,35 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         qmf_pair(s_win, s_lo1 + (2 * q + 118), lo, up);
         s_low[tid] = lo;
         s_mid[tid] = up;
+        s_dmid[tid] = (q & 1) ? up : -up;
     }
     __syncthreads();
 
     int mask = p.window_mask;
     if (p.window_auto) {
-        // TTransientDetector::HPFilter (transient_detector.cpp:48-66) for this unit and for the last short block of the
-        // previous one (its LastEnergy). Mid and high bands are fed through InvertSpectr (util.h:51-63).
+        // TTransientDetector::HPFilter (transient_detector.cpp:48-66) for this unit (512 outputs: each wave stays inside one
+        // band) and for the last short block of the previous unit (its LastEnergy, 48 outputs). The two running sums of the
+        // reference loop are independent and ride in the halves of packed fp32 operations.
+        const f2* firp = reinterpret_cast<const f2*>(s_fir);
         for (int j = tid; j < 560; j += 256) {
-            const int b = j < 144 ? 0 : j < 288 ? 1 : 2;
-            const int i = j - (b == 0 ? 0 : b == 1 ? 144 : 288) - 16;
-            const int B = b == 2 ? 256 : 128;
-            const float* src = (b == 0 ? s_low : b == 1 ? s_mid : s_up1) + 36;
-            auto x = [&](int idx) -> float {
-                // HPFBuffer[BlockSz + 20] is never written: the sample after the block reads as 0
-                if (idx == B || (i < 0 && idx == 0)) return 0.0f;
-                const float v = src[idx];
-                return (b && !(idx & 1)) ? -v : v;
-            };
-            float a = x(i - 10);
-            float a2 = 0.0f;
-#pragma unroll
-            for (int jj = 0; jj < 9; jj += 2) {
-                a += s_fir[jj] * (x(i - 20 + jj) + x(i + 1 - jj));
-                a2 += s_fir[jj + 1] * (x(i - 19 + jj) + x(i - jj));
+            int b, i;
+            if (j < 512) {
+                b = j < 128 ? 0 : j < 256 ? 1 : 2;
+                i = j - (b == 0 ? 0 : b == 1 ? 128 : 256);
+            } else {
+                if (j >= 512 + 48) break;
+                b = (j - 512) >> 4;
+                i = ((j - 512) & 15) - 16;
             }
-            s_filt[j] = (a + a2) / 2;
+            const float* d = (b == 0 ? s_low : b == 1 ? s_dmid : s_dhi) + 36;
+            // the previous unit's own last output saw 0 after its block, not this unit's first sample
+            const float nxt = i == -1 ? 0.0f : d[i + 1];
+            f2 acc = at3::mk2(d[i - 10], 0.0f);
+            acc += firp[0] * (at3::mk2(d[i - 20], d[i - 19]) + at3::mk2(nxt, d[i]));
+#pragma unroll
+            for (int jj = 2; jj < 9; jj += 2)
+                acc += firp[jj >> 1] * (at3::mk2(d[i - 20 + jj], d[i - 19 + jj]) + at3::mk2(d[i + 1 - jj], d[i - jj]));
+            s_filt[(b == 0 ? 0 : b == 1 ? 144 : 288) + 16 + i] = (acc.x + acc.y) / 2;
         }
         __syncthreads();
         // calculateRMS over the 16-sample short blocks, 19 log10 (transient_detector.cpp:40-46, 76)
@@ -212,47 +239,28 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         mask = s_mask;
     }
 
-    // TAtrac1MDCT::Mdct (atrac1denc.cpp:70-102): the three bands' windowed input buffers ...
-    for (int j = tid; j < 1024; j += 256) {
-        const int b = j < 256 ? 0 : j < 512 ? 1 : 2;
-        const int o = j - (b == 0 ? 0 : b == 1 ? 256 : 512);
-        const int B = b == 2 ? 256 : 128;
-        const float* src = (b == 0 ? s_low : b == 1 ? s_mid : s_up1) + 36;
-        float v = 0.0f;
-        if ((mask >> b) & 1) {
-            const int k = o >> 6, w = o & 63;
-            v = w < 32 ? s_sine[w] * src[32 * (k - 1) + w] : s_sine[63 - w] * src[32 * k + w - 32];
-        } else {
-            const int ws = b == 2 ? 112 : 48;
-            const int u = o - ws;
-            if (u >= 0 && u < 32) v = s_sine[u] * src[u - 32];
-            else if (u >= 32 && u < 32 + B) {
-                const int i = u - 32;
-                v = i < B - 32 ? src[i] : s_sine[31 - (i - (B - 32))] * src[i];
-            }
-        }
-        s_tmp[j] = v;
-    }
-    __syncthreads();
-    // ... TMDCT<N>::operator() pre-rotation (lib/mdct/mdct.h:51-87) straight into the FFT's leaf order
+    // TAtrac1MDCT::Mdct (atrac1denc.cpp:70-102): TMDCT<N>::operator() pre-rotation (lib/mdct/mdct.h:51-87) straight into
+    // the FFT's leaf order; the windowed input buffer of the reference is evaluated where it is read (mdct_in).
     {
         const int b = tid < 64 ? 0 : tid < 128 ? 1 : 2;
         const int c = tid - (b == 0 ? 0 : b == 1 ? 64 : 128);
         const bool sh = (mask >> b) & 1;
-        const int N = sh ? 64 : (b == 2 ? 512 : 256);
+        const int B = b == 2 ? 256 : 128;
+        const int N = sh ? 64 : 2 * B;
         const int n4 = N >> 2, n34 = 3 * n4, n54 = 5 * n4;
         const int k = sh ? c >> 4 : 0;
         const int pidx = sh ? (c & 15) : c;
         const int n = 2 * pidx;
-        const float* in = s_tmp + (b == 0 ? 0 : b == 1 ? 256 : 512) + 64 * k;
+        const float* src = (b == 0 ? s_low : b == 1 ? s_mid : s_up1) + 36;
         const float* cs = sh ? T->sc64 : (b == 2 ? T->sc512 : T->sc256);
+        auto in = [&](int o) { return mdct_in(src, s_sine, B, sh, k, o); };
         float r0, i0;
         if (n < n4) {
-            r0 = in[n34 - 1 - n] + in[n34 + n];
-            i0 = in[n4 + n] - in[n4 - 1 - n];
+            r0 = in(n34 - 1 - n) + in(n34 + n);
+            i0 = in(n4 + n) - in(n4 - 1 - n);
         } else {
-            r0 = in[n34 - 1 - n] - in[n - n4];
-            i0 = in[n4 + n] + in[n54 - 1 - n];
+            r0 = in(n34 - 1 - n) - in(n - n4);
+            i0 = in(n4 + n) + in(n54 - 1 - n);
         }
         const float cc = cs[n], ss = cs[n + 1];
         at3::cpx v;
@@ -262,12 +270,21 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         s_f[(b == 0 ? 0 : b == 1 ? 64 : 128) + 16 * k + leaf] = v;
     }
     __syncthreads();
-    if (mask & 1) fft_lds<16, false>(s_f, 16, 4, T->tw16, tid, 256);
-    else fft_lds<64, false>(s_f, 64, 1, T->tw64, tid, 256);
-    if (mask & 2) fft_lds<16, false>(s_f + 64, 16, 4, T->tw16, tid, 256);
-    else fft_lds<64, false>(s_f + 64, 64, 1, T->tw64, tid, 256);
-    if (mask & 4) fft_lds<16, false>(s_f + 128, 16, 8, T->tw16, tid, 256);
-    else fft_lds<128, false>(s_f + 128, 128, 1, T->tw128, tid, 256);
+    {
+        // one band per wave: the stages of a band's transforms only need that wave's own lanes
+        const int wave = tid >> 6, lane = tid & 63;
+        if (wave == 0) {
+            if (mask & 1) fft_lds<16, false, false, true>(s_f, 16, 4, T->tw16, lane, 64);
+            else fft_lds<64, false, false, true>(s_f, 64, 1, T->tw64, lane, 64);
+        } else if (wave == 1) {
+            if (mask & 2) fft_lds<16, false, false, true>(s_f + 64, 16, 4, T->tw16, lane, 64);
+            else fft_lds<64, false, false, true>(s_f + 64, 64, 1, T->tw64, lane, 64);
+        } else if (wave == 2) {
+            if (mask & 4) fft_lds<16, false, false, true>(s_f + 128, 16, 8, T->tw16, lane, 64);
+            else fft_lds<128, false, false, true>(s_f + 128, 128, 1, T->tw128, lane, 64);
+        }
+    }
+    __syncthreads();
     // post-rotation (mdct.h:89-101), the high band's short-window gain and the mirrored bands (atrac1denc.cpp:92-97)
     {
         const int b = tid < 64 ? 0 : tid < 128 ? 1 : 2;
@@ -359,24 +376,40 @@ struct ScanParams {
     int32_t n_streams, n_frames, nch;
 };
 
-// TrackLoudness (atrac/atrac_psy_common.h:46-54) as atrac1denc.cpp:243-247 applies it
+// TrackLoudness (atrac/atrac_psy_common.h:46-54) as atrac1denc.cpp:243-247 applies it. One wave per stream: the lanes
+// stage 256 sound units' masks and loudness sums in LDS with coalesced loads, lane 0 runs the recursion out of LDS (a
+// dependent global load per step would cost far more than the three double operations of the step itself), the lanes
+// store the tracked values.
 __global__ __launch_bounds__(64) void k_at1_loud_scan(ScanParams p)
 {
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= p.n_streams) return;
+    __shared__ float s_l0[256], s_l1[256], s_track[256];
+    __shared__ uint8_t s_long[256];   // bit 0: channel 0 all-long, bit 1: both channels all-long
+    const int s = blockIdx.x, lane = threadIdx.x;
     float L = p.loud_state[s];
-    for (int f = 0; f < p.n_frames; ++f) {
-        const size_t it = ((size_t)s * p.n_frames + f) * p.nch;
-        const int m0 = p.mask[it];
-        const float l0 = p.loud_ch[it];
-        if (p.nch == 2 && m0 == 0 && p.mask[it + 1] == 0) {
-            L = (float)(0.98 * (double)L + 0.01 * (double)(l0 + p.loud_ch[it + 1]));
-        } else if (m0 == 0) {
-            L = (float)(0.98 * (double)L + 0.02 * (double)l0);
+    for (int base = 0; base < p.n_frames; base += 256) {
+        const int cnt = p.n_frames - base < 256 ? p.n_frames - base : 256;
+        for (int j = lane; j < cnt; j += 64) {
+            const size_t it = ((size_t)s * p.n_frames + base + j) * p.nch;
+            const int m0 = p.mask[it];
+            const int m1 = p.nch == 2 ? p.mask[it + 1] : 1;
+            s_l0[j] = p.loud_ch[it];
+            s_l1[j] = p.nch == 2 ? p.loud_ch[it + 1] : 0.0f;
+            s_long[j] = (uint8_t)((m0 == 0 ? 1 : 0) | ((m0 == 0 && m1 == 0) ? 2 : 0));
         }
-        p.loud_track[(size_t)s * p.n_frames + f] = L;
+        wave_sync();
+        if (lane == 0) {
+            for (int j = 0; j < cnt; ++j) {
+                const int fl = s_long[j];
+                if (fl & 2) L = (float)(0.98 * (double)L + 0.01 * (double)(s_l0[j] + s_l1[j]));
+                else if (fl & 1) L = (float)(0.98 * (double)L + 0.02 * (double)s_l0[j]);
+                s_track[j] = L;
+            }
+        }
+        wave_sync();
+        for (int j = lane; j < cnt; j += 64) p.loud_track[(size_t)s * p.n_frames + base + j] = s_track[j];
+        wave_sync();
     }
-    p.loud_state[s] = L;
+    if (lane == 0) p.loud_state[s] = L;
 }
 
 struct PackParams {

@@ -194,7 +194,7 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     sp.n_streams = (int)S;
     sp.n_frames = n_blocks;
     sp.nch = (int)C;
-    hipLaunchKernelGGL(k_at1_loud_scan, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, sp);
+    hipLaunchKernelGGL(k_at1_loud_scan, dim3((unsigned)S), dim3(64), 0, st, sp);
     HIPCHK(c, hipEventRecord(c->ev[2], st));
 
     PackParams pp;

@@ -235,6 +235,13 @@ __device__ __forceinline__ float at3_log2f(const Tables* T, float x)   // tables
     return at3_log2f(reinterpret_cast<const Log2fTab*>(&T->log2f_tab[0][0]), x);
 }
 
+__device__ __forceinline__ void wave_sync_fwd()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- kissfft-order in-LDS FFT -------------------------------------------------------------------
 // F holds `nfft` arrays of N complex points (stride NS) whose inputs were already stored in the
 // decimation-in-time leaf order (see fft_leaf_pos). Recombination runs from the leaves up with the
@@ -257,9 +264,15 @@ __device__ __forceinline__ int fft_leaf_pos(int i)
     return o;
 }
 
-template <int N, bool INVERSE, bool LEAF_DONE = false>
+template <int N, bool INVERSE, bool LEAF_DONE = false, bool WAVE = false>
 __device__ __forceinline__ void fft_lds(cpx* F, int NS, int nfft, const cpx* tw, int tid, int nthr)
 {
+    // WAVE: all participating threads are the lanes of ONE wavefront (nthr = 64, tid = lane): the stages are separated by
+    // wave-level rendezvous instead of workgroup barriers
+    auto stage_sync = [] {
+        if (WAVE) wave_sync_fwd();
+        else __syncthreads();
+    };
     // number of radix-4 stages and whether a radix-2 leaf stage exists; LEAF_DONE: the caller already stored
     // the outputs of the radix-2 leaf butterflies (used when the leaf inputs are mostly exact zeros)
     int lg = 0;
@@ -277,7 +290,7 @@ __device__ __forceinline__ void fft_lds(cpx* F, int NS, int nfft, const cpx* tw,
             st2(a, a0);
             st2(a + 1, a1);
         }
-        __syncthreads();
+        stage_sync();
         m = 2;
     }
     for (; m < N; m <<= 2) {
@@ -293,7 +306,7 @@ __device__ __forceinline__ void fft_lds(cpx* F, int NS, int nfft, const cpx* tw,
             st2(B + 2 * m, x2);
             st2(B + 3 * m, x3);
         }
-        __syncthreads();
+        stage_sync();
     }
 }
 
