@@ -88,6 +88,7 @@ struct FrontParams {
     int32_t n_frames, nch;
     int32_t first;       // call starts at the stream start: the detectors' LastEnergy is 0.0
     int32_t window_auto, window_mask;
+    int32_t debug;       // AT1HIP_DEBUG_STOP: leave the kernel after phase n (timing experiments only)
     float* specs;        // [S][F][nch][512] MDCT spectrum (kept for the tap interface)
     float* values;       // [S][F][nch][512] scaled mantissa sources, BFU after BFU
     float* energy;       // [S][F][nch][52]
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
     }
     __syncthreads();
 
+    if (p.debug == 1) return;
     // Atrac1AnalysisFilterBank::Analysis (atrac/at1/atrac1_qmf.h:37-43): Qmf1 over the PCM ...
     for (int j = tid; j < 374; j += 256) {
         const int m = j - 118;
@@ -176,6 +178,7 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         }
     }
     __syncthreads();
+    if (p.debug == 2) return;
     // ... Qmf2 over its lower half; the upper half is delayed by 39 samples
     if (tid < 164) {
         const int q = tid - 36;
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
     }
     __syncthreads();
 
+    if (p.debug == 3) return;
     int mask = p.window_mask;
     if (p.window_auto) {
         // TTransientDetector::HPFilter (transient_detector.cpp:48-66) for this unit (512 outputs: each wave stays inside one
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         mask = s_mask;
     }
 
+    if (p.debug == 4) return;
     // TAtrac1MDCT::Mdct (atrac1denc.cpp:70-102): TMDCT<N>::operator() pre-rotation (lib/mdct/mdct.h:51-87) straight into
     // the FFT's leaf order; the windowed input buffer of the reference is evaluated where it is read (mdct_in).
     {
@@ -270,6 +275,7 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         s_f[(b == 0 ? 0 : b == 1 ? 64 : 128) + 16 * k + leaf] = v;
     }
     __syncthreads();
+    if (p.debug == 5) return;
     {
         // one band per wave: the stages of a band's transforms only need that wave's own lanes
         const int wave = tid >> 6, lane = tid & 63;
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         }
     }
     __syncthreads();
+    if (p.debug == 6) return;
     // post-rotation (mdct.h:89-101), the high band's short-window gain and the mirrored bands (atrac1denc.cpp:92-97)
     {
         const int b = tid < 64 ? 0 : tid < 128 ? 1 : 2;
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
     }
     __syncthreads();
 
+    if (p.debug == 7) return;
     for (int j = tid; j < 512; j += 256) {
         const float v = s_specs[j];
         const float e = v * v;

@@ -174,6 +174,10 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     fp.first = c->blocks_fed == 0;
     fp.window_auto = c->cfg.window_auto ? 1 : 0;
     fp.window_mask = c->cfg.window_mask;
+    {
+        const char* dbg = getenv("AT1HIP_DEBUG_STOP");
+        fp.debug = dbg ? atoi(dbg) : 0;
+    }
     fp.specs = c->d_specs;
     fp.values = c->d_values;
     fp.energy = c->d_energy;
