@@ -28,6 +28,24 @@ __device__ static const uint16_t c_start_long[kMaxBfus] = {
 __device__ static const uint16_t c_start_short[kMaxBfus] = {
     0,   32,  64,  96,  8,   40,  72,  104, 12,  44,  76,  108, 20,  52,  84,  116, 26,  58,  90,  122, 128, 160, 192, 224, 134, 166,
     198, 230, 141, 173, 205, 237, 150, 182, 214, 246, 256, 288, 320, 352, 384, 416, 448, 480, 268, 300, 332, 364, 396, 428, 460, 492};
+// BFU that owns position i of the BFU-ordered value array (the long-window line layout, SpecsStartLong)
+__device__ static const uint8_t c_bfu_of_pos[512] __attribute__((aligned(16))) = {
+    0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3,
+    4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9,
+    10, 10, 10, 10, 10, 10, 10, 10, 11, 11, 11, 11, 11, 11, 11, 11, 12, 12, 12, 12, 12, 12, 13, 13, 13, 13, 13, 13, 14, 14, 14, 14,
+    14, 14, 15, 15, 15, 15, 15, 15, 16, 16, 16, 16, 16, 16, 17, 17, 17, 17, 17, 17, 18, 18, 18, 18, 18, 18, 19, 19, 19, 19, 19, 19,
+    20, 20, 20, 20, 20, 20, 21, 21, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 23, 24, 24, 24, 24, 24, 24, 24, 25,
+    25, 25, 25, 25, 25, 25, 26, 26, 26, 26, 26, 26, 26, 27, 27, 27, 27, 27, 27, 27, 28, 28, 28, 28, 28, 28, 28, 28, 28, 29, 29, 29,
+    29, 29, 29, 29, 29, 29, 30, 30, 30, 30, 30, 30, 30, 30, 30, 31, 31, 31, 31, 31, 31, 31, 31, 31, 32, 32, 32, 32, 32, 32, 32, 32,
+    32, 32, 33, 33, 33, 33, 33, 33, 33, 33, 33, 33, 34, 34, 34, 34, 34, 34, 34, 34, 34, 34, 35, 35, 35, 35, 35, 35, 35, 35, 35, 35,
+    36, 36, 36, 36, 36, 36, 36, 36, 36, 36, 36, 36, 37, 37, 37, 37, 37, 37, 37, 37, 37, 37, 37, 37, 38, 38, 38, 38, 38, 38, 38, 38,
+    38, 38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39, 39, 39, 39, 39, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 41, 41, 41, 41,
+    41, 41, 41, 41, 41, 41, 41, 41, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 43, 43, 43, 43, 43, 43, 43, 43, 43, 43, 43, 43,
+    44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 44, 45, 45, 45, 45, 45, 45, 45, 45, 45, 45, 45, 45,
+    45, 45, 45, 45, 45, 45, 45, 45, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 46, 47, 47, 47, 47,
+    47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 47, 48, 48, 48, 48, 48, 48, 48, 48, 48, 48, 48, 48, 48, 48, 48, 48,
+    48, 48, 48, 48, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 49, 50, 50, 50, 50, 50, 50, 50, 50,
+    50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 50, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51,};
 __device__ __forceinline__ int bfu_amount(int idx)  // BfuAmountTab
 {
     return idx == 0 ? 20 : 24 + 4 * idx;
@@ -40,6 +58,8 @@ struct LogfTab {
     double poly[3];
 };
 static_assert(offsetof(Tables, logf_poly) - offsetof(Tables, logf_tab) == sizeof(double) * 33, "Tables keeps the logf data together");
+static_assert(offsetof(Tables, sc256) - offsetof(Tables, sc512) == 256 * 4 && offsetof(Tables, sc64) - offsetof(Tables, sc512) == 384 * 4,
+              "the three MDCT rotation tables are staged as one block");
 
 // logf of glibc 2.35, FMA build (sysdeps/ieee754/flt-32/e_logf.c with the multiarch -mfma variant): normal x only.
 __device__ __forceinline__ float at1_logf(const LogfTab* L, float x)
@@ -97,16 +117,37 @@ struct FrontParams {
     float* loud_ch;      // [S][F][nch]
 };
 
-// TQmf<N>::Analysis (qmf/qmf.h:47-64) for one output pair; b points at in[j] of the reference's loop (j = 2 m), 8-byte
-// aligned. The two 24-tap running sums are independent, so they ride in the two halves of packed fp32 operations:
-// Wp[i] = (QmfWindow[2i+1], QmfWindow[2i]) against the naturally ordered sample pair (in[j-2i], in[j-2i+1]).
-__device__ __forceinline__ void qmf_pair(const f2* Wp, const float* b, float& lower, float& upper)
+// LDS layout of the two QMF inputs: one extra pair of floats after every 8 (index p lives at p + 2 (p >> 3)). A thread
+// that produces four adjacent output pairs walks samples 8 floats apart from its neighbour's; with the padding the lanes'
+// 8-byte reads start 10 floats apart and 16 consecutive lanes cover all 32 banks exactly once.
+__device__ __forceinline__ constexpr int qmf_pad(int p) { return p + 2 * (p >> 3); }
+
+// TQmf<N>::Analysis (qmf/qmf.h:47-64) for FOUR adjacent output pairs m0 .. m0+3 of one thread: the 4 x 48 taps touch only
+// 27 distinct sample pairs, read once (the one-pair-per-thread form re-read every sample 24 times and was bound by LDS
+// bandwidth). `base` = padded address of sample pair (in[2 m0 - 46], in[2 m0 - 45]) for a thread whose unpadded float
+// index of that pair is = PHASE (mod 8), so every later offset is a compile-time constant. The two 24-tap running sums
+// of an output are independent and ride in the halves of packed fp32 operations: W[i] = (QmfWindow[2i+1], QmfWindow[2i])
+// (wave-uniform, scalar registers) against the naturally ordered sample pair (in[j-2i], in[j-2i+1]).
+template <int PHASE>
+__device__ __forceinline__ void qmf_quad(const float* __restrict__ win, const float* base, float (&lower)[4], float (&upper)[4])
 {
-    f2 acc = at3::mk2(0.0f, 0.0f);   // (upper-tap sum, lower-tap sum)
+    f2 P[27];
 #pragma unroll
-    for (int i = 0; i < 24; ++i) acc += Wp[i] * *reinterpret_cast<const f2*>(b - 2 * i);
-    upper = acc.y - acc.x;
-    lower = acc.y + acc.x;
+    for (int j = 0; j < 27; ++j) P[j] = *reinterpret_cast<const f2*>(base + (qmf_pad(PHASE + 2 * j) - qmf_pad(PHASE)));
+    f2 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = at3::mk2(0.0f, 0.0f);   // (upper-tap sum, lower-tap sum)
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const f2 w = at3::mk2(win[2 * i + 1], win[2 * i]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += w * P[23 + r - i];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        upper[r] = acc[r].y - acc[r].x;
+        lower[r] = acc[r].y + acc[r].x;
+    }
 }
 
 // The windowed MDCT input buffer of TAtrac1MDCT::Mdct (atrac1denc.cpp:83-90) at offset o: src = the band's samples with
@@ -125,21 +166,29 @@ __device__ __forceinline__ float mdct_in(const float* src, const float* sine, in
 
 __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
 {
-    // window of band signals kept per workgroup, indices relative to the sound unit's first sample of each rate
-    __shared__ __attribute__((aligned(16))) float s_pcm[800];   // t  in [-288, 512)
-    __shared__ __attribute__((aligned(16))) float s_lo1[376];                             // m  in [-118, 256)   first-stage lower band
-    __shared__ float s_up1[332];                                // m  in [-75, 256)    first-stage upper band; hi[i] = up1[i - 39]
-    __shared__ float s_low[166], s_mid[164];                    // q  in [-36, 128); s_low[164] = 0 for the detector
-    __shared__ float s_dmid[166], s_dhi[294];                   // InvertSpectr'ed mid [-36,128] / high [-36,256] band, last = 0
-    __shared__ float s_filt[560];                               // detector high-pass output: low/mid [-16,128), hi [-16,256)
+    // window of band signals kept per workgroup, indices relative to the sound unit's first sample of each rate.
+    // Two regions are reused once their first tenant is dead: the PCM window becomes the spectrum, the detector's
+    // filter output becomes the FFT buffer and then the loudness products (18.3 KB in all: 8 workgroups per CU).
+    __shared__ __attribute__((aligned(16))) float s_region_a[1008];
+    __shared__ __attribute__((aligned(16))) float s_region_b[560];
+    float* const s_pcm = s_region_a;                                     // t  in [-288, 512), padded (qmf_pad)
+    float* const s_specs = s_region_a;                                   // after the first QMF stage
+    float* const s_filt = s_region_b;                                    // detector high-pass output: low/mid [-16,128), hi [-16,256)
+    at3::cpx* const s_f = reinterpret_cast<at3::cpx*>(s_region_b);       // 256 points, after the detector
+    float* const s_tmp = s_region_b;                                     // e * LoudnessCurve, after the post-rotation
+    __shared__ __attribute__((aligned(16))) float s_lo1[480];            // m  in [-118, 256)   first-stage lower band, padded (qmf_pad)
+    __shared__ float s_up1[332];                                         // m  in [-75, 256)    first-stage upper band; hi[i] = up1[i - 39]
+    __shared__ float s_low[166], s_mid[164];                             // q  in [-36, 128); s_low[164] = 0 for the detector
+    __shared__ float s_dmid[166], s_dhi[294];                            // InvertSpectr'ed mid [-36,128] / high [-36,256] band, last = 0
     __shared__ float s_rms[3][17];
-    __shared__ __attribute__((aligned(16))) float s_tmp[512];   // e * LoudnessCurve
-    __shared__ __attribute__((aligned(16))) at3::cpx s_f[256];
-    __shared__ __attribute__((aligned(16))) float s_specs[512];
-    __shared__ __attribute__((aligned(16))) f2 s_win[24];
     __shared__ float s_scale[64], s_sine[32];
     __shared__ __attribute__((aligned(8))) float s_fir[10];
     __shared__ LogfTab s_logf;
+    __shared__ __attribute__((aligned(16))) at3::cpx s_tw[208];          // tw128 | tw64 | tw16
+    __shared__ float s_cs[416];                                          // sc512 | sc256 | sc64
+    __shared__ float s_loud[512];
+    __shared__ float s_sf[kMaxBfus];
+    __shared__ int s_srcoff[kMaxBfus];
     __shared__ int s_mask;
 
     const Tables* T = p.T;
@@ -148,15 +197,41 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
     const int tid = threadIdx.x;
     const size_t item = ((size_t)s * p.n_frames + f) * nch + ch;
 
-    for (int j = tid; j < 800; j += 256) {
-        const int t = 512 * f - 288 + j;
-        s_pcm[j] = t >= 0 ? p.pcm[((size_t)s * p.n_frames * 512 + t) * nch + ch] : p.hist[((size_t)s * 512 + (512 + t)) * nch + ch];
+    {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = tid + 256 * r;
+            const int t = 512 * f - 288 + j;
+            v[r] = j >= 800 ? 0.0f
+                 : t >= 0   ? p.pcm[((size_t)s * p.n_frames * 512 + t) * nch + ch]
+                            : p.hist[((size_t)s * 512 + (512 + t)) * nch + ch];
+        }
+        const float l0 = T->loud[tid], l1 = T->loud[tid + 256];
+        const float c0 = (&T->sc512[0])[tid], c1 = tid < 160 ? (&T->sc512[0])[tid + 256] : 0.0f;   // sc512 | sc256 | sc64 are contiguous
+        at3::cpx w = {0.0f, 0.0f};
+        if (tid < 208) w = tid < 128 ? T->tw128[tid] : tid < 192 ? T->tw64[tid - 128] : T->tw16[tid - 192];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (tid + 256 * r < 800) s_pcm[qmf_pad(tid + 256 * r)] = v[r];
+        s_loud[tid] = l0;
+        s_loud[tid + 256] = l1;
+        s_cs[tid] = c0;
+        if (tid < 160) s_cs[tid + 256] = c1;
+        if (tid < 208) s_tw[tid] = w;
     }
-    if (tid < 48) reinterpret_cast<float*>(s_win)[tid] = T->qmf_win[tid ^ 1];
-    else if (tid < 112) s_scale[tid - 48] = T->scale[tid - 48];
+    if (tid < 48) {
+    } else if (tid < 112) s_scale[tid - 48] = T->scale[tid - 48];
     else if (tid < 144) s_sine[tid - 112] = T->sine[tid - 112];
     else if (tid < 154) s_fir[tid - 144] = T->fir[tid - 144];
     else if (tid < 154 + 36) (&s_logf.tab[0][0])[tid - 154] = (&T->logf_tab[0][0])[tid - 154];
+    const int pos_bfu0 = c_bfu_of_pos[tid], pos_bfu1 = c_bfu_of_pos[tid + 256];
+    int bf_long = 0, bf_short = 0, bf_len = 0;
+    if (tid >= 64 && tid < 64 + kMaxBfus) {
+        bf_long = c_start_long[tid - 64];
+        bf_short = c_start_short[tid - 64];
+        bf_len = c_spb[tid - 64];
+    }
     if (tid == 255) {
         s_mask = 0;
         s_low[164] = 0.0f;   // HPFBuffer[BlockSz + 20] is never written: the sample after the block reads as 0
@@ -167,29 +242,38 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
 
     if (p.debug == 1) return;
     // Atrac1AnalysisFilterBank::Analysis (atrac/at1/atrac1_qmf.h:37-43): Qmf1 over the PCM ...
-    for (int j = tid; j < 374; j += 256) {
-        const int m = j - 118;
-        float lo, up;
-        qmf_pair(s_win, s_pcm + (2 * m + 288), lo, up);
-        s_lo1[j] = lo;
-        if (m >= -75) {
-            s_up1[m + 75] = up;
-            if (m < 217) s_dhi[m + 75] = (m & 1) ? -up : up;   // hi[i] = up1[i - 39]: i even <=> m odd (InvertSpectr, util.h:51-63)
+    if (tid < 94) {
+        // outputs m = -118 + 4 tid + r; the first pair read is PCM index 2 m - 46 = 8 tid - 282, window index 8 tid + 6
+        float lo[4], up[4];
+        qmf_quad<6>(T->qmf_win, s_pcm + qmf_pad(8 * tid + 6), lo, up);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * tid + r, m = j - 118;
+            if (j < 374) {
+                s_lo1[qmf_pad(j)] = lo[r];
+                if (m >= -75) {
+                    s_up1[m + 75] = up[r];
+                    if (m < 217) s_dhi[m + 75] = (m & 1) ? -up[r] : up[r];   // hi[i] = up1[i - 39]: i even <=> m odd (InvertSpectr, util.h:51-63)
+                }
+            }
         }
     }
     __syncthreads();
     if (p.debug == 2) return;
     // ... Qmf2 over its lower half; the upper half is delayed by 39 samples
-    if (tid < 164) {
-        const int q = tid - 36;
-        float lo, up;
-        qmf_pair(s_win, s_lo1 + (2 * q + 118), lo, up);
-        s_low[tid] = lo;
-        s_mid[tid] = up;
-        s_dmid[tid] = (q & 1) ? up : -up;
+    if (tid < 41) {
+        // outputs q = -36 + 4 tid + r; the first pair read is lower-band index 2 q - 46 = 8 tid - 118, buffer index 8 tid
+        float lo[4], up[4];
+        qmf_quad<0>(T->qmf_win, s_lo1 + qmf_pad(8 * tid), lo, up);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * tid + r, q = j - 36;
+            s_low[j] = lo[r];
+            s_mid[j] = up[r];
+            s_dmid[j] = (q & 1) ? up[r] : -up[r];
+        }
     }
     __syncthreads();
-
     if (p.debug == 3) return;
     int mask = p.window_mask;
     if (p.window_auto) {
@@ -218,26 +302,30 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
             s_filt[(b == 0 ? 0 : b == 1 ? 144 : 288) + 16 + i] = (acc.x + acc.y) / 2;
         }
         __syncthreads();
-        // calculateRMS over the 16-sample short blocks, 19 log10 (transient_detector.cpp:40-46, 76)
-        if (tid < 35) {
+        // calculateRMS over the 16-sample short blocks, 19 log10, the +16 / -20 jumps (transient_detector.cpp:40-46, 76-88):
+        // 35 lanes of wave 0, exchanged inside the wave
+        if (tid < 64) {
             const int b = tid < 9 ? 0 : tid < 18 ? 1 : 2;
             const int k = tid - (b == 0 ? 0 : b == 1 ? 9 : 18);
-            const float* fl = s_filt + (b == 0 ? 0 : b == 1 ? 144 : 288) + 16 * k;
-            float acc = 0.0f;
-            for (int i = 0; i < 16; ++i) acc += fl[i] * fl[i];
-            acc /= 16.0f;
-            float r = (float)(19.0 * (double)at1_log10f(&s_logf, sqrtf(acc)));
-            if (k == 0 && f == 0 && p.first) r = 0.0f;
-            s_rms[b][k] = r;
-        }
-        __syncthreads();
-        if (tid < 35) {
-            const int b = tid < 9 ? 0 : tid < 18 ? 1 : 2;
-            const int k = tid - (b == 0 ? 0 : b == 1 ? 9 : 18);
-            if (k > 0) {
-                const float r1 = s_rms[b][k], r0 = s_rms[b][k - 1];
-                if (r1 - r0 > 16 || r0 - r1 > 20) atomicOr(&s_mask, 1 << b);
+            float r = 0.0f;
+            if (tid < 35) {
+                const float* fl = s_filt + (b == 0 ? 0 : b == 1 ? 144 : 288) + 16 * k;
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc += fl[i] * fl[i];
+                acc /= 16.0f;
+                r = (float)(19.0 * (double)at1_log10f(&s_logf, sqrtf(acc)));
+                if (k == 0 && f == 0 && p.first) r = 0.0f;
+                s_rms[b][k] = r;
             }
+            wave_sync();
+            bool jump = false;
+            if (tid < 35 && k > 0) {
+                const float r0 = s_rms[b][k - 1];
+                jump = r - r0 > 16 || r0 - r > 20;
+            }
+            const unsigned long long jl = __ballot(jump && b == 0), jm = __ballot(jump && b == 1), jh = __ballot(jump && b == 2);
+            if (tid == 0) s_mask = (jl ? 1 : 0) | (jm ? 2 : 0) | (jh ? 4 : 0);
         }
         __syncthreads();
         mask = s_mask;
@@ -257,7 +345,6 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         const int pidx = sh ? (c & 15) : c;
         const int n = 2 * pidx;
         const float* src = (b == 0 ? s_low : b == 1 ? s_mid : s_up1) + 36;
-        const float* cs = sh ? T->sc64 : (b == 2 ? T->sc512 : T->sc256);
         auto in = [&](int o) { return mdct_in(src, s_sine, B, sh, k, o); };
         float r0, i0;
         if (n < n4) {
@@ -267,6 +354,7 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
             r0 = in(n34 - 1 - n) - in(n - n4);
             i0 = in(n4 + n) + in(n54 - 1 - n);
         }
+        const float* cs = s_cs + (sh ? 384 : b == 2 ? 0 : 256);
         const float cc = cs[n], ss = cs[n + 1];
         at3::cpx v;
         v.r = r0 * cc + i0 * ss;
@@ -280,14 +368,14 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         // one band per wave: the stages of a band's transforms only need that wave's own lanes
         const int wave = tid >> 6, lane = tid & 63;
         if (wave == 0) {
-            if (mask & 1) fft_lds<16, false, false, true>(s_f, 16, 4, T->tw16, lane, 64);
-            else fft_lds<64, false, false, true>(s_f, 64, 1, T->tw64, lane, 64);
+            if (mask & 1) fft_lds<16, false, false, true>(s_f, 16, 4, s_tw + 192, lane, 64);
+            else fft_lds<64, false, false, true>(s_f, 64, 1, s_tw + 128, lane, 64);
         } else if (wave == 1) {
-            if (mask & 2) fft_lds<16, false, false, true>(s_f + 64, 16, 4, T->tw16, lane, 64);
-            else fft_lds<64, false, false, true>(s_f + 64, 64, 1, T->tw64, lane, 64);
+            if (mask & 2) fft_lds<16, false, false, true>(s_f + 64, 16, 4, s_tw + 192, lane, 64);
+            else fft_lds<64, false, false, true>(s_f + 64, 64, 1, s_tw + 128, lane, 64);
         } else if (wave == 2) {
-            if (mask & 4) fft_lds<16, false, false, true>(s_f + 128, 16, 8, T->tw16, lane, 64);
-            else fft_lds<128, false, false, true>(s_f + 128, 128, 1, T->tw128, lane, 64);
+            if (mask & 4) fft_lds<16, false, false, true>(s_f + 128, 16, 8, s_tw + 192, lane, 64);
+            else fft_lds<128, false, false, true>(s_f + 128, 128, 1, s_tw, lane, 64);
         }
     }
     __syncthreads();
@@ -300,8 +388,8 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         const int n2 = sh ? 32 : (b == 2 ? 256 : 128);
         const int k = sh ? c >> 4 : 0;
         const int n = 2 * (sh ? (c & 15) : c);
-        const float* cs = sh ? T->sc64 : (b == 2 ? T->sc512 : T->sc256);
         const at3::cpx v = s_f[(b == 0 ? 0 : b == 1 ? 64 : 128) + c];
+        const float* cs = s_cs + (sh ? 384 : b == 2 ? 0 : 256);
         const float cc = cs[n], ss = cs[n + 1];
         float o1 = -v.r * cc - v.i * ss;
         float o2 = -v.r * ss + v.i * cc;
@@ -321,11 +409,12 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
     __syncthreads();
 
     if (p.debug == 7) return;
-    for (int j = tid; j < 512; j += 256) {
-        const float v = s_specs[j];
-        const float e = v * v;
-        s_tmp[j] = e * T->loud[j];
-        p.specs[item * 512 + j] = v;
+    {
+        const float v0 = s_specs[tid], v1 = s_specs[tid + 256];
+        s_tmp[tid] = (v0 * v0) * s_loud[tid];
+        s_tmp[tid + 256] = (v1 * v1) * s_loud[tid + 256];
+        p.specs[item * 512 + tid] = v0;
+        p.specs[item * 512 + tid + 256] = v1;
     }
     __syncthreads();
     if (tid == 0) {
@@ -343,15 +432,18 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         p.mask[item] = mask;
     }
     if (tid >= 64 && tid < 64 + kMaxBfus) {
-        // TScaler<TAtrac1Data>::Scale / ScaleFrame (atrac/atrac_scale.cpp:141-188)
+        // TScaler<TAtrac1Data>::Scale / ScaleFrame (atrac/atrac_scale.cpp:141-188), one lane per BFU: the scale factor and
+        // the in-order energy sum; the divisions are spread over the whole workgroup below
         const int bfu = tid - 64;
         const bool sh = (mask >> bfu_band(bfu)) & 1;
-        const float* in = s_specs + (sh ? c_start_short[bfu] : c_start_long[bfu]);
-        const int len = c_spb[bfu];
-        float max_abs = 0.0f;
-        for (int i = 0; i < len; ++i) {
-            const float a = fabsf(in[i]);
+        const int src0 = sh ? bf_short : bf_long;
+        const float* in = s_specs + src0;
+        float max_abs = 0.0f, e = 0.0f;
+        for (int i = 0; i < bf_len; ++i) {
+            const float xv = in[i];
+            const float a = fabsf(xv);
             if (a > max_abs) max_abs = a;
+            e += xv * xv;
         }
         if (max_abs > 1.0f) max_abs = 1.0f;
         int lo = 0, hi = 63;
@@ -361,18 +453,19 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
             if (s_scale[mid] < max_abs) lo = mid + 1;
             else hi = mid;
         }
-        const float sf = s_scale[lo];
-        float e = 0.0f;
-        float* vals = p.values + item * 512 + c_start_long[bfu];
-        for (int i = 0; i < len; ++i) {
-            const float xv = in[i];
-            float v = xv / sf;
-            e += xv * xv;
-            if (fabsf(v) >= 1.0f) v = (v > 0) ? 0.99999f : -0.99999f;
-            vals[i] = v;
-        }
+        s_sf[bfu] = s_scale[lo];
+        s_srcoff[bfu] = src0 - bf_long;
         p.sfi[item * 64 + bfu] = (uint8_t)lo;
         p.energy[item * kMaxBfus + bfu] = e;
+    }
+    __syncthreads();
+    {
+        float v0 = s_specs[s_srcoff[pos_bfu0] + tid] / s_sf[pos_bfu0];
+        float v1 = s_specs[s_srcoff[pos_bfu1] + tid + 256] / s_sf[pos_bfu1];
+        if (fabsf(v0) >= 1.0f) v0 = (v0 > 0) ? 0.99999f : -0.99999f;
+        if (fabsf(v1) >= 1.0f) v1 = (v1 > 0) ? 0.99999f : -0.99999f;
+        p.values[item * 512 + tid] = v0;
+        p.values[item * 512 + tid + 256] = v1;
     }
 }
 
@@ -433,9 +526,19 @@ struct PackParams {
     int32_t bfu_idx_const;
 };
 
+// Sum over the 64 lanes, wave-uniform result: Hillis-Steele inside each 16-lane row (row_shr), then the row totals travel
+// down with row_bcast:15 / row_bcast:31 so that lane 63 holds the total - seven DPP additions and one readlane, the
+// whole cost of a bisection step's "bits used" apart from the per-lane expression.
 __device__ __forceinline__ int wave_sum_i32(int v, int lane)
 {
-    return __builtin_amdgcn_readlane(wave_inclusive_scan(v, lane), 63);
+    (void)lane;
+    v += AT3_DPP(v, 0x111, true);   // row_shr:1
+    v += AT3_DPP(v, 0x112, true);   // row_shr:2
+    v += AT3_DPP(v, 0x114, true);   // row_shr:4
+    v += AT3_DPP(v, 0x118, true);   // row_shr:8   -> lane 15 of each row = row total
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // TAt1BitAlloc::Write (atrac/at1/atrac1_bitalloc.cpp:385-405): the part encoders driven by
@@ -463,6 +566,13 @@ __global__ __launch_bounds__(256) void k_at1_alloc_pack(PackParams p)
     const bool gate = !sh && energy < T->ath_bfu[bl] * loudness;
     const float spread = 0.4f;
     const float base = spread * ((float)sfi / 3.2f) + (1.0f - spread) * fix;
+
+    // the lane's share of the mantissa sources for the packing step at the end: eight consecutive positions of the
+    // BFU-ordered value array, their owning BFUs, and (lane = BFU) where each BFU's run starts. Fetched now, used last.
+    const uint2 pos_bfu = *reinterpret_cast<const uint2*>(c_bfu_of_pos + 8 * lane);
+    const float4 val_a = *reinterpret_cast<const float4*>(p.values + (size_t)item * 512 + 8 * lane);
+    const float4 val_b = *reinterpret_cast<const float4*>(p.values + (size_t)item * 512 + 8 * lane + 4);
+    const int run_start = in_tab ? c_start_long[lane] : 512;
 
     const int sum_low = wave_sum_i32(lane < 20 ? sfi : 0, lane);
     int bfu_idx = p.bfu_idx_const ? p.bfu_idx_const - 1 : 7;
@@ -561,15 +671,22 @@ __global__ __launch_bounds__(256) void k_at1_alloc_pack(PackParams p)
     if (lane < n) {
         put(16 + 4 * lane, (uint32_t)(bits ? bits - 1 : 0), 4);
         put(16 + 4 * n + 6 * lane, (uint32_t)sfi, 6);
-        if (bits > 1) {
-            int off = 16 + 10 * n + incl - spb * bits;
-            const float multiple = (float)((1 << (bits - 1)) - 1);
-            const float* vals = p.values + (size_t)item * 512 + c_start_long[lane];
-            const uint32_t field = (1u << bits) - 1;
-            for (int k = 0; k < spb; ++k) {
-                const int q = __float2int_rn(vals[k] * multiple);
-                put(off, (uint32_t)q & field, bits);
-                off += bits;
+    }
+    {
+        // mantissas, eight consecutive positions per lane (a per-BFU loop would run 20 rounds for the widest BFUs): word
+        // length, run start and bit offset of the owning BFU come from that BFU's lane
+        const int excl = incl - spb * bits;
+        const float v[8] = {val_a.x, val_a.y, val_a.z, val_a.w, val_b.x, val_b.y, val_b.z, val_b.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int bfu = (int)(((t < 4 ? pos_bfu.x : pos_bfu.y) >> (8 * (t & 3))) & 0xffu);
+            const int wl = __builtin_amdgcn_ds_bpermute(4 * bfu, bits);
+            const int st = __builtin_amdgcn_ds_bpermute(4 * bfu, run_start);
+            const int ex = __builtin_amdgcn_ds_bpermute(4 * bfu, excl);
+            if (wl > 1) {
+                const float multiple = (float)((1 << (wl - 1)) - 1);
+                const int q = __float2int_rn(v[t] * multiple);
+                put(16 + 10 * n + ex + (8 * lane + t - st) * wl, (uint32_t)q & ((1u << wl) - 1), wl);
             }
         }
     }
