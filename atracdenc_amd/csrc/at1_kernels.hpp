@@ -477,38 +477,47 @@ struct ScanParams {
     int32_t n_streams, n_frames, nch;
 };
 
-// TrackLoudness (atrac/atrac_psy_common.h:46-54) as atrac1denc.cpp:243-247 applies it. One wave per stream: the lanes
-// stage 256 sound units' masks and loudness sums in LDS with coalesced loads, lane 0 runs the recursion out of LDS (a
-// dependent global load per step would cost far more than the three double operations of the step itself), the lanes
-// store the tracked values.
+// TrackLoudness (atrac/atrac_psy_common.h:46-54) as atrac1denc.cpp:243-247 applies it. One wave per stream: every lane
+// loads four sound units' masks and loudness sums (coalesced), then the recursion walks the units in order with the
+// operands fetched by readlane into scalar registers - no memory access inside the dependent chain (a global load per
+// step cost 53 us for 128 units, LDS 19 us). All lanes compute the same value; lane j keeps the result of "its" unit.
 __global__ __launch_bounds__(64) void k_at1_loud_scan(ScanParams p)
 {
-    __shared__ float s_l0[256], s_l1[256], s_track[256];
-    __shared__ uint8_t s_long[256];   // bit 0: channel 0 all-long, bit 1: both channels all-long
     const int s = blockIdx.x, lane = threadIdx.x;
     float L = p.loud_state[s];
     for (int base = 0; base < p.n_frames; base += 256) {
         const int cnt = p.n_frames - base < 256 ? p.n_frames - base : 256;
-        for (int j = lane; j < cnt; j += 64) {
-            const size_t it = ((size_t)s * p.n_frames + base + j) * p.nch;
-            const int m0 = p.mask[it];
-            const int m1 = p.nch == 2 ? p.mask[it + 1] : 1;
-            s_l0[j] = p.loud_ch[it];
-            s_l1[j] = p.nch == 2 ? p.loud_ch[it + 1] : 0.0f;
-            s_long[j] = (uint8_t)((m0 == 0 ? 1 : 0) | ((m0 == 0 && m1 == 0) ? 2 : 0));
-        }
-        wave_sync();
-        if (lane == 0) {
-            for (int j = 0; j < cnt; ++j) {
-                const int fl = s_long[j];
-                if (fl & 2) L = (float)(0.98 * (double)L + 0.01 * (double)(s_l0[j] + s_l1[j]));
-                else if (fl & 1) L = (float)(0.98 * (double)L + 0.02 * (double)s_l0[j]);
-                s_track[j] = L;
+        float l0[4], l1[4], tr[4];
+        int fl[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = 64 * c + lane;
+            l0[c] = l1[c] = tr[c] = 0.0f;
+            fl[c] = 0;
+            if (j < cnt) {
+                const size_t it = ((size_t)s * p.n_frames + base + j) * p.nch;
+                const int m0 = p.mask[it];
+                const int m1 = p.nch == 2 ? p.mask[it + 1] : 1;
+                l0[c] = p.loud_ch[it];
+                l1[c] = p.nch == 2 ? p.loud_ch[it + 1] : 0.0f;
+                fl[c] = (m0 == 0 ? 1 : 0) | ((m0 == 0 && m1 == 0) ? 2 : 0);   // bit 0: channel 0 all-long, bit 1: both all-long
             }
         }
-        wave_sync();
-        for (int j = lane; j < cnt; j += 64) p.loud_track[(size_t)s * p.n_frames + base + j] = s_track[j];
-        wave_sync();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int lim = cnt - 64 * c < 64 ? cnt - 64 * c : 64;
+            for (int jj = 0; jj < lim; ++jj) {
+                const int f = __builtin_amdgcn_readlane(fl[c], jj);
+                const float a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(l0[c]), jj));
+                const float b = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(l1[c]), jj));
+                if (f & 2) L = (float)(0.98 * (double)L + 0.01 * (double)(a + b));
+                else if (f & 1) L = (float)(0.98 * (double)L + 0.02 * (double)a);
+                if (lane == jj) tr[c] = L;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (64 * c + lane < cnt) p.loud_track[(size_t)s * p.n_frames + base + 64 * c + lane] = tr[c];
     }
     if (lane == 0) p.loud_state[s] = L;
 }

@@ -167,3 +167,13 @@ def test_cli_file_parity(oracle, tmp_path, nsamp, ext, nch, opts, mode):
     else:
         tail = units[1:] if ext == "aea" else units
         assert got[len(got) - tail.size:] == tail.tobytes()
+
+
+def test_fuzz_slice(oracle):
+    """One small round of tools/fuzz_at1_gpu.py (the long runs - 24 M sound units clean - are done by hand on the GPU box)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_at1_gpu.py"), "1", "48", "6"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "FUZZ CLEAN" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
