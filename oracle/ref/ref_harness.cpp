@@ -39,6 +39,11 @@
 #include "at3.h"
 #include "raw.h"
 #include "aea.h"
+#include "atrac/at3p/at3p_mdct.h"
+extern "C" {
+#include "atrac/atrac3plus_pqf/atrac3plus_pqf.h"
+#include "atrac/atrac3plus_pqf/ut/atrac3plusdsp.h"
+}
 
 using namespace NAtracDEnc;
 using namespace NAtrac3;
@@ -375,6 +380,39 @@ int at1ref_encode(const float* pcm, int nch, int n_blocks, int window_auto, int 
     }
     memcpy(out, bytes.data(), bytes.size());
     return (int)bytes.size();
+}
+
+// ---- ATRAC3plus front end: PQF analysis and TAt3pMDCT, one channel ---------------------------------
+// in [n_frames][2048] -> subbands [n_frames][16][128], filter state carried over the frames (start-of-stream state first)
+void at3pref_pqf_analyse(const float* in, int n_frames, float* out)
+{
+    at3plus_pqf_a_ctx_t ctx = at3plus_pqf_create_a_ctx();
+    for (int f = 0; f < n_frames; ++f) at3plus_pqf_do_analyse(ctx, in + (size_t)f * 2048, out + (size_t)f * 2048);
+    at3plus_pqf_free_a_ctx(ctx);
+}
+
+// The decoder-side synthesis filter of the reference's unit test (atrac3plus_pqf/ut/atrac3plusdsp.c), for round trips.
+void at3pref_ipqf(const float* in, int n_frames, float* out)
+{
+    Atrac3pIPQFChannelCtx ctx;
+    memset(&ctx, 0, sizeof(ctx));
+    for (int f = 0; f < n_frames; ++f) ff_atrac3p_ipqf(&ctx, in + (size_t)f * 2048, out + (size_t)f * 2048);
+}
+
+// bands [n_frames][16][128], steep-window flag word per frame (bit b = subband b) -> specs [n_frames][2048]; the history
+// buffer starts zeroed like TChannelCtx::MdctBuf (at3p.cpp:76)
+void at3pref_mdct(const float* bands, const uint16_t* win_flags, int n_frames, float* specs)
+{
+    TAt3pMDCT mdct;
+    TAt3pMDCT::THistBuf hist = {{{0}}};
+    for (int f = 0; f < n_frames; ++f) {
+        TAt3pMDCT::TPcmBandsData p;
+        for (size_t b = 0; b < 16; ++b) p[b] = bands + (size_t)f * 2048 + b * 128;
+        TAt3pMDCTWin win;
+        for (size_t b = 0; b < 16; ++b)
+            if (win_flags && ((win_flags[f] >> b) & 1)) win.SetSteepWin(b);
+        mdct.Do(specs + (size_t)f * 2048, p, hist, win);
+    }
 }
 
 } // extern "C"

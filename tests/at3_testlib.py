@@ -356,3 +356,47 @@ def at1_ref_encode(pcm, mode="auto"):
     n = lib.at1ref_encode(_vp(pcm), nch, nb, auto, mask, bfu, _vp(out))
     assert n == out.size
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# ATRAC3plus front end: PQF analysis + TAt3pMDCT, one channel at a time
+# ----------------------------------------------------------------------------------------------
+def _at3p_lib(which):
+    if which == "oracle" and not os.path.exists(ORACLE_SO):
+        build_oracle()
+    return ctypes.CDLL(ORACLE_SO if which == "oracle" else REF_SO), ("at3po_" if which == "oracle" else "at3pref_")
+
+
+def at3p_pqf(x, which="oracle"):
+    """x float32 [n_frames, 2048] (one channel) -> subbands [n_frames, 16, 128], start-of-stream state first."""
+    lib, pre = _at3p_lib(which)
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros((x.shape[0], 16, 128), np.float32)
+    getattr(lib, pre + "pqf_analyse")(_vp(x), x.shape[0], _vp(out))
+    return out
+
+
+def at3p_mdct(bands, flags=None, which="oracle"):
+    """bands float32 [n_frames, 16, 128], flags uint16 [n_frames] (bit b = steep window in subband b) -> specs [n_frames, 2048]."""
+    lib, pre = _at3p_lib(which)
+    bands = np.ascontiguousarray(bands, np.float32)
+    specs = np.zeros((bands.shape[0], 2048), np.float32)
+    fl = None if flags is None else np.ascontiguousarray(flags, np.uint16)
+    getattr(lib, pre + "mdct")(_vp(bands), None if fl is None else _vp(fl), bands.shape[0], _vp(specs))
+    return specs
+
+
+def at3p_ipqf_ref(bands):
+    """The synthesis filter of the reference's unit test (decoder side), for round trips. Needs oracle/_ref."""
+    bands = np.ascontiguousarray(bands, np.float32)
+    out = np.zeros((bands.shape[0], 2048), np.float32)
+    ctypes.CDLL(REF_SO).at3pref_ipqf(_vp(bands), bands.shape[0], _vp(out))
+    return out
+
+
+def at3p_signal(name, n_frames, channel=0, scale=1.0):
+    """One channel of the ATRAC3 test signals cut into 2048-sample ATRAC3plus frames."""
+    gens = dict(SIGNALS)
+    gens["stress"] = pcm_stress
+    x = gens[name](2 * n_frames + (32 if name == "stress" else 0)).reshape(-1, 2)[: n_frames * 2048, channel]
+    return np.ascontiguousarray((x * np.float32(scale)).astype(np.float32).reshape(n_frames, 2048))

@@ -1,0 +1,66 @@
+"""ATRAC3plus front-end oracle (oracle/at3p_oracle.c) against golden vectors generated from the
+real reference (tools/gen_golden_at3p.py), against the reference itself where oracle/_ref exists, and through the
+properties the reference's own unit tests check (atrac3plus_pqf/ut/ipqf_ut.cpp, at3p/at3p_mdct_ut.cpp)."""
+import os
+
+import numpy as np
+import pytest
+
+from at3_testlib import at3p_ipqf_ref, at3p_mdct, at3p_pqf, at3p_signal, have_ref
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "at3p_frontend.npz"))
+NAMES = sorted(k[:-8] for k in GOLD.files if k.endswith("_pcm_s16"))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def gold_pcm(name):
+    return (GOLD[f"{name}_pcm_s16"].astype(np.float32) / np.float32(32768.0) * GOLD[f"{name}_scale"]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_golden(oracle, name):
+    bands = at3p_pqf(gold_pcm(name))
+    assert np.array_equal(bits(bands), bits(GOLD[f"{name}_bands"]))
+    assert np.array_equal(bits(at3p_mdct(bands)), bits(GOLD[f"{name}_specs_sine"]))
+    assert np.array_equal(bits(at3p_mdct(bands, GOLD[f"{name}_flags"])), bits(GOLD[f"{name}_specs_mixed"]))
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,scale", [("mix", 32768.0), ("tones", 1.0), ("silence", 1.0), ("noise", 32768.0), ("stress", 1.0)])
+def test_vs_reference(oracle, name, scale):
+    x = at3p_signal(name, 24, scale=scale)
+    bands = at3p_pqf(x)
+    assert np.array_equal(bits(bands), bits(at3p_pqf(x, "ref")))
+    rng = np.random.RandomState(3)
+    for flags in (None, np.full(24, 0xFFFF, np.uint16), rng.randint(0, 65536, size=24).astype(np.uint16)):
+        assert np.array_equal(bits(at3p_mdct(bands, flags)), bits(at3p_mdct(bands, flags, "ref")))
+
+
+def test_mdct_zero_and_dc_properties(oracle):
+    """at3p_mdct_ut.cpp: zero in -> zero out for every window combination; linearity in powers of two."""
+    z = np.zeros((3, 16, 128), np.float32)
+    for flags in (None, np.array([0xFFFF, 0, 0x5555], np.uint16)):
+        assert not at3p_mdct(z, flags).any()
+    x = np.random.RandomState(1).uniform(-1, 1, (4, 16, 128)).astype(np.float32)
+    f = np.array([0, 0xFFFF, 0x00FF, 0], np.uint16)
+    assert np.array_equal(bits(at3p_mdct(x * np.float32(0.25), f)), bits(at3p_mdct(x, f) * np.float32(0.25)))
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+def test_reference_ipqf_fixture_and_round_trip(oracle):
+    """ipqf_ut.cpp: the synthesis filter reproduces the reference's own data files (committed under tests/golden) to
+    2^-26; analysis -> synthesis returns the input delayed by the prototype's 368 samples (ipqf_ut.cpp DC / chirp tests,
+    tolerance 2^-21 relative to full scale)."""
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    mr = np.fromfile(os.path.join(gdir, "ipqftest_pcm_mr.dat"), np.float32).reshape(4, 2048)
+    want = np.fromfile(os.path.join(gdir, "ipqftest_pcm_out.dat"), np.float32).reshape(4, 2048)
+    assert np.abs(at3p_ipqf_ref(mr) - want).max() <= 1.0 / (1 << 26)
+    x = at3p_signal("mix", 8)
+    y = at3p_ipqf_ref(at3p_pqf(x).reshape(8, 2048)).reshape(-1)
+    assert np.abs(y[368:] - x.reshape(-1)[:-368]).max() < 1.0 / (1 << 21)
+    dc = np.ones((2, 2048), np.float32)
+    ydc = at3p_ipqf_ref(at3p_pqf(dc).reshape(2, 2048)).reshape(-1)
+    assert np.abs(ydc[368:] - 1.0).max() < 1.0 / (1 << 21)
