@@ -37,11 +37,18 @@ SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint
 # include/at1hip.h
 AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_encode", "at1hip_reset", "at1hip_get_timings",
                "at1hip_read_tap", "at1hip_host_tables"]
+# include/at3phip.h
+AT3P_SYMBOLS = ["at3phip_create", "at3phip_destroy", "at3phip_last_error", "at3phip_reset", "at3phip_pqf_analyse", "at3phip_mdct",
+                "at3phip_pqf_mdct", "at3phip_get_timings", "at3phip_host_tables"]
 
 
 class At1Config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("channels", "window_auto", "window_mask", "bfu_idx_const", "n_streams", "max_blocks",
                                               "device_id")]
+
+
+class At3pConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("channels", "n_streams", "max_frames", "device_id")]
 
 
 class At1Timings(ctypes.Structure):
@@ -51,7 +58,8 @@ class At1Timings(ctypes.Structure):
 def build_library(verbose=False):
     """Compile libat3hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-o", LIB_PATH, os.path.join(CSRC, "at3hip.hip"), os.path.join(CSRC, "at1hip.hip"), os.path.join(CSRC, "at3_tables.cpp")]
+           "-o", LIB_PATH, os.path.join(CSRC, "at3hip.hip"), os.path.join(CSRC, "at1hip.hip"), os.path.join(CSRC, "at3phip.hip"),
+           os.path.join(CSRC, "at3_tables.cpp")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -104,6 +112,17 @@ def load_library(path=None):
     lib.at1hip_get_timings.argtypes = [vp, ctypes.POINTER(At1Timings)]
     lib.at1hip_read_tap.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.at1hip_host_tables.argtypes = [vp, ctypes.c_size_t]
+    lib.at3phip_create.argtypes = [ctypes.POINTER(At3pConfig), ctypes.POINTER(vp)]
+    lib.at3phip_destroy.argtypes = [vp]
+    lib.at3phip_destroy.restype = None
+    lib.at3phip_last_error.argtypes = [vp]
+    lib.at3phip_last_error.restype = ctypes.c_char_p
+    lib.at3phip_reset.argtypes = [vp]
+    lib.at3phip_pqf_analyse.argtypes = [vp, vp, i32, vp, ctypes.c_uint32]
+    lib.at3phip_mdct.argtypes = [vp, vp, i32, vp, vp, ctypes.c_uint32]
+    lib.at3phip_pqf_mdct.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.c_uint32]
+    lib.at3phip_get_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    lib.at3phip_host_tables.argtypes = [vp, ctypes.c_size_t]
     _lib_cache[path] = lib
     return lib
 
@@ -281,3 +300,90 @@ class At1Hip:
         t = At1Timings()
         self._check(self.lib.at1hip_get_timings(self.ctx, ctypes.byref(t)), "at1hip_get_timings")
         return {n: getattr(t, n) for n, _ in At1Timings._fields_}
+
+
+AT3PHIP_RESIDUAL_SCALE = 16
+AT3P_TABLES_DTYPE = np.dtype([("fir", "<f4", 384), ("sc32", "<f4", 16), ("sc256", "<f4", 128), ("tw8", "<f4", 16), ("tw64", "<f4", 128),
+                              ("sine128", "<f4", 128), ("sine64", "<f4", 64)])
+assert AT3P_TABLES_DTYPE.itemsize == 3456
+
+
+def at3p_host_tables(lib_path=None):
+    out = np.zeros((), dtype=AT3P_TABLES_DTYPE)
+    rc = load_library(lib_path).at3phip_host_tables(_vp(out), out.nbytes)
+    if rc != 0:
+        raise At3HipError(f"at3phip_host_tables failed ({rc})")
+    return out
+
+
+class At3pHip:
+    """ATRAC3plus front end (include/at3phip.h): PQF analysis and windowed MDCT-256 x 16 for n_streams streams."""
+
+    def __init__(self, n_streams=1, max_frames=32, channels=2, device_id=0, lib_path=None):
+        self.lib = load_library(lib_path)
+        self.channels, self.n_streams = int(channels), int(n_streams)
+        self.cfg = At3pConfig(int(channels), int(n_streams), int(max_frames), int(device_id))
+        self.ctx = ctypes.c_void_p()
+        rc = self.lib.at3phip_create(ctypes.byref(self.cfg), ctypes.byref(self.ctx))
+        if rc != 0:
+            self.ctx = None
+            raise At3HipError(f"at3phip_create failed with {rc} (no usable MI355X / HIP runtime?)")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.at3phip_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise At3HipError(f"{what} failed ({rc}): {self.lib.at3phip_last_error(self.ctx).decode()}")
+
+    def reset(self):
+        self._check(self.lib.at3phip_reset(self.ctx), "at3phip_reset")
+
+    def _flags(self, win_flags, nf):
+        if win_flags is None:
+            return None, None
+        fl = np.ascontiguousarray(win_flags, dtype=np.uint16)
+        assert fl.shape == (self.n_streams, nf, self.channels), fl.shape
+        return fl, _vp(fl)
+
+    def pqf(self, pcm):
+        """pcm float32 [S, F, 2048, C] -> subbands [S, F, C, 16, 128]."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        assert pcm.ndim == 4 and pcm.shape[0] == self.n_streams and pcm.shape[2:] == (2048, self.channels), pcm.shape
+        out = np.zeros((self.n_streams, pcm.shape[1], self.channels, 16, 128), np.float32)
+        self._check(self.lib.at3phip_pqf_analyse(self.ctx, _vp(pcm), pcm.shape[1], _vp(out), 0), "at3phip_pqf_analyse")
+        return out
+
+    def mdct(self, bands, win_flags=None, residual_scale=False):
+        """bands [S, F, C, 16, 128], win_flags uint16 [S, F, C] or None -> specs [S, F, C, 2048]."""
+        bands = np.ascontiguousarray(bands, dtype=np.float32)
+        nf = bands.shape[1]
+        fl, flp = self._flags(win_flags, nf)
+        out = np.zeros((self.n_streams, nf, self.channels, 2048), np.float32)
+        self._check(self.lib.at3phip_mdct(self.ctx, _vp(bands), nf, flp, _vp(out), AT3PHIP_RESIDUAL_SCALE if residual_scale else 0),
+                    "at3phip_mdct")
+        return out
+
+    def pqf_mdct(self, pcm, win_flags=None, residual_scale=False, want_bands=True):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        nf = pcm.shape[1]
+        fl, flp = self._flags(win_flags, nf)
+        bands = np.zeros((self.n_streams, nf, self.channels, 16, 128), np.float32) if want_bands else None
+        specs = np.zeros((self.n_streams, nf, self.channels, 2048), np.float32)
+        self._check(self.lib.at3phip_pqf_mdct(self.ctx, _vp(pcm), nf, flp, _vp(bands) if want_bands else None, _vp(specs),
+                                              AT3PHIP_RESIDUAL_SCALE if residual_scale else 0), "at3phip_pqf_mdct")
+        return bands, specs
+
+    def pqf_mdct_device(self, pcm_ptr, n_frames, specs_ptr):
+        self._check(self.lib.at3phip_pqf_mdct(self.ctx, ctypes.c_void_p(pcm_ptr), n_frames, None, None, ctypes.c_void_p(specs_ptr),
+                                              AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE), "at3phip_pqf_mdct")
+
+    def timings(self):
+        a, b = ctypes.c_float(), ctypes.c_float()
+        self._check(self.lib.at3phip_get_timings(self.ctx, ctypes.byref(a), ctypes.byref(b)), "at3phip_get_timings")
+        return {"pqf_ms": a.value, "mdct_ms": b.value}

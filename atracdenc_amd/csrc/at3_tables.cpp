@@ -2,6 +2,7 @@
 // float expressions round exactly like the reference's x86-64 baseline build.
 #include "at3_tables.hpp"
 #include "at1_tables.hpp"
+#include "at3p_tables.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -247,3 +248,40 @@ AT3_RUNTIME_LIBM void build_tables(Tables* t)
 }
 
 }  // namespace at1
+
+// ---- ATRAC3plus front end ----------------------------------------------------------------------------------------
+namespace at3p {
+
+namespace {
+
+const float kFir[384] = {
+#include "at3p_fir.inc"
+};
+
+AT3_RUNTIME_LIBM void mdct_sincos(float* dst, size_t n, float scale)   // CalcSinCos, lib/mdct/mdct.cpp:25-36
+{
+    const float alpha = 2.0 * M_PI / (8.0 * n);
+    const float omiga = 2.0 * M_PI / n;
+    scale = sqrtf(scale / n);
+    for (size_t i = 0; i < (n >> 2); ++i) {
+        dst[2 * i + 0] = scale * cosf(omiga * i + alpha);
+        dst[2 * i + 1] = scale * sinf(omiga * i + alpha);
+    }
+}
+
+}  // namespace
+
+AT3_RUNTIME_LIBM void build_tables(Tables* t)
+{
+    memset(t, 0, sizeof(*t));
+    memcpy(t->fir, kFir, sizeof(kFir));
+    const float dct_scale = 32.0 * (float)(128 * 512.0);   // atde_create_dct4_16(128 * 512.0) -> TMIDCT<32>(32.0 * scale)
+    mdct_sincos(t->sc32, 32, dct_scale / 2);               // TMIDCT(float scale) : TMDCTBase(TN, scale / 2)
+    mdct_sincos(t->sc256, 256, 1.0f);
+    at3::fill_twiddles(t->tw8, 8, false);
+    at3::fill_twiddles(t->tw64, 64, false);
+    for (size_t i = 0; i < 128; i++) t->sine128[i] = 2.0 * sinf((i + 0.5) * (M_PI / (2.0 * 128)));
+    for (size_t i = 0; i < 64; i++) t->sine64[i] = 2.0 * sinf((i + 0.5) * (M_PI / (2.0 * 64)));
+}
+
+}  // namespace at3p

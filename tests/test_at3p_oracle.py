@@ -64,3 +64,19 @@ def test_reference_ipqf_fixture_and_round_trip(oracle):
     dc = np.ones((2, 2048), np.float32)
     ydc = at3p_ipqf_ref(at3p_pqf(dc).reshape(2, 2048)).reshape(-1)
     assert np.abs(ydc[368:] - 1.0).max() < 1.0 / (1 << 21)
+
+
+def test_product_host_tables_equal_oracle_tables(oracle):
+    import ctypes
+    import atracdenc_amd
+    from atracdenc_amd.binding import at3p_host_tables
+    from at3_testlib import ORACLE_SO, _vp
+    if not os.path.exists(atracdenc_amd.LIB_PATH):
+        atracdenc_amd.build_library()
+    t = at3p_host_tables()
+    names = ["sc32", "sc256", "tw8", "tw64", "sine128", "sine64", "fir"]
+    n = sum(t[k].size for k in names)
+    ref = np.zeros(n, np.float32)
+    assert ctypes.CDLL(ORACLE_SO).at3po_tables(_vp(ref), n) == n
+    got = np.concatenate([t[k].ravel() for k in names])
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

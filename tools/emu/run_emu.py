@@ -15,6 +15,7 @@ def build():
                            "-I", os.path.join(ROOT, "tools", "emu"), "-o", EMU,
                            os.path.join(ROOT, "atracdenc_amd/csrc/at3hip.hip"),
                            os.path.join(ROOT, "atracdenc_amd/csrc/at1hip.hip"),
+                           os.path.join(ROOT, "atracdenc_amd/csrc/at3phip.hip"),
                            os.path.join(ROOT, "atracdenc_amd/csrc/at3_tables.cpp"),
                            os.path.join(ROOT, "tools/emu/emu_runtime.cpp")])
 
