@@ -109,7 +109,7 @@ struct MdctParams {
     const float* hist;         // [S][nch][16][128]: the windowed first halves left by the previous call
     float* specs;              // [S][F][nch][2048]
     int32_t n_frames, nch;
-    int32_t residual_scale;    // divide the subband samples by 32768 / 1.122018 first (at3p.cpp:147-150)
+    int32_t residual_scale;    // divide the subband samples by 32768 / 1.122018 first (at3p.cpp:143-147)
 };
 
 // first / second half of TAt3pMDCT::Do's work buffer for one subband (at3p_mdct.cpp:60-71, 83-95): v = the subband

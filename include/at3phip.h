@@ -1,6 +1,6 @@
 /* at3phip.h - C ABI of the MI355X-native ATRAC3plus front end: the 16-band polyphase analysis
  * filter and the windowed MDCT-256 x 16 that turn PCM into the 2048-line spectrum TAt3PEnc::EncodeFrame scales and packs
- * (at3p.cpp:93-99, 139-157). The tonal (GHA) analysis between them needs libgha, an un-vendored submodule of the
+ * (at3p.cpp:93-99, 139-159). The tonal (GHA) analysis between them needs libgha, an un-vendored submodule of the
  * reference, and is not part of this row. Same library (libat3hip.so) and error codes as at3hip.h.
  */
 #ifndef AT3PHIP_H
@@ -17,7 +17,7 @@ extern "C" {
 
 #define AT3PHIP_FRAME 2048            /* TAt3PEnc::NumSamples, samples per channel and frame */
 #define AT3PHIP_RESIDUAL_SCALE 16u    /* at3phip_mdct / at3phip_pqf_mdct: divide the subband samples by 32768 / 1.122018 first,
-                                       * as EncodeFrame does for the residual spectrum (at3p.cpp:147-150) */
+                                       * as EncodeFrame does for the residual spectrum (at3p.cpp:143-147) */
 
 typedef struct at3phip_ctx at3phip_ctx;
 
