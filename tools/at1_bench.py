@@ -40,10 +40,17 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     units = a.streams * a.blocks
+    # the reference encoder (oracle/_ref, else the oracle port) on one host core, bounded sample of the same material
+    from at3_testlib import at1_oracle_encode, at1_ref_encode, have_ref
+    sample = np.ascontiguousarray(np.concatenate([base[i] for i in range(4)], axis=0))   # 4 streams' worth of blocks, one after another
+    t1 = time.perf_counter()
+    (at1_ref_encode if have_ref() else at1_oracle_encode)(sample, "auto")
+    cpu = {"value": sample.shape[0] / (time.perf_counter() - t1), "unit": "sound unit pairs/s", "cores": 1,
+           "kind": "reference" if have_ref() else "port", "sample": f"{sample.shape[0]} stereo blocks, one thread"}
     med = {k: float(np.median([t[k] for t in tms])) for k in tms[0]}
     print(json.dumps({"metric": "atrac1_sound_unit_pairs_per_s", "value": units * a.steps / dt, "ms_per_step": 1e3 * dt / a.steps,
                       "audio_seconds_per_s": units * a.steps * 512 / 44100 / dt, "device_ms": med,
-                      "config": {"streams": a.streams, "blocks": a.blocks, "channels": 2}}))
+                      "config": {"streams": a.streams, "blocks": a.blocks, "channels": 2}, "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":

@@ -40,10 +40,18 @@ def main():
     units = a.streams * a.frames
     med = {k: float(np.median([t[k] for t in tms])) for k in tms[0]}
     algo = units * 2 * 2048 * 4 * 4   # PCM in, subbands out + in, spectrum out
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from at3_testlib import at3p_mdct, at3p_pqf, have_ref
+    which = "ref" if have_ref() else "oracle"
+    sample = np.ascontiguousarray(pcm[:8, :, :, 0].reshape(-1, 2048))
+    t1 = time.perf_counter()
+    at3p_mdct(at3p_pqf(sample, which), None, which)
+    cpu = {"value": sample.shape[0] / 2 / (time.perf_counter() - t1), "unit": "frame pairs/s", "cores": 1,
+           "kind": "reference" if which == "ref" else "port", "sample": f"{sample.shape[0]} mono frames, one thread"}
     print(json.dumps({"metric": "atrac3plus_frontend_frame_pairs_per_s", "value": units * a.steps / dt, "ms_per_step": 1e3 * dt / a.steps,
                       "audio_seconds_per_s": units * a.steps * 2048 / 44100 / dt, "device_ms": med,
                       "algorithmic_GBps": algo / ((med["pqf_ms"] + med["mdct_ms"]) * 1e-3) / 1e9,
-                      "config": {"streams": a.streams, "frames": a.frames, "channels": 2}}))
+                      "config": {"streams": a.streams, "frames": a.frames, "channels": 2}, "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":
