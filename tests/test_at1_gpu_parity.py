@@ -177,3 +177,14 @@ def test_fuzz_slice(oracle):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_at1_gpu.py"), "1", "48", "6"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "FUZZ CLEAN" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_long_call_crosses_scan_chunks(oracle):
+    """600 blocks in ONE call: the loudness scan walks the units in chunks of 256 (k_at1_loud_scan), and the front
+    kernel's grid grows with the block count - results must not depend on either."""
+    blocks = np.stack([at1_blocks(pcm_mix(300, seed=s)) for s in (21, 22)])
+    enc = _enc(n_streams=2, max_blocks=600)
+    got = enc.encode(blocks)
+    enc.close()
+    for s in range(2):
+        assert np.array_equal(got[s], at1_oracle_encode(blocks[s], "auto")), s
