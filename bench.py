@@ -78,6 +78,45 @@ def cpu_baseline(seconds_budget=12.0):
     }
 
 
+def widened_rows(S):
+    """SURVEY 8(f) rows f3 / f4 measured in the same process, after the headline (not part of `value`): the ATRAC1 encode
+    path and the ATRAC3plus front end on the same audio shape (S stereo streams x 65536 samples, PCM resident in HBM)."""
+    out = {}
+    try:
+        import torch
+        import atracdenc_amd
+        rng = np.random.RandomState(3)
+        pcm = torch.from_numpy((rng.randint(-8192, 8192, size=(S, 65536, 2)).astype(np.float32) / np.float32(32768.0))).cuda()
+
+        def timed(fn, steps=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps
+
+        e1 = atracdenc_amd.At1Hip(n_streams=S, max_blocks=128)
+        o1 = torch.zeros((S, 128, 2, 212), dtype=torch.uint8, device="cuda")
+        dt = timed(lambda: e1.encode_device(pcm.data_ptr(), 128, o1.data_ptr()))
+        out["atrac1_encode"] = {"value": round(S * 128 / dt, 1), "unit": "512-sample stereo sound-unit pairs/s", "ms_per_step": round(dt * 1e3, 4),
+                                "x_realtime": round(S * 65536 / 44100.0 / dt, 1), "device_ms": {k: round(v, 4) for k, v in e1.timings().items()}}
+        e1.close()
+        ep = atracdenc_amd.At3pHip(n_streams=S, max_frames=32)
+        op = torch.zeros((S, 32, 2, 2048), dtype=torch.float32, device="cuda")
+        dt = timed(lambda: ep.pqf_mdct_device(pcm.data_ptr(), 32, op.data_ptr()))
+        tm = ep.timings()
+        out["atrac3plus_pqf_mdct"] = {"value": round(S * 32 / dt, 1), "unit": "2048-sample stereo frames/s", "ms_per_step": round(dt * 1e3, 4),
+                                      "x_realtime": round(S * 65536 / 44100.0 / dt, 1), "device_ms": {k: round(v, 4) for k, v in tm.items()},
+                                      "algorithmic_GBps": round(S * 32 * 2 * 2048 * 16 / ((tm["pqf_ms"] + tm["mdct_ms"]) * 1e-3) / 1e9, 1)}
+        ep.close()
+    except Exception as ex:   # the headline line must not depend on these
+        out["error"] = repr(ex)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +232,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+        if world == 1:
+            line["widened_rows"] = widened_rows(S)
         print(json.dumps(line))
     enc.close()
     if dist is not None:
