@@ -364,18 +364,43 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
     }
     __syncthreads();
     if (p.debug == 5) return;
-    {
-        // one band per wave: the stages of a band's transforms only need that wave's own lanes
-        const int wave = tid >> 6, lane = tid & 63;
-        if (wave == 0) {
-            if (mask & 1) fft_lds<16, false, false, true>(s_f, 16, 4, s_tw + 192, lane, 64);
-            else fft_lds<64, false, false, true>(s_f, 64, 1, s_tw + 128, lane, 64);
-        } else if (wave == 1) {
-            if (mask & 2) fft_lds<16, false, false, true>(s_f + 64, 16, 4, s_tw + 192, lane, 64);
-            else fft_lds<64, false, false, true>(s_f + 64, 64, 1, s_tw + 128, lane, 64);
-        } else if (wave == 2) {
-            if (mask & 4) fft_lds<16, false, false, true>(s_f + 128, 16, 8, s_tw + 192, lane, 64);
-            else fft_lds<128, false, false, true>(s_f + 128, 128, 1, s_tw, lane, 64);
+    if (tid < 64) {
+        // All three bands' transforms in ONE wave: a radix-4 stage has 32 butterflies in the high band (one 128-point or
+        // eight 16-point transforms) and 16 each in the low and middle bands (one 64-point or four 16-point) - 64 lanes.
+        // Lanes 0..31 own the high band, 32..47 the low, 48..63 the middle band; the 128-point transform's radix-2
+        // leaves (64 butterflies) take all lanes first. Stages are separated by wave-level rendezvous only.
+        const int lane = tid;
+        if (!(mask & 4)) {
+            at3::cpx* a = s_f + 128 + 2 * lane;
+            f2 a0 = at3::ld2(a), a1 = at3::ld2(a + 1);
+            at3::bfly2(a0, a1, at3::ld2(s_tw));
+            at3::st2(a, a0);
+            at3::st2(a + 1, a1);
+        }
+        wave_sync();
+        const int bsel = lane < 32 ? 2 : lane < 48 ? 0 : 1;
+        const int j = lane < 32 ? lane : (lane - 32) & 15;
+        const bool sh = (mask >> bsel) & 1;
+        const int N = sh ? 16 : (bsel == 2 ? 128 : 64);
+        at3::cpx* F = s_f + (bsel == 0 ? 0 : bsel == 1 ? 64 : 128);
+        const at3::cpx* tw = s_tw + (sh ? 192 : bsel == 2 ? 0 : 128);
+        const int f = j / (N >> 2), r = j % (N >> 2);   // transform inside the band, butterfly inside the transform
+        int m = N == 128 ? 2 : 1;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            if (m < N) {
+                const int fstride = N / (4 * m);
+                const int g = r / m, k = r % m;
+                at3::cpx* B = F + f * N + g * 4 * m + k;
+                f2 x0 = at3::ld2(B), x1 = at3::ld2(B + m), x2 = at3::ld2(B + 2 * m), x3 = at3::ld2(B + 3 * m);
+                at3::bfly4<false>(x0, x1, x2, x3, at3::ld2(tw + k * fstride), at3::ld2(tw + 2 * k * fstride), at3::ld2(tw + 3 * k * fstride));
+                at3::st2(B, x0);
+                at3::st2(B + m, x1);
+                at3::st2(B + 2 * m, x2);
+                at3::st2(B + 3 * m, x3);
+            }
+            m <<= 2;
+            wave_sync();
         }
     }
     __syncthreads();
