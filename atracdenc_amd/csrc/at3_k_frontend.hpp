@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
 }
 
 template <bool GAIN>
-__global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables* T)
+__global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) float s_pcm[2 * kPcmRing];
     __shared__ __attribute__((aligned(16))) float s_s1[4 * kS1Ring];      // stage-1 rings: lower halves of both channels, then upper
@@ -498,19 +498,27 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
     __syncthreads();
     // block b carries frame f = b + 1; the block before the first frame only primes the overlap.
     for (int b = b0; b <= fb - 2; ++b) {
+        // Thread-derived addresses and roles are the same for every block of the run; left alone the compiler computes
+        // them all in front of the loop and keeps them in registers for the whole kernel. The opaque copy of the thread
+        // index makes them per-block work again.
+        int tid_ = tid;
+#if !defined(AT3_EMU_HOST)
+        asm volatile("" : "+v"(tid_));
+#endif
+        const int c_ = tid_ >> 5, lane_ = tid_ & 31;
         const int f = b + 1;
         const bool is_frame = (f >= fa);
-        if (GAIN && tid < 8) {
-            *reinterpret_cast<uint4*>(&s_curve[tid]) = ncv;
-            if (b + 1 <= fb - 2) ncv = *reinterpret_cast<const uint4*>(&p.curves[((size_t)s * p.n_blocks + f + 1) * 8 + tid]);
+        if (GAIN && tid_ < 8) {
+            *reinterpret_cast<uint4*>(&s_curve[tid_]) = ncv;
+            if (b + 1 <= fb - 2) ncv = *reinterpret_cast<const uint4*>(&p.curves[((size_t)s * p.n_blocks + f + 1) * 8 + tid_]);
         }
-        if (tid < 184 && b > b0) {   // stage-1 histories return to the rings (they shared storage with the FFT buffers)
-            const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
+        if (tid_ < 184 && b > b0) {   // stage-1 histories return to the rings (they shared storage with the FFT buffers)
+            const int hlf = tid_ / 92, r = tid_ % 92, ch = r / 46, k = r % 46;
             ((hlf ? s_hi : s_lo) + ch * kS1Ring)[ring_at<kS1H>(k)] = keep1;
         }
         // ---- stage 1 (Qmf1): 2 channels x 128 tasks x 4 outputs ----
         {
-            const int ch = tid >> 7, g = tid & 127;
+            const int ch = tid_ >> 7, g = tid_ & 127;
             float lw[4], up[4];
             qmf4<kPcmH>(reinterpret_cast<const float4*>(s_pcm + ch * kPcmRing) + g, Wp, lw, up);
             float4 a, bq;
@@ -529,27 +537,27 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
         __syncthreads();
         // PCM history for the next block (stage 1 is done with the ring), then the next block's tile and the
         // coalesced float2 loads of the block after it: they land during this block's remaining math
-        if (tid >= 210) {
-            s_pcm[ring_at<kPcmH>(tid - 210)] = hv.x;
-            s_pcm[kPcmRing + ring_at<kPcmH>(tid - 210)] = hv.y;
+        if (tid_ >= 210) {
+            s_pcm[ring_at<kPcmH>(tid_ - 210)] = hv.x;
+            s_pcm[kPcmRing + ring_at<kPcmH>(tid_ - 210)] = hv.y;
         }
         if (b + 1 <= fb - 2) {
             store_tile();
             if (b + 2 <= fb - 2) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int g = (b + 2) * 1024 + tid + 256 * q;
+                    const int g = (b + 2) * 1024 + tid_ + 256 * q;
                     nxt[q] = (g >= 0) ? pcm2[g] : hist2[kHist + g];
                 }
             }
         }
-        if (tid < 184) {   // stage-1 history for the next block, parked in a register across the MDCT phase
-            const int hlf = tid / 92, r = tid % 92, ch = r / 46, k = r % 46;
+        if (tid_ < 184) {   // stage-1 history for the next block, parked in a register across the MDCT phase
+            const int hlf = tid_ / 92, r = tid_ % 92, ch = r / 46, k = r % 46;
             keep1 = ((hlf ? s_hi : s_lo) + ch * kS1Ring)[ring_at<kS1H>(512 + k)];
         }
         // ---- stage 2: Qmf2 on the lower half -> bands 0, 1; Qmf3 on the upper half -> bands 3, 2 ----
         {
-            const int ch = tid >> 7, which = (tid >> 6) & 1, g = tid & 63;
+            const int ch = tid_ >> 7, which = (tid_ >> 6) & 1, g = tid_ & 63;
             float lw[4], up[4];
             qmf4<kS1H>(reinterpret_cast<const float4*>((which ? s_hi : s_lo) + ch * kS1Ring) + g, Wp, lw, up);
             float4 a, bq;
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
         }
         __syncthreads();
         if (p.js) {  // M/S matrixing in the subband domain
-            for (int idx = tid; idx < 1024; idx += 256) {
+            for (int idx = tid_; idx < 1024; idx += 256) {
                 const float l = s_sub[idx], r = s_sub[1024 + idx];
                 s_sub[idx] = (l + r) * 0.5f;         // (l + r) / 2.0, exact halving
                 s_sub[1024 + idx] = (l - r) * 0.5f;
@@ -570,32 +578,32 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
         }
 
         // ======== from here on every wavefront works on its own two (channel, band) combos ========
-        float* xs = s_sub + c * 256;
-        float* pw = s_prevw + c * 256;
+        float* xs = s_sub + c_ * 256;
+        float* pw = s_prevw + c_ * 256;
         bool has_curve = false;
         float scale = 1.0f;
         if (GAIN) {
-            has_curve = s_curve[c].n > 0 && p.debug != 2;
+            has_curve = s_curve[c_].n > 0 && p.debug != 2;
             if (has_curve) {
-                // lane j owns samples 8j .. 8j+7 of the modulated new half (modulate_cell)
-                const Curve& cv = s_curve[c];
+                // lane_ j owns samples 8j .. 8j+7 of the modulated new half (modulate_cell)
+                const Curve& cv = s_curve[c_];
                 scale = gain_level_of(cv.level[0]);
-                const int cell = 8 * lane;
+                const int cell = 8 * lane_;
                 const float4 xa = *reinterpret_cast<const float4*>(xs + cell), xb = *reinterpret_cast<const float4*>(xs + cell + 4);
                 float v[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
                 modulate_cell(cv, s_gi, cell, v);
                 float4 oa, ob;
                 oa.x = v[0]; oa.y = v[1]; oa.z = v[2]; oa.w = v[3];
                 ob.x = v[4]; ob.y = v[5]; ob.z = v[6]; ob.w = v[7];
-                *reinterpret_cast<float4*>(s_mod + c * 256 + cell) = oa;
-                *reinterpret_cast<float4*>(s_mod + c * 256 + cell + 4) = ob;
+                *reinterpret_cast<float4*>(s_mod + c_ * 256 + cell) = oa;
+                *reinterpret_cast<float4*>(s_mod + c_ * 256 + cell + 4) = ob;
             }
             wave_sync();
             // (CalcGainEnergyScale runs in k_gain_energy_scale, from the same subbands and curves)
             if (has_curve) {   // Modulate (gain_processor.h:87-121): new half / ramp, overlap half / first level
                 const float inv_scale = 1.0f / scale;   // scale is a power of two
-                for (int i = lane; i < 256; i += 32) {
-                    xs[i] = s_mod[c * 256 + i];
+                for (int i = lane_; i < 256; i += 32) {
+                    xs[i] = s_mod[c_ * 256 + i];
                     pw[i] = pw[i] * inv_scale;
                 }
             }
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
         if (is_frame) {
             // MDCT-512 fold + pre-rotation straight from the overlap and the windowed new half
             // (in[k] = overlap[k] for k < 256, EncodeWindow[511 - k] * new[k - 256] otherwise; mdct.h:64-86)
-            for (int n2 = lane; n2 < 128; n2 += 32) {
+            for (int n2 = lane_; n2 < 128; n2 += 32) {
                 const int n = 2 * n2;
                 float r0, i0;
                 if (n < 128) {
@@ -618,20 +626,20 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
                 cpx v;
                 v.r = r0 * cc + i0 * ss;
                 v.i = i0 * cc - r0 * ss;
-                s_fft[c * 128 + fft_leaf_pos<128>(n2)] = v;
+                s_fft[c_ * 128 + fft_leaf_pos<128>(n2)] = v;
             }
         }
         wave_sync();
         // next frame's overlap = EncodeWindow[i] * new[i] (atrac3denc.cpp:47)
-        for (int i = lane; i < 256; i += 32) pw[i] = s_win[i] * xs[i];
+        for (int i = lane_; i < 256; i += 32) pw[i] = s_win[i] * xs[i];
         if (is_frame) {
             // 128-point FFT of this combo by its 32 lanes: radix-2 leaves, then three radix-4 passes
-            cpx* F = s_fft + c * 128;
+            cpx* F = s_fft + c_ * 128;
             {
                 const f2 w = ld2(s_tw);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    cpx* a = F + 2 * (lane + 32 * q);
+                    cpx* a = F + 2 * (lane_ + 32 * q);
                     f2 a0 = ld2(a), a1 = ld2(a + 1);
                     bfly2(a0, a1, w);
                     st2(a, a0);
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
 #pragma unroll
             for (int m = 2; m < 128; m <<= 2) {
                 const int fstride = 128 / (4 * m);
-                const int g = lane / m, k = lane % m;
+                const int g = lane_ / m, k = lane_ % m;
                 cpx* B = F + g * 4 * m + k;
                 f2 x0 = ld2(B), x1 = ld2(B + m), x2 = ld2(B + 2 * m), x3 = ld2(B + 3 * m);
                 bfly4<false>(x0, x1, x2, x3, ld2(s_tw + k * fstride), ld2(s_tw + 2 * k * fstride), ld2(s_tw + 3 * k * fstride));
@@ -652,11 +660,11 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
                 st2(B + 3 * m, x3);
                 wave_sync();
             }
-            // post-rotation (mdct.h:92-101) in place: read this lane's four bins, then scatter the 256 lines
+            // post-rotation (mdct.h:92-101) in place: read this lane_'s four bins, then scatter the 256 lines
             float oa[4], ob[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n2 = lane + 32 * q, n = 2 * n2;
+                const int n2 = lane_ + 32 * q, n = 2 * n2;
                 const float r0 = F[n2].r, i0 = F[n2].i;
                 const float cc = s_cs[n], ss = s_cs[n + 1];
                 oa[q] = -r0 * cc - i0 * ss;
@@ -664,18 +672,18 @@ __global__ __launch_bounds__(256, 3) void k_qmf_mdct(FrontParams p, const Tables
             }
             wave_sync();
             float* out = reinterpret_cast<float*>(F);
-            const bool odd = (c & 1);   // odd bands are stored reversed (atrac3denc.cpp:53-55)
+            const bool odd = (c_ & 1);   // odd bands are stored reversed (atrac3denc.cpp:53-55)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = 2 * (lane + 32 * q);
+                const int n = 2 * (lane_ + 32 * q);
                 out[odd ? 255 - n : n] = oa[q];
                 out[odd ? n : 255 - n] = ob[q];
             }
             wave_sync();
-            float* dst = p.specs + ((size_t)s * n_out + (f - p.f0)) * 2048 + c * 256;
+            float* dst = p.specs + ((size_t)s * n_out + (f - p.f0)) * 2048 + c_ * 256;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-                *reinterpret_cast<float4*>(dst + 4 * (lane + 32 * q)) = *reinterpret_cast<const float4*>(out + 4 * (lane + 32 * q));
+                *reinterpret_cast<float4*>(dst + 4 * (lane_ + 32 * q)) = *reinterpret_cast<const float4*>(out + 4 * (lane_ + 32 * q));
         }
         __syncthreads();   // s_sub / rings are rewritten by the next block
     }
