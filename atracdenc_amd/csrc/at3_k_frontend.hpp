@@ -384,6 +384,12 @@ __global__ __launch_bounds__(256) void k_qmf_sub(FrontParams p, const Tables* T)
     }
 }
 
+// FFT buffer layout of the fused kernel: one spare complex slot after every 8, 144 slots per 128-point transform. The
+// radix-4 passes with butterfly distance m = 2 and m = 8 put a half-wave's 8-byte accesses 64 B / 256 B apart; the
+// padding spreads them over the banks (an 8-way conflict becomes conflict free, a 4-way one 2-way).
+constexpr int kFftSlot = 144;
+__device__ __forceinline__ constexpr int fft_pad(int i) { return i + (i >> 3); }
+
 template <bool GAIN>
 __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables* T)
 {
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
     float* s_hi = s_s1 + 2 * kS1Ring;
     // The stage-1 rings are dead between stage 2 and the next block's stage 1 (their 46-sample histories wait in
     // registers meanwhile), so the eight 128-point FFT buffers of the MDCT phase live in the same storage.
-    static_assert(4 * kS1Ring * sizeof(float) >= 8 * 128 * sizeof(cpx), "FFT buffers must fit in the stage-1 rings");
+    static_assert(4 * kS1Ring * sizeof(float) >= 8 * kFftSlot * sizeof(cpx), "FFT buffers must fit in the stage-1 rings");
     cpx* s_fft = reinterpret_cast<cpx*>(s_s1);
     __shared__ __attribute__((aligned(16))) float s_win[256];
     __shared__ float s_cs[256];
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
     // Gain-path scratch aliases buffers that are dead between stage 2 and the MDCT fold of the same block:
     // the modulated samples live in the FFT buffer (written by the fold afterwards), the energy-term staging in
     // each channel's PCM ring behind the 46-sample history (rewritten by the next block's tile load).
-    float* s_mod = reinterpret_cast<float*>(s_fft);          // [8][256]
+    float* s_mod = reinterpret_cast<float*>(s_fft);          // 256 floats at the head of each combo's own FFT slot
 
     const int tid = threadIdx.x;
     const int nchunks = (p.n_blocks - p.f0 + p.frames_per_wg - 1) / p.frames_per_wg;
@@ -595,15 +601,15 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
                 float4 oa, ob;
                 oa.x = v[0]; oa.y = v[1]; oa.z = v[2]; oa.w = v[3];
                 ob.x = v[4]; ob.y = v[5]; ob.z = v[6]; ob.w = v[7];
-                *reinterpret_cast<float4*>(s_mod + c_ * 256 + cell) = oa;
-                *reinterpret_cast<float4*>(s_mod + c_ * 256 + cell + 4) = ob;
+                *reinterpret_cast<float4*>(s_mod + c_ * (2 * kFftSlot) + cell) = oa;
+                *reinterpret_cast<float4*>(s_mod + c_ * (2 * kFftSlot) + cell + 4) = ob;
             }
             wave_sync();
             // (CalcGainEnergyScale runs in k_gain_energy_scale, from the same subbands and curves)
             if (has_curve) {   // Modulate (gain_processor.h:87-121): new half / ramp, overlap half / first level
                 const float inv_scale = 1.0f / scale;   // scale is a power of two
                 for (int i = lane_; i < 256; i += 32) {
-                    xs[i] = s_mod[c_ * 256 + i];
+                    xs[i] = s_mod[c_ * (2 * kFftSlot) + i];
                     pw[i] = pw[i] * inv_scale;
                 }
             }
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
                 cpx v;
                 v.r = r0 * cc + i0 * ss;
                 v.i = i0 * cc - r0 * ss;
-                s_fft[c_ * 128 + fft_leaf_pos<128>(n2)] = v;
+                s_fft[c_ * kFftSlot + fft_pad(fft_leaf_pos<128>(n2))] = v;
             }
         }
         wave_sync();
@@ -634,12 +640,12 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
         for (int i = lane_; i < 256; i += 32) pw[i] = s_win[i] * xs[i];
         if (is_frame) {
             // 128-point FFT of this combo by its 32 lanes: radix-2 leaves, then three radix-4 passes
-            cpx* F = s_fft + c_ * 128;
+            cpx* F = s_fft + c_ * kFftSlot;
             {
                 const f2 w = ld2(s_tw);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    cpx* a = F + 2 * (lane_ + 32 * q);
+                    cpx* a = F + fft_pad(2 * (lane_ + 32 * q));   // an even index and its successor share a group of 8
                     f2 a0 = ld2(a), a1 = ld2(a + 1);
                     bfly2(a0, a1, w);
                     st2(a, a0);
@@ -651,13 +657,14 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
             for (int m = 2; m < 128; m <<= 2) {
                 const int fstride = 128 / (4 * m);
                 const int g = lane_ / m, k = lane_ % m;
-                cpx* B = F + g * 4 * m + k;
-                f2 x0 = ld2(B), x1 = ld2(B + m), x2 = ld2(B + 2 * m), x3 = ld2(B + 3 * m);
+                const int i0 = g * 4 * m + k;
+                cpx *B0 = F + fft_pad(i0), *B1 = F + fft_pad(i0 + m), *B2 = F + fft_pad(i0 + 2 * m), *B3 = F + fft_pad(i0 + 3 * m);
+                f2 x0 = ld2(B0), x1 = ld2(B1), x2 = ld2(B2), x3 = ld2(B3);
                 bfly4<false>(x0, x1, x2, x3, ld2(s_tw + k * fstride), ld2(s_tw + 2 * k * fstride), ld2(s_tw + 3 * k * fstride));
-                st2(B, x0);
-                st2(B + m, x1);
-                st2(B + 2 * m, x2);
-                st2(B + 3 * m, x3);
+                st2(B0, x0);
+                st2(B1, x1);
+                st2(B2, x2);
+                st2(B3, x3);
                 wave_sync();
             }
             // post-rotation (mdct.h:92-101) in place: read this lane_'s four bins, then scatter the 256 lines
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n2 = lane_ + 32 * q, n = 2 * n2;
-                const float r0 = F[n2].r, i0 = F[n2].i;
+                const float r0 = F[fft_pad(n2)].r, i0 = F[fft_pad(n2)].i;
                 const float cc = s_cs[n], ss = s_cs[n + 1];
                 oa[q] = -r0 * cc - i0 * ss;
                 ob[q] = -r0 * ss + i0 * cc;
