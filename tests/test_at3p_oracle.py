@@ -51,12 +51,10 @@ def test_mdct_zero_and_dc_properties(oracle):
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
 def test_reference_ipqf_fixture_and_round_trip(oracle):
-    """ipqf_ut.cpp: the synthesis filter reproduces the reference's own data files (committed under tests/golden) to
+    """ipqf_ut.cpp: the synthesis filter reproduces the reference's own test vectors (kept in the golden fixture) to
     2^-26; analysis -> synthesis returns the input delayed by the prototype's 368 samples (ipqf_ut.cpp DC / chirp tests,
     tolerance 2^-21 relative to full scale)."""
-    gdir = os.path.join(os.path.dirname(__file__), "golden")
-    mr = np.fromfile(os.path.join(gdir, "ipqftest_pcm_mr.dat"), np.float32).reshape(4, 2048)
-    want = np.fromfile(os.path.join(gdir, "ipqftest_pcm_out.dat"), np.float32).reshape(4, 2048)
+    mr, want = GOLD["ipqf_ut_in"], GOLD["ipqf_ut_out"]
     assert np.abs(at3p_ipqf_ref(mr) - want).max() <= 1.0 / (1 << 26)
     x = at3p_signal("mix", 8)
     y = at3p_ipqf_ref(at3p_pqf(x).reshape(8, 2048)).reshape(-1)

@@ -27,6 +27,11 @@ def main():
         d[f"{name}_flags"] = flags
         d[f"{name}_specs_sine"] = at3p_mdct(bands, None, "ref")
         d[f"{name}_specs_mixed"] = at3p_mdct(bands, flags, "ref")
+    # the reference's own synthesis-filter test vectors (atrac3plus_pqf/ut/test_data, used by ipqf_ut.cpp): inputs and
+    # expected outputs, kept as two arrays of this fixture
+    tdir = "/root/reference/src/atrac/atrac3plus_pqf/ut/test_data"
+    d["ipqf_ut_in"] = np.fromfile(os.path.join(tdir, "ipqftest_pcm_mr.dat"), np.float32).reshape(4, 2048)
+    d["ipqf_ut_out"] = np.fromfile(os.path.join(tdir, "ipqftest_pcm_out.dat"), np.float32).reshape(4, 2048)
     path = os.path.join(ROOT, "tests", "golden", "at3p_frontend.npz")
     np.savez_compressed(path, **d)
     print(path, os.path.getsize(path), "bytes")
