@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
     static_assert(4 * kS1Ring * sizeof(float) >= 8 * kFftSlot * sizeof(cpx), "FFT buffers must fit in the stage-1 rings");
     cpx* s_fft = reinterpret_cast<cpx*>(s_s1);
     __shared__ __attribute__((aligned(16))) float s_win[256];
-    __shared__ float s_cs[256];
+    __shared__ __attribute__((aligned(8))) float s_cs[256];
     __shared__ cpx s_tw[128];
     __shared__ __attribute__((aligned(16))) Curve s_curve[8];
     __shared__ float s_gi[32];               // GainInterpolation
@@ -628,7 +628,8 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
                     r0 = pw[383 - n] - pw[n - 128];
                     i0 = s_win[383 - n] * xs[n - 128] + s_win[n - 128] * xs[383 - n];
                 }
-                const float cc = s_cs[n], ss = s_cs[n + 1];
+                const f2 csn = *reinterpret_cast<const f2*>(s_cs + n);   // (cos, sin) of this bin as one 8-byte read
+                const float cc = csn.x, ss = csn.y;
                 cpx v;
                 v.r = r0 * cc + i0 * ss;
                 v.i = i0 * cc - r0 * ss;
@@ -673,7 +674,8 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
             for (int q = 0; q < 4; ++q) {
                 const int n2 = lane_ + 32 * q, n = 2 * n2;
                 const float r0 = F[fft_pad(n2)].r, i0 = F[fft_pad(n2)].i;
-                const float cc = s_cs[n], ss = s_cs[n + 1];
+                const f2 csn = *reinterpret_cast<const f2*>(s_cs + n);   // (cos, sin) of this bin as one 8-byte read
+                const float cc = csn.x, ss = csn.y;
                 oa[q] = -r0 * cc - i0 * ss;
                 ob[q] = -r0 * ss + i0 * cc;
             }
