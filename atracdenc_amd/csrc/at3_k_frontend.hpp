@@ -443,9 +443,12 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
                                                       : &p.curves[((size_t)s * p.n_blocks + f) * 8 + tid]);
     }
 
-    // ---- prologue: FIR histories of the first block (b0 = fa - 2) ----
-    // stage-1 outputs m = -46..-1 need samples -138..-1; they are computed once per workgroup run.
-    const int b0 = fa - 2;
+    // ---- prologue: FIR histories of the first block ----
+    // stage-1 outputs m = -46..-1 need samples -138..-1; they are computed once per workgroup run. The block before the
+    // first frame only primes the MDCT overlap: without gain control it runs through the filter bank like any other
+    // (b0 = fa - 2); with gain control its subbands already sit in HBM (k_qmf_sub wrote every block's for the gain
+    // analysis, same arithmetic), so the run starts at b0 = fa - 1 and the priming block is read instead of recomputed.
+    const int b0 = GAIN ? fa - 1 : fa - 2;
     for (int k = tid; k < 138; k += 256) {
         const int g = b0 * 1024 - 138 + k;
         const float2 v = (g >= 0) ? pcm2[g] : hist2[kHist + g];
@@ -502,7 +505,42 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
         }
     }
     __syncthreads();
-    // block b carries frame f = b + 1; the block before the first frame only primes the overlap.
+    if (GAIN) {
+        // priming block fa - 2: subbands from k_qmf_sub, M/S matrixing, modulation by frame fa-1's curve, overlap window
+        const size_t sublen = (size_t)(p.n_blocks + 2) * 256;
+        for (int i = tid; i < 2048; i += 256)
+            s_sub[i] = p.sub[((size_t)s * 8 + (i >> 8)) * sublen + (size_t)fa * 256 + (i & 255)];   // block b lives at (b + 2) * 256
+        if (tid < 8) {
+            *reinterpret_cast<uint4*>(&s_curve[tid]) = ncv;
+            ncv = *reinterpret_cast<const uint4*>(&p.curves[((size_t)s * p.n_blocks + fa) * 8 + tid]);
+        }
+        __syncthreads();
+        if (p.js) {
+            for (int idx = tid; idx < 1024; idx += 256) {
+                const float l = s_sub[idx], r = s_sub[1024 + idx];
+                s_sub[idx] = (l + r) * 0.5f;
+                s_sub[1024 + idx] = (l - r) * 0.5f;
+            }
+            __syncthreads();
+        }
+        float* xs = s_sub + c * 256;
+        if (s_curve[c].n > 0 && p.debug != 2) {
+            const Curve& cv = s_curve[c];
+            const int cell = 8 * lane;   // the lane's own eight samples: modulated in place
+            const float4 xa = *reinterpret_cast<const float4*>(xs + cell), xb = *reinterpret_cast<const float4*>(xs + cell + 4);
+            float v[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            modulate_cell(cv, s_gi, cell, v);
+            float4 oa, ob;
+            oa.x = v[0]; oa.y = v[1]; oa.z = v[2]; oa.w = v[3];
+            ob.x = v[4]; ob.y = v[5]; ob.z = v[6]; ob.w = v[7];
+            *reinterpret_cast<float4*>(xs + cell) = oa;
+            *reinterpret_cast<float4*>(xs + cell + 4) = ob;
+        }
+        wave_sync();
+        for (int i = lane; i < 256; i += 32) s_prevw[c * 256 + i] = s_win[i] * xs[i];
+        __syncthreads();
+    }
+    // block b carries frame f = b + 1; without gain control the block before the first frame only primes the overlap.
     for (int b = b0; b <= fb - 2; ++b) {
         // Thread-derived addresses and roles are the same for every block of the run; left alone the compiler computes
         // them all in front of the loop and keeps them in registers for the whole kernel. The opaque copy of the thread
