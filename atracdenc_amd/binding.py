@@ -33,7 +33,8 @@ class Timings(ctypes.Structure):
 
 SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint_stereo", "at3hip_last_error",
            "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
-           "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago", "at3hip_read_tap"]
+           "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago", "at3hip_read_tap",
+           "at3hip_mdct_levels", "at3hip_gain_energy_scale"]
 # include/at1hip.h
 AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_encode", "at1hip_reset", "at1hip_get_timings",
                "at1hip_read_tap", "at1hip_host_tables"]
@@ -95,6 +96,8 @@ def load_library(path=None):
     lib.at3hip_encode.argtypes = [vp, vp, i32, vp, ctypes.POINTER(i32), ctypes.c_uint32]
     lib.at3hip_reset.argtypes = [vp]
     lib.at3hip_mdct.argtypes = [vp, vp, vp, vp, vp, vp, i32, ctypes.c_uint32]
+    lib.at3hip_mdct_levels.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, ctypes.c_uint32]
+    lib.at3hip_gain_energy_scale.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, ctypes.c_uint32]
     lib.at3hip_qmf_mdct.argtypes = [vp, vp, i32, vp, ctypes.c_uint32]
     lib.at3hip_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
     lib.at3hip_set_stream.argtypes = [vp, vp]
@@ -208,20 +211,41 @@ class At3Hip:
         self._check(self.lib.at3hip_qmf_mdct(self.ctx, ctypes.c_void_p(pcm_ptr), n_blocks, ctypes.c_void_p(specs_ptr),
                                              AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE), "at3hip_qmf_mdct")
 
-    def mdct(self, bands, n_points=None, level=None, loc=None):
-        """Batched TAtrac3MDCT::Mdct. bands float32 [n,4,512] -> (specs [n,1024], mutated bands)."""
+    def mdct(self, bands, n_points=None, level=None, loc=None, max_levels=False):
+        """Batched TAtrac3MDCT::Mdct. bands float32 [n,4,512] -> (specs [n,1024], mutated bands[, max levels [n,4]])."""
         bands = np.ascontiguousarray(bands, dtype=np.float32).copy()
         n = bands.shape[0]
         specs = np.zeros((n, 1024), dtype=np.float32)
-        if n_points is None:
-            rc = self.lib.at3hip_mdct(self.ctx, _vp(bands), _vp(specs), None, None, None, n, 0)
-        else:
+        curves = (None, None, None)
+        if n_points is not None:
             n_points = np.ascontiguousarray(n_points, dtype=np.int32)
             level = np.ascontiguousarray(level, dtype=np.int32)
             loc = np.ascontiguousarray(loc, dtype=np.int32)
-            rc = self.lib.at3hip_mdct(self.ctx, _vp(bands), _vp(specs), _vp(n_points), _vp(level), _vp(loc), n, 0)
-        self._check(rc, "at3hip_mdct")
+            curves = (_vp(n_points), _vp(level), _vp(loc))
+        if max_levels:
+            mx = np.zeros((n, 4), dtype=np.float32)
+            self._check(self.lib.at3hip_mdct_levels(self.ctx, _vp(bands), _vp(specs), _vp(mx), *curves, n, 0), "at3hip_mdct_levels")
+            return specs, bands, mx
+        self._check(self.lib.at3hip_mdct(self.ctx, _vp(bands), _vp(specs), *curves, n, 0), "at3hip_mdct")
         return specs, bands
+
+    def gain_energy_scale(self, prev_overlap, cur_input, prev_scale, n_points=None, level=None, loc=None):
+        """Batched TAtrac3MDCT::CalcGainEnergyScale. prev_overlap / cur_input float32 [n,256], prev_scale [n], optional
+        n_points [n], level / loc [n,8] -> float32 [n,4] (PrevHalf, CurHalf, Frame, NextOverlapScale)."""
+        prev_overlap = np.ascontiguousarray(prev_overlap, dtype=np.float32)
+        cur_input = np.ascontiguousarray(cur_input, dtype=np.float32)
+        prev_scale = np.ascontiguousarray(prev_scale, dtype=np.float32)
+        n = prev_overlap.shape[0]
+        out = np.zeros((n, 4), dtype=np.float32)
+        curves = (None, None, None)
+        if n_points is not None:
+            n_points = np.ascontiguousarray(n_points, dtype=np.int32)
+            level = np.ascontiguousarray(level, dtype=np.int32)
+            loc = np.ascontiguousarray(loc, dtype=np.int32)
+            curves = (_vp(n_points), _vp(level), _vp(loc))
+        self._check(self.lib.at3hip_gain_energy_scale(self.ctx, _vp(prev_overlap), _vp(cur_input), *curves, _vp(prev_scale),
+                                                      _vp(out), n, 0), "at3hip_gain_energy_scale")
+        return out
 
     def timings(self):
         t = Timings()

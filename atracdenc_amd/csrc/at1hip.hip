@@ -8,6 +8,7 @@
 
 #include "../../include/at1hip.h"
 #include "at1_kernels.hpp"
+#include "at3_host_util.hpp"
 
 using namespace at1;
 
@@ -15,6 +16,8 @@ static_assert(sizeof(Tables) == AT1HIP_TABLES_BYTES, "at1hip.h documents the tab
 
 struct at1hip_ctx {
     at1hip_config cfg;
+    int device = 0;
+    int debug_stop = 0;           // AT1HIP_DEBUG_STOP, honoured by -DAT3HIP_DEBUG_KNOBS builds only
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {};
     Tables* d_tables = nullptr;
@@ -88,18 +91,24 @@ int at1hip_create(const at1hip_config* cfg, at1hip_ctx** out)
     if ((cfg->channels != 1 && cfg->channels != 2) || cfg->n_streams < 1 || cfg->max_blocks < 1 || cfg->bfu_idx_const < 0 ||
         cfg->bfu_idx_const > 8 || cfg->window_mask < 0 || cfg->window_mask > 7)
         return AT3HIP_EINVAL;
+    if ((long long)cfg->n_streams * cfg->channels > at3host::kMaxGridY) return AT3HIP_EINVAL;   // (stream, channel) is gridDim.y
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AT3HIP_EDEVICE;
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return AT3HIP_EINVAL;
     at1hip_ctx* c = new (std::nothrow) at1hip_ctx();
     if (!c) return AT3HIP_ENOMEM;
     c->cfg = *cfg;
+    c->device = cfg->device_id;
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (const char* dbg = getenv("AT1HIP_DEBUG_STOP")) c->debug_stop = atoi(dbg);
+#endif
     int rc = AT3HIP_OK;
     auto bail = [&](int code) {
         at1hip_destroy(c);
         return code;
     };
-    if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    at3host::DeviceGuard guard(c->device);
+    if (guard.error() != hipSuccess) return bail(AT3HIP_EDEVICE);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(AT3HIP_EDEVICE);
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(AT3HIP_EDEVICE);
@@ -132,6 +141,7 @@ int at1hip_create(const at1hip_config* cfg, at1hip_ctx** out)
 void at1hip_destroy(at1hip_ctx* c)
 {
     if (!c) return;
+    at3host::DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_tables, c->d_pcm_in, c->d_hist,       c->d_specs,      c->d_values, c->d_energy,
                     c->d_sfi,    c->d_mask,   c->d_loud_ch,    c->d_loud_state, c->d_loud_track, c->d_out};
@@ -148,6 +158,8 @@ const char* at1hip_last_error(const at1hip_ctx* c) { return c ? c->err : "null c
 int at1hip_reset(at1hip_ctx* c)
 {
     if (!c) return AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     return reset_state(c);
 }
 
@@ -155,6 +167,8 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
 {
     if (!c || !pcm || !out_frames || n_blocks < 1 || n_blocks > c->cfg.max_blocks)
         return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const size_t S = c->cfg.n_streams, C = c->cfg.channels, F = (size_t)n_blocks;
     hipStream_t st = c->stream;
     const float* d_pcm = pcm;
@@ -174,10 +188,7 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     fp.first = c->blocks_fed == 0;
     fp.window_auto = c->cfg.window_auto ? 1 : 0;
     fp.window_mask = c->cfg.window_mask;
-    {
-        const char* dbg = getenv("AT1HIP_DEBUG_STOP");
-        fp.debug = dbg ? atoi(dbg) : 0;
-    }
+    fp.debug = c->debug_stop;
     fp.specs = c->d_specs;
     fp.values = c->d_values;
     fp.energy = c->d_energy;
@@ -255,6 +266,8 @@ int at1hip_read_tap(at1hip_ctx* c, int32_t kind, void* dst, size_t bytes)
         default: return fail(c, AT3HIP_EINVAL, "unknown tap");
     }
     if (bytes != need || (kind != AT1HIP_TAP_TABLES && F == 0)) return fail(c, AT3HIP_EINVAL, "tap size");
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
     return AT3HIP_OK;

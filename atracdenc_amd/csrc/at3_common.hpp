@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "at3_pk.hpp"
 #include "at3_tables.hpp"
 
 namespace at3 {
@@ -125,54 +126,8 @@ __device__ __forceinline__ cpx cmul(cpx a, cpx b)
     return m;
 }
 
-// ---- packed fp32 --------------------------------------------------------------------------------------------
-// CDNA issues a wave64 fp32 VALU instruction over four cycles; v_pk_mul_f32 / v_pk_add_f32 (VOP3P) carry TWO
-// independent IEEE fp32 operations per lane in the same four cycles. The reference arithmetic has no fused
-// multiply-add (-ffp-contract=off is part of the parity contract), so mul/add-bound code is issue bound and packing
-// doubles its rate without changing a single rounding. `f2` maps to an aligned VGPR pair; plain vector expressions
-// are selected as packed instructions by the compiler, the three complex forms whose lanes need DIFFERENT negate /
-// half-select modifiers are spelled out below.
-typedef float f2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ f2 ld2(const cpx* q) { return *reinterpret_cast<const f2*>(q); }
 __device__ __forceinline__ void st2(cpx* q, f2 v) { *reinterpret_cast<f2*>(q) = v; }
-__device__ __forceinline__ f2 mk2(float x, float y)
-{
-    f2 v;
-    v.x = x;
-    v.y = y;
-    return v;
-}
-
-#if defined(AT3_EMU_HOST)   // tools/emu development harness: same operations, one at a time
-__device__ __forceinline__ f2 pk_cmul(f2 a, f2 w) { return mk2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
-__device__ __forceinline__ f2 pk_add_ib(f2 a, f2 b) { return mk2(a.x - b.y, a.y + b.x); }
-__device__ __forceinline__ f2 pk_sub_ib(f2 a, f2 b) { return mk2(a.x + b.y, a.y - b.x); }
-#else
-// a * w, complex: (a.x w.x - a.y w.y, a.x w.y + a.y w.x) - the four products and two sums of C_MUL (_kiss_fft_guts.h)
-__device__ __forceinline__ f2 pk_cmul(f2 a, f2 w)
-{
-    f2 t1, t2, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t1) : "v"(a), "v"(w));                  // (a.x w.x, a.x w.y)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t2) : "v"(a), "v"(w));     // (a.y w.y, a.y w.x)
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t1), "v"(t2));                    // (t1.x - t2.x, t1.y + t2.y)
-    return r;
-}
-// a + i b = (a.x - b.y, a.y + b.x)
-__device__ __forceinline__ f2 pk_add_ib(f2 a, f2 b)
-{
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// a - i b = (a.x + b.y, a.y - b.x)
-__device__ __forceinline__ f2 pk_sub_ib(f2 a, f2 b)
-{
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-#endif
 
 // kf_bfly4 (kiss_fft.c:42-90) on four points held in registers; w1..w3 = tw[k fstride], tw[2k fstride], tw[3k fstride]
 template <bool INVERSE>

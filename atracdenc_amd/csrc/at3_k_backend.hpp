@@ -30,6 +30,7 @@ struct BackParams {
     int js;
     int frame_sz;
     int bfu_idx_const;
+    int mono_js;             // one input channel in a joint-stereo container: empty second sound unit (atrac3denc.cpp:843-849)
     struct QuantRec* quant;  // [S][n_out][2] per-unit tables written by k_quant, read by k_rate_pack
     int8_t* mant;            // [S][n_out][2][7][1024] mantissas for every wordlen
     int debug_stop;          // profiling aid (env AT3HIP_DEBUG_STOP): leave k_quant after phase N; 0 = run everything
@@ -1072,10 +1073,15 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
         int bits = (p.js && c2 == 1) ? 14 : 6;
         bits += 2;
         for (int b = 0; b < 4; ++b) bits += 3 + 9 * curves[c2 * 4 + b].n;
+        // one input channel, joint stereo: the second element has ONE subband and no gain points (atrac3denc.cpp:843-849)
+        if (p.mono_js && c2 == 1) bits = 14 + 2 + 3;
         hdr[c2] = bits;
     }
     int shift = 0;
-    if (p.js) {
+    if (p.mono_js) {   // CalcMSBytesShift with an empty second element: the maximum (atrac3_bitstream.cpp:745-747)
+        const int totalUsed = 12 + hdr[0] + hdr[1];
+        shift = (int)((uint32_t)p.frame_sz / 2 - (1 + ((uint32_t)totalUsed - 1) / 8));
+    } else if (p.js) {
         const int b0 = -6 - hdr[0], b1 = -6 - hdr[1];
         const int totalUsed = 0 - b0 - b1;
         const int maxShift = (int)((uint32_t)p.frame_sz / 2 - (1 + ((uint32_t)totalUsed - 1) / 8));
@@ -1093,6 +1099,31 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
     if (target < 1) target = 1;
     target &= 0xffff;
     const float loudness = p.loud[(size_t)s * n_out + fo] / 0.006f;
+
+    if (p.mono_js && ch == 1) {
+        // TConfigure / TAlloc with empty ScaledBlocks (atrac3_bitstream.cpp:590-597, 623-626): JS parameters, one subband
+        // without gain points, no tonal components, one BFU of precision 0 in coding mode 1 - 33 bits, then zeros
+        __syncthreads();
+        if (lane == 0) {
+            put_bits(s_words, 0, 0, 1);
+            put_bits(s_words, 1, 7, 3);
+            for (int k = 0; k < 4; ++k) put_bits(s_words, 4 + 2 * k, 3, 2);
+            put_bits(s_words, 12, 3, 2);
+            put_bits(s_words, 14, 0, 2);       // numQmfBand - 1
+            put_bits(s_words, 16, 0, 3);       // gain points of band 0
+            put_bits(s_words, 19, 0, 5);       // tonal sub-groups
+            put_bits(s_words, 24, 0, 5);       // numBlocks - 1
+            put_bits(s_words, 29, 1, 1);       // coding mode
+            put_bits(s_words, 30, 0, 3);       // precision of the one block
+        }
+        __syncthreads();
+        uint8_t* frame1 = p.out + ((size_t)s * n_out + fo) * p.frame_sz;
+        for (int j = lane; j < nbytes; j += 64) {
+            const int src = nbytes - 1 - j;
+            frame1[half + shift + j] = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
+        }
+        return;
+    }
 
     // ---- TConfigure: spread (sequential float sums, every lane computes the same value) ----
     const int i = lane & 31;   // BFU owned by this lane (lanes 32..63 mirror 0..31 but never contribute)
@@ -1389,8 +1420,9 @@ __global__ __launch_bounds__(256) void k_mono_to_pairs(const float* __restrict__
 
 __global__ void k_state_update(StateParams p)
 {
-    const int s = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int kChunks = (kHist + 255) / 256;
+    const int s = blockIdx.x / kChunks;
+    const int k = (blockIdx.x % kChunks) * blockDim.x + threadIdx.x;
     if (k < kHist) {
         const float2* pcm2 = reinterpret_cast<const float2*>(p.pcm) + (size_t)s * p.n_blocks * 1024;
         const float2* hin = reinterpret_cast<const float2*>(p.hist_in) + (size_t)s * kHist;

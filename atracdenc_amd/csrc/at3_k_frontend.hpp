@@ -545,10 +545,7 @@ __global__ __launch_bounds__(256, 4) void k_qmf_mdct(FrontParams p, const Tables
         // Thread-derived addresses and roles are the same for every block of the run; left alone the compiler computes
         // them all in front of the loop and keeps them in registers for the whole kernel. The opaque copy of the thread
         // index makes them per-block work again.
-        int tid_ = tid;
-#if !defined(AT3_EMU_HOST)
-        asm volatile("" : "+v"(tid_));
-#endif
+        const int tid_ = opaque_lane_value(tid);
         const int c_ = tid_ >> 5, lane_ = tid_ & 31;
         const int f = b + 1;
         const bool is_frame = (f >= fa);
@@ -743,6 +740,7 @@ struct MdctItemsParams {
     const int32_t* n_points;  // [n][4] or null
     const int32_t* level;     // [n][4][8]
     const int32_t* loc;       // [n][4][8]
+    float* max_levels;        // [n][4] or null: max |new half| after modulation (the maxLevels overload, atrac3denc.cpp:33-58)
 };
 
 __global__ __launch_bounds__(128) void k_mdct_items(MdctItemsParams p, const Tables* T)
@@ -772,6 +770,7 @@ __global__ __launch_bounds__(128) void k_mdct_items(MdctItemsParams p, const Tab
     const bool has_curve = s_curve[c].n > 0;
     const float scale = has_curve ? gain_level_of(s_curve[c].level[0]) : 1.0f;
     float* tmp = s_tmp + c * 512;
+    float mx = 0.0f;
     for (int i = lane; i < 256; i += 32) {
         float ov = band[i];
         float v = band[256 + i];
@@ -781,9 +780,15 @@ __global__ __launch_bounds__(128) void k_mdct_items(MdctItemsParams p, const Tab
             v = v / d;
             band[256 + i] = v;
         }
+        mx = fmaxf(mx, fabsf(v));
         tmp[i] = ov;
         band[i] = T->enc_win[i] * v;
         tmp[256 + i] = T->enc_win[255 - i] * v;
+    }
+    if (p.max_levels) {   // order-free maximum over the band's 32 lanes (one half of the wavefront)
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        if (lane == 0) p.max_levels[item * 4 + c] = mx;
     }
     __syncthreads();
     for (int n2 = lane; n2 < 128; n2 += 32) {
@@ -812,6 +817,83 @@ __global__ __launch_bounds__(128) void k_mdct_items(MdctItemsParams p, const Tab
         const float cc = T->mdct_sincos[n], ss = T->mdct_sincos[n + 1];
         out[odd ? 255 - n : n] = -r0 * cc - i0 * ss;
         out[odd ? n : 255 - n] = -r0 * ss + i0 * cc;
+    }
+}
+
+// Batched TAtrac3MDCT::CalcGainEnergyScale (atrac3denc.h:75-79, atrac3denc.cpp:175-224) on caller-provided buffers: one
+// wavefront per item. Lane j forms the five terms of samples 4j .. 4j+3; lanes 0..4 then run the five strictly ordered
+// 256-term sums (stored-overlap energy, windowed original / modulated energy of this half and of the next overlap).
+struct GesItemsParams {
+    const float* prev_overlap;   // [n][256]
+    const float* cur_input;      // [n][256]
+    const int32_t* n_points;     // [n] or null (no gain points anywhere)
+    const int32_t* level;        // [n][8]
+    const int32_t* loc;          // [n][8]
+    const float* prev_scale;     // [n] prevOverlapScale
+    float* out;                  // [n][4]: Scale.PrevHalf, Scale.CurHalf, Scale.Frame, NextOverlapScale
+};
+
+__global__ __launch_bounds__(64) void k_ges_items(GesItemsParams p, const Tables* T)
+{
+    __shared__ __attribute__((aligned(16))) float s_terms[5][256];
+    __shared__ Curve s_cv;
+    const int lane = threadIdx.x;
+    const size_t item = blockIdx.x;
+    if (lane == 0) {
+        Curve cv;
+        cv.n = 0;
+        if (p.n_points) {
+            cv.n = (uint8_t)p.n_points[item];
+            for (int i = 0; i < cv.n && i < 7; ++i) {
+                cv.level[i] = (uint8_t)p.level[item * 8 + i];
+                cv.loc[i] = (uint8_t)p.loc[item * 8 + i];
+            }
+        }
+        s_cv = cv;
+    }
+    __syncthreads();
+    const float4 pv = *reinterpret_cast<const float4*>(p.prev_overlap + item * 256 + 4 * lane);
+    const float4 cu = *reinterpret_cast<const float4*>(p.cur_input + item * 256 + 4 * lane);
+    const float pvv[4] = {pv.x, pv.y, pv.z, pv.w}, cuv[4] = {cu.x, cu.y, cu.z, cu.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = 4 * lane + k;
+        const float cur = cuv[k];
+        const float mod = cur / curve_divisor(T->gain_interp, s_cv, i);
+        const float winCur = T->enc_win[255 - i], winNext = T->enc_win[i];
+        const float curWin = cur * winCur, modCurWin = mod * winCur, nextWin = cur * winNext, modNextWin = mod * winNext;
+        s_terms[0][i] = pvv[k] * pvv[k];
+        s_terms[1][i] = curWin * curWin;
+        s_terms[2][i] = modCurWin * modCurWin;
+        s_terms[3][i] = nextWin * nextWin;
+        s_terms[4][i] = modNextWin * modNextWin;
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    if (lane < 5) {
+        const float4* t4 = reinterpret_cast<const float4*>(s_terms[lane]);
+        for (int q = 0; q < 64; ++q) {
+            const float4 v = t4[q];
+            acc += v.x;
+            acc += v.y;
+            acc += v.z;
+            acc += v.w;
+        }
+    }
+    const float prevStored = __shfl(acc, 0, 64), curOrig = __shfl(acc, 1, 64), curMod = __shfl(acc, 2, 64);
+    const float nextOrig = __shfl(acc, 3, 64), nextMod = __shfl(acc, 4, 64);
+    if (lane == 0) {
+        float ps = p.prev_scale[item];
+        if (!isfinite(ps) || ps <= 0.0f) ps = 1.0f;
+        const float prevDiv = s_cv.n > 0 ? gain_level_of(s_cv.level[0]) : 1.0f;
+        const float prevOrig = prevStored * ps;
+        const float prevMod = prevStored / (prevDiv * prevDiv);
+        float4 o;
+        o.x = safe_energy_scale(prevOrig, prevMod);
+        o.y = safe_energy_scale(curOrig, curMod);
+        o.z = safe_energy_scale(prevOrig + curOrig, prevMod + curMod);
+        o.w = safe_energy_scale(nextOrig, nextMod);
+        *reinterpret_cast<float4*>(p.out + item * 4) = o;
     }
 }
 

@@ -1,0 +1,57 @@
+// Packed fp32 helpers of the gfx950 kernels (inline VOP3P assembly; see at3_common.hpp for how they are used).
+#ifndef AT3_PK_HPP
+#define AT3_PK_HPP
+#include <hip/hip_runtime.h>
+
+namespace at3 {
+
+// CDNA issues a wave64 fp32 VALU instruction over four cycles; v_pk_mul_f32 / v_pk_add_f32 (VOP3P) carry TWO
+// independent IEEE fp32 operations per lane in the same four cycles. The reference arithmetic has no fused
+// multiply-add (-ffp-contract=off is part of the parity contract), so mul/add-bound code is issue bound and packing
+// doubles its rate without changing a single rounding. `f2` maps to an aligned VGPR pair; plain vector expressions
+// are selected as packed instructions by the compiler, the three complex forms whose lanes need DIFFERENT negate /
+// half-select modifiers are spelled out below.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 mk2(float x, float y)
+{
+    f2 v;
+    v.x = x;
+    v.y = y;
+    return v;
+}
+
+// a * w, complex: (a.x w.x - a.y w.y, a.x w.y + a.y w.x) - the four products and two sums of C_MUL (_kiss_fft_guts.h)
+__device__ __forceinline__ f2 pk_cmul(f2 a, f2 w)
+{
+    f2 t1, t2, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t1) : "v"(a), "v"(w));                  // (a.x w.x, a.x w.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t2) : "v"(a), "v"(w));     // (a.y w.y, a.y w.x)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t1), "v"(t2));                    // (t1.x - t2.x, t1.y + t2.y)
+    return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ f2 pk_add_ib(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ f2 pk_sub_ib(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// A copy of a per-lane value the optimiser cannot see through: address arithmetic derived from it is redone where it is
+// used instead of being hoisted in front of a long loop and parked in registers for the whole kernel.
+__device__ __forceinline__ int opaque_lane_value(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+}  // namespace at3
+#endif  // AT3_PK_HPP

@@ -10,6 +10,7 @@
 
 #include "../../include/at3hip.h"
 #include "at3_common.hpp"
+#include "at3_host_util.hpp"
 #include "at3_k_backend.hpp"
 #include "at3_k_frontend.hpp"
 #include "at3_k_gain.hpp"
@@ -55,6 +56,7 @@ struct at3hip_ctx {
     int frames_per_wg = 0;
     int n_cus = 256;
     int wgs_per_cu = 3;   // resident workgroups of the fused front-end kernel per CU
+    int dbg_front = 0, dbg_gain = 0, dbg_stop = 0;   // AT3HIP_DEBUG_* (profiling aids), honoured by -DAT3HIP_DEBUG_KNOBS builds only
 
     Tables* d_tables = nullptr;
     float* d_pcm_in = nullptr;       // staging for host PCM [S][max_blocks][1024][2]
@@ -74,6 +76,9 @@ struct at3hip_ctx {
     QuantRec* d_quant = nullptr;
     int8_t* d_mant = nullptr;
     at3hip_timings tm = {};
+    // grow-only device staging of the stage-level entry points (at3hip_mdct, at3hip_gain_energy_scale) for host buffers
+    void* d_stage = nullptr;
+    size_t stage_bytes = 0;
 };
 
 namespace {
@@ -100,6 +105,20 @@ int dev_alloc(at3hip_ctx* c, Tp** p, size_t count)
     hipError_t e = hipMalloc(&q, count * sizeof(Tp) + 256);
     if (e != hipSuccess) return fail(c, AT3HIP_ENOMEM, "hipMalloc", e);
     *p = (Tp*)q;
+    return AT3HIP_OK;
+}
+
+// Device staging area of at least `bytes` bytes (reallocated only when a call needs more than any call before).
+int stage_reserve(at3hip_ctx* c, size_t bytes)
+{
+    if (bytes <= c->stage_bytes) return AT3HIP_OK;
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    hipError_t e = hipMalloc(&c->d_stage, want);
+    if (e != hipSuccess) return fail(c, AT3HIP_ENOMEM, "hipMalloc (staging)", e);
+    c->stage_bytes = want;
     return AT3HIP_OK;
 }
 
@@ -166,7 +185,7 @@ int reset_state(at3hip_ctx* c)
 
 extern "C" {
 
-uint32_t at3hip_version(void) { return (1u << 16) | 0u; }
+uint32_t at3hip_version(void) { return (1u << 16) | 1u; }
 
 int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
 {
@@ -175,6 +194,8 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((cfg->channels != 1 && cfg->channels != 2) || cfg->n_streams < 1 || cfg->max_blocks < 1 || cfg->bfu_idx_const < 0 ||
         cfg->bfu_idx_const > 32)
         return AT3HIP_EINVAL;
+    // the largest grid is one workgroup per (stream, frame, channel, band < 3); gridDim.x is a 31-bit quantity
+    if ((long long)cfg->n_streams * cfg->max_blocks * 6 > 0x7fffffffLL) return AT3HIP_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AT3HIP_EDEVICE;
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return AT3HIP_EINVAL;
@@ -187,17 +208,19 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     while (idx < 7 && kContainer[idx].bitrate < br) ++idx;  // lower_bound, atrac3.cpp:47-53
     c->frame_sz = kContainer[idx].frame_sz;
     c->js = kContainer[idx].js;
-    if (cfg->channels == 1 && c->js) {   // mono joint-stereo frames carry an empty second unit (atrac3denc.cpp:843-849): not built
-        delete c;
-        return AT3HIP_EINVAL;
-    }
 
     int rc = AT3HIP_OK;
     auto bail = [&](int code) {
         at3hip_destroy(c);
         return code;
     };
-    if (hipSetDevice(c->device) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    at3host::DeviceGuard guard(c->device);
+    if (guard.error() != hipSuccess) return bail(AT3HIP_EDEVICE);
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (const char* e = getenv("AT3HIP_DEBUG_FRONT")) c->dbg_front = atoi(e);
+    if (const char* e = getenv("AT3HIP_DEBUG_GAIN")) c->dbg_gain = atoi(e);
+    if (const char* e = getenv("AT3HIP_DEBUG_STOP")) c->dbg_stop = atoi(e);
+#endif
     {
         // the front half is short, latency-bound kernels; it gets the higher stream priority so that its workgroups are
         // placed ahead of the back half's long throughput kernels when both streams have work
@@ -266,13 +289,14 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
 void at3hip_destroy(at3hip_ctx* c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    at3host::DeviceGuard guard(c->device);
+    // only the context's own streams are waited for: a caller-owned stream (at3hip_set_stream) may already be gone, and
+    // everything queued on it is ordered before the back stream's work by events
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->back_stream) (void)hipStreamSynchronize(c->back_stream);
     void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
                     c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
-                    c->d_out,       c->d_quant,     c->d_mant,     c->d_pcm_mono};
+                    c->d_out,       c->d_quant,     c->d_mant,     c->d_pcm_mono,  c->d_stage};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& row : c->ev)
@@ -292,7 +316,8 @@ const char* at3hip_last_error(const at3hip_ctx* c) { return c ? c->err : "null c
 int at3hip_set_stream(at3hip_ctx* c, void* hip_stream)
 {
     if (!c) return AT3HIP_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const int rc = drain(c);
     if (rc != AT3HIP_OK) return rc;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -302,7 +327,8 @@ int at3hip_set_stream(at3hip_ctx* c, void* hip_stream)
 int at3hip_reset(at3hip_ctx* c)
 {
     if (!c) return AT3HIP_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const int rc = drain(c);
     if (rc != AT3HIP_OK) return rc;
     return reset_state(c);
@@ -319,7 +345,8 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
                   uint32_t flags)
 {
     if (!c || !pcm || n_blocks < 1 || n_blocks > c->cfg.max_blocks) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const int S = c->cfg.n_streams;
     const int f0 = (c->blocks_fed == 0) ? 1 : 0;
     const int n_out = n_blocks - f0;
@@ -332,6 +359,8 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         // "No mono mode for atrac3, just make duplicate of first channel" (atrac3_bitstream.cpp:836-843): the one-channel
         // frame is two identical sound units, i.e. the discrete-stereo frame of L = R (TrackLoudness' 0.02 l equals
         // 0.01 (l + l) exactly). The samples are duplicated in HBM and the stereo pipeline runs unchanged.
+        // Joint-stereo containers: M = (x + x) / 2 = x exactly, so the M unit is the mono unit (gain analysis, loudness
+        // with 0.02 l and all); the rate/pack kernel replaces the S unit by the empty element of atrac3denc.cpp:843-849.
         const float* d_mono = pcm;
         const size_t n = (size_t)S * n_blocks * 1024;
         if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
@@ -372,7 +401,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         fp.n_blocks = n_blocks;
         fp.f0 = f0;
         fp.frames_per_wg = pick_frames_per_wg(c, n_out);
-        fp.debug = getenv("AT3HIP_DEBUG_FRONT") ? atoi(getenv("AT3HIP_DEBUG_FRONT")) : 0;
+        fp.debug = c->dbg_front;
         fp.js = c->js;
         if (gain) {
             GainParams gp;
@@ -384,7 +413,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.f0 = f0;
             gp.js = c->js;
             gp.n_streams = S;
-            gp.debug = getenv("AT3HIP_DEBUG_GAIN") ? atoi(getenv("AT3HIP_DEBUG_GAIN")) : 0;
+            gp.debug = c->dbg_gain;
             {   // one round of workgroups over the chip, like the fused kernel
                 const int slots = c->n_cus * c->wgs_per_cu;
                 int runs = slots / S;
@@ -421,7 +450,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         sp.state = c->d_state;
         sp.n_blocks = n_blocks;
         sp.n_streams = S;
-        hipLaunchKernelGGL(k_state_update, dim3((kHist + 255) / 256, S), dim3(256), 0, st, sp);
+        hipLaunchKernelGGL(k_state_update, dim3((unsigned)(((kHist + 255) / 256) * S)), dim3(256), 0, st, sp);
     }
     if (n_out > 0) {
         // ---- back half, on its own stream, after the fused kernel of THIS call ----
@@ -442,7 +471,8 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.js = c->js;
         bp.frame_sz = c->frame_sz;
         bp.bfu_idx_const = c->cfg.bfu_idx_const;
-        bp.debug_stop = getenv("AT3HIP_DEBUG_STOP") ? atoi(getenv("AT3HIP_DEBUG_STOP")) : 0;
+        bp.mono_js = (c->cfg.channels == 1 && c->js) ? 1 : 0;
+        bp.debug_stop = c->dbg_stop;
         bp.quant = c->d_quant;
         bp.mant = c->d_mant;
         hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, bk, bp, c->d_tables);
@@ -474,7 +504,8 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
 int at3hip_sync(at3hip_ctx* c)
 {
     if (!c) return AT3HIP_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const int rc = drain(c);
     if (rc != AT3HIP_OK) return rc;
     read_timings(c, c->last_slot, &c->tm);
@@ -484,7 +515,8 @@ int at3hip_sync(at3hip_ctx* c)
 int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
 {
     if (!c || !dst) return AT3HIP_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const int rc = drain(c);
     if (rc != AT3HIP_OK) return rc;
     if (c->enc_calls == 0) return fail(c, AT3HIP_EINVAL, "no encode call yet");
@@ -509,20 +541,24 @@ int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
 int at3hip_get_timings_ago(at3hip_ctx* c, int32_t ago, at3hip_timings* out)
 {
     if (!c || !out || ago < 0 || ago >= at3hip_ctx::kSlots || ago >= c->enc_calls) return AT3HIP_EINVAL;
-    HIPCHK(c, hipSetDevice(c->device));
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const int rc = drain(c);
     if (rc != AT3HIP_OK) return rc;
     read_timings(c, (int)((c->enc_calls - 1 - ago) % at3hip_ctx::kSlots), out);
     return AT3HIP_OK;
 }
 
-int at3hip_mdct(at3hip_ctx* c, float* bands, float* specs, const int32_t* n_points, const int32_t* level,
-                const int32_t* loc, int32_t n_items, uint32_t flags)
+namespace {
+
+int mdct_impl(at3hip_ctx* c, float* bands, float* specs, float* max_levels, const int32_t* n_points, const int32_t* level,
+              const int32_t* loc, int32_t n_items, uint32_t flags)
 {
     if (!c || !bands || !specs || n_items < 1) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
     if ((n_points != nullptr) != (level != nullptr) || (n_points != nullptr) != (loc != nullptr))
         return fail(c, AT3HIP_EINVAL, "n_points/level/loc must be all null or all set");
-    HIPCHK(c, hipSetDevice(c->device));
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     hipStream_t st = c->stream;
     const bool dev = (flags & AT3HIP_PCM_ON_DEVICE) && (flags & AT3HIP_OUT_ON_DEVICE);
     if (!dev && (flags & (AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE)))
@@ -536,50 +572,119 @@ int at3hip_mdct(at3hip_ctx* c, float* bands, float* specs, const int32_t* n_poin
                     return fail(c, AT3HIP_EINVAL, "gain point out of range");
         }
     }
-    float *d_bands = bands, *d_specs = specs;
-    int32_t *d_np = (int32_t*)n_points, *d_lv = (int32_t*)level, *d_lc = (int32_t*)loc;
-    void* tmp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    int rc = AT3HIP_OK;
+    MdctItemsParams mp;
+    mp.bands = bands;
+    mp.specs = specs;
+    mp.n_points = n_points;
+    mp.level = level;
+    mp.loc = loc;
+    mp.max_levels = max_levels;
     if (!dev) {
-        hipError_t e = hipMalloc(&tmp[0], n * 2048 * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&tmp[1], n * 1024 * sizeof(float));
-        if (e == hipSuccess && n_points) {
-            e = hipMalloc(&tmp[2], n * 4 * sizeof(int32_t));
-            if (e == hipSuccess) e = hipMalloc(&tmp[3], n * 32 * sizeof(int32_t));
-            if (e == hipSuccess) e = hipMalloc(&tmp[4], n * 32 * sizeof(int32_t));
+        // host buffers: one staging block per context, laid out [bands | specs | max_levels | n_points | level | loc]
+        const size_t o_specs = n * 2048 * sizeof(float), o_max = o_specs + n * 1024 * sizeof(float);
+        const size_t o_np = o_max + n * 4 * sizeof(float), o_lv = o_np + n * 4 * sizeof(int32_t), o_lc = o_lv + n * 32 * sizeof(int32_t);
+        const size_t total = o_lc + n * 32 * sizeof(int32_t);
+        const int rc = stage_reserve(c, total);
+        if (rc != AT3HIP_OK) return rc;
+        char* base = (char*)c->d_stage;
+        mp.bands = (float*)base;
+        mp.specs = (float*)(base + o_specs);
+        mp.max_levels = max_levels ? (float*)(base + o_max) : nullptr;
+        HIPCHK(c, hipMemcpyAsync(mp.bands, bands, n * 2048 * sizeof(float), hipMemcpyHostToDevice, st));
+        if (n_points) {
+            mp.n_points = (const int32_t*)(base + o_np);
+            mp.level = (const int32_t*)(base + o_lv);
+            mp.loc = (const int32_t*)(base + o_lc);
+            HIPCHK(c, hipMemcpyAsync(base + o_np, n_points, n * 4 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(base + o_lv, level, n * 32 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(base + o_lc, loc, n * 32 * sizeof(int32_t), hipMemcpyHostToDevice, st));
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(tmp[0], bands, n * 2048 * sizeof(float), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess && n_points) {
-            e = hipMemcpyAsync(tmp[2], n_points, n * 4 * sizeof(int32_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(tmp[3], level, n * 32 * sizeof(int32_t), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(tmp[4], loc, n * 32 * sizeof(int32_t), hipMemcpyHostToDevice, st);
-        }
-        if (e != hipSuccess) rc = fail(c, AT3HIP_EDEVICE, "mdct staging", e);
-        d_bands = (float*)tmp[0];
-        d_specs = (float*)tmp[1];
-        d_np = (int32_t*)tmp[2];
-        d_lv = (int32_t*)tmp[3];
-        d_lc = (int32_t*)tmp[4];
     }
-    if (rc == AT3HIP_OK) {
-        MdctItemsParams mp;
-        mp.bands = d_bands;
-        mp.specs = d_specs;
-        mp.n_points = n_points ? d_np : nullptr;
-        mp.level = d_lv;
-        mp.loc = d_lc;
-        hipLaunchKernelGGL(k_mdct_items, dim3((unsigned)n), dim3(128), 0, st, mp, c->d_tables);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess && !dev) {
-            e = hipMemcpyAsync(bands, d_bands, n * 2048 * sizeof(float), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(specs, d_specs, n * 1024 * sizeof(float), hipMemcpyDeviceToHost, st);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) rc = fail(c, AT3HIP_EDEVICE, "mdct", e);
+    hipLaunchKernelGGL(k_mdct_items, dim3((unsigned)n), dim3(128), 0, st, mp, c->d_tables);
+    HIPCHK(c, hipGetLastError());
+    if (!dev) {
+        HIPCHK(c, hipMemcpyAsync(bands, mp.bands, n * 2048 * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(specs, mp.specs, n * 1024 * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (max_levels) HIPCHK(c, hipMemcpyAsync(max_levels, mp.max_levels, n * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
     }
-    for (void* t : tmp)
-        if (t) (void)hipFree(t);
-    return rc;
+    HIPCHK(c, hipStreamSynchronize(st));
+    return AT3HIP_OK;
+}
+
+}  // namespace
+
+int at3hip_mdct(at3hip_ctx* c, float* bands, float* specs, const int32_t* n_points, const int32_t* level,
+                const int32_t* loc, int32_t n_items, uint32_t flags)
+{
+    return mdct_impl(c, bands, specs, nullptr, n_points, level, loc, n_items, flags);
+}
+
+int at3hip_mdct_levels(at3hip_ctx* c, float* bands, float* specs, float* max_levels, const int32_t* n_points,
+                       const int32_t* level, const int32_t* loc, int32_t n_items, uint32_t flags)
+{
+    if (!max_levels) return c ? fail(c, AT3HIP_EINVAL, "max_levels is null") : AT3HIP_EINVAL;
+    return mdct_impl(c, bands, specs, max_levels, n_points, level, loc, n_items, flags);
+}
+
+int at3hip_gain_energy_scale(at3hip_ctx* c, const float* prev_overlap, const float* cur_input, const int32_t* n_points,
+                             const int32_t* level, const int32_t* loc, const float* prev_overlap_scale, float* out,
+                             int32_t n_items, uint32_t flags)
+{
+    if (!c || !prev_overlap || !cur_input || !prev_overlap_scale || !out || n_items < 1)
+        return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    if ((n_points != nullptr) != (level != nullptr) || (n_points != nullptr) != (loc != nullptr))
+        return fail(c, AT3HIP_EINVAL, "n_points/level/loc must be all null or all set");
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
+    hipStream_t st = c->stream;
+    const bool dev = (flags & AT3HIP_PCM_ON_DEVICE) && (flags & AT3HIP_OUT_ON_DEVICE);
+    if (!dev && (flags & (AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE)))
+        return fail(c, AT3HIP_EINVAL, "buffers must be all host or all device");
+    const size_t n = n_items;
+    if (!dev && n_points) {
+        for (size_t i = 0; i < n; ++i) {
+            if (n_points[i] < 0 || n_points[i] > 7) return fail(c, AT3HIP_EINVAL, "n_points out of range");
+            for (int k = 0; k < n_points[i]; ++k)
+                if (level[i * 8 + k] < 0 || level[i * 8 + k] > 15 || loc[i * 8 + k] < 0 || loc[i * 8 + k] > 31)
+                    return fail(c, AT3HIP_EINVAL, "gain point out of range");
+        }
+    }
+    GesItemsParams gp;
+    gp.prev_overlap = prev_overlap;
+    gp.cur_input = cur_input;
+    gp.n_points = n_points;
+    gp.level = level;
+    gp.loc = loc;
+    gp.prev_scale = prev_overlap_scale;
+    gp.out = out;
+    if (!dev) {
+        const size_t o_cur = n * 256 * sizeof(float), o_ps = 2 * o_cur, o_out = o_ps + n * sizeof(float);
+        const size_t o_np = o_out + n * 4 * sizeof(float), o_lv = o_np + n * sizeof(int32_t), o_lc = o_lv + n * 8 * sizeof(int32_t);
+        const size_t total = o_lc + n * 8 * sizeof(int32_t);
+        const int rc = stage_reserve(c, total);
+        if (rc != AT3HIP_OK) return rc;
+        char* base = (char*)c->d_stage;
+        HIPCHK(c, hipMemcpyAsync(base, prev_overlap, n * 256 * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(base + o_cur, cur_input, n * 256 * sizeof(float), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(base + o_ps, prev_overlap_scale, n * sizeof(float), hipMemcpyHostToDevice, st));
+        gp.prev_overlap = (const float*)base;
+        gp.cur_input = (const float*)(base + o_cur);
+        gp.prev_scale = (const float*)(base + o_ps);
+        gp.out = (float*)(base + o_out);
+        if (n_points) {
+            HIPCHK(c, hipMemcpyAsync(base + o_np, n_points, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(base + o_lv, level, n * 8 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(base + o_lc, loc, n * 8 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            gp.n_points = (const int32_t*)(base + o_np);
+            gp.level = (const int32_t*)(base + o_lv);
+            gp.loc = (const int32_t*)(base + o_lc);
+        }
+    }
+    hipLaunchKernelGGL(k_ges_items, dim3((unsigned)n), dim3(64), 0, st, gp, c->d_tables);
+    HIPCHK(c, hipGetLastError());
+    if (!dev) HIPCHK(c, hipMemcpyAsync(out, gp.out, n * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return AT3HIP_OK;
 }
 
 int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* specs, uint32_t flags)
@@ -587,7 +692,8 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
     if (!c || !pcm || !specs || n_blocks < 2) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
     if ((flags & (AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE)) != (AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE))
         return fail(c, AT3HIP_EINVAL, "qmf_mdct needs device pointers");
-    HIPCHK(c, hipSetDevice(c->device));
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     {
         const int rc = drain(c);
         if (rc != AT3HIP_OK) return rc;

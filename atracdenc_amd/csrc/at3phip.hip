@@ -8,6 +8,7 @@
 
 #include "../../include/at3phip.h"
 #include "at3p_kernels.hpp"
+#include "at3_host_util.hpp"
 
 using namespace at3p;
 
@@ -15,6 +16,7 @@ static_assert(sizeof(Tables) == AT3PHIP_TABLES_BYTES, "at3phip.h documents the t
 
 struct at3phip_ctx {
     at3phip_config cfg;
+    int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {};
     Tables* d_tables = nullptr;
@@ -111,18 +113,21 @@ int at3phip_create(const at3phip_config* cfg, at3phip_ctx** out)
     if (!cfg || !out) return AT3HIP_EINVAL;
     *out = nullptr;
     if ((cfg->channels != 1 && cfg->channels != 2) || cfg->n_streams < 1 || cfg->max_frames < 1) return AT3HIP_EINVAL;
+    if ((long long)cfg->n_streams * cfg->channels > at3host::kMaxGridY) return AT3HIP_EINVAL;   // (stream, channel) is gridDim.y
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return AT3HIP_EDEVICE;
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return AT3HIP_EINVAL;
     at3phip_ctx* c = new (std::nothrow) at3phip_ctx();
     if (!c) return AT3HIP_ENOMEM;
     c->cfg = *cfg;
+    c->device = cfg->device_id;
     int rc = AT3HIP_OK;
     auto bail = [&](int code) {
         at3phip_destroy(c);
         return code;
     };
-    if (hipSetDevice(cfg->device_id) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    at3host::DeviceGuard guard(c->device);
+    if (guard.error() != hipSuccess) return bail(AT3HIP_EDEVICE);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(AT3HIP_EDEVICE);
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(AT3HIP_EDEVICE);
@@ -148,6 +153,7 @@ int at3phip_create(const at3phip_config* cfg, at3phip_ctx** out)
 void at3phip_destroy(at3phip_ctx* c)
 {
     if (!c) return;
+    at3host::DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_tables, c->d_pcm_in, c->d_bands, c->d_specs, c->d_flags, c->d_pqf_hist, c->d_mdct_hist};
     for (void* b : bufs)
@@ -163,12 +169,16 @@ const char* at3phip_last_error(const at3phip_ctx* c) { return c ? c->err : "null
 int at3phip_reset(at3phip_ctx* c)
 {
     if (!c) return AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     return reset_state(c);
 }
 
 int at3phip_pqf_analyse(at3phip_ctx* c, const float* pcm, int32_t n_frames, float* bands, uint32_t flags)
 {
     if (!c || !pcm || !bands || n_frames < 1 || n_frames > c->cfg.max_frames) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const size_t n = (size_t)c->cfg.n_streams * n_frames * c->cfg.channels * 2048;
     const float* d_pcm = pcm;
     if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
@@ -190,6 +200,8 @@ int at3phip_pqf_analyse(at3phip_ctx* c, const float* pcm, int32_t n_frames, floa
 int at3phip_mdct(at3phip_ctx* c, const float* bands, int32_t n_frames, const uint16_t* win_flags, float* specs, uint32_t flags)
 {
     if (!c || !bands || !specs || n_frames < 1 || n_frames > c->cfg.max_frames) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const size_t n = (size_t)c->cfg.n_streams * n_frames * c->cfg.channels * 2048;
     const float* d_bands = bands;
     if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
@@ -211,6 +223,8 @@ int at3phip_mdct(at3phip_ctx* c, const float* bands, int32_t n_frames, const uin
 int at3phip_pqf_mdct(at3phip_ctx* c, const float* pcm, int32_t n_frames, const uint16_t* win_flags, float* bands, float* specs, uint32_t flags)
 {
     if (!c || !pcm || !specs || n_frames < 1 || n_frames > c->cfg.max_frames) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     const size_t n = (size_t)c->cfg.n_streams * n_frames * c->cfg.channels * 2048;
     const float* d_pcm = pcm;
     if (!(flags & AT3HIP_PCM_ON_DEVICE)) {

@@ -105,6 +105,54 @@ public:
         for (int b = 0; b < 4; ++b) memcpy(bands[b], packed + 512 * b, 512 * sizeof(float));
     }
 
+    // The maxLevels overload (atrac3denc.h:80-83): additionally max |new half| per band after gain modulation.
+    void Mdct(float specs[1024], float* bands[4], float maxLevels[4], const TGainCurves& curves = TGainCurves())
+    {
+        float packed[4 * 512];
+        int32_t n[4], level[32] = {0}, loc[32] = {0};
+        bool any = false;
+        for (int b = 0; b < 4; ++b) {
+            memcpy(packed + 512 * b, bands[b], 512 * sizeof(float));
+            n[b] = (int32_t)curves[b].size();
+            any = any || n[b] > 0;
+            for (int i = 0; i < n[b] && i < 8; ++i) {
+                level[8 * b + i] = (int32_t)curves[b][i].Level;
+                loc[8 * b + i] = (int32_t)curves[b][i].Location;
+            }
+        }
+        Check(at3hip_mdct_levels(Ctx, packed, specs, maxLevels, any ? n : nullptr, any ? level : nullptr, any ? loc : nullptr, 1, 0),
+              Ctx, "at3hip_mdct_levels");
+        for (int b = 0; b < 4; ++b) memcpy(bands[b], packed + 512 * b, 512 * sizeof(float));
+    }
+
+    // TAtrac3MDCT::CalcGainEnergyScale (atrac3denc.h:69-79; static in the reference, a member here because the work
+    // runs on this object's device context).
+    struct TGainEnergyScale {
+        float PrevHalf = 1.0f, CurHalf = 1.0f, Frame = 1.0f;
+    };
+    struct TGainEnergyAnalysis {
+        TGainEnergyScale Scale;
+        float NextOverlapScale = 1.0f;
+    };
+    TGainEnergyAnalysis CalcGainEnergyScale(const float prevOverlap[256], const float curInput[256],
+                                            const std::vector<TGainPoint>& gainPoints, float prevOverlapScale)
+    {
+        int32_t n = (int32_t)gainPoints.size(), level[8] = {0}, loc[8] = {0};
+        for (int i = 0; i < n && i < 8; ++i) {
+            level[i] = (int32_t)gainPoints[i].Level;
+            loc[i] = (int32_t)gainPoints[i].Location;
+        }
+        float out[4];
+        Check(at3hip_gain_energy_scale(Ctx, prevOverlap, curInput, n ? &n : nullptr, n ? level : nullptr, n ? loc : nullptr,
+                                       &prevOverlapScale, out, 1, 0), Ctx, "at3hip_gain_energy_scale");
+        TGainEnergyAnalysis res;
+        res.Scale.PrevHalf = out[0];
+        res.Scale.CurHalf = out[1];
+        res.Scale.Frame = out[2];
+        res.NextOverlapScale = out[3];
+        return res;
+    }
+
 private:
     at3hip_ctx* Ctx = nullptr;
 };

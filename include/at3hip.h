@@ -42,8 +42,9 @@ typedef struct at3hip_config {
     int32_t bitrate;          /* bit/s as TAtrac3EncoderSettings takes it; 0 = LP2 (132300). The container
                                  row {Bitrate, FrameSz, Js} is chosen like GetContainerParamsForBitrate
                                  (atrac3.cpp:47-53): 66150 -> LP4 192 B joint stereo, 132300 -> LP2 384 B. */
-    int32_t channels;         /* SourceChannels: 2, or 1 with a discrete-stereo bitrate (the frame then holds the one
-                               * sound unit twice, atrac3_bitstream.cpp:836-843). Mono joint-stereo bitrates are refused. */
+    int32_t channels;         /* SourceChannels: 2, or 1. One channel with a discrete-stereo bitrate: the frame holds the one
+                               * sound unit twice (atrac3_bitstream.cpp:836-843); with a joint-stereo bitrate: the mono unit
+                               * plus the empty second element of atrac3denc.cpp:843-849. */
     int32_t no_gain_control;  /* NoGainControll */
     int32_t no_tonal;         /* NoTonalComponents */
     int32_t bfu_idx_const;    /* BfuIdxConst (0 = automatic) */
@@ -104,6 +105,22 @@ int at3hip_reset(at3hip_ctx* ctx);
  *   n_points [n_items][4], level/loc [n_items][4][8] (int32) or all NULL for no gain modulation. */
 int at3hip_mdct(at3hip_ctx* ctx, float* bands, float* specs, const int32_t* n_points,
                 const int32_t* level, const int32_t* loc, int32_t n_items, uint32_t flags);
+
+/* Replaces: TAtrac3MDCT::Mdct(float specs[1024], float* bands[4], float maxLevels[4], TGainModulatorArray)
+ * (atrac3denc.h:80-83, atrac3denc.cpp:33-58): as at3hip_mdct, plus
+ *   max_levels [n_items][4] float32 out: max |new half| per band after gain modulation. */
+int at3hip_mdct_levels(at3hip_ctx* ctx, float* bands, float* specs, float* max_levels, const int32_t* n_points,
+                       const int32_t* level, const int32_t* loc, int32_t n_items, uint32_t flags);
+
+/* Replaces: static TAtrac3MDCT::CalcGainEnergyScale(prevOverlap[256], curInput[256], gainPoints, prevOverlapScale)
+ * (atrac3denc.h:75-79, atrac3denc.cpp:175-224), batched over n_items (one band each).
+ *   prev_overlap [n_items][256], cur_input [n_items][256] float32; prev_overlap_scale [n_items]
+ *   n_points [n_items], level/loc [n_items][8] (int32) or all NULL for no gain points
+ *   out [n_items][4] float32: Scale.PrevHalf, Scale.CurHalf, Scale.Frame, NextOverlapScale
+ * Buffers are all host (flags 0) or all device (AT3HIP_PCM_ON_DEVICE|AT3HIP_OUT_ON_DEVICE). */
+int at3hip_gain_energy_scale(at3hip_ctx* ctx, const float* prev_overlap, const float* cur_input, const int32_t* n_points,
+                             const int32_t* level, const int32_t* loc, const float* prev_overlap_scale, float* out,
+                             int32_t n_items, uint32_t flags);
 
 /* The fused batched QMF + windowed MDCT-512 kernel on its own (start-of-stream state, no gain
  * control): PCM [n_streams][n_blocks][1024][channels] -> spectra [n_streams][n_blocks-1][channels][1024].

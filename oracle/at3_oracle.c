@@ -1749,11 +1749,15 @@ static void write_sound_unit(at3o_encoder* e, float loudness, unsigned char* out
     const int half = e->frame_sz >> 1;
     static _Thread_local bitw bs[2];
     int32_t bitsToAlloc[2] = {-6, -6};
-    const int nsce = e->nch;
+    /* One input channel in a joint-stereo container: the lambda appends an empty second element with ONE subband
+     * and no scaled blocks (atrac3denc.cpp:843-849) so that the frame still carries two sound units. */
+    const int mono_js = e->js && e->nch == 1;
+    const int nsce = mono_js ? 2 : e->nch;
     memset(bs, 0, sizeof(bs));
     for (int ch = 0; ch < nsce; ++ch) {
         const sce_t* sce = &e->sce[ch];
         bitw* w = &bs[ch];
+        const int nqmf = (mono_js && ch == 1) ? 1 : 4;   /* SubbandInfo.GetQmfNum() */
         if (e->js && ch == 1) {
             bw_write(w, 0, 1); bw_write(w, 7, 3);
             for (int i = 0; i < 4; ++i) bw_write(w, 3, 2);
@@ -1761,15 +1765,22 @@ static void write_sound_unit(at3o_encoder* e, float loudness, unsigned char* out
         } else {
             bw_write(w, 0x28, 6);
         }
-        bw_write(w, 4 - 1, 2);
-        for (int band = 0; band < 4; ++band) {
+        bw_write(w, (uint32_t)nqmf - 1, 2);
+        for (int band = 0; band < nqmf; ++band) {
             const curve_t* c = &sce->curve[band];
-            bw_write(w, (uint32_t)c->n, 3);
-            for (int i = 0; i < c->n; ++i) { bw_write(w, c->level[i], 4); bw_write(w, c->loc[i], 5); }
+            const int n = (mono_js && ch == 1) ? 0 : c->n;
+            bw_write(w, (uint32_t)n, 3);
+            for (int i = 0; i < n; ++i) { bw_write(w, c->level[i], 4); bw_write(w, c->loc[i], 5); }
         }
         bitsToAlloc[ch] -= (int16_t)w->bits;
     }
-    const int32_t shift = e->js ? ms_bytes_shift((uint32_t)e->frame_sz, e->sce, bitsToAlloc) : 0;
+    int32_t shift = 0;
+    if (mono_js) {   /* CalcMSBytesShift with elements[1].ScaledBlocks.empty(): the maximum (atrac3_bitstream.cpp:745-747) */
+        const int32_t totalUsedBits = 0 - bitsToAlloc[0] - bitsToAlloc[1];
+        shift = (int32_t)((uint32_t)e->frame_sz / 2 - (1 + ((uint32_t)totalUsedBits - 1) / 8));
+    } else if (e->js) {
+        shift = ms_bytes_shift((uint32_t)e->frame_sz, e->sce, bitsToAlloc);
+    }
     bitsToAlloc[0] += 8 * (half + shift);
     bitsToAlloc[1] += 8 * (half - shift);
 
@@ -1783,7 +1794,17 @@ static void write_sound_unit(at3o_encoder* e, float loudness, unsigned char* out
         c->loudness = loudness;
         c->num_bfu = 1;
         c->coding_mode = 1;
-        encode_channel(c, &bs[ch]);
+        if (mono_js && ch == 1) {
+            /* TConfigure / TAlloc with empty ScaledBlocks (atrac3_bitstream.cpp:590-597, 623-626): one BFU of
+             * precision 0, coding mode 1, no tonal components - EncodeSpecs writes 5 + 5 + 1 + 3 bits. */
+            bitw* w = &bs[ch];
+            bw_write(w, 0, 5);       /* tonal sub-group count */
+            bw_write(w, 1 - 1, 5);   /* numBlocks - 1 */
+            bw_write(w, 1, 1);       /* coding mode */
+            bw_write(w, 0, 3);       /* precision of the one block */
+        } else {
+            encode_channel(c, &bs[ch]);
+        }
         if (e->js && ch == 1) {
             const int n = half - shift;
             for (int i = 0; i < n; ++i) out[outPos + i] = bs[ch].buf[n - 1 - i];

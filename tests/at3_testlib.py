@@ -315,6 +315,57 @@ SIGNALS = {
 }
 
 
+def flatness_threshold_walk(oracle, n_iter=48):
+    """Stationary tones + g x white noise: as g grows, the BFUs around the tones stop being "tonal" one by one, each when
+    its spectral flatness crosses 0.01 (atrac3denc.cpp:606, atrac_psy_common.cpp:158-199). Bisecting g on the number of
+    tonal blocks of one frame converges onto such a crossing from both sides until two neighbouring f32 PCM inputs
+    decide differently. Returns every PCM stream visited ([n, nb, 1024, 2]) and, for the last pair of each walk, the
+    distance |flat - 0.01| of the deciding BFU."""
+    nb, k = 6, 3
+    n = nb * 1024
+    t = np.arange(n, dtype=np.float64)
+    tone = sum(0.1 * np.sin(2 * np.pi * f * t / 44100.0 + 0.3 * i) for i, f in enumerate((440.0, 1000.0, 3000.0, 7000.0, 11000.0)))
+    noise = np.random.RandomState(11).randn(n)
+
+    def pcm_of(g):
+        return np.repeat((tone + g * noise)[:, None], 2, axis=1).astype(np.float32).reshape(nb, 1024, 2)
+
+    def n_tonal(pcm):
+        return int(oracle.encode(pcm, LP2, 1, 0, taps=True)[1]["n_tonal"][k, 0])
+
+    def flat_of(pcm):
+        sub = oracle.qmf(np.ascontiguousarray(pcm[:, :, 0]).reshape(-1) * np.float32(0.25))
+        bands = np.zeros((4, 512), np.float32)
+        for f in range(k + 1):      # frame k = the (k+1)-th MDCT of the stream (no gain control in this walk)
+            bands[:, 256:] = sub[:, f * 256:(f + 1) * 256]
+            specs, bands = oracle.mdct(bands)
+        return oracle.flatness(specs * specs)
+
+    visited, closest = [], []
+    top = n_tonal(pcm_of(0.01))
+    assert top >= 2 and n_tonal(pcm_of(0.1)) == 0
+    for target in range(1, top + 1):
+        lo, hi = 0.01, 0.1                       # n_tonal(lo) >= target > n_tonal(hi)
+        p_lo, p_hi = pcm_of(lo), pcm_of(hi)
+        for _ in range(n_iter):
+            mid = 0.5 * (lo + hi)
+            p_mid = pcm_of(mid)
+            if np.array_equal(p_mid, p_lo) or np.array_equal(p_mid, p_hi):
+                break
+            visited.append(p_mid)
+            if n_tonal(p_mid) >= target:
+                lo, p_lo = mid, p_mid
+            else:
+                hi, p_hi = mid, p_mid
+        f_lo, f_hi = flat_of(p_lo), flat_of(p_hi)
+        flip = np.nonzero((f_lo < np.float32(0.01)) != (f_hi < np.float32(0.01)))[0]
+        flip = flip[(flip >= 8) & (flip < 29)]
+        assert flip.size >= 1
+        closest.append(min(float(min(abs(np.float64(f_lo[b]) - 0.01), abs(np.float64(f_hi[b]) - 0.01))) for b in flip))
+    return np.stack(visited), closest
+
+
+
 # ----------------------------------------------------------------------------------------------
 # ATRAC1 (SURVEY.md 8(f) row f3): oracle/at1_oracle.c and the reference's TAtrac1Encoder (oracle/_ref)
 # ----------------------------------------------------------------------------------------------

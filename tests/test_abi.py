@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(atracdenc_amd.binding.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.at3hip_version() == (1 << 16)
+    assert lib.at3hip_version() >> 16 == 1
     header1 = open(os.path.join(os.path.dirname(atracdenc_amd.__file__), "..", "include", "at1hip.h")).read()
     declared1 = set(re.findall(r"\b(at1hip_[a-z_]+)\s*\(", header1))
     assert declared1 == set(atracdenc_amd.binding.AT1_SYMBOLS)

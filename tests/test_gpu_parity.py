@@ -36,6 +36,47 @@ def test_frames_all_signals(hip, oracle, br, opts):
     assert bad.size == 0, f"mismatching (stream, frame): {bad[:10].tolist()} of {names}"
 
 
+CONTAINER_ROWS = [(66150, 192), (93713, 272), (104738, 304), (132300, 384), (146081, 424), (176400, 512), (264600, 768), (352800, 1024)]
+
+
+@pytest.mark.parametrize("br,fsz", CONTAINER_ROWS)
+def test_container_rows_and_bfu_idx_const(hip, oracle, br, fsz):
+    """Every container row at3hip_create accepts (atrac3.h:211-220) x BfuIdxConst in {0, 1, 8, 20, 32}
+    (atrac3_bitstream.cpp:567-585, 646); the oracle is pinned against the reference on the same settings
+    (test_oracle_vs_ref.py::test_container_rows_and_bfu_idx_const)."""
+    nb = 24
+    names = ["burst", "mix", "tones", "noise"]
+    pcm = np.stack([SIGNALS[n](nb) for n in names] + [pcm_stress(nb, seed=5)])
+    for bfu in (0, 1, 8, 20, 32):
+        enc = hip.At3Hip(n_streams=pcm.shape[0], max_blocks=nb, bitrate=br, bfu_idx_const=bfu)
+        assert enc.frame_size == fsz
+        got = enc.encode(pcm)
+        enc.close()
+        exp = np.stack([oracle.encode(pcm[i], br, 0, 0, bfu)[0] for i in range(pcm.shape[0])])
+        bad = np.argwhere((got != exp).any(axis=2))
+        assert bad.size == 0, f"bfu_idx_const={bfu}: mismatching (stream, frame): {bad[:10].tolist()}"
+    enc = hip.At3Hip(n_streams=pcm.shape[0], max_blocks=nb, bitrate=br, bfu_idx_const=5, no_gain=1, no_tonal=1)
+    got = enc.encode(pcm)
+    enc.close()
+    assert np.array_equal(got, np.stack([oracle.encode(pcm[i], br, 1, 1, 5)[0] for i in range(pcm.shape[0])]))
+
+
+@pytest.mark.parametrize("br", [66150, 93713])
+def test_mono_joint_stereo(hip, oracle, br):
+    """One input channel, joint-stereo container: M unit = the mono unit with the maximum byte shift, S unit = the empty
+    element of atrac3denc.cpp:843-849 (oracle pinned against the reference: test_oracle_vs_ref.py::test_mono_joint_stereo)."""
+    nb = 30
+    names = ["burst", "mix", "tones", "noise", "silence"]
+    pcm = np.stack([np.ascontiguousarray(SIGNALS[n](nb)[:, :, :1]) for n in names])
+    for ng, nt, bfu in ((0, 0, 0), (1, 1, 0), (0, 0, 12)):
+        enc = hip.At3Hip(n_streams=len(names), max_blocks=16, bitrate=br, channels=1, no_gain=ng, no_tonal=nt, bfu_idx_const=bfu)
+        got = np.concatenate([enc.encode(pcm[:, :7]), enc.encode(pcm[:, 7:23]), enc.encode(pcm[:, 23:])], axis=1)
+        enc.close()
+        exp = np.stack([oracle.encode(pcm[i], br, ng, nt, bfu)[0] for i in range(len(names))])
+        bad = np.argwhere((got != exp).any(axis=2))
+        assert bad.size == 0, f"{(ng, nt, bfu)}: mismatching (stream, frame): {bad[:10].tolist()}"
+
+
 @pytest.mark.parametrize("br", [LP2, LP4])
 def test_stress_signal(hip, oracle, br):
     """Full-scale noise and square waves (scale-factor clamp, +-0.99999 clip), impulses, DC with denormal-range
@@ -82,6 +123,27 @@ def test_stage_taps(hip, oracle, br):
                 n = int(tap["n_points"][f, ch, b])
                 assert np.array_equal(curves[i, f + 1, ch, b, 1:1 + n], tap["level"][f, ch, b, :n].astype(np.uint8))
                 assert np.array_equal(curves[i, f + 1, ch, b, 8:8 + n], tap["loc"][f, ch, b, :n].astype(np.uint8))
+
+
+def test_flatness_threshold_adversarial(hip, oracle):
+    """The one documented arithmetic deviation of the device path (one f64 log of the product of the lines' mantissas
+    instead of the reference's sum of per-line logs) sits in front of the `flat < 0.01` tonal
+    decision. This walks the decision boundary: ~150 inputs that close in on a threshold crossing of four different
+    BFUs from both sides, down to neighbouring f32 PCM inputs whose flatness lies within 1e-7 of 0.01 - the device has to
+    take the reference's side every time (frame bytes and tonal-block counts)."""
+    from atracdenc_amd import binding as B
+    from at3_testlib import flatness_threshold_walk
+    pcm, closest = flatness_threshold_walk(oracle)
+    assert max(closest) < 1e-7, closest            # the walk really ends at the threshold (relative distance < 1e-5)
+    S, nb = pcm.shape[0], pcm.shape[1]
+    enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2, no_gain=True)
+    got = enc.encode(pcm)
+    psy = enc.read_tap(B.TAP_PSY, B.At3Hip.PSY_DTYPE, (S, nb - 1, 2))
+    enc.close()
+    for i in range(S):
+        frames, tap = oracle.encode(pcm[i], LP2, 1, 0, taps=True)
+        assert np.array_equal(psy[i]["n_tonal"], tap["n_tonal"]), i
+        assert np.array_equal(got[i], frames), i
 
 
 def test_fuzz_slice(hip, oracle):
@@ -164,6 +226,10 @@ def test_mdct_api(hip, oracle, golden_stages):
         es, eb = oracle.mdct(b[i], npnts[i], level[i], loc[i])
         assert np.array_equal(es.view(np.uint32), s[i].view(np.uint32)), i
         assert np.array_equal(eb.view(np.uint32), bo[i].view(np.uint32)), i
+    # the maxLevels overload (atrac3denc.cpp:33-58): max |new half| after modulation, per band
+    s2, bo2, mx = enc.mdct(b, npnts, level, loc, max_levels=True)
+    assert np.array_equal(s2.view(np.uint32), s.view(np.uint32)) and np.array_equal(bo2.view(np.uint32), bo.view(np.uint32))
+    assert np.array_equal(mx.view(np.uint32), np.abs(bo[:, :, 256:]).max(axis=2).view(np.uint32))
     # reference property tests: zero in -> zero out (atrac3denc_ut.cpp:96-123); no-gain call leaves new half alone
     s0, b0 = enc.mdct(np.zeros((1, 4, 512), np.float32))
     assert not s0.any() and not b0.any()
@@ -172,6 +238,29 @@ def test_mdct_api(hip, oracle, golden_stages):
     with pytest.raises(hip.At3HipError):
         enc.mdct(b[:1], np.full((1, 4), 9, np.int32), level[:1], loc[:1])
     enc.close()
+
+
+def test_gain_energy_scale_api(hip, oracle):
+    """at3hip_gain_energy_scale = TAtrac3MDCT::CalcGainEnergyScale (atrac3denc.cpp:175-224), against the oracle's stage
+    function (pinned against the reference by test_oracle_golden / test_oracle_vs_ref) - bit patterns."""
+    rng = np.random.RandomState(8)
+    n = 200
+    prev = (rng.uniform(-0.5, 0.5, (n, 256)) * rng.choice([1.0, 1e-3, 0.0, 1e-12], (n, 1))).astype(np.float32)
+    cur = (rng.uniform(-0.5, 0.5, (n, 256)) * rng.choice([1.0, 1e-2, 0.0, 1e-11], (n, 1))).astype(np.float32)
+    npnts = rng.randint(0, 8, n).astype(np.int32)
+    level = rng.randint(0, 16, (n, 8)).astype(np.int32)
+    loc = np.sort(rng.randint(0, 32, (n, 8)), axis=1).astype(np.int32)
+    ps = rng.choice([1.0, 0.5, 3.7, 0.0, -1.0, np.inf, np.nan], n).astype(np.float32)
+    enc = hip.At3Hip(n_streams=1, max_blocks=2)
+    got = enc.gain_energy_scale(prev, cur, ps, npnts, level, loc)
+    none = enc.gain_energy_scale(prev[:5], cur[:5], ps[:5])
+    enc.close()
+    for i in range(n):
+        exp = oracle.gain_energy_scale(prev[i], cur[i], level[i, :npnts[i]], loc[i, :npnts[i]], ps[i])
+        assert np.array_equal(got[i].view(np.uint32), exp.view(np.uint32)), (i, got[i], exp)
+    for i in range(5):
+        exp = oracle.gain_energy_scale(prev[i], cur[i], np.zeros(0, np.int32), np.zeros(0, np.int32), ps[i])
+        assert np.array_equal(none[i].view(np.uint32), exp.view(np.uint32)), i
 
 
 def _oracle_spectra(oracle, pcm):
@@ -218,7 +307,7 @@ def test_full_batch_config_properties(hip, oracle):
     for i in range(8, S):
         assert np.array_equal(got[i], got[i % 8])             # identical streams -> identical frames (no cross-talk)
     assert (got[:, :, 0] == 0xA3).all()                       # sound-unit id 0x28 << 2 | (numQmf - 1)
-    for i in (0, 5):                                          # spot streams against the oracle
+    for i in range(8):                                        # every distinct stream against the oracle
         assert np.array_equal(got[i], oracle.encode(pcm[i], LP2)[0]), i
 
 
@@ -237,7 +326,7 @@ def test_config3_shard_properties(hip, oracle, br):
     assert got.shape == (S, 128, fsz)
     for i in range(8, S, 37):
         assert np.array_equal(got[i], got[i % 8]), i           # identical streams -> identical frames, wherever they run
-    for i in (1, 2, 3):                                        # spot streams against the oracle (burst: multi-point curves)
+    for i in range(8):                                         # every distinct stream against the oracle
         assert np.array_equal(got[i], oracle.encode(pcm[i], br)[0]), i
 
 
@@ -280,8 +369,6 @@ def test_mono_input_lp2(hip, oracle):
     exp = np.stack([oracle.encode(pcm[i], LP2)[0] for i in range(len(names))])
     assert np.array_equal(got, exp)
     assert np.array_equal(got[:, :, :192], got[:, :, 192:])
-    with pytest.raises(hip.At3HipError):   # mono joint stereo needs the empty second unit: refused, not approximated
-        hip.At3Hip(n_streams=1, bitrate=LP4, channels=1)
 
 
 def test_error_handling(hip):

@@ -71,6 +71,7 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 static inline const char* hipGetErrorString(hipError_t) { return "emu error"; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
 #define hipStreamNonBlocking 1
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
@@ -104,6 +105,8 @@ int emu_bpermute(int addr, int v);
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
 int emu_readlane(int v, int lane);
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((int)(v), (lane))
+static inline float __shfl(float v, int lane, int = 64) { float r; int i; memcpy(&i, &v, 4); i = emu_readlane(i, lane); memcpy(&r, &i, 4); return r; }
+static inline float __shfl_xor(float v, int mask, int = 64) { return __shfl(v, (int)((threadIdx.x & 63u) ^ (unsigned)mask)); }
 void emu_wave_barrier();
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)

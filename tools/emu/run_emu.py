@@ -12,7 +12,7 @@ EMU = os.path.join(ROOT, "tools", "emu", "libat3hip_emu.so")
 
 def build():
     subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
-                           "-I", os.path.join(ROOT, "tools", "emu"), "-o", EMU,
+                           "-I", os.path.join(ROOT, "tools", "emu"), "-include", os.path.join(ROOT, "tools", "emu", "at3_pk_emu.hpp"), "-o", EMU,
                            os.path.join(ROOT, "atracdenc_amd/csrc/at3hip.hip"),
                            os.path.join(ROOT, "atracdenc_amd/csrc/at1hip.hip"),
                            os.path.join(ROOT, "atracdenc_amd/csrc/at3phip.hip"),
