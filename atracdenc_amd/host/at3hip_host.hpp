@@ -1,8 +1,7 @@
 // Host-side C++ mirror of the reference's surface for the ATRAC3 encode hot path, over the C ABI
 // (include/at3hip.h). Same names, argument meaning and error behaviour as the reference classes:
 //
-//   TAtrac3MDCT      atrac3denc.h:56-92   (Mdct with in-place band mutation, CalcGainEnergyScale omitted:
-//                                          it is computed inside the fused kernel of the encoder)
+//   TAtrac3MDCT      atrac3denc.h:56-92   (Mdct with in-place band mutation, both overloads; CalcGainEnergyScale)
 //   TAtrac3Encoder   atrac3denc.h:94-134  (IProcessor::GetLambda() -> functor called once per 1024-sample
 //                                          block; ICompressedOutput::WriteFrame once per encoded frame)
 //
@@ -10,7 +9,9 @@
 // per launch, so TAtrac3Encoder here buffers `BatchBlocks` lambda calls, returns PROCESSED immediately
 // (LOOK_AHEAD for the very first call, as the reference does) and flushes WriteFrame calls in order when
 // the batch is full or on Flush()/destruction: observable behaviour equals the reference except latency.
-// TAtrac3EncoderBatch is the natural multi-stream form (n independent streams side by side).
+// TAtrac3EncoderBatch is the natural multi-stream form (n independent streams side by side on one GPU) and
+// TAtrac3EncoderNode the multi-GPU form: streams are independent, so a node shards them contiguously over its
+// devices - one TAtrac3EncoderBatch and one host thread per device, no exchange between devices, no RCCL.
 //
 // Header-only; link with -lat3hip. Exceptions: std::runtime_error on any at3hip error (the reference
 // throws from its sinks and aborts on impossible states; it never returns error codes).
@@ -23,6 +24,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/at1hip.h"
@@ -195,6 +197,70 @@ public:
 private:
     at3hip_ctx* Ctx = nullptr;
     int NStreams;
+    int FrameSz = 0;
+};
+
+// ---- all GPUs of a node: the stream-sharded form --------------------------------------------------------------
+// Contiguous, balanced partition of `total` streams over `parts` devices: (first, count) of part `idx`.
+inline std::pair<int, int> ShardStreams(int total, int parts, int idx)
+{
+    if (parts < 1 || idx < 0 || idx >= parts) throw std::runtime_error("ShardStreams: bad partition");
+    const int base = total / parts, rem = total % parts;
+    return {idx * base + (idx < rem ? idx : rem), base + (idx < rem ? 1 : 0)};
+}
+
+class TAtrac3EncoderNode {
+public:
+    // deviceIds: the HIP ordinals to use (e.g. {0,1,...,7}); streams [first, first + count) of ShardStreams go to deviceIds[i]
+    TAtrac3EncoderNode(const TAtrac3EncoderSettings& s, int nStreams, int maxBlocks, const std::vector<int>& deviceIds)
+        : NStreams(nStreams), Channels(s.SourceChannels)
+    {
+        if (deviceIds.empty() || nStreams < (int)deviceIds.size()) throw std::runtime_error("TAtrac3EncoderNode: need >= 1 stream per device");
+        for (size_t i = 0; i < deviceIds.size(); ++i) {
+            const auto part = ShardStreams(nStreams, (int)deviceIds.size(), (int)i);
+            First.push_back(part.first);
+            Count.push_back(part.second);
+            Parts.emplace_back(new TAtrac3EncoderBatch(s, part.second, maxBlocks, deviceIds[i]));
+        }
+        FrameSz = Parts[0]->FrameSize();
+    }
+    int FrameSize() const { return FrameSz; }
+    int Devices() const { return (int)Parts.size(); }
+    // pcm [nStreams][nBlocks][1024][SourceChannels] -> frames [nStreams][nFrames][FrameSize()]; returns nFrames per stream.
+    // Every device encodes its slice on its own host thread; the slices are disjoint in both buffers.
+    int Encode(const float* pcm, int nBlocks, std::vector<uint8_t>& frames)
+    {
+        const size_t blockFloats = (size_t)1024 * Channels;
+        std::vector<std::vector<uint8_t>> out(Parts.size());
+        std::vector<int> nf(Parts.size(), 0);
+        std::vector<std::string> err(Parts.size());
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < Parts.size(); ++i)
+            th.emplace_back([&, i] {
+                try {
+                    nf[i] = Parts[i]->Encode(pcm + (size_t)First[i] * nBlocks * blockFloats, nBlocks, out[i]);
+                } catch (const std::exception& e) {
+                    err[i] = e.what();
+                }
+            });
+        for (auto& t : th) t.join();
+        for (size_t i = 0; i < Parts.size(); ++i)
+            if (!err[i].empty()) throw std::runtime_error("TAtrac3EncoderNode device " + std::to_string(i) + ": " + err[i]);
+        frames.resize((size_t)NStreams * nf[0] * FrameSz);
+        for (size_t i = 0; i < Parts.size(); ++i)
+            memcpy(frames.data() + (size_t)First[i] * nf[0] * FrameSz, out[i].data(), out[i].size());
+        return nf[0];
+    }
+    void Reset()
+    {
+        for (auto& p : Parts) p->Reset();
+    }
+
+private:
+    std::vector<std::unique_ptr<TAtrac3EncoderBatch>> Parts;
+    std::vector<int> First, Count;
+    int NStreams;
+    int Channels;
     int FrameSz = 0;
 };
 

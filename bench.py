@@ -1,26 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py - ATRAC3 LP2 stereo encode throughput on MI355X (BASELINE.json metric).
+"""bench.py - ATRAC3 stereo encode throughput on MI355X (BASELINE.json metric: 1024-sample stereo frames/s).
 
-A "step" = one pass of the whole hot path (QMF -> gain control -> MDCT -> psy -> bit allocation ->
-quantisation -> sound-unit packing) over one batch of synthetic PCM that is already resident in HBM:
-`--streams` independent streams x `--frames` new 1024-sample stereo frames each (default 64 x 64 = 4096
-frames = BASELINE configs[1]). Streams continue across steps (the encoder carries its state), so every
-step does identical, full work and emits streams*frames ATRAC3 frames into device memory.
+A "step" = one pass of the whole hot path (QMF -> gain control -> MDCT -> psy -> bit allocation -> quantisation ->
+sound-unit packing) over one batch of synthetic PCM that is already resident in HBM: S independent streams x F new
+1024-sample stereo frames each, per GPU. Streams continue across steps (the encoder carries its state), so every step
+does identical, full work and emits S*F ATRAC3 frames into device memory.
 
-N GPUs: one process per GPU (torch.distributed / RCCL only for the barrier and the MAX of the elapsed
-time); streams are sharded, per-GPU work is fixed ("weak" scaling), there is no data-path collective.
+Workloads (BASELINE.json configs):
+  N = 1   configs[1]: LP2 132 kbps, 64 streams x 64 frames = 4096 frames per step
+  N > 1   configs[2]: LP2, 8192 streams x 128 frames = 1 048 576 frames on 8 GPUs, i.e. 1024 streams x 128 frames PER GPU;
+          the same per-GPU shard is used for N = 2 and 4 ("weak" scaling, per-GPU work fixed for N > 1). The N = 1 line
+          carries the rate of that shard on one GPU (`other_workloads.shard_1024x128`), which is the like-for-like
+          single-GPU reference for the N > 1 lines.
+
+Multi-GPU (streams are independent: sharded, no data-path collective, NO RCCL):
+  * `python bench.py --gpus N` alone: ONE process drives N devices - one at3hip context and one host thread per
+    device, every thread queues its K asynchronous steps and waits for its device. Fails loudly when fewer than N
+    devices are visible.
+  * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: one rank per GPU; the ranks only
+    share a start/stop barrier and the MAX of the elapsed time over the CPU-side gloo backend.
 
 One JSON line on rank 0. Extra objects:
-  roofline     - fused QMF+MDCT kernel (k_qmf_mdct): algorithmic 16384 B/frame x frames per launch /
-                 average launch duration measured with HIP events on the ctx stream inside the timed region
-                 (where it co-runs with the previous step's back half); "isolated" = the same launch alone.
-  cpu_baseline - the real reference (oracle/_ref, kind "reference") or the C port (oracle/, kind "port")
-                 timed on this box's host cores on a bounded sample of the same workload.
+  roofline        - fused QMF+MDCT kernel (k_qmf_mdct): algorithmic 16384 B/frame x frames per launch / average launch
+                    duration measured with HIP events on the ctx stream inside the timed region (where it co-runs with the
+                    previous step's back half); "isolated" = the same launch alone.
+  cpu_baseline    - the real reference (oracle/_ref, kind "reference") or the C port (oracle/, kind "port") timed on this
+                    box's host cores on a bounded sample of the same workload.
+  other_workloads - (N = 1 only, after the headline, never part of `value`) SURVEY 8(d)'s other inputs and shapes.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,13 +43,52 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_FRAME_K1 = 16384   # 8192 B interleaved PCM in + 8192 B spectra out
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LP2, LP4 = 132300, 66150
 
 
 def synth_pcm(n_streams, n_blocks, seed):
-    """Uniform white noise, s16 in [-8192, 8191] / 32768 (SURVEY.md 8(d) 'noise'), per-stream seeds."""
+    """Host-side uniform white noise, s16 in [-8192, 8191] / 32768 (SURVEY.md 8(d) 'noise') for the CPU baseline."""
     rng = np.random.RandomState(seed)
     return (rng.randint(-8192, 8192, size=(n_streams, n_blocks, 1024, 2)).astype(np.float32)
             / np.float32(32768.0)).astype(np.float32)
+
+
+def synth_pcm_device(kind, n_streams, n_blocks, seed, device):
+    """SURVEY.md 8(d) synthetic inputs generated in HBM: float32 [S][n_blocks][1024][2] = s16 / 32768.
+    noise: uniform s16 in [-8192, 8191]; burst: 3 kHz sine whose amplitude toggles 0.02 / 0.6 every 3000 samples,
+    right = 0.5 left (drives the gain-control path); tones: five stationary sines at 0.1 (drives tonal extraction).
+    Streams differ by seed (noise) or by a per-stream phase (burst, tones)."""
+    import torch
+    n = n_blocks * 1024
+    if kind == "noise":
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        x = torch.randint(-8192, 8192, (n_streams, n_blocks, 1024, 2), generator=g, device=device, dtype=torch.int32)
+        return (x.to(torch.float32) / 32768.0).contiguous()
+    out = torch.empty((n_streams, n, 2), dtype=torch.float32, device=device)
+    t = torch.arange(n, dtype=torch.float64, device=device)
+    chunk = 64
+    for s0 in range(0, n_streams, chunk):       # float64 phases, bounded temporaries
+        s1 = min(n_streams, s0 + chunk)
+        sid = torch.arange(s0, s1, dtype=torch.float64, device=device)[:, None] + 7.0 * (seed % 13)
+        if kind == "burst":
+            tt = t[None, :] + 97.0 * sid
+            amp = torch.where((torch.floor(tt / 3000.0) % 2) == 0, 0.02, 0.6)
+            left = amp * torch.sin(2 * np.pi * 3000.0 * tt / 44100.0)
+            right = 0.5 * left
+        elif kind == "tones":
+            left = torch.zeros((s1 - s0, n), dtype=torch.float64, device=device)
+            right = torch.zeros_like(left)
+            for i, f in enumerate((440.0, 1000.0, 3000.0, 7000.0, 11000.0)):
+                ph = 2 * np.pi * f * t[None, :] / 44100.0 + 0.05 * sid
+                left += 0.1 * torch.sin(ph)
+                right += 0.1 * torch.sin(ph + 0.3 * i)
+        else:
+            raise ValueError(kind)
+        x = torch.stack([left, right], dim=-1)
+        x = torch.round(torch.clamp(x, -1.0, 32767.0 / 32768.0) * 32768.0) / 32768.0
+        out[s0:s1] = x.to(torch.float32)
+    return out.reshape(n_streams, n_blocks, 1024, 2).contiguous()
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -76,6 +127,141 @@ def cpu_baseline(seconds_budget=12.0):
         "all_cores_sample": f"{nthreads} threads x {nfr_mt} frames (one stream per thread)",
         "x_realtime": round(single * 1024 / 44100.0, 1),
     }
+
+
+class DeviceJob:
+    """One GPU's share: an at3hip context, its PCM batches resident in HBM, and the step loop."""
+
+    def __init__(self, device, S, F, bitrate, no_gain, kind, seed):
+        import torch
+        import atracdenc_amd
+        self.torch = torch
+        self.device, self.S, self.F = device, S, F
+        self.dev = torch.device("cuda", device)
+        self.enc = atracdenc_amd.At3Hip(n_streams=S, max_blocks=F + 1, bitrate=bitrate, no_gain=no_gain, device_id=device)
+        self.fsz = self.enc.frame_size
+        # synthetic PCM resident in HBM before timing: a priming look-ahead block + two alternating batches that are
+        # re-fed (the encoder does full work on every step; distinct data for every step would only cost memory)
+        pcm = synth_pcm_device(kind, S, 2 * F + 1, seed, self.dev)
+        self.d_prime = pcm[:, :1].contiguous()
+        self.d_batches = [pcm[:, 1 + i * F: 1 + (i + 1) * F].contiguous() for i in range(2)]
+        del pcm
+        self.d_out = torch.zeros((S, F, self.fsz), dtype=torch.uint8, device=self.dev)
+        self.calls = 0
+        self.enc.encode_device(self.d_prime.data_ptr(), 1, self.d_out.data_ptr())     # LOOK_AHEAD call, emits nothing
+
+    def step(self, asynchronous):
+        n = self.enc.encode_device(self.d_batches[self.calls % 2].data_ptr(), self.F, self.d_out.data_ptr(),
+                                   asynchronous=asynchronous)
+        self.calls += 1
+        return n
+
+    def warmup(self, w):
+        for _ in range(w):
+            assert self.step(False) == self.F
+        self.torch.cuda.synchronize(self.dev)
+
+    def run_steps(self, k):
+        """K steps queued back to back (AT3HIP_ASYNC) and completed by one sync. Inside the context the front half of
+        step i+1 (QMF, gain control, fused QMF+MDCT) runs beside the back half of step i (psychoacoustics, quantisation,
+        rate loop, packing) on a second HIP stream - every step still does its full work on its own batch."""
+        for _ in range(k):
+            self.step(True)
+        self.enc.sync()
+        self.torch.cuda.synchronize(self.dev)
+
+    def k1_stats(self, n_timed, first_ago):
+        k1_ms, stage_ms = [], {}
+        for ago in range(first_ago, first_ago + n_timed):
+            tm = self.enc.timings_ago(ago)
+            k1_ms.append(tm["qmf_mdct_ms"] / max(1, tm["qmf_mdct_launches"]))
+            for k, v in tm.items():
+                if k.endswith("_ms"):
+                    stage_ms[k] = stage_ms.get(k, 0.0) + v
+        return k1_ms, {k: v / max(1, n_timed) for k, v in stage_ms.items()}
+
+    def isolated_k1(self, reps=3):
+        ms = []
+        for _ in range(reps):
+            self.step(False)
+            ms.append(self.enc.timings()["qmf_mdct_ms"])
+        return float(np.mean(ms))
+
+    def checksum(self):
+        return int(self.d_out.to(self.torch.int64).sum().item())
+
+    def close(self):
+        self.enc.close()
+
+
+def timed_region(jobs, steps, dist):
+    """Barrier + synchronize on both sides; returns wall seconds for `steps` steps on every job (max over devices)."""
+    import torch
+    for j in jobs:
+        torch.cuda.synchronize(j.dev)
+    if dist is not None:
+        dist.barrier()
+    if len(jobs) == 1:
+        t0 = time.perf_counter()
+        jobs[0].run_steps(steps)
+        elapsed = time.perf_counter() - t0
+    else:
+        gate = threading.Barrier(len(jobs) + 1)
+        errs = []
+
+        def work(j):
+            try:
+                gate.wait()
+                j.run_steps(steps)
+            except Exception as ex:   # noqa: BLE001 - reported by the main thread
+                errs.append(repr(ex))
+
+        threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+        for t in threads:
+            t.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in threads:
+            t.join()
+        elapsed = time.perf_counter() - t0
+        if errs:
+            raise SystemExit("device thread failed: " + "; ".join(errs))
+    for j in jobs:
+        torch.cuda.synchronize(j.dev)
+    if dist is not None:
+        dist.barrier()
+    return elapsed
+
+
+def roofline_of(k1_avg_ms, frames_per_launch):
+    achieved = ALGO_BYTES_PER_FRAME_K1 * frames_per_launch / (k1_avg_ms * 1e-3) / 1e9
+    return round(achieved, 2), round(achieved / HBM_PEAK_GBS, 5)
+
+
+def side_workload(name, S, F, bitrate, kind, steps, warmup):
+    """One of SURVEY 8(d)'s other workloads on device 0, after the headline: whole-pipeline rate + K1 launch time."""
+    out = {"workload": name}
+    try:
+        job = DeviceJob(0, S, F, bitrate, False, kind, seed=11)
+        job.warmup(warmup)
+        dt = timed_region([job], steps, None)
+        iso = job.isolated_k1()
+        k1_ms, stage = job.k1_stats(min(steps, 28), 3)
+        k1 = float(np.mean(k1_ms))
+        ach, frac = roofline_of(k1, S * F)
+        ach_i, frac_i = roofline_of(iso, S * F)
+        out.update({"value": round(S * F * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 4),
+                    "frames_per_step": S * F, "frame_bytes": job.fsz, "input": kind,
+                    "k1_avg_launch_ms": round(k1, 5), "k1_GBps": ach, "k1_frac": frac,
+                    "k1_isolated_ms": round(iso, 5), "k1_isolated_GBps": ach_i, "k1_isolated_frac": frac_i,
+                    "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(stage.items())}})
+        job.close()
+        del job
+        import torch
+        torch.cuda.empty_cache()
+    except Exception as ex:   # noqa: BLE001 - the headline line must not depend on these
+        out["error"] = repr(ex)
+    return out
 
 
 def widened_rows(S):
@@ -122,121 +308,141 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
-    ap.add_argument("--frames", type=int, default=64, help="frames per stream per step")
-    ap.add_argument("--bitrate", type=int, default=132300)
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: 64 at N=1, 1024 at N>1)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per stream per step (default: 64 at N=1, 128 at N>1)")
+    ap.add_argument("--bitrate", type=int, default=LP2)
+    ap.add_argument("--input", choices=["noise", "burst", "tones"], default="noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-workloads", action="store_true")
     ap.add_argument("--no-gain", action="store_true")
+    ap.add_argument("--device-map", default="", help="TEST AID: comma list of device ordinals to use instead of 0..N-1 (e.g. 0,0 runs the "
+                                                     "two-device code path on one GPU); recorded in the JSON line, never a valid N-GPU result")
     args = ap.parse_args()
 
     import torch
-    import atracdenc_amd
 
     from atracdenc_amd import dist as at3dist
     rank, local_rank, world = at3dist.env_world()
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU or none at all")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
+    n_gpus = args.gpus
+    n_visible = torch.cuda.device_count()
     dist = None
     if world > 1:
-        dist = at3dist.init("nccl", local_rank)   # RCCL: barrier + MAX of elapsed time only, no data-path collective
+        # one rank per GPU (torch.distributed.run): CPU-side gloo for the barrier and the MAX only - the data path has no
+        # exchange step, and north_star asks for no RCCL
+        if local_rank >= n_visible:
+            raise SystemExit(f"rank {rank}: local_rank {local_rank} but only {n_visible} GPU(s) visible")
+        dist = at3dist.init("gloo")
+        devices = [local_rank]
+        mode = f"{world} ranks x 1 GPU (torch.distributed.run, gloo barrier)"
+    else:
+        if args.device_map:
+            devices = [int(x) for x in args.device_map.split(",")]
+            if len(devices) != n_gpus or max(devices) >= n_visible:
+                raise SystemExit("--device-map needs --gpus entries, all visible")
+            mode = f"TEST AID --device-map {args.device_map}: {n_gpus} contexts on {len(set(devices))} physical GPU(s) - not an N-GPU measurement"
+        else:
+            if n_visible < n_gpus:
+                raise SystemExit(f"--gpus {n_gpus} requested but only {n_visible} GPU(s) are visible: refusing to measure fewer")
+            devices = list(range(n_gpus))
+            mode = f"1 process x {n_gpus} GPU(s), one host thread and one at3hip context per device"
+    torch.cuda.set_device(devices[0])
 
-    S, F = args.streams, args.frames
-    enc = atracdenc_amd.At3Hip(n_streams=S, max_blocks=F + 1, bitrate=args.bitrate, no_gain=args.no_gain,
-                               device_id=local_rank)
-    fsz = enc.frame_size
-    # synthetic PCM resident in HBM before timing: a priming look-ahead block + (warmup+steps) distinct batches
-    # would be large; instead two alternating batches are kept resident and re-fed (the encoder does full work).
-    host = synth_pcm(S, 2 * F + 1, seed=1 + rank)
-    d_prime = torch.from_numpy(host[:, :1].copy()).cuda()
-    d_batches = [torch.from_numpy(host[:, 1 + i * F: 1 + (i + 1) * F].copy()).cuda() for i in range(2)]
-    d_out = torch.zeros((S, F, fsz), dtype=torch.uint8, device="cuda")
-    enc.encode_device(d_prime.data_ptr(), 1, d_out.data_ptr())     # LOOK_AHEAD call, emits nothing
-    for i in range(args.warmup):
-        n = enc.encode_device(d_batches[i % 2].data_ptr(), F, d_out.data_ptr())
-        assert n == F
+    S = args.streams or (64 if n_gpus == 1 else 1024)
+    F = args.frames or (64 if n_gpus == 1 else 128)
+    jobs = [DeviceJob(d, S, F, args.bitrate, args.no_gain, args.input, seed=1 + rank * 64 + i) for i, d in enumerate(devices)]
+    fsz = jobs[0].fsz
+    for j in jobs:
+        j.warmup(args.warmup)
 
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    one_gpu_ref = None
+    if world == 1 and n_gpus > 1:
+        # like-for-like reference for the scaling figure: the same per-GPU shard on device 0 ALONE, same step count
+        timed_region(jobs[:1], min(args.steps, 5), None)
+        dt1 = timed_region(jobs[:1], args.steps, None)
+        one_gpu_ref = {"value": round(S * F * args.steps / dt1, 1), "unit": "frames/s", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                       "note": "device 0 alone on the same per-GPU shard, measured in this run before the N-GPU timed region"}
 
-    # Timed region: K steps queued back to back (AT3HIP_ASYNC) and completed by one sync. Inside the context the front
-    # half of step i+1 (QMF, gain control, fused QMF+MDCT) runs beside the back half of step i (psychoacoustics,
-    # quantisation, rate loop, packing) on a second HIP stream - every step still does its full work on its own batch.
-    k1_ms, stage_ms = [], {}
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        enc.encode_device(d_batches[(args.warmup + i) % 2].data_ptr(), F, d_out.data_ptr(), asynchronous=True)
-    enc.sync()
-    sync()
-    elapsed = time.perf_counter() - t0
-    elapsed = at3dist.max_over_ranks(elapsed, dist, device="cuda")
-    checksum = int(d_out.to(torch.int64).sum().item())
-    # after the timed region: the same launch without a co-running back half (synchronous calls), for reference
-    iso_ms = []
-    for i in range(3):
-        enc.encode_device(d_batches[(args.warmup + args.steps + i) % 2].data_ptr(), F, d_out.data_ptr())
-        iso_ms.append(enc.timings()["qmf_mdct_ms"])
-    n_timed = min(args.steps, 28)           # per-step HIP-event timings of the timed region (history of 32 calls)
-    first_ago = 3                           # the three reference calls above are the most recent ones
-    for ago in range(first_ago, first_ago + n_timed):
-        tm = enc.timings_ago(ago)
-        k1_ms.append(tm["qmf_mdct_ms"] / max(1, tm["qmf_mdct_launches"]))
-        for k, v in tm.items():
-            if k.endswith("_ms"):
-                stage_ms[k] = stage_ms.get(k, 0.0) + v
+    elapsed = timed_region(jobs, args.steps, dist)
+    elapsed = at3dist.max_over_ranks(elapsed, dist, device="cpu")
+    j0 = jobs[0]
+    checksum = j0.checksum()
+    iso_ms = j0.isolated_k1()                       # 3 synchronous steps after the timed region
+    k1_ms, stage_ms = j0.k1_stats(min(args.steps, 28), 3)
 
     if rank == 0:
-        frames_total = world * S * F * args.steps
+        frames_total = n_gpus * S * F * args.steps
         value = frames_total / elapsed
         k1_avg_ms = float(np.mean(k1_ms))
-        achieved = ALGO_BYTES_PER_FRAME_K1 * S * F / (k1_avg_ms * 1e-3) / 1e9
-        traffic = None
+        achieved, frac = roofline_of(k1_avg_ms, S * F)
+        ach_iso, frac_iso = roofline_of(iso_ms, S * F)
+        traffic, traffic_note = None, "not measured"
         prof = os.path.join(ROOT, "profiles", "k1_traffic.json")
-        if os.path.exists(prof):
+        if os.path.exists(prof) and (S, F) == (64, 64):
             try:
                 traffic = json.load(open(prof)).get("bytes_per_launch")
+                traffic_note = ("read from profiles/k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on "
+                                "this workload, collected separately as the guide prescribes) - not measured in this run")
             except Exception:
                 traffic = None
+        cfgname = {384: "LP2 132 kbps", 192: "LP4 66 kbps joint stereo"}.get(fsz, f"{fsz} B/frame")
         line = {
             "metric": "ATRAC3 1024-sample stereo frames/sec", "value": round(value, 1), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "x_realtime": round(value * 1024 / 44100.0, 1),
-            "config": {"workload": f"ATRAC3 {'LP2 132 kbps' if fsz == 384 else str(fsz) + ' B/frame'} stereo, "
-                                   f"{S} streams x {F} frames = {S * F} frames per GPU per step, white-noise PCM "
-                                   f"resident in HBM, frames written to HBM (PCIe excluded)",
-                       "streams_per_gpu": S, "frames_per_stream_per_step": F, "frame_bytes": fsz,
-                       "gain_control": not args.no_gain, "tonal_components": True, "parallelism": f"streams/{world}"},
+            "config": {"workload": f"ATRAC3 {cfgname} stereo, {S} streams x {F} frames = {S * F} frames per GPU per step "
+                                   f"({'BASELINE configs[1]' if (S, F) == (64, 64) else 'per-GPU shard of BASELINE configs[2]' if (S, F) == (1024, 128) else 'custom'}), "
+                                   f"'{args.input}' PCM resident in HBM, frames written to HBM (PCIe excluded)",
+                       "streams_per_gpu": S, "frames_per_stream_per_step": F, "frames_per_step_all_gpus": n_gpus * S * F,
+                       "frame_bytes": fsz, "input": args.input,
+                       "gain_control": not args.no_gain, "tonal_components": True, "parallelism": f"streams/{n_gpus}",
+                       "launch": mode, "collectives": "none (no RCCL); start/stop barrier only"},
+            "per_gpu_value": round(value / n_gpus, 1),
             "roofline": {"bound": "hbm", "kernel": "k_qmf_mdct (fused QMF + gain modulation + windowed MDCT-512)",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": frac, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME_K1 * S * F,
                          "avg_launch_ms": round(k1_avg_ms, 5),
-                         "note": "launches of the timed region; they share the GPU with the previous step's back half "
+                         "limiter": "VALU issue + LDS (FMA-free fp32 arithmetic contract), not HBM: see DESIGN.md section 5; the HBM "
+                                    "fraction is reported because it is the roofline north_star names",
+                         "note": "launches of the timed region (device 0); they share the GPU with the previous step's back half "
                                  "(quantisation / rate loop) running on the context's second stream",
-                         "isolated": {"avg_launch_ms": round(float(np.mean(iso_ms)), 5),
-                                      "achieved": round(ALGO_BYTES_PER_FRAME_K1 * S * F / (float(np.mean(iso_ms)) * 1e-3) / 1e9, 2),
-                                      "frac": round(ALGO_BYTES_PER_FRAME_K1 * S * F / (float(np.mean(iso_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "isolated": {"avg_launch_ms": round(iso_ms, 5), "achieved": ach_iso, "frac": frac_iso,
                                       "note": "same kernel, same batch, launched alone (3 synchronous steps after the timed region)"}},
-            "stage_ms_per_step": {k: round(v / max(1, len(k1_ms)), 4) for k, v in sorted(stage_ms.items())},
+            "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
             "pipelining": "front half of step i+1 overlaps the back half of step i (two HIP streams inside the context); "
                           "stage_ms are per-step HIP-event spans and overlap in time, total_ms is one step's latency",
             "checksum": checksum,
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
-        if world == 1:
-            line["widened_rows"] = widened_rows(S)
+        if one_gpu_ref is not None:
+            line["one_gpu_same_workload"] = one_gpu_ref
+        for j in jobs:
+            j.close()
+        jobs = []
+        torch.cuda.empty_cache()
+        if n_gpus == 1 and world == 1:
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline()
+            if not args.no_side_workloads:
+                line["other_workloads"] = [
+                    side_workload("configs[1] shape, 'burst' input (gain-control path busy)", 64, 64, LP2, "burst", 10, 2),
+                    side_workload("configs[1] shape, 'tones' input (tonal extraction busy)", 64, 64, LP2, "tones", 10, 2),
+                    side_workload("configs[3]: LP4 66 kbps joint stereo, configs[1] shape, 'noise'", 64, 64, LP4, "noise", 10, 2),
+                    side_workload("shard_1024x128: per-GPU shard of configs[2] (1024 streams x 128 frames) on one GPU, 'noise'", 1024, 128, LP2, "noise", 6, 2),
+                ]
+                line["widened_rows"] = widened_rows(64)
         print(json.dumps(line))
-    enc.close()
+    for j in jobs:
+        j.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

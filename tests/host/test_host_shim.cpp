@@ -1,6 +1,7 @@
 // GPU test of the host-side C++ mirror (atracdenc_amd/host/at3hip_host.hpp): reads like the reference's own
 // tests (atrac3denc_ut.cpp) - drive the encoder through GetLambda()/WriteFrame and TAtrac3MDCT::Mdct - and
 // checks the results bit-for-bit against the CPU oracle (test infrastructure, linked only into this test).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +81,56 @@ int main()
         EXPECT(memcmp(specs, especs, sizeof(specs)) == 0);
         EXPECT(memcmp(bands, ref, sizeof(ref)) == 0);
         printf("TAtrac3MDCT::Mdct compared\n");
+    }
+    // ---- the maxLevels overload and CalcGainEnergyScale (atrac3denc.h:69-83) ----
+    {
+        TAtrac3MDCT mdct;
+        float bands[4][512];
+        for (int b = 0; b < 4; ++b)
+            for (int i = 0; i < 512; ++i) bands[b][i] = 0.3f * (float)sin(0.013 * (i + 3) * (b + 1));
+        float* p[4] = {bands[0], bands[1], bands[2], bands[3]};
+        TAtrac3MDCT::TGainCurves curves;
+        curves[1] = {{2, 7}};
+        float specs[1024], maxLevels[4];
+        mdct.Mdct(specs, p, maxLevels, curves);
+        for (int b = 0; b < 4; ++b) {
+            float m = 0.0f;
+            for (int i = 0; i < 256; ++i) m = std::max(m, std::fabs(bands[b][256 + i]));   // new half as the call left it
+            EXPECT(m == maxLevels[b]);
+        }
+        float prev[256], cur[256], out[4];
+        for (int i = 0; i < 256; ++i) {
+            prev[i] = 0.2f * (float)cos(0.05 * i);
+            cur[i] = 0.4f * (float)sin(0.02 * i + 0.3);
+        }
+        const std::vector<TGainPoint> pts = {{5, 3}, {3, 17}, {6, 30}};
+        const auto res = mdct.CalcGainEnergyScale(prev, cur, pts, 0.75f);
+        const int32_t level[8] = {5, 3, 6}, loc[8] = {3, 17, 30};
+        at3o_gain_energy_scale(prev, cur, 3, level, loc, 0.75f, out);
+        EXPECT(memcmp(&res.Scale.PrevHalf, &out[0], 4) == 0 && memcmp(&res.Scale.CurHalf, &out[1], 4) == 0);
+        EXPECT(memcmp(&res.Scale.Frame, &out[2], 4) == 0 && memcmp(&res.NextOverlapScale, &out[3], 4) == 0);
+        printf("TAtrac3MDCT maxLevels / CalcGainEnergyScale compared\n");
+    }
+    // ---- TAtrac3EncoderNode: streams sharded over devices (this box has one: two contexts on device 0) ----
+    {
+        EXPECT(ShardStreams(7, 3, 0) == std::make_pair(0, 3) && ShardStreams(7, 3, 1) == std::make_pair(3, 2) && ShardStreams(7, 3, 2) == std::make_pair(5, 2));
+        const int S = 5, n = 9;
+        std::vector<float> batch((size_t)S * n * 2048);
+        for (int s = 0; s < S; ++s)
+            for (int i = 0; i < n * 2048; ++i) batch[(size_t)s * n * 2048 + i] = pcm[(size_t)((i + 4096 * s) % (nb * 2048))];
+        TAtrac3EncoderSettings st;
+        TAtrac3EncoderNode node(st, S, n, {0, 0});
+        std::vector<uint8_t> frames;
+        const int nf = node.Encode(batch.data(), n, frames);
+        EXPECT(nf == n - 1 && node.Devices() == 2);
+        for (int s = 0; s < S; ++s) {
+            std::vector<unsigned char> exp((size_t)n * 1024);
+            int fsz = 0;
+            const int enf = at3o_encode(132300, 2, 0, 0, 0, batch.data() + (size_t)s * n * 2048, n, exp.data(), &fsz, nullptr);
+            EXPECT(enf == nf && fsz == node.FrameSize());
+            EXPECT(memcmp(frames.data() + (size_t)s * nf * fsz, exp.data(), (size_t)nf * fsz) == 0);
+        }
+        printf("TAtrac3EncoderNode (2 contexts) compared\n");
     }
     printf(fails ? "HOST SHIM TEST FAILED\n" : "HOST SHIM TEST OK\n");
     return fails ? 1 : 0;
