@@ -1048,6 +1048,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
     __shared__ uint16_t s_huff[130];
     __shared__ int s_misc[4];
     __shared__ uint32_t s_cost[8 * 32];
+    __shared__ unsigned long long s_tmask[4];   // per QMF band: set of (quantiser, length) groups among the live tonal blocks
 
     const int lane = threadIdx.x;
     const int n_out = p.n_blocks - p.f0;
@@ -1153,10 +1154,26 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
         for (int z = 0; z < tb.len; ++z) bits += (int)(huff_entry(qq, vlc_index(__float2int_rn(tb.values[z] * mul))) >> 8);
         s_tbits[t * 8 + qq] = (uint8_t)bits;
     }
+    // Lane t < n_tonal also owns tonal block t (its BFU, length and 64-line block): the cost of the tonal side
+    // information is evaluated by these lanes in parallel inside the rate loop (inside the bisection below).
+    int tb_bfu = 255, tb_len = 0, tb_blk = 0;
+    if (lane < n_tonal) {
+        const TonalBlock& tb = rec->tonal[lane];
+        tb_bfu = tb.bfu;
+        tb_len = tb.len;
+        tb_blk = tb.pos >> 6;
+    }
+    // GroupTonalComponents (atrac3_bitstream.cpp:338-380) closes a sub-group only after EIGHT members of one group inside one
+    // 64-line block. A 64-line block holds at most four tonal BFUs (BFUs 8..28 are 16 lines or wider, one run each), so
+    // that never happens and every (quantiser, length) group is exactly one sub-group; the check below proves it for this
+    // frame (blocks are ordered by position) and sends anything else down the literal, serial path.
+    const bool tonal_serial = __ballot(lane + 7 < n_tonal &&
+                                       __builtin_amdgcn_ds_bpermute(4 * ((lane + 7) & 63), tb_blk) == tb_blk) != 0ull;
     // per-BFU constants of CalcBitsAllocation (atrac3_bitstream.cpp:272-336)
     float A;
     bool gate;
     int tcount = 0;
+    for (int t = 0; t < n_tonal; ++t) tcount += (__builtin_amdgcn_readlane(tb_bfu, t) == (lane & 31));
     float err[8];
     uint32_t cost[8];
     {
@@ -1178,7 +1195,7 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
         else if (i <= 20) x = 3.6f;
         else if (i <= 28) x = 4.2f;
         A = spread * (csfi / x) + (1.0f - spread) * (float)c_fixed_alloc[i];
-        for (int t = 0; t < n_tonal; ++t) tcount += (rec->tonal[t].bfu == i);
+        // (tonal blocks per BFU: counted below from the per-lane copies of the blocks' BFU indices)
         err[0] = 0.0f;
         cost[0] = 0;
 #pragma unroll
@@ -1256,12 +1273,34 @@ __global__ __launch_bounds__(64) void k_rate_pack(BackParams p, const Tables* T)
             mode = clc <= vlc ? 1 : 0;
             const uint32_t spec_bits = (uint32_t)num_bfu * 3 + 6 * nz + (mode ? clc : vlc);
             uint32_t tonal_bits = 5;
-            if (n_tonal > 0) {
+            if (n_tonal > 0 && tonal_serial) {
                 if (lane < 32) s_alloc[lane] = bits;
                 __syncthreads();
                 if (lane == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
                 __syncthreads();
                 tonal_bits = (uint32_t)(s_misc[0] & 0xffff);
+            } else if (n_tonal > 0) {
+                // EncodeTonalComponents with a null stream (atrac3_bitstream.cpp:382-524), one lane per tonal block:
+                //   5 (+2 when anything is coded) + per group 4 + 3 + 3 + 12 per QMF band the group touches
+                //   + per coded block 6 + 6 + VLC bits of its values at the group's quantiser.
+                const bool live = lane < n_tonal && tb_bfu < num_bfu;
+                const int wl_t = __builtin_amdgcn_ds_bpermute(4 * (tb_bfu & 31), bits);   // this evaluation's wordlen of the block's BFU
+                int qn = wl_t + 4;
+                qn = qn > 7 ? 7 : qn;   // >= 4 always, so the lower clamp at 2 is never active here
+                if (lane < 4) s_tmask[lane] = 0ull;
+                wave_sync();
+                uint32_t member = 0;
+                if (live) {
+                    atomicOr(&s_tmask[tb_blk >> 2], 1ull << ((qn - 2) * 7 + (tb_len - 1)));
+                    member = 12u + s_tbits[lane * 8 + qn];
+                }
+                const uint32_t msum = row_allreduce_add(member);
+                const uint32_t members = (uint32_t)__builtin_amdgcn_readlane((int)msum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)msum, 16);
+                wave_sync();
+                const unsigned long long m0 = s_tmask[0], m1 = s_tmask[1], m2 = s_tmask[2], m3 = s_tmask[3];
+                const uint32_t groups = (uint32_t)__popcll(m0 | m1 | m2 | m3);
+                const uint32_t group_bands = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+                if (groups) tonal_bits = 5u + 2u + 10u * groups + 12u * group_bands + members;
             }
             const uint32_t total = spec_bits + tonal_bits;
             const int last_alloc = __builtin_amdgcn_readlane(bits, (num_bfu - 1) & 31);

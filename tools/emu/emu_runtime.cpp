@@ -112,6 +112,8 @@ int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool
     if (ctrl >= 0x101 && ctrl <= 0x10F) { srcpos = pos + (ctrl - 0x100); if (srcpos > 15) srcpos = -1; }       // row_shl
     else if (ctrl >= 0x111 && ctrl <= 0x11F) { srcpos = pos - (ctrl - 0x110); }                                 // row_shr
     else if (ctrl >= 0x121 && ctrl <= 0x12F) { srcpos = (pos - (ctrl - 0x120) + 16) % 16; }                     // row_ror
+    else if (ctrl == 0x140) { srcpos = 15 - pos; }                                                               // row_mirror
+    else if (ctrl == 0x141) { srcpos = (pos & 8) | (7 - (pos & 7)); }                                            // row_half_mirror
     else if (ctrl == 0x142) { if (row == 0) return old; return (int)all[row * 16 - 1]; }                         // row_bcast:15 (lane 15 of the previous row)
     else if (ctrl == 0x143) { if (row < 2) return old; return (int)all[31]; }                                   // row_bcast:31
     else if (ctrl == 0x138) { if (lane == 0) return bound_ctrl ? 0 : old; return (int)all[lane - 1]; }          // wave_shr:1

@@ -1,0 +1,201 @@
+// Micro-benchmark (development aid, not part of the product): issue cost of the instructions the ATRAC3 kernels are
+// built from, in shader cycles per wave64 instruction per SIMD, at 1, 2 and 4 resident waves per SIMD.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_lds_rates tools/ubench/valu_lds_rates.hip && ./valu_lds_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int kIters = 2048;
+constexpr int kUnroll = 16;
+
+#define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, float seed)
+{
+    __shared__ __attribute__((aligned(16))) float s_buf[16384];
+    const int tid = threadIdx.x;
+    float a[16];
+    f2 p[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        a[i] = seed + (float)(tid + i);
+        p[i].x = a[i];
+        p[i].y = a[i] * 0.5f;
+    }
+    for (int i = tid; i < 16384; i += 256) s_buf[i] = seed;
+    f4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    f2 acc2 = {0.f, 0.f};
+    float acc1 = 0.f;
+    const float w = seed * 0.999f;
+    f2 w2;
+    w2.x = w;
+    w2.y = w * 1.0001f;
+    __syncthreads();
+    const long long t0 = clock64();
+    for (int it = 0; it < kIters; ++it) {
+        if (KIND == 0) {
+#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+            REP16(X)
+#undef X
+        } else if (KIND == 1) {
+#define X(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
+            REP16(X)
+#undef X
+        } else if (KIND == 2) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(w));
+            REP16(X)
+#undef X
+        } else if (KIND == 3) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(w2));
+            REP16(X)
+#undef X
+        } else if (KIND == 4) {
+#define X(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(w2));
+            REP16(X)
+#undef X
+        } else if (KIND == 5) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[i]) : "v"(w2));
+            REP16(X)
+#undef X
+        } else if (KIND == 6) {   // mul with a scalar (SGPR) operand, as the QMF taps are
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "s"(w2));
+            REP16(X)
+#undef X
+        } else if (KIND == 7) {
+#define X(i) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+            REP16(X)
+#undef X
+        } else if (KIND == 8) {
+#define X(i) asm volatile("v_mul_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(w));
+            REP16(X)
+#undef X
+        } else if (KIND == 9) {   // 16-byte LDS reads, conflict free
+            const float4* q = reinterpret_cast<const float4*>(s_buf) + tid;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                f4 v;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)q));
+                acc4.x += v.x;
+            }
+        } else if (KIND == 10) {
+            const float2* q = reinterpret_cast<const float2*>(s_buf) + tid;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                f2 v;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)q));
+                acc2.x += v.x;
+            }
+        } else if (KIND == 11) {
+            const float* q = s_buf + tid;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)q));
+                acc1 += v;
+            }
+        } else if (KIND == 12) {
+            float2* q = reinterpret_cast<float2*>(s_buf) + tid;
+            f2 v = {a[0], a[1]};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(size_t)q), "v"(v) : "memory");
+        } else if (KIND == 13) {
+            float4* q = reinterpret_cast<float4*>(s_buf) + tid;
+            f4 v = {a[0], a[1], a[2], a[3]};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)q), "v"(v) : "memory");
+        } else if (KIND == 14) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int v = __builtin_amdgcn_ds_bpermute(4 * ((tid + 1) & 63), __float_as_int(a[i]));
+                a[i] = __int_as_float(v);
+            }
+        } else if (KIND == 15) {   // QMF inner step: packed multiply by a scalar tap pair + packed add (no FMA)
+#define X(i)                                                                      \
+    {                                                                             \
+        f2 t;                                                                     \
+        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(p[(i + 1) & 15]), "s"(w2)); \
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(t));          \
+    }
+            REP16(X)
+#undef X
+        } else if (KIND == 16) {   // the same with plain ops (two lanes' worth per step is twice as many instructions)
+#define X(i)                                                                   \
+    {                                                                          \
+        float t;                                                               \
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(a[(i + 1) & 15]), "s"(w)); \
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(t));          \
+    }
+            REP16(X)
+#undef X
+        } else if (KIND == 17) {
+#define X(i) asm volatile("v_cndmask_b32_dpp %0, %0, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(w) : "vcc");
+            REP16(X)
+#undef X
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const long long t1 = clock64();
+    float s = acc4.x + acc2.x + acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a[i] + p[i].x + p[i].y;
+    out[blockIdx.x * 256 + tid] = s;
+    if ((tid & 63) == 0) cyc[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+}
+
+template <int KIND>
+void run(const char* name, int per_iter_instr, int wgs_per_cu, float* d_out, long long* d_cyc)
+{
+    const int grid = 256 * wgs_per_cu;   // 4 waves per workgroup = one per SIMD
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), 0, 0, d_out, d_cyc, 1.0f);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), 0, 0, d_out, d_cyc, 1.0f);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long long> c(grid * 4);
+    hipMemcpy(c.data(), d_cyc, c.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    double avg = 0;
+    for (auto v : c) avg += (double)v;
+    avg /= c.size();
+    const double n = (double)kIters * per_iter_instr;
+    // clock64 = s_memtime at a fixed 100 MHz-class reference on some parts: report both the tick-based and the wall-based figure
+    printf("%-34s waves/SIMD=%d  ticks/instr(wave)=%7.3f  wall: %8.3f us  => %6.3f ns/instr/wave, %6.3f ns per instr-slot/SIMD\n", name,
+           wgs_per_cu, avg / n, ms * 1e3, ms * 1e6 / n, ms * 1e6 / n / wgs_per_cu);
+}
+
+int main()
+{
+    float* d_out;
+    long long* d_cyc;
+    hipMalloc(&d_out, 256 * 8 * 256 * sizeof(float));
+    hipMalloc(&d_cyc, 256 * 8 * 4 * sizeof(long long));
+    for (int w : {1, 2, 4}) {
+        run<0>("v_mul_f32", 16, w, d_out, d_cyc);
+        run<1>("v_add_f32", 16, w, d_out, d_cyc);
+        run<2>("v_fma_f32", 16, w, d_out, d_cyc);
+        run<3>("v_pk_mul_f32", 16, w, d_out, d_cyc);
+        run<4>("v_pk_add_f32", 16, w, d_out, d_cyc);
+        run<5>("v_pk_fma_f32", 16, w, d_out, d_cyc);
+        run<6>("v_pk_mul_f32 (sgpr operand)", 16, w, d_out, d_cyc);
+        run<7>("v_mov_b32_dpp quad_perm", 16, w, d_out, d_cyc);
+        run<8>("v_mul_f32_dpp row_shr:1", 16, w, d_out, d_cyc);
+        run<17>("v_cndmask_b32_dpp quad_perm", 16, w, d_out, d_cyc);
+        run<9>("ds_read_b128", 16, w, d_out, d_cyc);
+        run<10>("ds_read_b64", 16, w, d_out, d_cyc);
+        run<11>("ds_read_b32", 16, w, d_out, d_cyc);
+        run<12>("ds_write_b64", 16, w, d_out, d_cyc);
+        run<13>("ds_write_b128", 16, w, d_out, d_cyc);
+        run<14>("ds_bpermute_b32", 16, w, d_out, d_cyc);
+        run<15>("pk_mul(sgpr)+pk_add pair", 32, w, d_out, d_cyc);
+        run<16>("mul(sgpr)+add pair (plain)", 32, w, d_out, d_cyc);
+    }
+    return 0;
+}
