@@ -1440,6 +1440,8 @@ struct StateParams {
     float* hist_out;        // [S][kHist][2]
     const Curve* curves;    // [S][n_blocks][2][4]
     BandState* state;
+    const float* sub;       // [S][8][(n_blocks+2)*256] subbands of this call, or null (no gain control, discrete stereo)
+    float* sub_tail;        // [S][8][512]: the last two blocks' subbands, the next call's blocks -2 and -1
     int n_blocks;
     int n_streams;
 };
@@ -1470,6 +1472,11 @@ __global__ void k_state_update(StateParams p)
         hout[k] = (g >= 0) ? pcm2[g] : hin[kHist + g];
     }
     if (k < 8) p.state[(size_t)s * 8 + k].prev_curve = p.curves[((size_t)s * p.n_blocks + (p.n_blocks - 1)) * 8 + k];
+    if (p.sub && k < 8 * 128) {   // 8 rows x 512 floats as 16-byte words: the tail of every row (its front is the carried part)
+        const int row = k >> 7, i = k & 127;
+        const float4* src = reinterpret_cast<const float4*>(p.sub + ((size_t)s * 8 + row) * ((size_t)(p.n_blocks + 2) * 256) + (size_t)p.n_blocks * 256);
+        reinterpret_cast<float4*>(p.sub_tail + ((size_t)s * 8 + row) * 512)[i] = src[i];
+    }
 }
 
 }  // namespace at3

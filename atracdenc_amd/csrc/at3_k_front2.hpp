@@ -1,0 +1,747 @@
+// Front-end kernels, second generation: register-blocked QMF (eight outputs per work-item) and a register-resident
+// MDCT-512 whose 128-point FFT lives in the sixteen lanes of one DPP row.
+//
+// Reference path replaced (paths relative to the reference's src/):
+//   atrac3denc.cpp:701-713   PCM de-interleave, /4.0, Atrac3AnalysisFilterBank::Analysis
+//   qmf/qmf.h:47-64          TQmf<nIn>::Analysis (48-tap two-band QMF), atrac/at3/atrac3_qmf.h:37-41 (tree)
+//   atrac3denc.cpp:665-677   Matrixing (LP4 joint stereo)
+//   gain_processor.h:87-121  TGainProcessor::Modulate
+//   atrac3denc.cpp:33-58     TAtrac3MDCT::Mdct;  lib/mdct/mdct.h:51-104 TMDCT<512>;  kiss_fft.c (128-pt)
+//
+// QMF. One work-item produces EIGHT consecutive (lower, upper) output pairs of one two-band filter from 31 sample pairs
+// (sixteen 16-byte LDS reads that stay in registers for all 384 packed multiply-adds); taps are wave-uniform scalars.
+// Accumulation order per output is tap 0..23, multiply then add (no contraction), exactly as qmf.h:54-63.
+//
+// MDCT. A (channel, band) transform belongs to the 16 lanes of one DPP row: lane (q1, q2) = 4 q1 + q2 holds 8 complex
+// points. The decimation-in-time order of kissfft (radix 4, 4, 4, 2) puts a complete 8-point sub-transform (radix-2
+// leaves + the m = 2 pass) into one lane; the m = 8 pass combines the four lanes of a quad, the m = 32 pass four lanes
+// 4 apart - two 16-byte exchanges through a small conflict-free LDS scratch, no workgroup barrier. The fold needs, per
+// lane, sample indices {e, 128+e, 127-e, 255-e}; the odd-index two come from the mirror lane (DPP row_mirror), and the
+// windowed overlap of the next frame is a product of the same 16 samples, so it never leaves the registers. The
+// post-rotation's two outputs per bin interleave with the mirror lane's into runs of four consecutive spectral lines:
+// spectra go to HBM as 16-byte stores straight from registers.
+#pragma once
+#include "at3_common.hpp"
+#include "at3_k_frontend.hpp"
+
+namespace at3 {
+
+// ---- LDS rings of the QMF stages -----------------------------------------------------------------------------
+// Logical ring element e = 48 history samples + new samples. Groups of four floats (two sample pairs) are the unit of
+// the 16-byte reads; work-item g of a stage reads groups 4g .. 4g+15. Group G is stored in plane G & 3 at slot G >> 2,
+// so one read instruction (fixed group offset) touches consecutive slots in consecutive work-items: conflict free.
+// Inside a group the two floats of a pair are swapped, (x[2k+1], x[2k]): the operand order of the packed tap product.
+constexpr int kHist8 = 48;
+constexpr int kPcmH8 = 74;    // slots per plane, >= 67 and = 2 mod 8 (planes 32 bytes out of phase for the 16-byte stores)
+constexpr int kS1H8 = 42;     // >= 35
+constexpr int kPcmRing8 = 16 * kPcmH8;   // floats per channel
+constexpr int kS1Ring8 = 16 * kS1H8;     // floats per (channel, half)
+
+template <int H>
+__device__ __forceinline__ int ring8_slot(int G)
+{
+    return (G & 3) * H + (G >> 2);
+}
+template <int H>
+__device__ __forceinline__ int ring8_at(int e)   // physical float index of logical element e
+{
+    return (ring8_slot<H>(e >> 2) << 2) | ((e & 3) ^ 1);
+}
+
+// Eight outputs m = 8g .. 8g+7 of one two-band filter. Output r, tap i uses ring pair k = r + 24 - i (local to the
+// work-item's 32 pairs; pair 0 is never used): walking k downwards extends every sum in tap order.
+template <int H>
+__device__ __forceinline__ void qmf8(const float4* __restrict__ ring, int g, const f2 (&Wp)[24], f2 (&acc)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = mk2(0.0f, 0.0f);
+#pragma unroll
+    for (int q = 15; q >= 0; --q) {
+        const float4 v = ring[(q & 3) * H + g + (q >> 2)];
+        const f2 hi = mk2(v.z, v.w), lo = mk2(v.x, v.y);   // pairs 2q+1, 2q
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = r + 24 - (2 * q + 1);
+            if (i >= 0 && i < 24) acc[r] = acc[r] + Wp[i] * hi;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = r + 24 - 2 * q;
+            if (i >= 0 && i < 24) acc[r] = acc[r] + Wp[i] * lo;
+        }
+    }
+}
+
+// (lower, upper) outputs of eight accumulators as the two 16-byte groups a ring stores them in (pairs swapped).
+__device__ __forceinline__ void qmf8_groups(const f2 (&acc)[8], float4 (&lo)[2], float4 (&up)[2])
+{
+    float l[8], u[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        l[r] = acc[r].x + acc[r].y;
+        u[r] = acc[r].x - acc[r].y;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        lo[h] = make_float4(l[4 * h + 1], l[4 * h], l[4 * h + 3], l[4 * h + 2]);
+        up[h] = make_float4(u[4 * h + 1], u[4 * h], u[4 * h + 3], u[4 * h + 2]);
+    }
+}
+
+__device__ __forceinline__ void load_taps(const Tables* T, f2 (&Wp)[24])
+{
+#pragma unroll
+    for (int i = 0; i < 24; ++i)
+        Wp[i] = mk2(__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T->qmf_win[2 * i]))),
+                    __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(T->qmf_win[2 * i + 1]))));
+}
+
+// ---- the QMF tree of ONE CHANNEL of one stream, run by ONE wavefront ------------------------------------------------
+// 64 lanes = the 64 eight-output tasks of stage 1, then the 2 x 32 tasks of stage 2 (lanes 0..31: Qmf2 on the lower
+// half -> bands 0, 1; lanes 32..63: Qmf3 on the upper half -> bands 3, 2). The wavefront owns its rings, so stage
+// boundaries are wave-level rendezvous (LDS executes a wavefront's instructions in order): no workgroup barrier exists
+// in these kernels, and wavefronts drift apart freely - one's FIR arithmetic covers another's LDS and HBM latency.
+struct QmfLdsW {
+    float pcm[kPcmRing8];        // this channel's PCM ring
+    float s1[2 * kS1Ring8];      // stage-1 rings: lower half, upper half
+};
+
+struct QmfRunW {
+    const float2* pcm2;     // [n_blocks][1024] interleaved (L, R) of this stream
+    const float2* hist2;    // [kHist] samples before pcm (zeros at stream start)
+    int ch;
+    float4 nxt[8];          // interleaved PCM of the block after the one in the ring: lane t holds groups t + 64 w
+    float4 hist_keep;       // lanes 52..63: the last 48 samples of the tile stored last (the next block's FIR history)
+    float4 s1_keep;         // lanes 0..23: one group of stage-1 history
+};
+
+__device__ __forceinline__ float pcm_at(const QmfRunW& q, int g)   // sample g (this channel) relative to the call's first sample
+{
+    const float2 v = (g >= 0) ? q.pcm2[g] : q.hist2[kHist + g];
+    return q.ch ? v.y : v.x;
+}
+
+// Fetch the tile of block b into registers: group u = samples 4u .. 4u+3 arrive as two 16-byte loads of (L, R) pairs.
+__device__ __forceinline__ void tile_fetch(QmfRunW& q, int b, int lane)
+{
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int g = b * 1024 + 4 * (lane + 64 * w);
+        // (a block never straddles the history boundary: block starts are multiples of 1024 samples)
+        const float4* p4 = (g >= 0) ? reinterpret_cast<const float4*>(q.pcm2 + g) : reinterpret_cast<const float4*>(q.hist2 + (kHist + g));
+        q.nxt[2 * w] = p4[0];
+        q.nxt[2 * w + 1] = p4[1];
+    }
+}
+
+// Store the fetched tile into the ring (data / 4.0, exact) and keep the last 48 samples for the history.
+__device__ __forceinline__ void tile_store(QmfLdsW& S, QmfRunW& q, int lane)
+{
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float4 a = q.nxt[2 * w], b = q.nxt[2 * w + 1];   // (L0, R0, L1, R1), (L2, R2, L3, R3)
+        const float4 v = q.ch ? make_float4(a.w * 0.25f, a.y * 0.25f, b.w * 0.25f, b.y * 0.25f)
+                              : make_float4(a.z * 0.25f, a.x * 0.25f, b.z * 0.25f, b.x * 0.25f);
+        reinterpret_cast<float4*>(S.pcm)[ring8_slot<kPcmH8>(kHist8 / 4 + lane + 64 * w)] = v;
+        if (w == 3) q.hist_keep = v;
+    }
+}
+
+__device__ __forceinline__ void pcm_hist_store(QmfLdsW& S, const QmfRunW& q, int lane)
+{
+    if (lane >= 52) reinterpret_cast<float4*>(S.pcm)[ring8_slot<kPcmH8>(lane - 52)] = q.hist_keep;
+}
+
+__device__ __forceinline__ void qmf_stage1(QmfLdsW& S, const f2 (&Wp)[24], int lane)
+{
+    f2 acc[8];
+    qmf8<kPcmH8>(reinterpret_cast<const float4*>(S.pcm), lane, Wp, acc);
+    float4 lo[2], up[2];
+    qmf8_groups(acc, lo, up);
+    float4* rl = reinterpret_cast<float4*>(S.s1);
+    float4* rh = reinterpret_cast<float4*>(S.s1 + kS1Ring8);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int slot = ring8_slot<kS1H8>(kHist8 / 4 + 2 * lane + h);
+        rl[slot] = lo[h];
+        rh[slot] = up[h];
+    }
+}
+
+// Stage 2. Lane (which = lane >> 5, g = lane & 31) returns samples 8g .. 8g+7 of bands (which ? 3 : 0) in `lo` and
+// (which ? 2 : 1) in `up`.
+__device__ __forceinline__ void qmf_stage2(const QmfLdsW& S, const f2 (&Wp)[24], int lane, float (&lo)[8], float (&up)[8])
+{
+    const int which = lane >> 5, g = lane & 31;
+    f2 acc[8];
+    qmf8<kS1H8>(reinterpret_cast<const float4*>(S.s1 + which * kS1Ring8), g, Wp, acc);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        lo[r] = acc[r].x + acc[r].y;
+        up[r] = acc[r].x - acc[r].y;
+    }
+}
+
+__device__ __forceinline__ void s1_hist_fetch(const QmfLdsW& S, QmfRunW& q, int lane)
+{
+    if (lane < 24) q.s1_keep = reinterpret_cast<const float4*>(S.s1 + (lane / 12) * kS1Ring8)[ring8_slot<kS1H8>(128 + lane % 12)];
+}
+__device__ __forceinline__ void s1_hist_store(QmfLdsW& S, const QmfRunW& q, int lane)
+{
+    if (lane < 24) reinterpret_cast<float4*>(S.s1 + (lane / 12) * kS1Ring8)[ring8_slot<kS1H8>(lane % 12)] = q.s1_keep;
+}
+
+// The prologue's 144 floats of scratch sit in the body of the first stage-1 ring (behind its history slots, in front of
+// the second plane), which the first stage 1 overwrites afterwards.
+constexpr int kPrologueTmp = 16;
+static_assert(kPrologueTmp >= 12 && kPrologueTmp + 144 <= 4 * kS1H8, "prologue scratch must fit between the history and plane 1");
+
+// Prologue of a run that starts with block b0: PCM history and stage-1 history of that block, then its tile.
+// `tmp` = 144 floats of scratch. On return the tile of block b0 is in the ring; with PREFETCH block b0 + 1 is being fetched.
+template <bool PREFETCH>
+__device__ __forceinline__ void qmf_prologue(QmfLdsW& S, QmfRunW& q, float* tmp, const f2 (&Wp)[24], int b0, int b_last, int lane)
+{
+    // stage-1 outputs m = -48 .. -1 need samples -142 .. -1 (output m reads samples 2m - 46 .. 2m + 1)
+    tile_fetch(q, b0, lane);
+    float h[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) h[k] = (lane + 64 * k < 144) ? pcm_at(q, b0 * 1024 - 144 + lane + 64 * k) * 0.25f : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (lane + 64 * k < 144) tmp[lane + 64 * k] = h[k];
+    wave_sync();
+    if (lane < 48) {
+        const float* x = tmp + 144 + 2 * (lane - 48);   // output m = lane - 48; sample s sits at tmp[144 + s]
+        float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            lo += Wp[i].x * x[1 - 2 * i];
+            hi += Wp[i].y * x[-2 * i];
+        }
+        S.s1[ring8_at<kS1H8>(lane)] = lo + hi;
+        S.s1[kS1Ring8 + ring8_at<kS1H8>(lane)] = lo - hi;
+        S.pcm[ring8_at<kPcmH8>(lane)] = tmp[96 + lane];   // samples -48 .. -1
+    }
+    tile_store(S, q, lane);
+    if (PREFETCH && b0 + 1 <= b_last) tile_fetch(q, b0 + 1, lane);
+    wave_sync();
+}
+
+// ---- subband analysis only (feeds the gain-control kernels and the MDCT-from-subbands kernel) ----------------------
+// Raw L/R subbands of blocks 0 .. n_blocks-1 to HBM; blocks -2 and -1 (look-back of the gain analysis, overlap of the
+// first frame) are the previous call's last two, carried in `sub_tail` and copied in front by the run that starts at
+// block 0. One wavefront = (stream, channel, one of `sub_runs` runs of blocks); a workgroup is four independent wavefronts.
+__global__ __launch_bounds__(256) void k_qmf_sub8(FrontParams p, const Tables* T, int n_waves)
+{
+    __shared__ __attribute__((aligned(16))) QmfLdsW s_q[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int W = blockIdx.x * 4 + wave;
+    if (W >= n_waves) return;
+    QmfLdsW& S = s_q[wave];
+    const int nb2 = p.n_blocks + 2;
+    const int nchunks = p.sub_runs;   // runs per (stream, channel): the blocks are dealt out as evenly as possible
+    const int chunk = W % nchunks;
+    const int ch = (W / nchunks) & 1;
+    const int s = W / (2 * nchunks);
+    const int ba = (chunk * p.n_blocks) / nchunks;
+    const int bb = ((chunk + 1) * p.n_blocks) / nchunks;
+    const size_t sublen = (size_t)nb2 * 256;
+    if (chunk == 0) {   // 4 bands x 512 carried floats = 512 sixteen-byte words
+        const float4* src = reinterpret_cast<const float4*>(p.sub_tail + ((size_t)s * 8 + ch * 4) * 512);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = lane + 64 * k, band = i >> 7;
+            reinterpret_cast<float4*>(p.sub + ((size_t)s * 8 + ch * 4 + band) * sublen)[i & 127] = src[i];
+        }
+    }
+    f2 Wp[24];
+    load_taps(T, Wp);
+    QmfRunW q;
+    q.pcm2 = reinterpret_cast<const float2*>(p.pcm) + (size_t)s * p.n_blocks * 1024;
+    q.hist2 = reinterpret_cast<const float2*>(p.hist) + (size_t)s * kHist;
+    q.ch = ch;
+    q.s1_keep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    qmf_prologue<true>(S, q, S.s1 + kPrologueTmp, Wp, ba, bb - 1, lane);
+    const int which = lane >> 5, g = lane & 31;
+    float* out_lo = p.sub + ((size_t)s * 8 + ch * 4 + (which ? 3 : 0)) * sublen + 8 * g;
+    float* out_up = p.sub + ((size_t)s * 8 + ch * 4 + (which ? 2 : 1)) * sublen + 8 * g;
+    for (int b = ba; b < bb; ++b) {
+        if (b > ba) s1_hist_store(S, q, lane);
+        qmf_stage1(S, Wp, lane);
+        wave_sync();
+        pcm_hist_store(S, q, lane);
+        if (b + 1 < bb) tile_store(S, q, lane);          // block b + 1 (fetched during the previous block)
+        if (b + 2 < bb) tile_fetch(q, b + 2, lane);       // lands during stage 2 and the next stage 1
+        s1_hist_fetch(S, q, lane);
+        float lo[8], up[8];
+        qmf_stage2(S, Wp, lane, lo, up);
+        float4* o0 = reinterpret_cast<float4*>(out_lo + (size_t)(b + 2) * 256);
+        float4* o1 = reinterpret_cast<float4*>(out_up + (size_t)(b + 2) * 256);
+        o0[0] = make_float4(lo[0], lo[1], lo[2], lo[3]);
+        o0[1] = make_float4(lo[4], lo[5], lo[6], lo[7]);
+        o1[0] = make_float4(up[0], up[1], up[2], up[3]);
+        o1[1] = make_float4(up[4], up[5], up[6], up[7]);
+        wave_sync();
+    }
+}
+
+// ---- MDCT-512 of one (channel, band) in a 16-lane row ------------------------------------------------------------
+constexpr int kRowScratch4 = 80;   // 16-byte slots of exchange scratch per row (4 x 20: one spare 64-byte chunk per quad)
+
+__device__ __forceinline__ float dpp_row_mirror(float v)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xf, 0xf, false));
+}
+
+// Per-lane constants of the row transform. They depend on the lane's position in its row only (L = 4 q1 + q2), so one
+// table of 18 sixteen-byte entries per L serves every row of a workgroup; entry e of lane L sits at [e][L], which a
+// wavefront reads as sixteen consecutive slots (its four rows read the same sixteen).
+//   0..3    EncodeWindow at {e, 128+e, 127-e, 255-e}, e = 2 b + 32 q3, b = q1 + 4 q2          (q3 = entry)
+//   4..7    (cos, sin) of the FFT inputs n2 = b + 16 q3 and n2 = b + 16 q3 + 64                  (q3 = entry - 4)
+//   8..11   (cos, sin) of the output bins n2 = 8 q1 + 2 q2 + kappa + 32 i', kappa = 0, 1        (i' = entry - 8)
+//   12..14  pass m = 8 twiddles tw[4 j k], k = 2 q2 + kappa, kappa = 0, 1                         (j = entry - 11)
+//   15..17  pass m = 32 twiddles tw[j k], k = 8 q1 + 2 q2 + kappa                                 (j = entry - 14)
+struct MdctTab {
+    float4 e[18][16];
+};
+
+// Built by all threads of the workgroup; the caller synchronises before the first use.
+__device__ __forceinline__ void mdct_tab_build(MdctTab& tab, const Tables* T, int tid, int nthr)
+{
+    for (int idx = tid; idx < 18 * 16; idx += nthr) {
+        const int en = idx >> 4, L = idx & 15;
+        const int q1 = L >> 2, q2 = L & 3, b = q1 + 4 * q2;
+        float4 v;
+        if (en < 4) {
+            const int e = 2 * b + 32 * en;
+            v = make_float4(T->enc_win[e], T->enc_win[128 + e], T->enc_win[127 - e], T->enc_win[255 - e]);
+        } else if (en < 8) {
+            const int n = 2 * (b + 16 * (en - 4));
+            v = make_float4(T->mdct_sincos[n], T->mdct_sincos[n + 1], T->mdct_sincos[n + 128], T->mdct_sincos[n + 129]);
+        } else if (en < 12) {
+            const int n = 2 * (8 * q1 + 2 * q2 + 32 * (en - 8));
+            v = make_float4(T->mdct_sincos[n], T->mdct_sincos[n + 1], T->mdct_sincos[n + 2], T->mdct_sincos[n + 3]);
+        } else if (en < 15) {
+            const int j = en - 11, k = 2 * q2;
+            const cpx a = T->tw128[4 * j * k], c = T->tw128[4 * j * (k + 1)];
+            v = make_float4(a.r, a.i, c.r, c.i);
+        } else {
+            const int j = en - 14, k = 8 * q1 + 2 * q2;
+            const cpx a = T->tw128[j * k], c = T->tw128[j * (k + 1)];
+            v = make_float4(a.r, a.i, c.r, c.i);
+        }
+        tab.e[en][L] = v;
+    }
+}
+
+// The lane's sixteen samples from its row's 256. The lane reads the even-index pairs (x[i], x[i+1]) at i = e and
+// i = 128 + e (e = 2 b + 32 q3) - row_load - and the odd-index two of every q3 arrive from the mirror lane - row_finish.
+// `rd2(i)` returns the two consecutive floats (x[i], x[i+1]), i even. All lanes of the wavefront call row_finish.
+struct RowRaw {
+    f2 r0[4], r1[4];
+};
+template <typename Rd2>
+__device__ __forceinline__ void row_load(Rd2 rd2, int b, RowRaw& r)
+{
+#pragma unroll
+    for (int q3 = 0; q3 < 4; ++q3) {
+        const int e = 2 * b + 32 * q3;
+        r.r0[q3] = rd2(e);
+        r.r1[q3] = rd2(128 + e);
+    }
+}
+__device__ __forceinline__ void row_finish(const RowRaw& r, float (&X)[4][4])
+{
+#pragma unroll
+    for (int q3 = 0; q3 < 4; ++q3) {
+        X[q3][0] = r.r0[q3].x;
+        X[q3][1] = r.r1[q3].x;
+        // x[e + 1] is the mirror lane's x[127 - e''] at q3'' = 3 - q3, x[129 + e] its x[255 - e'']
+        X[q3][2] = dpp_row_mirror(r.r0[3 - q3].y);
+        X[q3][3] = dpp_row_mirror(r.r1[3 - q3].y);
+    }
+}
+template <typename Rd2>
+__device__ __forceinline__ void row_gather(Rd2 rd2, int b, float (&X)[4][4])
+{
+    RowRaw r;
+    row_load(rd2, b, r);
+    row_finish(r, X);
+}
+
+// Divisors of TGainProcessor::Modulate (gain_processor.h:93-112) for the eight samples of cell `cell / 8`: level
+// boundaries and the 8-sample ramps are aligned to these cells, so a cell is untouched (1.0), divided by one level or by
+// one running-product ramp. `cv` should be read in place (LDS).
+__device__ __forceinline__ void cell_divisors(const Curve& cv, const float* gain_interp, int cell, float (&d)[8])
+{
+    int kind = 0;
+    float lvl = 1.0f, inc = 1.0f;
+    int pos = 0;
+    for (int q = 0; q < cv.n; ++q) {
+        const int lastPos = (int)cv.loc[q] << 3;
+        if (cell >= pos && cell < lastPos) {
+            kind = 1;
+            lvl = gain_level_of(cv.level[q]);
+            break;
+        }
+        if (lastPos > pos) pos = lastPos;
+        if (pos < lastPos + 8) {
+            if (cell >= pos && cell < lastPos + 8) {
+                kind = 2;
+                lvl = gain_level_of(cv.level[q]);
+                inc = gain_interp[((q + 1) < cv.n ? (int)cv.level[q + 1] : 4) - (int)cv.level[q] + 15];
+                break;
+            }
+            pos = lastPos + 8;
+        }
+    }
+    float v = (kind == 0) ? 1.0f : lvl;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        d[k] = v;
+        if (kind == 2) v *= inc;
+    }
+}
+
+__device__ __forceinline__ f2 f2lo(float4 v) { return mk2(v.x, v.y); }
+__device__ __forceinline__ f2 f2hi(float4 v) { return mk2(v.z, v.w); }
+// (a.x * c + a.y * s, a.y * c - a.x * s): the pre-rotation of mdct.h:76-86 as three packed operations
+__device__ __forceinline__ f2 rot_pre(f2 a, f2 cs)
+{
+    const f2 t1 = a * mk2(cs.x, cs.x);
+    const f2 t2 = mk2(a.y, a.x) * mk2(cs.y, cs.y);
+    return mk2(t1.x + t2.x, t1.y - t2.y);
+}
+
+// One frame of one row. X = the new half's samples (after M/S matrixing and gain modulation) indexed [q3][{e, 128+e,
+// 127-e, 255-e}]; pw = the windowed overlap, same indexing, carried in registers from frame to frame; `inv_scale` =
+// 1 / GainLevel[first point] when the frame's curve is non-empty (the overlap half is divided by that level,
+// gain_processor.h:87-121), else 1. `scratch` = the row's kRowScratch4 16-byte slots. Returns the lane's sixteen
+// spectral lines as four runs of four consecutive lines: run i' starts at line 16 q1 + 4 q2 + 64 i' (natural order).
+// WAVE-UNIFORM: every lane of the wavefront must call (DPP and wave-level rendezvous inside).
+__device__ __forceinline__ void mdct_row_frame(const MdctTab& tab, const f2 (&tw2)[3], float (&pw)[4][4], const float (&X)[4][4], float inv_scale,
+                                               float4* scratch, int L, bool emit, float4 (&lines)[4])
+{
+    const int q1 = L >> 2, q2 = L & 3;
+    f2 z[8];   // element j = 2 q3 + q4 of the lane's 8-point sub-transform
+#pragma unroll
+    for (int q3 = 0; q3 < 4; ++q3) {
+        const float4 w = tab.e[q3][L];
+        const float p0 = pw[q3][0] * inv_scale, p1 = pw[q3][1] * inv_scale, p2 = pw[q3][2] * inv_scale, p3 = pw[q3][3] * inv_scale;
+        // next frame's overlap = EncodeWindow[i] * new[i] (atrac3denc.cpp:47)
+        pw[q3][0] = w.x * X[q3][0];
+        pw[q3][1] = w.y * X[q3][1];
+        pw[q3][2] = w.z * X[q3][2];
+        pw[q3][3] = w.w * X[q3][3];
+        if (emit) {
+            // fold (mdct.h:64-86): n = e < 128 and n = 128 + e
+            const float r0a = w.y * X[q3][2] + w.z * X[q3][1];
+            const float i0a = p1 - p2;
+            const float r0b = p3 - p0;
+            const float i0b = w.w * X[q3][0] + w.x * X[q3][3];
+            const float4 cs = tab.e[4 + q3][L];
+            z[2 * q3] = rot_pre(mk2(r0a, i0a), f2lo(cs));
+            z[2 * q3 + 1] = rot_pre(mk2(r0b, i0b), f2hi(cs));
+        }
+    }
+    if (!emit) return;   // priming block: only the overlap is wanted (uniform per wavefront)
+    // radix-2 leaves (m = 1, twiddle tw[0]) and the m = 2 pass (butterfly k on elements k, k+2, k+4, k+6)
+    {
+        const f2 w0 = mk2(1.0f, 0.0f);   // tw128[0] = (cos 0, sin 0)
+#pragma unroll
+        for (int q3 = 0; q3 < 4; ++q3) bfly2(z[2 * q3], z[2 * q3 + 1], w0);
+        bfly4<false>(z[0], z[2], z[4], z[6], w0, w0, w0);
+        bfly4<false>(z[1], z[3], z[5], z[7], tw2[0], tw2[1], tw2[2]);
+    }
+    // exchange 1: butterfly k = 2 q2 + kappa of the m = 8 pass takes element k of the four lanes of the quad
+    {
+        float4* w = scratch + 20 * q1 + 4 * q2;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) w[jj ^ q2] = make_float4(z[2 * jj].x, z[2 * jj].y, z[2 * jj + 1].x, z[2 * jj + 1].y);
+    }
+    wave_sync();
+    f2 y[2][4];   // [kappa][i]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = scratch[20 * q1 + 4 * i + (q2 ^ i)];
+        y[0][i] = f2lo(v);
+        y[1][i] = f2hi(v);
+    }
+    wave_sync();
+    {
+        const float4 t1 = tab.e[12][L], t2 = tab.e[13][L], t3 = tab.e[14][L];
+        bfly4<false>(y[0][0], y[0][1], y[0][2], y[0][3], f2lo(t1), f2lo(t2), f2lo(t3));
+        bfly4<false>(y[1][0], y[1][1], y[1][2], y[1][3], f2hi(t1), f2hi(t2), f2hi(t3));
+    }
+    // exchange 2: butterfly k = 8 a + 2 q2 + kappa of the m = 32 pass takes (kappa, i = a) of the lanes (i', q2)
+    {
+        float4* w = scratch + 20 * q2 + 4 * q1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i ^ q1] = make_float4(y[0][i].x, y[0][i].y, y[1][i].x, y[1][i].y);
+    }
+    wave_sync();
+    f2 u[2][4];   // [kappa][i']
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) {
+        const float4 v = scratch[20 * q2 + 4 * ip + (q1 ^ ip)];
+        u[0][ip] = f2lo(v);
+        u[1][ip] = f2hi(v);
+    }
+    wave_sync();
+    {
+        const float4 t1 = tab.e[15][L], t2 = tab.e[16][L], t3 = tab.e[17][L];
+        bfly4<false>(u[0][0], u[0][1], u[0][2], u[0][3], f2lo(t1), f2lo(t2), f2lo(t3));
+        bfly4<false>(u[1][0], u[1][1], u[1][2], u[1][3], f2hi(t1), f2hi(t2), f2hi(t3));
+    }
+    // post-rotation (mdct.h:92-101): bin n2 -> line 2 n2 (E) and line 255 - 2 n2 (O)
+    float E[2][4], O[2][4];
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) {
+        const float4 cs = tab.e[8 + ip][L];
+#pragma unroll
+        for (int kap = 0; kap < 2; ++kap) {
+            const float r0 = u[kap][ip].x, i0 = u[kap][ip].y;
+            const float cc = kap ? cs.z : cs.x, ss = kap ? cs.w : cs.y;
+            E[kap][ip] = -r0 * cc - i0 * ss;
+            O[kap][ip] = -r0 * ss + i0 * cc;
+        }
+    }
+    // lines 2B + 64 i' .. + 3 (B = 8 q1 + 2 q2) = E[0][i'], mirror O[1][3 - i'], E[1][i'], mirror O[0][3 - i']
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) {
+        const float o1 = dpp_row_mirror(O[1][3 - ip]);
+        const float o0 = dpp_row_mirror(O[0][3 - ip]);
+        lines[ip] = make_float4(E[0][ip], o1, E[1][ip], o0);
+    }
+}
+
+// Store a row's spectrum: odd bands are reversed (atrac3denc.cpp:53-55).
+__device__ __forceinline__ void mdct_row_store(float* dst256, const float4 (&lines)[4], int L, bool odd)
+{
+    const int base = 16 * (L >> 2) + 4 * (L & 3);
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) {
+        const int line = base + 64 * ip;
+        const float4 v = lines[ip];
+        if (odd) *reinterpret_cast<float4*>(dst256 + 252 - line) = make_float4(v.w, v.z, v.y, v.x);
+        else *reinterpret_cast<float4*>(dst256 + line) = v;
+    }
+}
+
+// ---- MDCT from subbands in HBM (the gain-control path: k_qmf_sub8 wrote them for the gain analysis anyway) -----------
+// One wavefront = the four bands of one (stream, channel) over a run of frames; no workgroup barrier after the table is
+// built. A workgroup is four independent wavefronts. With joint stereo both channels' subbands are read and matrixed.
+struct MdctSubParams {
+    const float* sub;        // [S][2][4][(n_blocks+2)*256]
+    const Curve* curves;     // [S][n_blocks][2][4] by frame index, or null (no gain control)
+    const BandState* state;  // [S][2][4]: prev_curve = curve of frame -1
+    float* specs;            // [S][n_out][2][1024]
+    int n_blocks, f0, frame_runs, js, n_waves;
+};
+
+// Request block f - 1 (frame f's new half) of the lane's row: own channel, or both channels for the M/S matrixing.
+__device__ __forceinline__ void rows_request(const float* sb_own, const float* sb_l, const float* sb_r, int js, int f, int b, RowRaw& ra, RowRaw& rb)
+{
+    const size_t off = (size_t)(f + 1) * 256;   // block f - 1 lives at (f - 1 + 2) * 256
+    const float* pa = (js ? sb_l : sb_own) + off;
+#pragma unroll
+    for (int q3 = 0; q3 < 4; ++q3) {
+        const int e = 2 * b + 32 * q3;
+        ra.r0[q3] = *reinterpret_cast<const f2*>(pa + e);
+        ra.r1[q3] = *reinterpret_cast<const f2*>(pa + 128 + e);
+    }
+    if (js) {
+        const float* pb = sb_r + off;
+#pragma unroll
+        for (int q3 = 0; q3 < 4; ++q3) {
+            const int e = 2 * b + 32 * q3;
+            rb.r0[q3] = *reinterpret_cast<const f2*>(pb + e);
+            rb.r1[q3] = *reinterpret_cast<const f2*>(pb + 128 + e);
+        }
+    }
+}
+
+template <bool JS>
+__global__ __launch_bounds__(256) void k_mdct_sub(MdctSubParams p, const Tables* T)
+{
+    __shared__ __attribute__((aligned(16))) MdctTab s_tab;
+    __shared__ __attribute__((aligned(16))) float4 s_x[4][4 * kRowScratch4];   // exchange scratch; also the rows' divisor tables
+    __shared__ __attribute__((aligned(16))) Curve s_cv[4][4];
+    __shared__ float s_gi[32];
+    static_assert(kRowScratch4 * 4 >= 256, "a row's 256 divisors share its exchange scratch");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < 32) s_gi[tid] = T->gain_interp[tid < 31 ? tid : 30];
+    mdct_tab_build(s_tab, T, tid, 256);
+    __syncthreads();   // the only workgroup-level rendezvous: the shared tables
+    const int W = blockIdx.x * 4 + wave;
+    if (W >= p.n_waves) return;
+    const int n_out = p.n_blocks - p.f0;
+    const int nchunks = p.frame_runs;   // runs per (stream, channel): the n_out frames are dealt out as evenly as possible
+    const int chunk = W % nchunks;
+    const int ch = (W / nchunks) & 1;
+    const int s = W / (2 * nchunks);
+    const int fa = p.f0 + (chunk * n_out) / nchunks;
+    const int fb = p.f0 + ((chunk + 1) * n_out) / nchunks;
+    const int band = lane >> 4, L = lane & 15;
+    const int b = (L >> 2) + 4 * (L & 3);
+    float pw[4][4];
+#pragma unroll
+    for (int q3 = 0; q3 < 4; ++q3)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[q3][k] = 0.0f;
+    f2 tw2[3];   // pass m = 2, butterfly k = 1: tw128[16 j], wave-uniform
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tw2[j] = ld2(T->tw128 + 16 * (j + 1));
+    const size_t sublen = (size_t)(p.n_blocks + 2) * 256;
+    const float* sb_own = p.sub + ((size_t)s * 8 + ch * 4 + band) * sublen;
+    const float* sb_l = p.sub + ((size_t)s * 8 + band) * sublen;
+    const float* sb_r = p.sub + ((size_t)s * 8 + 4 + band) * sublen;
+    float4* scratch = s_x[wave] + band * kRowScratch4;
+    float* divs = reinterpret_cast<float*>(scratch);
+    Curve& cv = s_cv[wave][band];
+    float* spec_base = p.specs + ((size_t)s * n_out * 2 + ch) * 1024 + band * 256;
+    // block f - 1 is frame f's new half; block fa - 2 primes the overlap of the run (modulated by frame fa - 1's curve).
+    // The subbands of the next block are requested before the current one is transformed: a wavefront waits for HBM once.
+    RowRaw raw_a, raw_b;
+    rows_request(sb_own, sb_l, sb_r, JS, fa - 1, b, raw_a, raw_b);
+    for (int f = fa - 1; f < fb; ++f) {
+        const bool emit = f >= fa;
+        float X[4][4];
+        if (JS) {
+            float XL[4][4], XR[4][4];
+            row_finish(raw_a, XL);
+            row_finish(raw_b, XR);
+#pragma unroll
+            for (int q3 = 0; q3 < 4; ++q3)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) X[q3][k] = ch ? (XL[q3][k] - XR[q3][k]) * 0.5f : (XL[q3][k] + XR[q3][k]) * 0.5f;
+        } else {
+            row_finish(raw_a, X);
+        }
+        if (f + 1 < fb) rows_request(sb_own, sb_l, sb_r, JS, f + 1, b, raw_a, raw_b);
+        float inv_scale = 1.0f;
+        if (p.curves) {
+            // the frame's curve: 16 bytes per row, kept in LDS so that its point list can be walked with run-time indices
+            if (L == 0) {
+                const uint4 c4 = *reinterpret_cast<const uint4*>((f < 0) ? &p.state[(size_t)s * 8 + ch * 4 + band].prev_curve
+                                                                         : &p.curves[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + band]);
+                *reinterpret_cast<uint4*>(&cv) = c4;
+            }
+            wave_sync();
+            const bool has_curve = cv.n > 0;
+            if (__ballot(has_curve) != 0ull) {   // rare on stationary material, the rule on transients
+                if (has_curve) {
+                    inv_scale = __uint_as_float((uint32_t)(127 - 4 + cv.level[0]) << 23);   // 1 / GainLevel[level[0]], a power of two
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        float d[8];
+                        cell_divisors(cv, s_gi, 8 * (2 * L + c2), d);
+                        float4* dst = reinterpret_cast<float4*>(divs + 16 * L + 8 * c2);
+                        dst[0] = make_float4(d[0], d[1], d[2], d[3]);
+                        dst[1] = make_float4(d[4], d[5], d[6], d[7]);
+                    }
+                }
+                wave_sync();
+                float D[4][4];
+                row_gather([&](int i) { return has_curve ? *reinterpret_cast<const f2*>(divs + i) : mk2(1.0f, 1.0f); }, b, D);
+                wave_sync();
+                if (has_curve) {
+#pragma unroll
+                    for (int q3 = 0; q3 < 4; ++q3)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) X[q3][k] = X[q3][k] / D[q3][k];
+                }
+            }
+        }
+        float4 lines[4];
+        mdct_row_frame(s_tab, tw2, pw, X, emit ? inv_scale : 1.0f, scratch, L, emit, lines);
+        if (emit) mdct_row_store(spec_base + (size_t)(f - p.f0) * 2048, lines, L, band & 1);
+    }
+}
+
+// ---- fused QMF + MDCT (no gain control, discrete stereo): ONE wavefront per (stream, channel, run of frames) ---------
+// Block b carries frame f = b + 1; the two blocks before the run's first frame prime the FIR histories and the MDCT
+// overlap. The wavefront runs stage 1, stage 2 and the four bands' transforms of a block back to back; its subbands
+// and exchange scratch reuse the rings that are dead at that point (the PCM ring after stage 1, the stage-1 rings after
+// stage 2), 10 KB of LDS per wavefront in all. A workgroup is four independent wavefronts sharing the MDCT table.
+__global__ __launch_bounds__(256) void k_qmf_mdct8(FrontParams p, const Tables* T, int n_waves)
+{
+    __shared__ __attribute__((aligned(16))) MdctTab s_tab;
+    __shared__ __attribute__((aligned(16))) QmfLdsW s_q[4];
+    static_assert(sizeof(float) * kPcmRing8 >= sizeof(float) * 4 * 264, "the block's subbands reuse the PCM ring");
+    static_assert(sizeof(float) * 2 * kS1Ring8 >= sizeof(float4) * 4 * kRowScratch4, "the exchange scratch reuses the stage-1 rings");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    mdct_tab_build(s_tab, T, tid, 256);
+    __syncthreads();   // the only workgroup-level rendezvous: the shared table
+    const int W = blockIdx.x * 4 + wave;
+    if (W >= n_waves) return;
+    QmfLdsW& S = s_q[wave];
+    const int n_out = p.n_blocks - p.f0;
+    const int nchunks = p.frame_runs;   // runs per (stream, channel): the n_out frames are dealt out as evenly as possible
+    const int chunk = W % nchunks;
+    const int ch = (W / nchunks) & 1;
+    const int s = W / (2 * nchunks);
+    const int fa = p.f0 + (chunk * n_out) / nchunks;
+    const int fb = p.f0 + ((chunk + 1) * n_out) / nchunks;
+    f2 Wp[24];
+    load_taps(T, Wp);
+    QmfRunW q;
+    q.pcm2 = reinterpret_cast<const float2*>(p.pcm) + (size_t)s * p.n_blocks * 1024;
+    q.hist2 = reinterpret_cast<const float2*>(p.hist) + (size_t)s * kHist;
+    q.ch = ch;
+    q.s1_keep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int band = lane >> 4, L = lane & 15;
+    const int b = (L >> 2) + 4 * (L & 3);
+    float pw[4][4];
+#pragma unroll
+    for (int q3 = 0; q3 < 4; ++q3)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[q3][k] = 0.0f;
+    f2 tw2[3];   // pass m = 2, butterfly k = 1: tw128[16 j], wave-uniform
+#pragma unroll
+    for (int j = 0; j < 3; ++j) tw2[j] = ld2(T->tw128 + 16 * (j + 1));
+    float (*sub)[264] = reinterpret_cast<float (*)[264]>(S.pcm);            // [band][256 + pad], after stage 1
+    float4* scratch = reinterpret_cast<float4*>(S.s1) + band * kRowScratch4;   // after stage 2
+    const int b0 = fa - 2, b_last = fb - 2;
+    qmf_prologue<false>(S, q, S.s1 + kPrologueTmp, Wp, b0, b_last, lane);
+    float* spec_base = p.specs + ((size_t)s * n_out * 2 + ch) * 1024 + band * 256;
+    const int which = lane >> 5, g = lane & 31;
+    for (int blk = b0; blk <= b_last; ++blk) {
+        if (blk > b0) {
+            // the ring held the previous block's subbands until its transform had gathered them: now the tile
+            // (fetched one block ago) and the FIR histories move in
+            pcm_hist_store(S, q, lane);   // the tail of the previous tile, before tile_store replaces the copy in registers
+            tile_store(S, q, lane);
+            s1_hist_store(S, q, lane);
+            wave_sync();
+        }
+        if (blk + 1 <= b_last) tile_fetch(q, blk + 1, lane);   // lands during this block's arithmetic
+        qmf_stage1(S, Wp, lane);
+        wave_sync();
+        s1_hist_fetch(S, q, lane);
+        {
+            float lo[8], up[8];
+            qmf_stage2(S, Wp, lane, lo, up);
+            wave_sync();   // every lane is done with the rings (the exchange scratch and the subbands overwrite them)
+            float4* o0 = reinterpret_cast<float4*>(&sub[which ? 3 : 0][8 * g]);
+            float4* o1 = reinterpret_cast<float4*>(&sub[which ? 2 : 1][8 * g]);
+            o0[0] = make_float4(lo[0], lo[1], lo[2], lo[3]);
+            o0[1] = make_float4(lo[4], lo[5], lo[6], lo[7]);
+            o1[0] = make_float4(up[0], up[1], up[2], up[3]);
+            o1[1] = make_float4(up[4], up[5], up[6], up[7]);
+        }
+        wave_sync();
+        {
+            const int f = blk + 1;
+            float X[4][4];
+            row_gather([&](int i) { return *reinterpret_cast<const f2*>(&sub[band][i]); }, b, X);
+            wave_sync();
+            const bool emit = f >= fa;
+            float4 lines[4];
+            mdct_row_frame(s_tab, tw2, pw, X, 1.0f, scratch, L, emit, lines);
+            if (emit) mdct_row_store(spec_base + (size_t)(f - p.f0) * 2048, lines, L, band & 1);
+        }
+    }
+}
+
+}  // namespace at3

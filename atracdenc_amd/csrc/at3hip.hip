@@ -13,6 +13,7 @@
 #include "at3_host_util.hpp"
 #include "at3_k_backend.hpp"
 #include "at3_k_frontend.hpp"
+#include "at3_k_front2.hpp"
 #include "at3_k_gain.hpp"
 
 using namespace at3;
@@ -53,9 +54,10 @@ struct at3hip_ctx {
     bool slot_has_frames[kSlots] = {};
     char err[256] = {0};
     long long blocks_fed = 0;   // per stream
-    int frames_per_wg = 0;
+    int runs_override = 0;   // AT3HIP_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
     int n_cus = 256;
-    int wgs_per_cu = 3;   // resident workgroups of the fused front-end kernel per CU
+    int wgs_per_cu = 3;        // resident workgroups per CU of the QMF kernel this context uses (k_qmf_sub8 or the fused one)
+    int wgs_per_cu_mdct = 3;   // the same of k_mdct_sub
     int dbg_front = 0, dbg_gain = 0, dbg_stop = 0;   // AT3HIP_DEBUG_* (profiling aids), honoured by -DAT3HIP_DEBUG_KNOBS builds only
 
     Tables* d_tables = nullptr;
@@ -64,6 +66,7 @@ struct at3hip_ctx {
     float* d_hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
     float* d_sub = nullptr;
+    float* d_sub_tail = nullptr;     // [S][8][512] subbands of the last two blocks of the previous call
     GainRec* d_rec = nullptr;
     BandState* d_state = nullptr;
     Curve* d_curves[2] = {nullptr, nullptr};   // by call parity
@@ -147,20 +150,33 @@ void read_timings(const at3hip_ctx* c, int slot, at3hip_timings* tm)
     tm->qmf_mdct_launches = 1;
 }
 
-// Frames per workgroup run of the fused kernel: long runs amortise the one-block prologue, short runs keep
-// every CU busy on small batches (four workgroups are resident per CU).
-int pick_frames_per_wg(const at3hip_ctx* c, int n_out)
+// Runs per (stream, channel) for the wavefront-per-run kernels (QMF, MDCT, fused): `items` blocks or frames are cut
+// into runs of at most 32, one wavefront each. A run costs its items plus a prologue of `prologue` items (FIR histories,
+// overlap priming); a SIMD with w resident wavefronts issues at roughly eff(w) of its peak. The run count with the
+// smallest estimated time wins: small batches get as many equal runs as one round of the grid holds, large batches long
+// runs.
+int pick_runs(const at3hip_ctx* c, int items, int wgs_per_cu, double prologue)
 {
-    if (c->frames_per_wg > 0) return c->frames_per_wg;
-    // cut every stream into as many runs as fit in ONE round of the grid (a partial second round would double the
-    // kernel time on small batches); wgs_per_cu is the occupancy the runtime reports for the fused kernel
-    const long long slots = (long long)c->n_cus * c->wgs_per_cu;
-    long long runs_per_stream = slots / c->cfg.n_streams;
-    if (runs_per_stream < 1) runs_per_stream = 1;
-    long long f = (n_out + runs_per_stream - 1) / runs_per_stream;
-    if (f < 1) f = 1;
-    if (f > 32) f = 32;
-    return (int)f;
+    if (c->runs_override > 0) return c->runs_override < items ? c->runs_override : items;
+    const long long pairs = 2LL * c->cfg.n_streams;   // (stream, channel)
+    const long long simds = (long long)c->n_cus * 4;
+    const int cap = wgs_per_cu;                        // resident wavefronts per SIMD (a workgroup is one per SIMD)
+    static const double eff[5] = {0.0, 0.55, 0.85, 0.95, 1.0};
+    int best = 1;
+    double best_t = 1e300;
+    const int r_min = (items + 31) / 32;
+    for (int r = r_min; r <= items && r <= 128; ++r) {
+        const long long waves = pairs * r;
+        const long long per_simd = (waves + simds - 1) / simds;   // the fullest SIMD
+        const double work = (double)((items + r - 1) / r) + prologue;   // the longest run
+        const long long resident = per_simd < cap ? per_simd : cap;
+        const double t = (double)per_simd * work / eff[resident > 4 ? 4 : resident];
+        if (t < best_t * 0.999) {
+            best_t = t;
+            best = r;
+        }
+    }
+    return best;
 }
 
 int reset_state(at3hip_ctx* c)
@@ -169,6 +185,7 @@ int reset_state(at3hip_ctx* c)
     HIPCHK(c, hipMemsetAsync(c->d_hist[0], 0, S * kHist * 2 * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_hist[1], 0, S * kHist * 2 * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_state, 0, S * 8 * sizeof(BandState), c->stream));
+    if (c->d_sub_tail) HIPCHK(c, hipMemsetAsync(c->d_sub_tail, 0, S * 8 * 512 * sizeof(float), c->stream));   // silence before the stream
     float* init = (float*)malloc(S * sizeof(float));
     if (!init) return fail(c, AT3HIP_ENOMEM, "malloc");
     for (size_t i = 0; i < S; ++i) init[i] = 0.006f;  // LoudFactor, atrac3denc.h:115-116
@@ -252,8 +269,13 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if (cfg->channels == 1 && (rc = dev_alloc(c, &c->d_pcm_mono, S * B * 1024)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_hist[0], S * kHist * 2)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_hist[1], S * kHist * 2)) != AT3HIP_OK) return bail(rc);
-    if (!cfg->no_gain_control) {
+    // subbands go through HBM when gain control analyses them, and for joint stereo (the M/S matrixing needs both channels'
+    // subbands, which the one-channel wavefronts of the fused kernel do not have)
+    if (!cfg->no_gain_control || c->js) {
         if ((rc = dev_alloc(c, &c->d_sub, S * 8 * (B + 2) * 256)) != AT3HIP_OK) return bail(rc);
+        if ((rc = dev_alloc(c, &c->d_sub_tail, S * 8 * 512)) != AT3HIP_OK) return bail(rc);
+    }
+    if (!cfg->no_gain_control) {
         if ((rc = dev_alloc(c, &c->d_rec, S * B * 6)) != AT3HIP_OK) return bail(rc);
         for (int q = 0; q < 2; ++q)
             if ((rc = dev_alloc(c, &c->d_ges[q], S * B * 8)) != AT3HIP_OK) return bail(rc);
@@ -270,17 +292,19 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_quant, S * B * 2)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_mant, S * B * 2 * 7168)) != AT3HIP_OK) return bail(rc);
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
-    const char* fpw = getenv("AT3HIP_FRAMES_PER_WG");
-    c->frames_per_wg = (fpw && atoi(fpw) > 0) ? atoi(fpw) : 0;   // 0 = choose per call
-    if (c->frames_per_wg > 32) c->frames_per_wg = 32;
+    const char* runs_env = getenv("AT3HIP_RUNS");
+    c->runs_override = (runs_env && atoi(runs_env) > 0) ? atoi(runs_env) : 0;   // 0 = choose per call
     hipDeviceProp_t prop;
     c->n_cus = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     {
         int nb = 0;
         const bool gain = !c->cfg.no_gain_control;
-        const hipError_t e = gain ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_mdct<true>, 256, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_mdct<false>, 256, 0);
+        const hipError_t e = (gain || c->js) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_sub8, 256, 0)
+                                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_mdct8, 256, 0);
         c->wgs_per_cu = (e == hipSuccess && nb > 0) ? nb : 3;
+        nb = 0;
+        c->wgs_per_cu_mdct = ((c->js ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mdct_sub<true>, 256, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mdct_sub<false>, 256, 0)) == hipSuccess && nb > 0) ? nb : 3;
     }
     *out = c;
     return AT3HIP_OK;
@@ -296,7 +320,7 @@ void at3hip_destroy(at3hip_ctx* c)
     if (c->back_stream) (void)hipStreamSynchronize(c->back_stream);
     void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
                     c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
-                    c->d_out,       c->d_quant,     c->d_mant,     c->d_pcm_mono,  c->d_stage};
+                    c->d_out,       c->d_quant,     c->d_mant,     c->d_pcm_mono,  c->d_stage,    c->d_sub_tail};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& row : c->ev)
@@ -389,6 +413,20 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     if (c->back_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_back_done[par], 0));
     HIPCHK(c, hipEventRecord(ev[0], st));
     HIPCHK(c, hipMemsetAsync(d_curves, 0, (size_t)S * n_blocks * 8 * sizeof(Curve), st));
+    if (n_out == 0 && (gain || c->js)) {
+        // a call that only primes the look-ahead still has to leave its subbands behind for the next call's look-back
+        FrontParams fp = {};
+        fp.pcm = d_pcm;
+        fp.hist = hist;
+        fp.sub = c->d_sub;
+        fp.sub_tail = c->d_sub_tail;
+        fp.n_blocks = n_blocks;
+        fp.f0 = f0;
+        fp.js = c->js;
+        fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35);
+        const int n_waves = S * 2 * fp.sub_runs;
+        hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
+    }
     if (n_out > 0) {
         FrontParams fp;
         fp.pcm = d_pcm;
@@ -398,11 +436,19 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         fp.specs = d_specs;
         fp.ges = d_ges;
         fp.sub = c->d_sub;
+        fp.sub_tail = c->d_sub_tail;
         fp.n_blocks = n_blocks;
         fp.f0 = f0;
-        fp.frames_per_wg = pick_frames_per_wg(c, n_out);
+        fp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu, 1.35);
+        fp.sub_runs = 0;
         fp.debug = c->dbg_front;
         fp.js = c->js;
+        const bool split = gain || c->js;   // QMF and MDCT as two kernels with the subbands in HBM between them
+        auto launch_qmf_sub = [&] {
+            fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35);
+            const int n_waves = S * 2 * fp.sub_runs;   // one wavefront per (stream, channel, run)
+            hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
+        };
         if (gain) {
             GainParams gp;
             gp.sub = c->d_sub;
@@ -414,16 +460,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.js = c->js;
             gp.n_streams = S;
             gp.debug = c->dbg_gain;
-            {   // one round of workgroups over the chip, like the fused kernel
-                const int slots = c->n_cus * c->wgs_per_cu;
-                int runs = slots / S;
-                if (runs < 1) runs = 1;
-                int bpw = (n_blocks + 2 + runs - 1) / runs;
-                if (bpw < 1) bpw = 1;
-                fp.sub_blocks_per_wg = bpw;
-                const int nch = (n_blocks + 2 + bpw - 1) / bpw;
-                hipLaunchKernelGGL(k_qmf_sub, dim3(S * nch), dim3(256), 0, st, fp, c->d_tables);
-            }
+            launch_qmf_sub();
             HIPCHK(c, hipEventRecord(ev[1], st));
             hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), 0, st, gp, c->d_tables);
             HIPCHK(c, hipEventRecord(ev[2], st));
@@ -431,14 +468,29 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), 0, st, gp, c->d_tables, S);
             hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), 0, st, fp, c->d_tables, S * n_out);
         } else {
-            fp.sub_blocks_per_wg = 0;
             HIPCHK(c, hipEventRecord(ev[1], st));
             HIPCHK(c, hipEventRecord(ev[2], st));
         }
         HIPCHK(c, hipEventRecord(ev[3], st));
-        const int nchunks = (n_out + fp.frames_per_wg - 1) / fp.frames_per_wg;
-        if (gain) hipLaunchKernelGGL(k_qmf_mdct<true>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
-        else hipLaunchKernelGGL(k_qmf_mdct<false>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
+        if (split) {
+            // with gain control the subbands are in HBM already (k_qmf_sub8 wrote them for the gain analysis)
+            if (!gain) launch_qmf_sub();
+            MdctSubParams mp;
+            mp.sub = c->d_sub;
+            mp.curves = gain ? d_curves : nullptr;
+            mp.state = c->d_state;
+            mp.specs = d_specs;
+            mp.n_blocks = n_blocks;
+            mp.f0 = f0;
+            mp.js = c->js;
+            mp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu_mdct, 0.3);
+            mp.n_waves = S * 2 * mp.frame_runs;
+            if (c->js) hipLaunchKernelGGL(k_mdct_sub<true>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, st, mp, c->d_tables);
+            else hipLaunchKernelGGL(k_mdct_sub<false>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, st, mp, c->d_tables);
+        } else {
+            const int n_waves = S * 2 * fp.frame_runs;
+            hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
+        }
         HIPCHK(c, hipEventRecord(ev[4], st));
     }
     {
@@ -448,6 +500,8 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         sp.hist_out = hist_next;
         sp.curves = d_curves;
         sp.state = c->d_state;
+        sp.sub = (gain || c->js) ? c->d_sub : nullptr;
+        sp.sub_tail = c->d_sub_tail;
         sp.n_blocks = n_blocks;
         sp.n_streams = S;
         hipLaunchKernelGGL(k_state_update, dim3((unsigned)(((kHist + 255) / 256) * S)), dim3(256), 0, st, sp);
@@ -711,16 +765,39 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
     fp.specs = specs;
     fp.ges = nullptr;
     fp.sub = nullptr;
-    fp.sub_blocks_per_wg = 0;
+    fp.sub_runs = 0;
     fp.debug = 0;
     fp.n_blocks = n_blocks;
     fp.f0 = 1;
     const int n_out = n_blocks - 1;
-    fp.frames_per_wg = pick_frames_per_wg(c, n_out);
     fp.js = c->js;
-    const int nchunks = (n_out + fp.frames_per_wg - 1) / fp.frames_per_wg;
+    fp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu, 1.35);
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
-    hipLaunchKernelGGL(k_qmf_mdct<false>, dim3(S * nchunks), dim3(256), 0, st, fp, c->d_tables);
+    if (c->js) {
+        // joint stereo: the M/S matrixing needs both channels' subbands, which go through HBM (as in at3hip_encode)
+        if (n_blocks > c->cfg.max_blocks) return fail(c, AT3HIP_EINVAL, "n_blocks exceeds max_blocks");
+        // the carried subbands must be the start-of-stream zeros this entry point is defined on
+        if (c->blocks_fed != 0) return fail(c, AT3HIP_EINVAL, "qmf_mdct on a joint-stereo context needs a fresh or reset context");
+        fp.sub = c->d_sub;
+        fp.sub_tail = c->d_sub_tail;
+        fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35);
+        const int n_waves = S * 2 * fp.sub_runs;
+        hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
+        MdctSubParams mp;
+        mp.sub = c->d_sub;
+        mp.curves = nullptr;
+        mp.state = nullptr;
+        mp.specs = specs;
+        mp.n_blocks = n_blocks;
+        mp.f0 = 1;
+        mp.js = 1;
+        mp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu_mdct, 0.3);
+        mp.n_waves = S * 2 * mp.frame_runs;
+        hipLaunchKernelGGL(k_mdct_sub<true>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, st, mp, c->d_tables);
+    } else {
+        const int n_waves = S * 2 * fp.frame_runs;
+        hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
+    }
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));

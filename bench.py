@@ -161,12 +161,14 @@ class DeviceJob:
             assert self.step(False) == self.F
         self.torch.cuda.synchronize(self.dev)
 
+    sync_steps = False   # --sync-steps (profiling aid)
+
     def run_steps(self, k):
         """K steps queued back to back (AT3HIP_ASYNC) and completed by one sync. Inside the context the front half of
         step i+1 (QMF, gain control, fused QMF+MDCT) runs beside the back half of step i (psychoacoustics, quantisation,
         rate loop, packing) on a second HIP stream - every step still does its full work on its own batch."""
         for _ in range(k):
-            self.step(True)
+            self.step(not DeviceJob.sync_steps)
         self.enc.sync()
         self.torch.cuda.synchronize(self.dev)
 
@@ -315,12 +317,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-workloads", action="store_true")
     ap.add_argument("--no-gain", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="PROFILING AID: run the timed steps synchronously (no overlap of "
+                                                              "consecutive calls) so that rocprofv3 sees every kernel alone; "
+                                                              "the line is marked and is not a valid throughput result")
     ap.add_argument("--device-map", default="", help="TEST AID: comma list of device ordinals to use instead of 0..N-1 (e.g. 0,0 runs the "
                                                      "two-device code path on one GPU); recorded in the JSON line, never a valid N-GPU result")
     args = ap.parse_args()
 
     import torch
 
+    DeviceJob.sync_steps = args.sync_steps
     from atracdenc_amd import dist as at3dist
     rank, local_rank, world = at3dist.env_world()
     if world > 1 and args.gpus != world:
@@ -421,6 +427,8 @@ def main():
                           "stage_ms are per-step HIP-event spans and overlap in time, total_ms is one step's latency",
             "checksum": checksum,
         }
+        if args.sync_steps:
+            line["INVALID_profiling_run"] = "--sync-steps: calls were not pipelined; not a throughput measurement"
         if one_gpu_ref is not None:
             line["one_gpu_same_workload"] = one_gpu_ref
         for j in jobs:

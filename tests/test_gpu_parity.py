@@ -197,16 +197,19 @@ def test_streaming_pieces_equal_one_shot(hip, oracle, br):
     assert np.array_equal(again, got[:, :15])
 
 
-def test_frames_per_workgroup_invariance(hip, oracle, monkeypatch):
+@pytest.mark.parametrize("br,ng", [(LP2, 0), (LP2, 1), (LP4, 0), (LP4, 1)])
+def test_run_length_invariance(hip, oracle, monkeypatch, br, ng):
+    """The front-end kernels cut every (stream, channel) into runs of blocks, one wavefront each, with recomputed FIR
+    histories and overlap priming at every cut (AT3HIP_RUNS overrides the automatic choice): any cut gives the same bytes."""
     nb = 13
     pcm = np.stack([SIGNALS["mix"](nb, seed=9), SIGNALS["burst"](nb, phase=700)])
-    exp = oracle_frames(oracle, pcm, LP2)
-    for fpw in ("1", "2", "5", "64"):
-        monkeypatch.setenv("AT3HIP_FRAMES_PER_WG", fpw)
-        enc = hip.At3Hip(n_streams=2, max_blocks=nb, bitrate=LP2)
-        got = enc.encode(pcm)
+    exp = oracle_frames(oracle, pcm, br, ng)
+    for runs in ("1", "2", "5", "12", "64"):
+        monkeypatch.setenv("AT3HIP_RUNS", runs)
+        enc = hip.At3Hip(n_streams=2, max_blocks=nb, bitrate=br, no_gain=ng)
+        got = np.concatenate([enc.encode(pcm[:, :6]), enc.encode(pcm[:, 6:])], axis=1)
         enc.close()
-        assert np.array_equal(got, exp), fpw
+        assert np.array_equal(got, exp), runs
 
 
 def test_mdct_api(hip, oracle, golden_stages):

@@ -9,7 +9,11 @@ cd /tmp
 for IN in $INPUTS; do
   OUT=$REPO/gpurun_out/prof_${TAG}_$IN
   mkdir -p $OUT
-  rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $REPO/bench.py --steps 5 --warmup 2 --input $IN --no-cpu-baseline --no-side-workloads > $OUT/bench_stats.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $REPO/bench.py --steps 5 --warmup 2 --input $IN --no-cpu-baseline --no-side-workloads $EXTRA > $OUT/bench_stats.log 2>&1
   python3 $REPO/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+  rm -rf $OUT/stats
+  # the same with synchronous steps: every kernel alone on the GPU
+  rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $REPO/bench.py --steps 5 --warmup 2 --input $IN --no-cpu-baseline --no-side-workloads --sync-steps $EXTRA > $OUT/bench_stats_sync.log 2>&1
+  python3 $REPO/tools/summarize_prof.py $OUT > $OUT/summary_isolated.txt 2>&1
   rm -rf $OUT/stats
 done
