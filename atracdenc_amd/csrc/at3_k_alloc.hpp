@@ -1,0 +1,829 @@
+// Bit allocation + quantisation + sound-unit packing in ONE kernel, one wavefront per (stream, output frame, channel).
+//
+// Reference path replaced (paths relative to the reference's src/):
+//   atrac/at3/atrac3_bitstream.cpp:92-847   CLC/VLC cost + emission, CalcBitsAllocation, ConsiderEnergyErr, tonal
+//                                           component grouping/coding, TConfigure/TAlloc, WriteSoundUnit
+//   atrac/atrac_enc_cache.cpp, atrac3_bitstream.cpp:154-173   TEncCache: quantised units computed ON DEMAND
+//   atrac/atrac_scale.cpp:40-130            QuantMantisas (rounding, energy sums, energy-adaptive re-rounding)
+//   lib/bs_encode/encode.cpp:57-129         bisection driver (Start / Continue / Submit / Repeat)
+//
+// The rate loop asks for quantised (BFU, wordlen) units as its bisection walks: on typical material about 100 of the
+// 224 possible units and a third of their spectral lines (a quarter of the lines that need the energy-adaptive pass).
+// The first version quantised all 224 up front in a separate kernel; here a unit is computed the first time an
+// allocation asks for it, exactly as the reference's cache does, by the wavefront that runs the loop:
+//   rounding and code lengths of the batch's lines       16 lines per lane
+//   the ordered energy sum of every new unit              one lane per unit
+//   energy-adaptive candidates (BFU > 18): compaction by ballot, rank by counting smaller keys, exact std::sort order
+//   on key ties, then the sequential re-rounding pass     one lane per unit
+// Lane i < 32 owns BFU i in the loop itself (allocation, cost look-up, DPP reductions).
+#pragma once
+#include "at3_k_backend.hpp"
+
+namespace at3 {
+
+struct AllocLds {
+    float val[1024];                 // scaled spectrum (TScaler::Scale)
+    union {
+        float term[1024];            // a batch's energy terms (mantissa / mul)^2, summed in line order by one lane per unit
+        struct {
+            float uk[kEaLines + 4];      // then the energy-adaptive pass: a unit's sort keys (+inf padded); tie-sort scratch
+            uint16_t rec[kEaLines];      // and its candidates ordered by |delta|: line | |m| << 7 | negative << 12
+        };
+        uint32_t words[kBitWords];   // after the rate loop: the sound unit being assembled
+    };
+    float err[8 * 32];               // cache: e1 / e2 per (wordlen, BFU)
+    uint32_t cost[8 * 32];           // cache: CLC bits | VLC bits << 13
+    int8_t bm[1024];                 // mantissas of the units of the current batch (one wordlen per BFU)
+    uint8_t code[256];               // 2 bits per line of the batch: 1 = re-roundable when e2 < e1, 2 = when e2 > e1
+    float e1[32];
+    uint32_t vlc[32];
+    int alloc[32];
+    uint8_t tbits[kMaxTonal * 8];
+    uint16_t huff[130];
+    int misc[4];
+    unsigned long long tmask[4];
+};
+static_assert(sizeof(SortItem) * 128 <= sizeof(float) * (kEaLines + 4), "tie-sort scratch must fit in the key lists");
+
+// 1 / MaxQuant[wl]^2 as QuantMantisas forms it (atrac_scale.cpp:61: float(1.0 / double(mul * mul))), folded per wordlen
+__device__ __forceinline__ float inv_mul2(int wl)
+{
+    switch (wl) {
+        case 1: return (float)(1.0 / (double)(1.5f * 1.5f));
+        case 2: return (float)(1.0 / (double)(2.5f * 2.5f));
+        case 3: return (float)(1.0 / (double)(3.5f * 3.5f));
+        case 4: return (float)(1.0 / (double)(4.5f * 4.5f));
+        case 5: return (float)(1.0 / (double)(7.5f * 7.5f));
+        case 6: return (float)(1.0 / (double)(15.5f * 15.5f));
+        default: return (float)(1.0 / (double)(31.5f * 31.5f));
+    }
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
+// MantissasToVlcIndex's 3x3 table {8, 4, 7, 2, 0, 1, 6, 3, 5} (atrac3_bitstream.cpp:92-113) as nibbles of one constant
+__device__ __forceinline__ uint32_t vlc_pair_index(int m0, int m1) { return (uint32_t)((0x536102748ull >> (4 * (3 * (m0 + 1) + (m1 + 1)))) & 15ull); }
+
+// Huffman code LENGTH of mantissa m under selector wl >= 2, and of a mantissa pair under selector 1 (VLCEnc with a null
+// stream, atrac3_bitstream.cpp:115-149). A code's length depends on |m| only (the sign is the code's last bit), so each
+// table is a row of 4-bit lengths indexed by |m|, held in one or two 64-bit constants instead of a memory look-up;
+// tests/test_abi.py::test_vlc_length_constants re-derives the constants from the code table in at3_common.hpp.
+__device__ __forceinline__ uint32_t vlc_len(int wl, int m)
+{
+    const uint32_t a = (uint32_t)(m < 0 ? -m : m);
+    unsigned long long k;
+    switch (wl) {
+        case 2: k = 0x331ull; break;
+        case 3: k = 0x4431ull; break;
+        case 4: k = 0x55431ull; break;
+        case 5: k = 0x46654432ull; break;
+        case 6: k = 0x4777766665554443ull; break;
+        default: k = a < 16 ? 0x7766666666555553ull : 0x4888888888877777ull; break;   // wl 7, |m| <= 31
+    }
+    return (uint32_t)(k >> (4 * (a & 15u))) & 15u;
+}
+__device__ __forceinline__ uint32_t vlc_pair_len(int m0, int m1) { return (uint32_t)((0x545313545ull >> (4 * (3 * (m0 + 1) + (m1 + 1)))) & 15ull); }
+
+__device__ __forceinline__ uint32_t vlc_bits8(int wl, const int (&m)[8])
+{
+    uint32_t vb = 0;
+    if (wl > 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vb += vlc_len(wl, m[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) vb += vlc_pair_len(m[k], m[k + 1]);
+    }
+    return vb;
+}
+
+// Quantise the units {(b, wl_b) : bit b of `need`}, wl_b = lane b's `bits` (QuantMantisas + CLC/VLC cost,
+// atrac3_bitstream.cpp:154-173, atrac_scale.cpp:40-130). Lane b < 32 passes BFU b's e1 in `my_e1`. Wave-uniform call.
+__device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bits, float my_e1, int lane, int8_t* gmant, int dbg = 0)
+{
+    // ---- (1) mantissa = lrint(value * MaxQuant[wl]) for the lines of the needed BFUs; energy-adaptive candidate codes ----
+    int wl_h[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int line0 = 16 * lane + 8 * h;
+        const int b = bfu_of_line(line0);
+        const int wl = __builtin_amdgcn_ds_bpermute(4 * b, bits);
+        wl_h[h] = ((need >> b) & 1u) ? wl : 0;
+        if (wl_h[h]) {
+            const float mul = max_quant(wl), inv2 = inv_mul2(wl);
+            const float4 va = *reinterpret_cast<const float4*>(L.val + line0), vb = *reinterpret_cast<const float4*>(L.val + line0 + 4);
+            const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+            uint32_t pk[2] = {0u, 0u}, code = 0;
+            float tm[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float t = v[k] * mul;
+                const int m = __float2int_rn(t);
+                pk[k >> 2] |= (uint32_t)(uint8_t)m << (8 * (k & 3));
+                tm[k] = (float)(m * m) * inv2;
+                // the pass may re-round a line only when it is close to a rounding boundary (|delta| < 0.25) AND lies on the
+                // side the pass moves: rounded towards zero and below the top code (pass taken when e2 < e1) or rounded
+                // away from zero (e2 > e1), atrac_scale.cpp:66-126; which pass runs is known after the energy sums
+                const float am = fabsf((float)m), at = fabsf(t);
+                const float delta = t - (truncf(t) + 0.5f);
+                const uint32_t c = (am < at && am < (mul - 1)) ? 1u : (am > at) ? 2u : 0u;
+                code |= (fabsf(delta) < 0.25f ? c : 0u) << (2 * k);
+            }
+            *reinterpret_cast<uint2*>(L.bm + line0) = make_uint2(pk[0], pk[1]);
+            *reinterpret_cast<uint16_t*>(L.code + (line0 >> 2)) = (uint16_t)code;
+            *reinterpret_cast<float4*>(L.term + line0) = make_float4(tm[0], tm[1], tm[2], tm[3]);
+            *reinterpret_cast<float4*>(L.term + line0 + 4) = make_float4(tm[4], tm[5], tm[6], tm[7]);
+        }
+    }
+    if (lane < 32) L.vlc[lane] = 0u;
+    wave_sync();
+    // ---- (2) e2 = sum of (mantissa / mul)^2, strictly in line order: one lane per unit ----
+    const bool mine = lane < 32 && ((need >> lane) & 1u);
+    const int my_start = bfu_start(lane & 31), my_n = bfu_start((lane & 31) + 1) - my_start;
+    float my_mul = 1.0f, my_inv2 = 1.0f, my_e2 = 0.0f;
+    if (mine) {
+        my_mul = max_quant(bits);
+        my_inv2 = inv_mul2(bits);
+        const float4* t4 = reinterpret_cast<const float4*>(L.term + my_start);
+        float acc = 0.0f;
+        float4 c0 = t4[0], c1 = t4[1];
+        for (int off = 0; off < my_n; off += 8) {   // eight terms per step, the next eight in flight
+            float4 n0 = c0, n1 = c1;
+            if (off + 8 < my_n) {
+                n0 = t4[(off >> 2) + 2];
+                n1 = t4[(off >> 2) + 3];
+            }
+            acc += c0.x;
+            acc += c0.y;
+            acc += c0.z;
+            acc += c0.w;
+            acc += c1.x;
+            acc += c1.y;
+            acc += c1.z;
+            acc += c1.w;
+            c0 = n0;
+            c1 = n1;
+        }
+        my_e2 = acc;
+    }
+    wave_sync();   // the terms' storage becomes the key list and the candidate records
+    // ---- (3) energy-adaptive re-rounding of the new units above BFU 18 (atrac_scale.cpp:66-128) ----
+    // A line is a candidate when it passes the side test of the pass that will run (skipped candidates change no state),
+    // and the pass visits the candidates by ascending |delta|: the position of a candidate is the number of keys of its unit
+    // below its own. Units are walked one after the other (uniform), a unit's lines by the lanes; the candidate's rank, its
+    // current |mantissa| and the sign its new mantissa would get go into a 16-bit record at the rank's position.
+#ifdef AT3HIP_DEBUG_KNOBS
+    const uint32_t ea_need = dbg == 5 ? 0u : (need & 0xfff80000u);
+#else
+    const uint32_t ea_need = need & 0xfff80000u;
+#endif
+    int my_nc = 0;   // lane 19 + ub: candidates of its unit
+    if (ea_need) {
+        uint32_t tie_units = 0;
+        for (uint32_t rem = ea_need >> 19; rem; rem &= rem - 1u) {
+            const int ub = __builtin_ctz(rem), bfu = 19 + ub;
+            const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start, ustart = start - kEaLine0;
+            const float e1 = readlane_f(my_e1, bfu), e2 = readlane_f(my_e2, bfu);
+            const uint32_t want = (e2 < e1) ? 1u : (e2 > e1) ? 2u : 3u;   // 3: equal energies, no pass
+            const float mul = max_quant(__builtin_amdgcn_readlane(bits, bfu));
+            bool flag[2];
+            float key[2];
+            uint32_t recv[2];
+            int cnt_u = 0;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int j = 64 * r + lane, line = start + j;
+                flag[r] = j < n && ((L.code[line >> 2] >> (2 * (line & 3))) & 3u) == want;
+                key[r] = 0.0f;
+                recv[r] = 0u;
+                const unsigned long long mask = __ballot(flag[r]);
+                if (flag[r]) {
+                    const int slot = cnt_u + __popcll(mask & ((1ull << lane) - 1ull));
+                    const float t = L.val[line] * mul;
+                    key[r] = fabsf(t - (truncf(t) + 0.5f));   // sort key |delta|
+                    L.uk[slot] = key[r];
+                    const int m0 = (int)L.bm[line];
+                    const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
+                    recv[r] = (uint32_t)j | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12);
+                }
+                cnt_u += __popcll(mask);
+            }
+            if (lane < 16 && cnt_u + lane < ((cnt_u + 15) & ~15)) L.uk[cnt_u + lane] = __builtin_huge_valf();   // pad the list to sixteen
+            wave_sync();
+            int rank[2] = {0, 0};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (flag[r]) {
+                    const float4* t4 = reinterpret_cast<const float4*>(L.uk);
+                    int rr = 0;
+                    for (int q = 0; q < cnt_u; q += 16) {
+                        const float4 c0 = t4[(q >> 2)], c1 = t4[(q >> 2) + 1], c2 = t4[(q >> 2) + 2], c3 = t4[(q >> 2) + 3];
+                        rr += (c0.x < key[r]) + (c0.y < key[r]) + (c0.z < key[r]) + (c0.w < key[r]);
+                        rr += (c1.x < key[r]) + (c1.y < key[r]) + (c1.z < key[r]) + (c1.w < key[r]);
+                        rr += (c2.x < key[r]) + (c2.y < key[r]) + (c2.z < key[r]) + (c2.w < key[r]);
+                        rr += (c3.x < key[r]) + (c3.y < key[r]) + (c3.z < key[r]) + (c3.w < key[r]);
+                    }
+                    rank[r] = rr;
+                    L.rec[ustart + rr] = (uint16_t)recv[r];
+                }
+            }
+            wave_sync();
+            // equal keys collide on a rank; the loser notices on read-back and the unit goes to the exact path
+            const bool lost = (flag[0] && L.rec[ustart + rank[0]] != (uint16_t)recv[0]) || (flag[1] && L.rec[ustart + rank[1]] != (uint16_t)recv[1]);
+            if (__ballot(lost) != 0ull) tie_units |= 1u << ub;
+            if (lane == bfu) my_nc = cnt_u;
+            wave_sync();   // the key list is reused by the next unit
+        }
+        // equal keys among listed candidates: libstdc++'s std::sort order decides (rare). The order of equal elements
+        // depends on the whole array the reference sorts, so the full |delta| < 0.25 list is rebuilt, sorted with the
+        // restated algorithm and then filtered.
+        for (uint32_t rem = tie_units; rem; rem &= rem - 1u) {
+            const int ub = __builtin_ctz(rem), bfu = 19 + ub;
+            const float e1 = readlane_f(my_e1, bfu), e2 = readlane_f(my_e2, bfu);
+            const float mul = max_quant(__builtin_amdgcn_readlane(bits, bfu));
+            if (lane == 0) {
+                SortItem* s_items = reinterpret_cast<SortItem*>(L.uk);
+                const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start;
+                int nall = 0;
+                for (int j = 0; j < n; ++j) {
+                    const float t = L.val[start + j] * mul;
+                    const float delta = t - (truncf(t) + 0.5f);
+                    if (fabsf(delta) < 0.25f) {
+                        s_items[nall].key = delta;
+                        s_items[nall].idx = j;
+                        ++nall;
+                    }
+                }
+                std_sort_abs(s_items, nall);
+                const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
+                uint16_t* sorted = L.rec + (start - kEaLine0);
+                int nc = 0;
+                for (int q = 0; q < nall; ++q) {
+                    const int j = s_items[q].idx;
+                    const float t = L.val[start + j] * mul;
+                    const int m0 = __float2int_rn(t);
+                    const int a0 = m0 < 0 ? -m0 : m0;
+                    const bool side = (dir > 0) ? ((float)a0 < fabsf(t) && (float)a0 < (mul - 1)) : (dir < 0) ? ((float)a0 > fabsf(t)) : false;
+                    const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
+                    if (side) sorted[nc++] = (uint16_t)((uint32_t)j | ((uint32_t)a0 << 7) | ((uint32_t)neg << 12));
+                }
+                // (the same candidates the ballot pass listed, so the unit's count stands)
+            }
+            wave_sync();
+        }
+        // the sequential pass, one lane per unit: only |mantissa| enters the energy bookkeeping - the re-rounded code is
+        // |m0| + 1 (e2 < e1; a zero becomes +-1) or |m0| - 1 (e2 > e1), atrac_scale.cpp:86-118; the ordered part per
+        // candidate is ex = (e2 - d0) + d1 and the test, everything else is ready before the chain reaches it
+#ifdef AT3HIP_DEBUG_KNOBS
+        if (dbg == 6) my_nc = 0;
+#endif
+        if (mine && lane > 18 && my_nc > 0) {
+            const float e1 = my_e1;
+            float e2 = my_e2;
+            const bool grow = e2 < e1;
+            float dist = fabsf(e2 - e1);
+            const uint16_t* rp = L.rec + (my_start - kEaLine0);
+            int8_t* mant = L.bm + my_start;
+            uint2 r4 = *reinterpret_cast<const uint2*>(rp);
+            for (int c0 = 0; c0 < my_nc; c0 += 4) {
+                uint2 n4 = r4;
+                if (c0 + 4 < my_nc) n4 = *reinterpret_cast<const uint2*>(rp + c0 + 4);
+                float d0[4], d1[4];
+                int idx[4], mnew[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t rc = ((k < 2 ? r4.x : r4.y) >> (16 * (k & 1))) & 0xffffu;
+                    const int a0 = (int)((rc >> 7) & 31u);
+                    const int a1 = grow ? a0 + 1 : (a0 > 0 ? a0 - 1 : 0);
+                    idx[k] = (int)(rc & 127u);
+                    mnew[k] = ((rc >> 12) & 1u) ? -a1 : a1;
+                    d0[k] = (float)(a0 * a0) * my_inv2;
+                    d1[k] = (float)(a1 * a1) * my_inv2;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (c0 + k < my_nc) {
+                        float ex = e2;
+                        ex -= d0[k];
+                        ex += d1[k];
+                        const float nd = fabsf(ex - e1);
+                        if (nd < dist) {
+                            mant[idx[k]] = (int8_t)mnew[k];
+                            e2 = ex;
+                            dist = nd;
+                        }
+                    }
+                }
+                r4 = n4;
+            }
+            my_e2 = e2;
+        }
+    }
+    wave_sync();
+    // ---- (4) VLC cost of the final mantissas; (5) cache entries; (6) mantissas to HBM for the packing step ----
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int wl = wl_h[h];
+        if (wl) {
+            const int line0 = 16 * lane + 8 * h;
+            const uint2 pk = *reinterpret_cast<const uint2*>(L.bm + line0);
+            int m[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m[k] = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
+            atomicAdd(&L.vlc[bfu_of_line(line0)], vlc_bits8(wl, m));
+            *reinterpret_cast<uint2*>(gmant + (wl - 1) * 1024 + line0) = pk;
+        }
+    }
+    wave_sync();
+    if (mine) {
+        const uint32_t clc = (bits > 1) ? (uint32_t)clc_len(bits) * my_n : 2u * my_n;
+        L.err[bits * 32 + lane] = my_e1 / my_e2;
+        L.cost[bits * 32 + lane] = clc | (L.vlc[lane] << 13);
+    }
+    wave_sync();
+}
+
+// The 70 units of BFUs 0..9 (8 or 16 lines each, no energy-adaptive pass below BFU 19), one lane per unit: ConsiderEnergyErr
+// (atrac3_bitstream.cpp:241-257) looks at the first ten BFUs' energy errors at whatever wordlen the allocation gives them,
+// and the whole set costs less than one large unit.
+__device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant)
+{
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int u = lane + 64 * rd;
+        if (u < 70) {
+            const int bfu = u % 10, wl = 1 + u / 10;
+            const int start = bfu_start(bfu), n = bfu < 8 ? 8 : 16;
+            const float mul = max_quant(wl);
+            const float inv2 = inv_mul2(wl);
+            float e2 = 0.0f;
+            uint32_t vb = 0;
+            for (int off = 0; off < n; off += 8) {
+                const float4 va = *reinterpret_cast<const float4*>(L.val + start + off), vb4 = *reinterpret_cast<const float4*>(L.val + start + off + 4);
+                const float v[8] = {va.x, va.y, va.z, va.w, vb4.x, vb4.y, vb4.z, vb4.w};
+                int m[8];
+                uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    m[k] = __float2int_rn(v[k] * mul);
+                    pk[k >> 2] |= (uint32_t)(uint8_t)m[k] << (8 * (k & 3));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e2 += (float)(m[k] * m[k]) * inv2;
+                vb += vlc_bits8(wl, m);
+                *reinterpret_cast<uint2*>(gmant + (wl - 1) * 1024 + start + off) = make_uint2(pk[0], pk[1]);
+            }
+            const uint32_t clc = (wl > 1) ? (uint32_t)clc_len(wl) * n : 2u * n;
+            L.err[wl * 32 + bfu] = L.e1[bfu] / e2;
+            L.cost[wl * 32 + bfu] = clc | (vb << 13);
+        }
+    }
+    wave_sync();
+}
+
+__global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T)
+{
+    __shared__ __attribute__((aligned(16))) AllocLds L;
+    uint32_t* s_words = L.words;
+    int* s_alloc = L.alloc;
+    uint8_t* s_tbits = L.tbits;
+    uint16_t* s_huff = L.huff;
+    int* s_misc = L.misc;
+    uint32_t* s_cost = L.cost;
+    float* s_err = L.err;
+    unsigned long long* s_tmask = L.tmask;
+
+    const int lane = threadIdx.x;
+    const int n_out = p.n_blocks - p.f0;
+    const size_t cf = blockIdx.x;
+    const int ch = (int)(cf & 1);
+    const int fo = (int)((cf >> 1) % n_out);
+    const int s = (int)((cf >> 1) / n_out);
+    const int f = fo + p.f0;
+    const PsyRec* recs = p.psy + (cf & ~(size_t)1);
+    const PsyRec* rec = recs + ch;
+    const Curve* curves = p.curves + ((size_t)s * p.n_blocks + f) * 8;
+    int8_t* gmant = p.mant + cf * 7168;
+    const int half = p.frame_sz >> 1;
+    const int n_tonal = rec->n_tonal;
+
+    for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
+    for (int i = lane; i < 130; i += 64) s_huff[i] = c_huff[i];
+    for (int i = lane; i < 8 * 32; i += 64) {
+        s_err[i] = 0.0f;
+        s_cost[i] = 0u;
+    }
+
+    // ---- header + gain info bits, joint-stereo byte shift, target bits (WriteSoundUnit :759-810) ----
+    int hdr[2];
+    for (int c2 = 0; c2 < 2; ++c2) {
+        int bits = (p.js && c2 == 1) ? 14 : 6;
+        bits += 2;
+        for (int b = 0; b < 4; ++b) bits += 3 + 9 * curves[c2 * 4 + b].n;
+        // one input channel, joint stereo: the second element has ONE subband and no gain points (atrac3denc.cpp:843-849)
+        if (p.mono_js && c2 == 1) bits = 14 + 2 + 3;
+        hdr[c2] = bits;
+    }
+    int shift = 0;
+    if (p.mono_js) {   // CalcMSBytesShift with an empty second element: the maximum (atrac3_bitstream.cpp:745-747)
+        const int totalUsed = 12 + hdr[0] + hdr[1];
+        shift = (int)((uint32_t)p.frame_sz / 2 - (1 + ((uint32_t)totalUsed - 1) / 8));
+    } else if (p.js) {
+        const int b0 = -6 - hdr[0], b1 = -6 - hdr[1];
+        const int totalUsed = 0 - b0 - b1;
+        const int maxShift = (int)((uint32_t)p.frame_sz / 2 - (1 + ((uint32_t)totalUsed - 1) / 8));
+        const float m = recs[0].loud_ch, sd = recs[1].loud_ch;
+        const float total = sd + m;
+        float ratio = 0.0f;
+        if (total > 0) ratio = (float)((double)(m / total) - 0.5);
+        int v = __float2int_rn((float)p.frame_sz * ratio);
+        if (v > maxShift) v = maxShift;
+        if (v < -maxShift) v = -maxShift;
+        shift = v;
+    }
+    const int nbytes = (ch == 0) ? half + shift : half - shift;
+    int target = -6 - hdr[ch] + 8 * nbytes;
+    if (target < 1) target = 1;
+    target &= 0xffff;
+    const float loudness = p.loud[(size_t)s * n_out + fo] / 0.006f;
+
+    if (p.mono_js && ch == 1) {
+        // TConfigure / TAlloc with empty ScaledBlocks (atrac3_bitstream.cpp:590-597, 623-626): JS parameters, one subband
+        // without gain points, no tonal components, one BFU of precision 0 in coding mode 1 - 33 bits, then zeros
+        __syncthreads();
+        if (lane == 0) {
+            put_bits(s_words, 0, 0, 1);
+            put_bits(s_words, 1, 7, 3);
+            for (int k = 0; k < 4; ++k) put_bits(s_words, 4 + 2 * k, 3, 2);
+            put_bits(s_words, 12, 3, 2);
+            put_bits(s_words, 14, 0, 2);       // numQmfBand - 1
+            put_bits(s_words, 16, 0, 3);       // gain points of band 0
+            put_bits(s_words, 19, 0, 5);       // tonal sub-groups
+            put_bits(s_words, 24, 0, 5);       // numBlocks - 1
+            put_bits(s_words, 29, 1, 1);       // coding mode
+            put_bits(s_words, 30, 0, 3);       // precision of the one block
+        }
+        __syncthreads();
+        uint8_t* frame1 = p.out + ((size_t)s * n_out + fo) * p.frame_sz;
+        for (int j = lane; j < nbytes; j += 64) {
+            const int src = nbytes - 1 - j;
+            frame1[half + shift + j] = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
+        }
+        return;
+    }
+
+
+    // ---- scaled values (TScaler::Scale, atrac_scale.cpp:141-172) and e1 = sum of value^2 per BFU, in line order ----
+    {
+        const float* specs = p.specs + cf * 1024;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i0 = 4 * (lane + 64 * k);
+            const float sf = T->scale[rec->sfi[bfu_of_line(i0)]];
+            const float4 x = *reinterpret_cast<const float4*>(specs + i0);
+            float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (fabsf(v[j]) >= 1.0f) v[j] = (v[j] > 0) ? 0.99999f : -0.99999f;
+            *reinterpret_cast<float4*>(L.val + i0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    float my_e1 = 0.0f;   // lane b < 32: e1 of BFU b
+    if (lane < 32) {
+        const int start = bfu_start(lane), n = bfu_start(lane + 1) - start;
+        float acc = 0.0f;
+        for (int off = 0; off < n; off += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(L.val + start + off), b = *reinterpret_cast<const float4*>(L.val + start + off + 4);
+            const float term[8] = {a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w, b.x * b.x, b.y * b.y, b.z * b.z, b.w * b.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += term[k];
+        }
+        L.e1[lane] = acc;
+        my_e1 = acc;
+    }
+    __syncthreads();
+    // units of the first ten BFUs at every wordlen: ConsiderEnergyErr (atrac3_bitstream.cpp:241-257) looks at their energy
+    // errors whatever the allocation, and they are 96 lines in all
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug_stop == 1) return;
+#endif
+    small_units(L, lane, gmant);
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug_stop == 2) return;
+#endif
+    uint32_t valid = lane < 10 ? 0xfeu : 0u;   // lane i: bit wl set = unit (BFU i, wl) is in the cache
+    // ---- TConfigure: spread (sequential float sums, every lane computes the same value) ----
+    const int i = lane & 31;   // BFU owned by this lane (lanes 32..63 mirror 0..31 but never contribute)
+    float spread;
+    {
+        const int my_sfi = rec->sfi[i];   // one load per lane; the ordered sums walk the lanes
+        float sum = 0.0f;
+        for (int k = 0; k < 32; ++k) sum += (float)__builtin_amdgcn_readlane(my_sfi, k);
+        sum /= 32;
+        float sigma = 0.0f;
+        for (int k = 0; k < 32; ++k) {
+            float t = ((float)__builtin_amdgcn_readlane(my_sfi, k) - sum);
+            t *= t;
+            sigma += t;
+        }
+        sigma /= 32;
+        sigma = sqrtf(sigma);
+        if (sigma > 14.0f) sigma = 14.0f;
+        spread = sigma / 14.0f;
+    }
+    // tonal blocks: VLC bit cost for every quantiser 2..7
+    for (int idx = lane; idx < n_tonal * 6; idx += 64) {
+        const int t = idx / 6, qq = 2 + idx % 6;
+        const TonalBlock& tb = rec->tonal[t];
+        const float mul = max_quant(qq);
+        int bits = 0;
+        for (int z = 0; z < tb.len; ++z) bits += (int)(huff_entry(qq, vlc_index(__float2int_rn(tb.values[z] * mul))) >> 8);
+        s_tbits[t * 8 + qq] = (uint8_t)bits;
+    }
+    // Lane t < n_tonal also owns tonal block t (its BFU, length and 64-line block): the cost of the tonal side
+    // information is evaluated by these lanes in parallel inside the rate loop (inside the bisection below).
+    int tb_bfu = 255, tb_len = 0, tb_blk = 0;
+    if (lane < n_tonal) {
+        const TonalBlock& tb = rec->tonal[lane];
+        tb_bfu = tb.bfu;
+        tb_len = tb.len;
+        tb_blk = tb.pos >> 6;
+    }
+    // GroupTonalComponents (atrac3_bitstream.cpp:338-380) closes a sub-group only after EIGHT members of one group inside one
+    // 64-line block. A 64-line block holds at most four tonal BFUs (BFUs 8..28 are 16 lines or wider, one run each), so
+    // that never happens and every (quantiser, length) group is exactly one sub-group; the check below proves it for this
+    // frame (blocks are ordered by position) and sends anything else down the literal, serial path.
+    const bool tonal_serial = __ballot(lane + 7 < n_tonal &&
+                                       __builtin_amdgcn_ds_bpermute(4 * ((lane + 7) & 63), tb_blk) == tb_blk) != 0ull;
+    // per-BFU constants of CalcBitsAllocation (atrac3_bitstream.cpp:272-336)
+    float A;
+    bool gate;
+    int tcount = 0;
+    for (int t = 0; t < n_tonal; ++t) tcount += (__builtin_amdgcn_readlane(tb_bfu, t) == (lane & 31));
+    {
+        int band = 0;
+        if (i >= 18) band = 1;
+        if (i >= 26) band = 2;
+        if (i >= 30) band = 3;
+        float g = 1.0f;
+        if (p.ges) g = p.ges[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + band];
+        if (!(isfinite(g) && g > 0.0f)) g = 1.0f;
+        const float corrected = rec->energy[i] * g;
+        const float ath = T->ath_bfu[i] * loudness;
+        gate = corrected < ath;
+        const float csfi = fmaxf(0.0f, fminf(63.0f, (float)rec->sfi[i] + 1.5f * at3_log2f(T, g)));
+        float x = 6.0f;
+        if (i < 3) x = 2.8f;
+        else if (i < 10) x = 2.6f;
+        else if (i < 15) x = 3.3f;
+        else if (i <= 20) x = 3.6f;
+        else if (i <= 28) x = 4.2f;
+        A = spread * (csfi / x) + (1.0f - spread) * (float)c_fixed_alloc[i];
+        // (tonal blocks per BFU: counted below from the per-lane copies of the blocks' BFU indices)
+    }
+    // ConsiderEnergyErr as a per-BFU map wl -> wl' (first 10 BFUs, atrac3_bitstream.cpp:241-257, :638-641): BFUs are
+    // independent, so iterating the reference's do/while to its fixed point is a closure per BFU. A wordlen keeps
+    // climbing while its energy error is out of range, so the map sends wl to the first k >= wl that is acceptable
+    // (k = 0 and k = 7 always are): a backward scan over the eight entries.
+    uint32_t gmap = 0;
+    {
+        int g = 7;
+        gmap = 7u << 21;
+#pragma unroll
+        for (int k = 6; k >= 0; --k) {
+            const float e = s_err[k * 32 + i];
+            const bool climbs = i < 10 && k > 0 && ((e > 0 && e < 0.7f) || e > 1.2f);
+            g = climbs ? g : k;
+            gmap |= (uint32_t)g << (3 * k);
+        }
+    }
+    // ---- rate loop: TConfigure / TAlloc under the bisection driver (uniform control flow) ----
+    int num_bfu = p.bfu_idx_const ? p.bfu_idx_const : 32;
+    if (target < 101) {
+        int lim = 1;
+        if (target > 5) lim = (target - 5) / 3;
+        if (lim < 1) lim = 1;
+        if (num_bfu > lim) num_bfu = lim;
+    }
+    if (num_bfu < 1) num_bfu = 1;
+    int mode = 1;
+    int bits = 0;
+    for (;;) {
+        float minL = -8.0f, maxL = 20.0f, curL = 0.0f, lastL = 20.0f;
+        bool restart = false;
+        for (;;) {
+            const bool exhausted = (maxL <= minL);
+            float lam;
+            if (exhausted) {
+                lam = lastL;
+            } else {
+                curL = (maxL + minL) * 0.5f;
+                lam = curL;
+            }
+            bits = 0;
+            if (lane < num_bfu) {
+                if (!gate) {
+                    const int tmp = (int)(A - lam);
+                    if (tmp > 7) bits = 7;
+                    else if (tmp < 0) bits = 0;
+                    else if (tmp == 0) bits = 1;
+                    else bits = tmp;
+                }
+                // one decrement per tonal block in this BFU while the wordlen is above 2 (:325-333)
+                if (bits > 2 && tcount) bits = (bits - tcount > 2) ? bits - tcount : 2;
+                bits = (int)((gmap >> (3 * bits)) & 7u);
+            }
+            // quantise what this allocation asks for and the cache does not hold yet (TEncCache, atrac_enc_cache.cpp)
+            {
+                const uint32_t need = (uint32_t)__ballot(lane < 32 && bits != 0 && !((valid >> bits) & 1u));
+#ifdef AT3HIP_DEBUG_KNOBS
+                if (need && p.debug_stop == 4) {   // the loop without the units (their cache entries stay zero)
+                    if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
+                } else
+#endif
+                if (need) {
+                    if (lane < 32) s_alloc[lane] = bits;
+                    wave_sync();
+                    compute_units(L, need, bits, my_e1, lane, gmant, p.debug_stop);
+                    if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
+                }
+            }
+            const uint32_t mine = (lane < num_bfu) ? s_cost[bits * 32 + i] : 0u;
+            const uint32_t rsum = row_allreduce_add(mine);
+            const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
+            // the count of non-zero BFUs comes from a ballot: summed as a third field it would need six bits at
+            // 32 of 32 (and silently wrapped to zero when every BFU of the frame was coded)
+            const uint32_t clc = acc & 0x1fffu, vlc = (acc >> 13) & 0x3fffu;
+            const uint32_t nz = (uint32_t)__popcll(__ballot(lane < num_bfu && bits != 0));
+            mode = clc <= vlc ? 1 : 0;
+            const uint32_t spec_bits = (uint32_t)num_bfu * 3 + 6 * nz + (mode ? clc : vlc);
+            uint32_t tonal_bits = 5;
+            if (n_tonal > 0 && tonal_serial) {
+                if (lane < 32) s_alloc[lane] = bits;
+                __syncthreads();
+                if (lane == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
+                __syncthreads();
+                tonal_bits = (uint32_t)(s_misc[0] & 0xffff);
+            } else if (n_tonal > 0) {
+                // EncodeTonalComponents with a null stream (atrac3_bitstream.cpp:382-524), one lane per tonal block:
+                //   5 (+2 when anything is coded) + per group 4 + 3 + 3 + 12 per QMF band the group touches
+                //   + per coded block 6 + 6 + VLC bits of its values at the group's quantiser.
+                const bool live = lane < n_tonal && tb_bfu < num_bfu;
+                const int wl_t = __builtin_amdgcn_ds_bpermute(4 * (tb_bfu & 31), bits);   // this evaluation's wordlen of the block's BFU
+                int qn = wl_t + 4;
+                qn = qn > 7 ? 7 : qn;   // >= 4 always, so the lower clamp at 2 is never active here
+                if (lane < 4) s_tmask[lane] = 0ull;
+                wave_sync();
+                uint32_t member = 0;
+                if (live) {
+                    atomicOr(&s_tmask[tb_blk >> 2], 1ull << ((qn - 2) * 7 + (tb_len - 1)));
+                    member = 12u + s_tbits[lane * 8 + qn];
+                }
+                const uint32_t msum = row_allreduce_add(member);
+                const uint32_t members = (uint32_t)__builtin_amdgcn_readlane((int)msum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)msum, 16);
+                wave_sync();
+                const unsigned long long m0 = s_tmask[0], m1 = s_tmask[1], m2 = s_tmask[2], m3 = s_tmask[3];
+                const uint32_t groups = (uint32_t)__popcll(m0 | m1 | m2 | m3);
+                const uint32_t group_bands = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+                if (groups) tonal_bits = 5u + 2u + 10u * groups + 12u * group_bands + members;
+            }
+            const uint32_t total = spec_bits + tonal_bits;
+            const int last_alloc = __builtin_amdgcn_readlane(bits, (num_bfu - 1) & 31);
+            bool done;
+            if (exhausted) {
+                done = true;
+            } else if (total < (uint32_t)target) {
+                lastL = curL;
+                maxL = curL - 0.01f;
+                done = false;
+            } else if (total > (uint32_t)target) {
+                minL = curL + 0.01f;
+                done = false;
+            } else {
+                done = true;
+            }
+            if (!done) continue;
+            if (!p.bfu_idx_const && num_bfu > 1 && last_alloc == 0) {
+                num_bfu--;
+                restart = true;
+            }
+            break;
+        }
+        if (!restart) break;
+    }
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug_stop == 3) return;
+#endif
+    if (p.quant) {   // the QUANT tap: what the cache holds at the end (err e1 / e2, cost CLC | VLC << 13; zero = never computed)
+        QuantRec* qr = p.quant + cf;
+        for (int k = lane; k < 7 * 32; k += 64) {
+            qr->err[k >> 5][k & 31] = s_err[32 + k];
+            qr->cost[k >> 5][k & 31] = s_cost[32 + k];
+        }
+    }
+    if (lane < 32) s_alloc[lane] = bits;
+    for (int k = lane; k < kBitWords; k += 64) s_words[k] = 0;   // the key lists are dead: their storage becomes the bit buffer
+    __syncthreads();
+
+    // ---- emission (WriteSoundUnit header, EncodeSpecs) ----
+    int pos = 0;
+    if (lane == 0) {
+        if (p.js && ch == 1) {
+            put_bits(s_words, 0, 0, 1);
+            put_bits(s_words, 1, 7, 3);
+            for (int k = 0; k < 4; ++k) put_bits(s_words, 4 + 2 * k, 3, 2);
+            put_bits(s_words, 12, 3, 2);
+            pos = 14;
+        } else {
+            put_bits(s_words, 0, 0x28, 6);
+            pos = 6;
+        }
+        put_bits(s_words, pos, 3, 2);
+        pos += 2;
+        for (int b = 0; b < 4; ++b) {
+            const Curve& c = curves[ch * 4 + b];
+            put_bits(s_words, pos, c.n, 3);
+            pos += 3;
+            for (int k = 0; k < c.n; ++k) {
+                put_bits(s_words, pos, c.level[k], 4);
+                put_bits(s_words, pos + 4, c.loc[k], 5);
+                pos += 9;
+            }
+        }
+        pos += tonal_encode<true>(rec, s_tbits, s_alloc, num_bfu, s_words, pos);
+        put_bits(s_words, pos, (uint32_t)num_bfu - 1, 5);
+        put_bits(s_words, pos + 5, (uint32_t)mode, 1);
+        pos += 6;
+        s_misc[1] = pos;
+    }
+    __syncthreads();
+    pos = s_misc[1];
+    const unsigned long long nzmask = __ballot(lane < num_bfu && bits != 0);
+    if (lane < num_bfu) put_bits(s_words, pos + 3 * lane, (uint32_t)bits, 3);
+    pos += 3 * num_bfu;
+    if (lane < num_bfu && bits)
+        put_bits(s_words, pos + 6 * __popcll(nzmask & ((1ull << lane) - 1ull)), rec->sfi[lane], 6);
+    pos += 6 * __popcll(nzmask);
+    // mantissas: 16 spectral lines per lane (BFU sizes are multiples of 8, so at most two BFUs per lane)
+    {
+        const int base = lane * 16;
+        uint32_t code[16];
+        int sum = 0;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int i0 = base + 8 * hlf;
+            const int b = bfu_of_line(i0);
+            const int wl = (b < num_bfu) ? s_alloc[b] : 0;
+            int8_t m8[8];
+            if (wl) {
+                const uint2 pk = *reinterpret_cast<const uint2*>(gmant + (wl - 1) * 1024 + i0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m8[k] = (int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t cl = 0;
+                if (wl > 1) {
+                    if (mode == 1) {
+                        const int nb = clc_len(wl);
+                        cl = ((uint32_t)m8[k] & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
+                    } else {
+                        const uint32_t e = lds_huff(s_huff, wl, vlc_index(m8[k]));
+                        cl = (e & 0xffu) | ((e >> 8) << 16);
+                    }
+                } else if (wl == 1 && (k & 1) == 0) {
+                    if (mode == 1) {
+                        // MantissaToCLcIdx {2, 3, 0, 1}[m + 2] == m & 3 (atrac3_bitstream.cpp:77-90)
+                        cl = ((((uint32_t)m8[k] & 3u) << 2) | ((uint32_t)m8[k + 1] & 3u)) | (4u << 16);
+                    } else {
+                        const uint32_t e = lds_huff(s_huff, 1, vlc_pair_index(m8[k], m8[k + 1]));
+                        cl = (e & 0xffu) | ((e >> 8) << 16);
+                    }
+                }
+                code[8 * hlf + k] = cl;
+                sum += (int)(cl >> 16);
+            }
+        }
+        int off = pos + wave_inclusive_scan(sum, lane) - sum;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int n = (int)(code[k] >> 16);
+            if (n) {
+                put_bits(s_words, off, code[k] & 0xffffu, n);
+                off += n;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- frame assembly (atrac3_bitstream.cpp:826-834): ch0 bytes, then ch1 (byte-reversed when JS) ----
+    uint8_t* frame = p.out + ((size_t)s * n_out + fo) * p.frame_sz;
+    const int dst0 = (ch == 0) ? 0 : half + shift;
+    for (int j = lane; j < nbytes; j += 64) {
+        const int src = (p.js && ch == 1) ? (nbytes - 1 - j) : j;
+        const uint8_t byte = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
+        frame[dst0 + j] = byte;
+    }
+}
+
+}  // namespace at3

@@ -12,6 +12,7 @@
 #include "at3_common.hpp"
 #include "at3_host_util.hpp"
 #include "at3_k_backend.hpp"
+#include "at3_k_alloc.hpp"
 #include "at3_k_frontend.hpp"
 #include "at3_k_front2.hpp"
 #include "at3_k_gain.hpp"
@@ -532,8 +533,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, bk, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(ev[6], bk));
         hipLaunchKernelGGL(k_loudness, dim3(S), dim3(64), 0, bk, bp);
-        hipLaunchKernelGGL(k_quant, dim3(S * n_out * 2), dim3(256), 0, bk, bp, c->d_tables);
-        hipLaunchKernelGGL(k_rate_pack, dim3(S * n_out * 2), dim3(64), 0, bk, bp, c->d_tables);
+        hipLaunchKernelGGL(k_alloc_pack, dim3(S * n_out * 2), dim3(64), 0, bk, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(ev[7], bk));
         if (!(flags & AT3HIP_OUT_ON_DEVICE))
             HIPCHK(c, hipMemcpyAsync(out_frames, c->d_out, (size_t)S * n_out * c->frame_sz, hipMemcpyDeviceToHost, bk));

@@ -32,12 +32,14 @@ struct float4 {
 };
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
+
 struct uint2 {
     unsigned x, y;
 };
 struct uint4 {
     unsigned x, y, z, w;
 };
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 

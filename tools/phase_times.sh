@@ -1,19 +1,19 @@
 #!/bin/bash
-# usage (on the GPU box): tools/phase_times.sh <kernel-substring> "<stops>" [bench args] - kernel time per AT3HIP_DEBUG_STOP value
-K=$1; STOPS=$2; shift 2
-export TMPDIR=/tmp
+# Run on the GPU box: isolated duration of k_alloc_pack cut short at its stage exits (debug build of the library).
+# usage: tools/phase_times.sh   (builds atracdenc_amd/libat3hip_dbg.so with -DAT3HIP_DEBUG_KNOBS)
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/phase
-mkdir -p $OUT
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DAT3HIP_DEBUG_KNOBS -o $REPO/gpurun_out/libat3hip_dbg.so \
+  $REPO/atracdenc_amd/csrc/at3hip.hip $REPO/atracdenc_amd/csrc/at1hip.hip $REPO/atracdenc_amd/csrc/at3phip.hip $REPO/atracdenc_amd/csrc/at3_tables.cpp 2>/dev/null
+export TMPDIR=/tmp
 cd /tmp
-for st in $STOPS; do
-  rm -rf $OUT/s$st
-  AT3HIP_DEBUG_STOP=$st rocprofv3 --kernel-trace -d $OUT/s$st -o t -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/run$st.log 2>&1
+for STOP in ${STOPS:-1 2 3 4 0}; do
+  rm -rf /tmp/ph
+  AT3HIP_LIB=$REPO/gpurun_out/libat3hip_dbg.so AT3HIP_DEBUG_STOP=$STOP rocprofv3 --kernel-trace --stats -d /tmp/ph -o ph -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-workloads --sync-steps "$@" > /dev/null 2>&1
   python3 - <<PY
 import glob, sqlite3
-for f in glob.glob("$OUT/s$st/**/*.db", recursive=True):
+for f in glob.glob("/tmp/ph/**/*.db", recursive=True):
     db = sqlite3.connect(f)
-    for name, calls, avg in db.execute("select name, count(*), avg(end-start) from kernels where name like '%$K%' group by name"):
-        print("stop=$st", name[:50], calls, round(avg/1e3, 2))
+    for name, calls, avg in db.execute("select name, count(*), avg(end-start) from kernels where name like '%k_alloc_pack%' group by name"):
+        print("stop=$STOP", name[:30], "avg_us=%.2f" % (avg/1e3))
 PY
 done
