@@ -80,12 +80,119 @@ __device__ inline int scale_block(const float* scale_tab, const float* in, int l
     return sfi;
 }
 
+// ---- loudness of a channel-frame (atrac3denc.cpp:811-818) --------------------------------------------------------------
+// l = sum over the 1024 lines, IN ORDER, of e * GainEnergyScale[band].Frame * LoudnessCurve[i]. The sum is a 1024-step
+// chain whatever the hardware, so one lane runs one channel-frame's chain and a wavefront kLoudCf of them side by side
+// (k_psy used to spend half its instructions on one lane per workgroup). A lone wavefront issues one instruction every
+// ~5 cycles, so the chain wavefront does nothing but read terms (16 bytes at a time) and add them: three producer
+// wavefronts of the workgroup fetch the spectra (coalesced 16-byte loads, two chunks in flight), form the terms and lay
+// them out per channel-frame in LDS, one 64-line chunk ahead of the consumer.
+// A channel-frame's 64 terms of a chunk are a row of kLoudRow floats: 16-byte aligned, and rows 4 banks apart, so that
+// the sixteen lanes a 16-byte LDS read serves together hit sixteen different bank quads.
+constexpr int kLoudRow = 68;
+constexpr int kLoudCf = 32;                        // channel-frames per workgroup
+constexpr int kLoudWords = kLoudCf * 16;           // 16-byte words of a chunk
+constexpr int kLoudPer = (kLoudWords + 191) / 192; // words per producer thread
+
+// (free functions: array arguments of lambdas end up in scratch memory)
+__device__ __forceinline__ void loud_request(const float* specs, int c0, int n_cf, int u, int k, float4 (&xr)[kLoudPer])
+{
+#pragma unroll
+    for (int i = 0; i < kLoudPer; ++i) {
+        const int w = u + 192 * i, c = c0 + (w >> 4);
+        xr[i] = (w < kLoudWords && c < n_cf) ? *reinterpret_cast<const float4*>(specs + (size_t)c * 1024 + 64 * k + 4 * (w & 15))
+                                             : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+__device__ __forceinline__ void loud_produce(float* tile, const float* s_curve, const float* s_ges, int u, int k, const float4 (&xr)[kLoudPer])
+{
+    const float4 cv = *reinterpret_cast<const float4*>(s_curve + 64 * k + 4 * (u & 15));   // (u + 192 i) & 15 == u & 15
+#pragma unroll
+    for (int i = 0; i < kLoudPer; ++i) {
+        const int w = u + 192 * i;
+        if (w < kLoudWords) {
+            const float gg = s_ges[4 * (w >> 4) + (k >> 2)];
+            const float4 x = xr[i];
+            *reinterpret_cast<float4*>(tile + (w >> 4) * kLoudRow + 4 * (w & 15)) =
+                make_float4(x.x * x.x * gg * cv.x, x.y * x.y * gg * cv.y, x.z * x.z * gg * cv.z, x.w * x.w * gg * cv.w);
+        }
+    }
+}
+__device__ __forceinline__ void loud_consume(const float* row, float& l)
+{
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) {
+        const float4 a = r4[q], b = r4[q + 1], c = r4[q + 2], d = r4[q + 3];
+        l += a.x; l += a.y; l += a.z; l += a.w;
+        l += b.x; l += b.y; l += b.z; l += b.w;
+        l += c.x; l += c.y; l += c.z; l += c.w;
+        l += d.x; l += d.y; l += d.z; l += d.w;
+    }
+}
+
+// Runs before k_psy, which removes the tonal lines from the spectra.
+__global__ __launch_bounds__(256) void k_loud_sum(BackParams p, const Tables* T, int n_cf)
+{
+    __shared__ __attribute__((aligned(16))) float s_t[2][kLoudCf * kLoudRow];   // [buffer][channel-frame][line in chunk]
+    __shared__ __attribute__((aligned(16))) float s_curve[1024];   // LoudnessCurve: a global load per chunk would stall the producers
+    __shared__ __attribute__((aligned(16))) float s_ges[kLoudCf * 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    *reinterpret_cast<float4*>(s_curve + 4 * tid) = *reinterpret_cast<const float4*>(T->loud_curve + 4 * tid);
+    const int c0 = blockIdx.x * kLoudCf;
+    const int n_out = p.n_blocks - p.f0;
+    if (tid < kLoudCf) {   // the channel-frames' four band scales
+        const int c = c0 + tid;
+        float4 gv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (p.ges && c < n_cf) {
+            const int ch = c & 1, fo = (c >> 1) % n_out, s = (c >> 1) / n_out;
+            gv = *reinterpret_cast<const float4*>(p.ges + ((size_t)s * p.n_blocks + fo + p.f0) * 8 + ch * 4);
+        }
+        *reinterpret_cast<float4*>(s_ges + 4 * tid) = gv;
+    }
+    // producer role: thread u = tid - 64 of 192 forms the terms of the 16-byte words w = u + 192 i of a chunk (word w =
+    // lines 4 (w & 15) .. + 3 of channel-frame w >> 4). The spectra of chunk k + 2 are requested while chunk k + 1 is turned
+    // into terms: a producer never waits for a load it has just issued.
+    const int u = tid - 64;
+    const bool chain = wave == 0 && lane < kLoudCf;
+    float4 xa[kLoudPer], xb[kLoudPer];
+    if (wave > 0) {
+        loud_request(p.specs, c0, n_cf, u, 0, xa);
+        loud_request(p.specs, c0, n_cf, u, 1, xb);
+    }
+    __syncthreads();   // the curve is in LDS
+    if (wave > 0) {
+        loud_produce(s_t[0], s_curve, s_ges, u, 0, xa);
+        loud_request(p.specs, c0, n_cf, u, 2, xa);
+    }
+    __syncthreads();
+    float l = 0.0f;
+    for (int k = 0; k < 16; k += 2) {   // chunk k + 1 comes from xb, chunk k + 2 from xa
+        if (wave > 0) {
+            loud_produce(s_t[(k + 1) & 1], s_curve, s_ges, u, k + 1, xb);
+            if (k + 3 < 16) loud_request(p.specs, c0, n_cf, u, k + 3, xb);
+        } else if (chain) {
+            loud_consume(s_t[k & 1] + lane * kLoudRow, l);
+        }
+        __syncthreads();
+        if (wave > 0) {
+            if (k + 2 < 16) {
+                loud_produce(s_t[k & 1], s_curve, s_ges, u, k + 2, xa);
+                if (k + 4 < 16) loud_request(p.specs, c0, n_cf, u, k + 4, xa);
+            }
+        } else if (chain) {
+            loud_consume(s_t[(k + 1) & 1] + lane * kLoudRow, l);
+        }
+        __syncthreads();
+    }
+    if (chain && c0 + lane < n_cf) p.psy[c0 + lane].loud_ch = l;
+}
+
 // One workgroup per (stream, output frame, channel).
 __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) float s_spec[1024];
     __shared__ __attribute__((aligned(16))) float s_e[1024];
-    __shared__ __attribute__((aligned(16))) float s_term[1024];
     __shared__ int s_run_start[32];
     __shared__ int s_run_len[32];
     __shared__ uint16_t s_tv_pos[112];
@@ -98,25 +205,16 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     const int ch = blockIdx.x & 1;
     const int fo = (blockIdx.x >> 1) % n_out;
     const int s = (blockIdx.x >> 1) / n_out;
-    const int f = fo + p.f0;
     float* specs = p.specs + (((size_t)s * n_out + fo) * 2 + ch) * 1024;
     PsyRec* rec = p.psy + ((size_t)s * n_out + fo) * 2 + ch;
 
-    // energies, loudness terms (e * GainEnergyScale.Frame * LoudnessCurve, atrac3denc.cpp:811-818) and - for the
-    // flatness measure - log(max(e, floor)) are produced by all work-items; only the additions are ordered.
+    // line energies for the flatness measure (the loudness sum of atrac3denc.cpp:811-818 is k_loud_sum's)
     {
-        float g[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-        if (p.ges)
-            for (int b = 0; b < 4; ++b) g[b] = p.ges[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + b];
         const float4 x4 = *reinterpret_cast<const float4*>(specs + 4 * tid);
-        const float4 c4 = *reinterpret_cast<const float4*>(T->loud_curve + 4 * tid);
-        const float gg = g[tid >> 6];
-        float4 e4, t4;
+        float4 e4;
         e4.x = x4.x * x4.x; e4.y = x4.y * x4.y; e4.z = x4.z * x4.z; e4.w = x4.w * x4.w;
-        t4.x = e4.x * gg * c4.x; t4.y = e4.y * gg * c4.y; t4.z = e4.z * gg * c4.z; t4.w = e4.w * gg * c4.w;
         *reinterpret_cast<float4*>(s_spec + 4 * tid) = x4;
         *reinterpret_cast<float4*>(s_e + 4 * tid) = e4;
-        *reinterpret_cast<float4*>(s_term + 4 * tid) = t4;
     }
     if (tid < 32) {
         s_run_len[tid] = 0;
@@ -124,26 +222,6 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     }
     if (tid >= 64 && tid < 128) s_scale[tid - 64] = T->scale[tid - 64];
     __syncthreads();
-
-    if (tid == 192) {
-        // loudness: strictly sequential 1024-term sum, on its own wavefront, at raised issue priority: the workgroup's
-        // lifetime is this chain, and a dependent add that has to queue behind seven other wavefronts costs 8x
-        __builtin_amdgcn_s_setprio(3);
-        const float4* t4 = reinterpret_cast<const float4*>(s_term);
-        float l = 0.0f;
-        float4 cur = t4[0];
-        for (int i = 0; i < 256; ++i) {
-            float4 nxt = cur;
-            if (i + 1 < 256) nxt = t4[i + 1];
-            l += cur.x;
-            l += cur.y;
-            l += cur.z;
-            l += cur.w;
-            cur = nxt;
-        }
-        rec->loud_ch = l;
-        __builtin_amdgcn_s_setprio(0);
-    }
 
     if (!p.no_tonal && tid >= 8 && tid < 29) {
         const int b = tid;

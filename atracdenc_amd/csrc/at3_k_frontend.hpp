@@ -83,7 +83,6 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
     __shared__ __attribute__((aligned(16))) Curve s_cv[1][8][2];           // every frame of a 4096-frame batch is resident at once
     __shared__ __attribute__((aligned(16))) float s_win[256];
     const int wave = 0, lane = threadIdx.x;
-    *reinterpret_cast<float4*>(s_win + 4 * lane) = *reinterpret_cast<const float4*>(T->enc_win + 4 * lane);
     const int sf = blockIdx.x;
     if (sf >= n_frames_total) return;
     const int nfr = p.n_blocks - p.f0;
@@ -103,6 +102,8 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
     float* out8 = p.ges + ((size_t)s * p.n_blocks + f) * 8;
     if (lane < 8 && !((active >> lane) & 1u)) out8[lane] = 1.0f;   // no modulation on either side: every ratio is exactly 1
     if (active == 0u || p.debug == 3) return;
+    // (most frames leave above: the window is fetched only by those that modulate something)
+    *reinterpret_cast<float4*>(s_win + 4 * lane) = *reinterpret_cast<const float4*>(T->enc_win + 4 * lane);
     wave_sync();
     const int c = lane >> 3, slot = lane & 7;
     const bool on = (active >> c) & 1u;

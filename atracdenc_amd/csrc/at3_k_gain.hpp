@@ -275,6 +275,10 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     }
     __syncthreads();
     // 2. kiss_fftr post-processing -> 257 bins (k = tid + 1)
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 11) return;
+#endif
+
     if (tid == 0) {
         const float tr = L.f[0].r, ti = L.f[0].i;
         cpx a, b;
@@ -338,6 +342,10 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         L.f[irfft_pad(pb)] = nb;
     }
     // twiddles of the last three inverse passes: issued here, consumed after the energy sums below
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 12) return;
+#endif
+
     const Tw32_128 tw_b = irfft_tw_32_128(T->tw2048, tid);
     const Tw512<128> tw_c = irfft_tw_512<128>(T->tw2048, tid);
     // highFreqRatio (transient_spectral_upsampler.cpp:99-118): two ordered f64 sums over the 257 bin energies, the second
@@ -392,13 +400,29 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         }
     }
     // inverse transform: 128 radix-16 units per pass pair, one per work-item
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 13) return;
+#endif
+
     if (wave == 0) irfft_pass_2_8<0>(L.f, T->tw2048, lane);
     else irfft_pass_2_8<1>(L.f, T->tw2048, lane);
     __syncthreads();
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 14) return;
+#endif
+
     irfft_pass_32_128(L.f, tw_b, tid);
     __syncthreads();
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 15) return;
+#endif
+
     irfft_pass_512<128>(L.f, tw_c, tid);
     __syncthreads();
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 16) return;
+#endif
+
 
     // 4. AnalyzeGain over the upsampled samples [1024, 3072): 256 micro-chunks of 8 (4 per lane), 32 sub-frames of 64
     // complex output j holds the real samples 2j, 2j+1; sample 1024 is complex slot 512 = padded slot 528

@@ -530,6 +530,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.debug_stop = c->dbg_stop;
         bp.quant = c->d_quant;
         bp.mant = c->d_mant;
+        hipLaunchKernelGGL(k_loud_sum, dim3((unsigned)((S * n_out * 2 + kLoudCf - 1) / kLoudCf)), dim3(256), 0, bk, bp, c->d_tables, S * n_out * 2);
         hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, bk, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(ev[6], bk));
         hipLaunchKernelGGL(k_loudness, dim3(S), dim3(64), 0, bk, bp);
