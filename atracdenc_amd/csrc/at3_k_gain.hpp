@@ -19,6 +19,7 @@ namespace at3 {
 struct GainParams {
     const float* sub;     // [S][2][4][(n_blocks+2)*256] raw L/R subbands, block b at (b+2)*256
     GainRec* rec;         // [S][n_blocks][2][3] by frame index
+    cpx* bins;            // [items][kGainBins] rfft-512 bins 38 .. 256 of every item, k_gain_spec -> k_gain_analysis
     BandState* state;     // [S][2][4]
     Curve* curves;        // [S][n_blocks][2][4]
     int n_blocks;
@@ -188,30 +189,33 @@ __device__ __forceinline__ void irfft_pass_512(cpx* F, const Tw512<NT>& t, int t
     }
 }
 
-// One 128-thread workgroup (two wavefronts) per (stream, frame, channel, band<3) item. Every pass of the inverse
-// transform gives each work-item one register-resident radix-16 unit or four butterflies; the 19 KB working set allows
-// eight items = 16 wavefronts per CU. The strictly ordered sums (two f64 energy chains of 257 terms, 32 sub-frame RMS
-// chains of 64 terms) and the small forward transform run on wavefront 0 while wavefront 1 waits at the barrier.
-struct GainLds {
-    cpx f[2048 + 64];   // rfft-512 core in f[0..255]; then the irfft-4096 core / upsampled samples, padded (irfft_pad)
-    cpx freq[304];      // 257 bins, then 300 f64 energies (257 + zero padding), then the AnalyzeGain scratch below
-    double hsum[2];
-};
-// AnalyzeGain scratch inside `freq` (dead once the two energy sums are done): float offsets
-constexpr int kGaMicro = 0, kGaGain = 256, kGaFilt = 288, kGaMinv = 320;
+// The analysis of one (stream, frame, channel, band < 3) item is two kernels:
+//   k_gain_spec      Planck window, rFFT-512, the two ordered f64 energy sums and the high-frequency ratio; the 219 bins
+//                    that survive the high-pass go to HBM. One wavefront per item (the 256-point complex core is 64
+//                    butterflies per pass), four items per workgroup, 4.4 KB of LDS per item: a CU holds 32 items, and
+//                    the eight 257-term f64 chains of a workgroup run side by side in eight lanes of one wavefront.
+//   k_gain_analysis  x8 zero-padded irFFT-4096 (2048-point complex core, 17 KB of LDS), AnalyzeGain, plateau target - only for
+//                    items whose ratio reaches 5 % (atrac3denc.cpp:319-327), two wavefronts per item.
+// (One kernel did both at first: its cheap first half then ran at the 8-items-per-CU occupancy of the LDS-hungry second
+// half, with its sequential chains on two lanes of 128.)
+constexpr int kGainBins = 220;   // bins 38 .. 256 (219), padded to an even count
 
-__global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Tables* T)
+struct SpecLds {
+    cpx f[256];       // rfft-512 core
+    cpx freq[304];    // 257 bins, then 300 f64 energies (257 + zero padding) over the same bytes
+};
+
+__global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T, int n_items)
 {
-    __shared__ __attribute__((aligned(16))) GainLds s_item[1];
-    const int tid = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    GainLds& L = s_item[0];
-    float* s_micro = reinterpret_cast<float*>(L.freq) + kGaMicro;
-    float* s_gain = reinterpret_cast<float*>(L.freq) + kGaGain;
-    float* s_filt = reinterpret_cast<float*>(L.freq) + kGaFilt;
-    float* s_minv = reinterpret_cast<float*>(L.freq) + kGaMinv;
+    __shared__ __attribute__((aligned(16))) SpecLds s_item[4];
+    __shared__ double s_hsum[4][2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    SpecLds& L = s_item[wave];
     const int nfr = p.n_blocks - p.f0;
-    const bool valid = true;
-    int wg = blockIdx.x;
+    int item = blockIdx.x * 4 + wave;
+    const bool valid = item < n_items;
+    if (!valid) item = n_items - 1;   // keep the workgroup's barriers uniform; nothing is stored
+    int wg = item;
     const int band = wg % 3; wg /= 3;
     const int ch = wg % 2; wg /= 2;
     const int f = p.f0 + wg % nfr;
@@ -221,8 +225,9 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     const float* sb0 = p.sub + ((size_t)s * 8 + 0 * 4 + band) * sublen + (size_t)(cb + 2) * 256 - 128;
     const float* sb1 = p.sub + ((size_t)s * 8 + 1 * 4 + band) * sublen + (size_t)(cb + 2) * 256 - 128;
     GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
+    cpx* bins = p.bins + (size_t)item * kGainBins;
 
-    // Table entries this work-item will need depend on its index only: all fetched now, so that the kernel pays one
+    // Table entries this lane will need depend on its index only: all fetched now, so that the kernel pays one
     // global-memory latency instead of one per pass.
     f2 tw_a[4][3];                     // forward 256-point core: pass m = 4^st, k = lane % m, fstride 64 / m
 #pragma unroll
@@ -232,14 +237,12 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         tw_a[st][1] = ld2(T->tw256 + 2 * k * fs);
         tw_a[st][2] = ld2(T->tw256 + 3 * k * fs);
     }
-    const cpx stw_post = T->stw256[tid];                                         // bin k = tid + 1
-    const cpx stw_in0 = T->stw2048[kLowCutBin + tid - 1];                        // bins k = 38 + tid, 166 + tid
-    const cpx stw_in1 = T->stw2048[kLowCutBin + 128 + tid - 1 < 1024 ? kLowCutBin + 128 + tid - 1 : 1023];
+    const cpx stw_post0 = T->stw256[lane], stw_post1 = T->stw256[lane + 64];   // bins k = lane + 1, lane + 65
     const float hpf1 = T->hpf_w[1], hpf2 = T->hpf_w[2];
-    // 1. window and pack as 256 complex points in FFT leaf order (2 points per work-item)
+    // 1. window and pack as 256 complex points in FFT leaf order (4 points per lane)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int i = tid + 128 * q;
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
         float2 a = *reinterpret_cast<const float2*>(sb0 + 2 * i);
         if (p.js) {
             const float2 b = *reinterpret_cast<const float2*>(sb1 + 2 * i);
@@ -258,28 +261,22 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         z.i = a.y * T->planck[2 * i + 1];
         L.f[fft_leaf_pos<256>(i)] = z;
     }
-    __syncthreads();
-    if (wave == 0) {   // 256-point forward core, one butterfly per lane and pass, twiddles fetched at kernel entry
+    wave_sync();
+    // 256-point forward core, one butterfly per lane and pass
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int m = 1 << (2 * st);
-            cpx* B = L.f + (lane / m) * 4 * m + lane % m;
-            f2 x0 = ld2(B), x1 = ld2(B + m), x2 = ld2(B + 2 * m), x3 = ld2(B + 3 * m);
-            bfly4<false>(x0, x1, x2, x3, tw_a[st][0], tw_a[st][1], tw_a[st][2]);
-            st2(B, x0);
-            st2(B + m, x1);
-            st2(B + 2 * m, x2);
-            st2(B + 3 * m, x3);
-            wave_sync();
-        }
+    for (int st = 0; st < 4; ++st) {
+        const int m = 1 << (2 * st);
+        cpx* B = L.f + (lane / m) * 4 * m + lane % m;
+        f2 x0 = ld2(B), x1 = ld2(B + m), x2 = ld2(B + 2 * m), x3 = ld2(B + 3 * m);
+        bfly4<false>(x0, x1, x2, x3, tw_a[st][0], tw_a[st][1], tw_a[st][2]);
+        st2(B, x0);
+        st2(B + m, x1);
+        st2(B + 2 * m, x2);
+        st2(B + 3 * m, x3);
+        wave_sync();
     }
-    __syncthreads();
-    // 2. kiss_fftr post-processing -> 257 bins (k = tid + 1)
-#ifdef AT3HIP_DEBUG_KNOBS
-    if (p.debug == 11) return;
-#endif
-
-    if (tid == 0) {
+    // 2. kiss_fftr post-processing -> 257 bins (tools/kiss_fftr.c:61-100): lane handles k = lane + 1 and k = lane + 65
+    if (lane == 0) {
         const float tr = L.f[0].r, ti = L.f[0].i;
         cpx a, b;
         a.r = tr + ti; a.i = 0.0f;
@@ -287,8 +284,9 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         L.freq[0] = a;
         L.freq[256] = b;
     }
-    {
-        const int k = tid + 1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = lane + 1 + 64 * q;
         const cpx fpk = L.f[k];
         cpx fpnk;
         fpnk.r = L.f[256 - k].r;
@@ -296,14 +294,114 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         cpx f1k, f2k;
         f1k.r = fpk.r + fpnk.r; f1k.i = fpk.i + fpnk.i;
         f2k.r = fpk.r - fpnk.r; f2k.i = fpk.i - fpnk.i;
-        const cpx tw = cmul(f2k, stw_post);
+        const cpx tw = cmul(f2k, q ? stw_post1 : stw_post0);
         cpx a, b;
         a.r = (f1k.r + tw.r) * 0.5f; a.i = (f1k.i + tw.i) * 0.5f;
         b.r = (f1k.r - tw.r) * 0.5f; b.i = (tw.i - f1k.i) * 0.5f;
         if (k != 128) L.freq[k] = a;   // k == 128: the second store wins in the reference
         L.freq[256 - k] = b;
     }
+    wave_sync();
+    // the bins that survive the high-pass (38 .. 256) go to HBM for k_gain_analysis; whether it will want them is known
+    // only after the energy sums, and the stores cost less than waiting for that
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q;
+            if (j < 219) bins[j] = L.freq[kLowCutBin + j];
+        }
+    }
+    // highFreqRatio (transient_spectral_upsampler.cpp:99-118): two ordered f64 sums over the 257 bin energies, the second
+    // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on). The energies are formed by
+    // all lanes and parked (as f64) over the spectrum; after the workgroup's rendezvous lanes 0..7 of the first wavefront
+    // add them up - item lane / 2: even lanes e[0..256], odd lanes the two weighted terms followed by e[40..256] (the
+    // skipped terms of the reference are exact zeros and the padding read past bin 256 is zero).
+    {
+        double e[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int k = lane + 64 * t;
+            const cpx z = L.freq[k < 257 ? k : 256];
+            e[t] = (k < 257) ? (double)z.r * z.r + (double)z.i * z.i : 0.0;
+        }
+        wave_sync();
+        double* E = reinterpret_cast<double*>(L.freq);
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int k = lane + 64 * t;
+            if (k < 300) E[k] = e[t];
+        }
+    }
     __syncthreads();
+    if (tid < 8) {
+        const int it = tid >> 1, kind = tid & 1;
+        const double* E = reinterpret_cast<const double*>(s_item[it].freq);
+        const double h1 = (double)hpf1, h2 = (double)hpf2;
+        double acc = 0.0;
+        if (kind == 1) {
+            acc += E[kLowCutBin] * h1 * h1;
+            acc += E[kLowCutBin + 1] * h2 * h2;
+        }
+        const double* src = E + (kind ? kLowCutBin + 2 : 0);
+        for (int k0 = 0; k0 < 256; k0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = src[k0 + i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc += v[i];
+        }
+        acc += src[256];
+        s_hsum[it][kind] = acc;
+    }
+    __syncthreads();
+    if (valid && lane == 0) {
+        const double totalE = s_hsum[wave][0], filtE = s_hsum[wave][1];
+        rec->hfr = (totalE > 0.0) ? (float)(filtE / totalE) : 0.0f;
+    }
+}
+
+// Second half of the analysis of one item (see k_gain_spec): one 128-thread workgroup (two wavefronts). Every pass of the
+// inverse transform gives each work-item one register-resident radix-16 unit or four butterflies; the 17 KB working set
+// allows eight items = 16 wavefronts per CU.
+struct GainLds {
+    cpx f[2048 + 64];   // the irfft-4096 core / upsampled samples, padded (irfft_pad)
+    float scratch[352]; // AnalyzeGain scratch
+};
+// AnalyzeGain scratch: float offsets
+constexpr int kGaMicro = 0, kGaGain = 256, kGaFilt = 288, kGaMinv = 320;
+
+__global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Tables* T)
+{
+    __shared__ __attribute__((aligned(16))) GainLds s_item[1];
+    const int tid = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    GainLds& L = s_item[0];
+    float* s_micro = L.scratch + kGaMicro;
+    float* s_gain = L.scratch + kGaGain;
+    float* s_filt = L.scratch + kGaFilt;
+    float* s_minv = L.scratch + kGaMinv;
+    const int nfr = p.n_blocks - p.f0;
+    const bool valid = true;
+    int wg = blockIdx.x;
+    const size_t item = blockIdx.x;
+    const int band = wg % 3; wg /= 3;
+    const int ch = wg % 2; wg /= 2;
+    const int f = p.f0 + wg % nfr;
+    const int s = wg / nfr;
+    GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
+    // below 5 % high-band energy the reference drops the band before the upsampler output is looked at
+    // (atrac3denc.cpp:319-327): nothing downstream reads the other fields of such a record
+    const float hfr = rec->hfr;
+    if (hfr < 0.05f) return;
+    const cpx* bins = p.bins + item * kGainBins;
+    // this work-item's bins (k = 38 + tid and 166 + tid), tables and twiddles: one global-memory latency for all of them
+    const int k0 = kLowCutBin + tid, k1 = kLowCutBin + 128 + tid;
+    const cpx bin0 = bins[tid];
+    const cpx bin1 = (k1 <= 256) ? bins[128 + tid] : bin0;
+    const cpx stw_in0 = T->stw2048[k0 - 1];
+    const cpx stw_in1 = T->stw2048[k1 - 1 < 1024 ? k1 - 1 : 1023];
+    const float hpf1 = T->hpf_w[1], hpf2 = T->hpf_w[2];
+    const Tw32_128 tw_b = irfft_tw_32_128(T->tw2048, tid);
+    const Tw512<128> tw_c = irfft_tw_512<128>(T->tw2048, tid);
     // 3. kiss_fftri input. Only bins 38..256 survive the high-pass, so tmpbuf is non-zero at k in [38,256] and
     //    [1792,2010]; each of those meets an exact zero in its radix-2 leaf butterfly (x +- 0*w), whose two outputs
     //    are therefore stored directly.
@@ -314,91 +412,39 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
             if (tid + 128 * k < (2048 + 64) / 2) z4[tid + 128 * k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     __syncthreads();
-    for (int k = kLowCutBin + tid; k <= 256; k += 128) {
-        cpx fk;
-        const float scale = 8.0f;
-        if (k == 256) {
-            fk.r = L.freq[256].r * scale * 0.5f;
-            fk.i = 0.0f;
-        } else if (k >= kLowCutBin + 2) {
-            fk.r = L.freq[k].r * scale;
-            fk.i = L.freq[k].i * scale;
-        } else {
-            const float w = (k == kLowCutBin) ? hpf1 : hpf2;
-            fk.r = L.freq[k].r * scale * w;
-            fk.i = L.freq[k].i * scale * w;
-        }
-        // fnkc = conj(freq[2048 - k]) = (0, -0): fek = fk, tmp = fk
-        const cpx fok = cmul(fk, (k < kLowCutBin + 128) ? stw_in0 : stw_in1);
-        cpx a, b, nb;
-        a.r = fk.r + fok.r; a.i = fk.i + fok.i;
-        b.r = fk.r - fok.r; b.i = -(fk.i - fok.i);
-        nb.r = 0.0f - b.r; nb.i = 0.0f - b.i;
-        const int pa = fft_leaf_pos<2048>(k);          // even slot: partner input k + 1024 is zero
-        L.f[irfft_pad(pa)] = a;
-        L.f[irfft_pad(pa) + 1] = a;
-        const int pb = fft_leaf_pos<2048>(2048 - k);   // odd slot: partner input 1024 - k is zero
-        L.f[irfft_pad(pb) - 1] = b;
-        L.f[irfft_pad(pb)] = nb;
-    }
-    // twiddles of the last three inverse passes: issued here, consumed after the energy sums below
-#ifdef AT3HIP_DEBUG_KNOBS
-    if (p.debug == 12) return;
-#endif
-
-    const Tw32_128 tw_b = irfft_tw_32_128(T->tw2048, tid);
-    const Tw512<128> tw_c = irfft_tw_512<128>(T->tw2048, tid);
-    // highFreqRatio (transient_spectral_upsampler.cpp:99-118): two ordered f64 sums over the 257 bin energies, the second
-    // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on). The energies are formed by
-    // all lanes and parked (as f64) over the spectrum, which the inverse transform no longer needs; lane 0 then adds
-    // e[0..256] and lane 1 its two weighted terms followed by e[40..256] - the skipped terms of the reference are
-    // exact zeros and the padding read past bin 256 is zero.
-    {
-        double e[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int k = tid + 128 * t;
-            const cpx z = L.freq[k < 257 ? k : 256];
-            e[t] = (k < 257) ? (double)z.r * z.r + (double)z.i * z.i : 0.0;
-        }
-        __syncthreads();
-        double* E = reinterpret_cast<double*>(L.freq);
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int k = tid + 128 * t;
-            if (k < 300) E[k] = e[t];
-        }
-        __syncthreads();
-        if (tid < 2) {
-            const double h1 = (double)hpf1, h2 = (double)hpf2;
-            double acc = 0.0;
-            if (lane == 1) {
-                acc += E[kLowCutBin] * h1 * h1;
-                acc += E[kLowCutBin + 1] * h2 * h2;
+    for (int q = 0; q < 2; ++q) {
+        const int k = q ? k1 : k0;
+        if (k <= 256) {
+            const cpx fr = q ? bin1 : bin0;
+            cpx fk;
+            const float scale = 8.0f;
+            if (k == 256) {
+                fk.r = fr.r * scale * 0.5f;
+                fk.i = 0.0f;
+            } else if (k >= kLowCutBin + 2) {
+                fk.r = fr.r * scale;
+                fk.i = fr.i * scale;
+            } else {
+                const float w = (k == kLowCutBin) ? hpf1 : hpf2;
+                fk.r = fr.r * scale * w;
+                fk.i = fr.i * scale * w;
             }
-            const double* src = E + (lane ? kLowCutBin + 2 : 0);
-            for (int k0 = 0; k0 < 256; k0 += 16) {
-                double v[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = src[k0 + i];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc += v[i];
-            }
-            acc += src[256];
-            L.hsum[lane] = acc;
+            // fnkc = conj(freq[2048 - k]) = (0, -0): fek = fk, tmp = fk
+            const cpx fok = cmul(fk, q ? stw_in1 : stw_in0);
+            cpx a, b, nb;
+            a.r = fk.r + fok.r; a.i = fk.i + fok.i;
+            b.r = fk.r - fok.r; b.i = -(fk.i - fok.i);
+            nb.r = 0.0f - b.r; nb.i = 0.0f - b.i;
+            const int pa = fft_leaf_pos<2048>(k);          // even slot: partner input k + 1024 is zero
+            L.f[irfft_pad(pa)] = a;
+            L.f[irfft_pad(pa) + 1] = a;
+            const int pb = fft_leaf_pos<2048>(2048 - k);   // odd slot: partner input 1024 - k is zero
+            L.f[irfft_pad(pb) - 1] = b;
+            L.f[irfft_pad(pb)] = nb;
         }
     }
     __syncthreads();
-    {
-        // below 5 % high-band energy the reference drops the band before the upsampler output is looked at
-        // (atrac3denc.cpp:319-327): nothing downstream reads the other fields of such a record
-        const double totalE = L.hsum[0], filtE = L.hsum[1];
-        const float hfr = (totalE > 0.0) ? (float)(filtE / totalE) : 0.0f;
-        if (hfr < 0.05f) {
-            if (valid && tid == 0) rec->hfr = hfr;
-            return;
-        }
-    }
     // inverse transform: 128 radix-16 units per pass pair, one per work-item
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug == 13) return;
@@ -521,8 +567,6 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         }
         const bool usePlateau = plateau > 1e-6f && !release && plateau >= maxRaw * 0.4f;
         if (valid && lane == 0) {
-            const double totalE = L.hsum[0], filtE = L.hsum[1];
-            rec->hfr = (totalE > 0.0) ? (float)(filtE / totalE) : 0.0f;
             rec->cur_hpf = sum / 32.0f;
             rec->target = usePlateau ? plateau : last;
         }

@@ -53,6 +53,7 @@ struct at3hip_ctx {
     long long enc_calls = 0;             // at3hip_encode calls so far
     int last_slot = -1;                  // slot of the most recent call that produced frames
     bool slot_has_frames[kSlots] = {};
+    int slot_k1_launches[kSlots] = {};   // kernels the QMF + MDCT work of the slot's call was spread over (1 = fused, 2)
     char err[256] = {0};
     long long blocks_fed = 0;   // per stream
     int runs_override = 0;   // AT3HIP_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
@@ -69,6 +70,7 @@ struct at3hip_ctx {
     float* d_sub = nullptr;
     float* d_sub_tail = nullptr;     // [S][8][512] subbands of the last two blocks of the previous call
     GainRec* d_rec = nullptr;
+    cpx* d_bins = nullptr;           // [S][B][6][kGainBins] high-passed rfft bins, k_gain_spec -> k_gain_analysis
     BandState* d_state = nullptr;
     Curve* d_curves[2] = {nullptr, nullptr};   // by call parity
     float* d_specs[2] = {nullptr, nullptr};
@@ -148,7 +150,7 @@ void read_timings(const at3hip_ctx* c, int slot, at3hip_timings* tm)
     (void)hipEventElapsedTime(&ms, ev[5], ev[6]); tm->psy_ms = ms;
     (void)hipEventElapsedTime(&ms, ev[6], ev[7]); tm->alloc_ms = ms;
     (void)hipEventElapsedTime(&ms, ev[0], ev[7]); tm->total_ms = ms;   // first front-half kernel to last back-half kernel
-    tm->qmf_mdct_launches = 1;
+    tm->qmf_mdct_launches = c->slot_k1_launches[slot];
 }
 
 // Runs per (stream, channel) for the wavefront-per-run kernels (QMF, MDCT, fused): `items` blocks or frames are cut
@@ -278,6 +280,7 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     }
     if (!cfg->no_gain_control) {
         if ((rc = dev_alloc(c, &c->d_rec, S * B * 6)) != AT3HIP_OK) return bail(rc);
+        if ((rc = dev_alloc(c, &c->d_bins, S * B * 6 * kGainBins)) != AT3HIP_OK) return bail(rc);
         for (int q = 0; q < 2; ++q)
             if ((rc = dev_alloc(c, &c->d_ges[q], S * B * 8)) != AT3HIP_OK) return bail(rc);
     }
@@ -321,7 +324,7 @@ void at3hip_destroy(at3hip_ctx* c)
     if (c->back_stream) (void)hipStreamSynchronize(c->back_stream);
     void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
                     c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
-                    c->d_out,       c->d_quant,     c->d_mant,     c->d_pcm_mono,  c->d_stage,    c->d_sub_tail};
+                    c->d_out,       c->d_quant,     c->d_mant,     c->d_pcm_mono,  c->d_stage,    c->d_sub_tail, c->d_bins};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& row : c->ev)
@@ -412,8 +415,8 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
 
     // the back half of the call before the previous one must be done with this parity's spectra / curves / scales
     if (c->back_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_back_done[par], 0));
-    HIPCHK(c, hipEventRecord(ev[0], st));
     HIPCHK(c, hipMemsetAsync(d_curves, 0, (size_t)S * n_blocks * 8 * sizeof(Curve), st));
+    HIPCHK(c, hipEventRecord(ev[0], st));
     if (n_out == 0 && (gain || c->js)) {
         // a call that only primes the look-ahead still has to leave its subbands behind for the next call's look-back
         FrontParams fp = {};
@@ -454,6 +457,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             GainParams gp;
             gp.sub = c->d_sub;
             gp.rec = c->d_rec;
+            gp.bins = c->d_bins;
             gp.state = c->d_state;
             gp.curves = d_curves;
             gp.n_blocks = n_blocks;
@@ -463,6 +467,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.debug = c->dbg_gain;
             launch_qmf_sub();
             HIPCHK(c, hipEventRecord(ev[1], st));
+            hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(256), 0, st, gp, c->d_tables, S * n_out * 6);
             hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), 0, st, gp, c->d_tables);
             HIPCHK(c, hipEventRecord(ev[2], st));
             hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), 0, st, gp, S);
@@ -493,6 +498,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
         }
         HIPCHK(c, hipEventRecord(ev[4], st));
+        c->slot_k1_launches[slot] = split ? 2 : 1;
     }
     {
         StateParams sp;

@@ -58,13 +58,14 @@ typedef struct at3hip_config {
  * call (its latency); with AT3HIP_ASYNC consecutive calls overlap, so throughput is not 1 / total_ms. */
 typedef struct at3hip_timings {
     float total_ms;
-    float qmf_ms;        /* subband analysis for the gain path */
+    float qmf_ms;        /* QMF tree as its own kernel (subbands to HBM: gain control and joint stereo); ~0 when fused */
     float gain_ms;       /* spectral upsampler + AnalyzeGain */
     float curve_ms;      /* CalcCurve / point-0 logic / context scan */
-    float qmf_mdct_ms;   /* fused QMF + gain modulation + windowed MDCT-512 (the roofline kernel) */
+    float qmf_mdct_ms;   /* MDCT-512 from the subbands, or the fused QMF + MDCT kernel (no gain control, discrete stereo).
+                          * The QMF + MDCT work of a call (the roofline kernel pair) takes qmf_ms + qmf_mdct_ms. */
     float psy_ms;        /* loudness, flatness, tonal extraction, scale factors */
     float alloc_ms;      /* loudness scan + bit allocation + quantisation + sound-unit packing */
-    int32_t qmf_mdct_launches; /* launches of the fused kernel covered by qmf_mdct_ms */
+    int32_t qmf_mdct_launches; /* kernels the QMF + MDCT work was spread over: 1 (fused) or 2 */
 } at3hip_timings;
 
 /* Replaces: TAtrac3Encoder::TAtrac3Encoder(TCompressedOutputPtr&&, TAtrac3EncoderSettings&&)

@@ -45,16 +45,23 @@ def avg_counter(sub, counter, like):
             return row[0], row[1]
     return None, None
 
-kn, fetch = avg_counter("pmc_fetch", "FETCH_SIZE", "%k_qmf_mdct%")
-_, write = avg_counter("pmc_write", "WRITE_SIZE", "%k_qmf_mdct%")
-if fetch is not None and write is not None:
+# the QMF + MDCT work: two kernels around the gain analysis (k_qmf_sub8 + k_mdct_sub), or the fused k_qmf_mdct8
+parts = []
+for like in ("%k_qmf_sub8%", "%k_mdct_sub%", "%k_qmf_mdct8%"):
+    kn, fetch = avg_counter("pmc_fetch", "FETCH_SIZE", like)
+    _, write = avg_counter("pmc_write", "WRITE_SIZE", like)
+    if fetch is not None and write is not None:
+        parts.append({"kernel": short(kn), "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
+                      "bytes_per_launch": (2.0 * fetch + write) * 1024.0})
+if parts:
     algo = 16384 * 4096
-    total = (2.0 * fetch + write) * 1024.0
+    total = sum(q["bytes_per_launch"] for q in parts)
     out = {
-        "kernel": short(kn), "workload": "64 streams x 64 frames (4096 frames/launch), frames_per_wg auto",
-        "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
+        "kernels": parts, "workload": "64 streams x 64 frames (4096 frames per step), run lengths automatic",
         "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section)",
         "bytes_per_launch": total, "algorithmic_bytes_per_launch": algo, "ratio": total / algo,
+        "note": "bytes_per_launch = the kernels' sum: with gain control the subbands cross HBM between the two kernels (8 KB written + 8 KB "
+                "read per frame on top of the 16 KB of PCM in and spectra out) because the gain analysis needs them there anyway",
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/profile_gpu.sh)",
     }
     json.dump(out, open(os.path.join(root, "k1_traffic.json"), "w"), indent=1)
