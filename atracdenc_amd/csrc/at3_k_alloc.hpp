@@ -29,17 +29,19 @@ struct AllocLds {
             float uk[kEaLines + 4];      // then the energy-adaptive pass: a unit's sort keys (+inf padded); tie-sort scratch
             uint16_t rec[kEaLines];      // and its candidates ordered by |delta|: line | |m| << 7 | negative << 12
         };
-        uint32_t words[kBitWords];   // after the rate loop: the sound unit being assembled
+        struct {
+            uint32_t words[kBitWords];   // after the rate loop: the sound unit being assembled
+            uint16_t huff[130];          // and the code tables
+        };
     };
     float err[8 * 32];               // cache: e1 / e2 per (wordlen, BFU)
-    uint32_t cost[8 * 32];           // cache: CLC bits | VLC bits << 13
+    uint16_t cost[8 * 32];           // cache: VLC bits (the CLC bits are wordlen x lines)
     int8_t bm[1024];                 // mantissas of the units of the current batch (one wordlen per BFU)
     uint8_t code[256];               // 2 bits per line of the batch: 1 = re-roundable when e2 < e1, 2 = when e2 > e1
     float e1[32];
     uint32_t vlc[32];
     int alloc[32];
     uint8_t tbits[kMaxTonal * 8];
-    uint16_t huff[130];
     int misc[4];
     unsigned long long tmask[4];
 };
@@ -58,6 +60,9 @@ __device__ __forceinline__ float inv_mul2(int wl)
         default: return (float)(1.0 / (double)(31.5f * 31.5f));
     }
 }
+
+// CLC bits of a unit: clc_len(wordlen) per line, two per line at wordlen 1 (pairs of 4 bits, atrac3_bitstream.cpp:77-90)
+__device__ __forceinline__ uint32_t clc_bits(int wl, int n_lines) { return (wl > 1) ? (uint32_t)clc_len(wl) * (uint32_t)n_lines : 2u * (uint32_t)n_lines; }
 
 __device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
 // MantissasToVlcIndex's 3x3 table {8, 4, 7, 2, 0, 1, 6, 3, 5} (atrac3_bitstream.cpp:92-113) as nibbles of one constant
@@ -335,9 +340,8 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
     }
     wave_sync();
     if (mine) {
-        const uint32_t clc = (bits > 1) ? (uint32_t)clc_len(bits) * my_n : 2u * my_n;
         L.err[bits * 32 + lane] = my_e1 / my_e2;
-        L.cost[bits * 32 + lane] = clc | (L.vlc[lane] << 13);
+        L.cost[bits * 32 + lane] = (uint16_t)L.vlc[lane];
     }
     wave_sync();
 }
@@ -372,9 +376,8 @@ __device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant
                 vb += vlc_bits8(wl, m);
                 *reinterpret_cast<uint2*>(gmant + (wl - 1) * 1024 + start + off) = make_uint2(pk[0], pk[1]);
             }
-            const uint32_t clc = (wl > 1) ? (uint32_t)clc_len(wl) * n : 2u * n;
             L.err[wl * 32 + bfu] = L.e1[bfu] / e2;
-            L.cost[wl * 32 + bfu] = clc | (vb << 13);
+            L.cost[wl * 32 + bfu] = (uint16_t)vb;
         }
     }
     wave_sync();
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     uint8_t* s_tbits = L.tbits;
     uint16_t* s_huff = L.huff;
     int* s_misc = L.misc;
-    uint32_t* s_cost = L.cost;
+    uint16_t* s_cost = L.cost;
     float* s_err = L.err;
     unsigned long long* s_tmask = L.tmask;
 
@@ -407,18 +410,23 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     const int n_tonal = rec->n_tonal;
 
     for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
-    for (int i = lane; i < 130; i += 64) s_huff[i] = c_huff[i];
     for (int i = lane; i < 8 * 32; i += 64) {
         s_err[i] = 0.0f;
         s_cost[i] = 0u;
     }
 
     // ---- header + gain info bits, joint-stereo byte shift, target bits (WriteSoundUnit :759-810) ----
+    // lanes 0..7 hold the frame's eight gain curves (16 bytes each) from here to the emission
+    uint4 cw = {0u, 0u, 0u, 0u};
+    if (lane < 8) cw = *reinterpret_cast<const uint4*>(curves + lane);
+    const int curve_n = (int)(cw.x & 0xffu);
+    // the code tables the emission will want in LDS (their storage is the key lists' until then)
+    const uint32_t huff_a = c_huff[lane], huff_b = c_huff[64 + lane], huff_c = lane < 2 ? c_huff[128 + lane] : 0u;
     int hdr[2];
     for (int c2 = 0; c2 < 2; ++c2) {
         int bits = (p.js && c2 == 1) ? 14 : 6;
         bits += 2;
-        for (int b = 0; b < 4; ++b) bits += 3 + 9 * curves[c2 * 4 + b].n;
+        for (int b = 0; b < 4; ++b) bits += 3 + 9 * __builtin_amdgcn_readlane(curve_n, c2 * 4 + b);
         // one input channel, joint stereo: the second element has ONE subband and no gain points (atrac3denc.cpp:843-849)
         if (p.mono_js && c2 == 1) bits = 14 + 2 + 3;
         hdr[c2] = bits;
@@ -473,13 +481,19 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
 
 
     // ---- scaled values (TScaler::Scale, atrac_scale.cpp:141-172) and e1 = sum of value^2 per BFU, in line order ----
+    const int my_sfi = rec->sfi[lane & 31];   // one load per lane (lanes 32..63 mirror 0..31)
     {
         const float* specs = p.specs + cf * 1024;
+        const float my_scale = T->scale[lane];   // ScaleTable has 64 entries: looked up across lanes, not through memory
+        float4 x4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x4[k] = *reinterpret_cast<const float4*>(specs + 4 * (lane + 64 * k));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i0 = 4 * (lane + 64 * k);
-            const float sf = T->scale[rec->sfi[bfu_of_line(i0)]];
-            const float4 x = *reinterpret_cast<const float4*>(specs + i0);
+            const int sfi = __builtin_amdgcn_ds_bpermute(4 * bfu_of_line(i0), my_sfi);
+            const float sf = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * sfi, (int)__float_as_uint(my_scale)));
+            const float4 x = x4[k];
             float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -514,9 +528,9 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     uint32_t valid = lane < 10 ? 0xfeu : 0u;   // lane i: bit wl set = unit (BFU i, wl) is in the cache
     // ---- TConfigure: spread (sequential float sums, every lane computes the same value) ----
     const int i = lane & 31;   // BFU owned by this lane (lanes 32..63 mirror 0..31 but never contribute)
+    const int n_i = opaque_lane_value(bfu_start(i + 1) - bfu_start(i));   // (computed once: not re-derived inside the rate loop)
     float spread;
     {
-        const int my_sfi = rec->sfi[i];   // one load per lane; the ordered sums walk the lanes
         float sum = 0.0f;
         for (int k = 0; k < 32; ++k) sum += (float)__builtin_amdgcn_readlane(my_sfi, k);
         sum /= 32;
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
                     if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
                 }
             }
-            const uint32_t mine = (lane < num_bfu) ? s_cost[bits * 32 + i] : 0u;
+            const uint32_t mine = (lane < num_bfu && bits) ? (clc_bits(bits, n_i) | ((uint32_t)s_cost[bits * 32 + i] << 13)) : 0u;
             const uint32_t rsum = row_allreduce_add(mine);
             const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
             // the count of non-zero BFUs comes from a ballot: summed as a third field it would need six bits at
@@ -718,68 +732,92 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         QuantRec* qr = p.quant + cf;
         for (int k = lane; k < 7 * 32; k += 64) {
             qr->err[k >> 5][k & 31] = s_err[32 + k];
-            qr->cost[k >> 5][k & 31] = s_cost[32 + k];
+            const uint32_t vb = s_cost[32 + k];
+            qr->cost[k >> 5][k & 31] = vb ? (clc_bits(1 + (k >> 5), bfu_start((k & 31) + 1) - bfu_start(k & 31)) | (vb << 13)) : 0u;
         }
     }
     if (lane < 32) s_alloc[lane] = bits;
     for (int k = lane; k < kBitWords; k += 64) s_words[k] = 0;   // the key lists are dead: their storage becomes the bit buffer
+    s_huff[lane] = (uint16_t)huff_a;
+    s_huff[64 + lane] = (uint16_t)huff_b;
+    if (lane < 2) s_huff[128 + lane] = (uint16_t)huff_c;
     __syncthreads();
 
     // ---- emission (WriteSoundUnit header, EncodeSpecs) ----
-    int pos = 0;
+    // mantissas: 16 spectral lines per lane (BFU sizes are multiples of 8, so at most two BFUs per lane), requested
+    // from HBM before lane 0 writes the header
+    int wl_h[2];
+    uint2 pk_h[2];
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        const int i0 = lane * 16 + 8 * hlf;
+        const int b = bfu_of_line(i0);
+        wl_h[hlf] = (b < num_bfu) ? s_alloc[b] : 0;
+        pk_h[hlf] = make_uint2(0u, 0u);
+        if (wl_h[hlf]) pk_h[hlf] = *reinterpret_cast<const uint2*>(gmant + (wl_h[hlf] - 1) * 1024 + i0);
+    }
+    int pos = (p.js && ch == 1) ? 14 : 6;
     if (lane == 0) {
         if (p.js && ch == 1) {
             put_bits(s_words, 0, 0, 1);
             put_bits(s_words, 1, 7, 3);
             for (int k = 0; k < 4; ++k) put_bits(s_words, 4 + 2 * k, 3, 2);
             put_bits(s_words, 12, 3, 2);
-            pos = 14;
         } else {
             put_bits(s_words, 0, 0x28, 6);
-            pos = 6;
         }
         put_bits(s_words, pos, 3, 2);
-        pos += 2;
-        for (int b = 0; b < 4; ++b) {
-            const Curve& c = curves[ch * 4 + b];
-            put_bits(s_words, pos, c.n, 3);
-            pos += 3;
-            for (int k = 0; k < c.n; ++k) {
-                put_bits(s_words, pos, c.level[k], 4);
-                put_bits(s_words, pos + 4, c.loc[k], 5);
-                pos += 9;
+    }
+    pos += 2;
+    {   // gain points: lane ch * 4 + b writes band b's count and (level, location) pairs out of its registers
+        const int n0 = __builtin_amdgcn_readlane(curve_n, ch * 4), n1 = __builtin_amdgcn_readlane(curve_n, ch * 4 + 1);
+        const int n2 = __builtin_amdgcn_readlane(curve_n, ch * 4 + 2), n3 = __builtin_amdgcn_readlane(curve_n, ch * 4 + 3);
+        const int b = lane - ch * 4;
+        if (b >= 0 && b < 4) {
+            int at = pos + 3 * b + 9 * ((b > 0 ? n0 : 0) + (b > 1 ? n1 : 0) + (b > 2 ? n2 : 0));
+            put_bits(s_words, at, (uint32_t)curve_n, 3);
+            at += 3;
+            const uint64_t lo = (uint64_t)cw.x | ((uint64_t)cw.y << 32), hi = (uint64_t)cw.z | ((uint64_t)cw.w << 32);
+            for (int k = 0; k < curve_n; ++k) {   // Curve: n, level[7] | loc[7], pad
+                const uint32_t level = (uint32_t)(lo >> (8 * (k + 1))) & 0xffu, loc = (uint32_t)(hi >> (8 * k)) & 0xffu;
+                put_bits(s_words, at, level, 4);
+                put_bits(s_words, at + 4, loc, 5);
+                at += 9;
             }
         }
-        pos += tonal_encode<true>(rec, s_tbits, s_alloc, num_bfu, s_words, pos);
+        pos += 12 + 9 * (n0 + n1 + n2 + n3);
+    }
+    if (n_tonal == 0) {   // EncodeTonalComponents without components: five zero bits (atrac3_bitstream.cpp:382-400)
+        pos += 5;
+    } else {
+        if (lane == 0) s_misc[1] = tonal_encode<true>(rec, s_tbits, s_alloc, num_bfu, s_words, pos);
+        __syncthreads();
+        pos += s_misc[1];
+    }
+    if (lane == 0) {
         put_bits(s_words, pos, (uint32_t)num_bfu - 1, 5);
         put_bits(s_words, pos + 5, (uint32_t)mode, 1);
-        pos += 6;
-        s_misc[1] = pos;
     }
-    __syncthreads();
-    pos = s_misc[1];
+    pos += 6;
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug_stop == 7) return;
+#endif
     const unsigned long long nzmask = __ballot(lane < num_bfu && bits != 0);
     if (lane < num_bfu) put_bits(s_words, pos + 3 * lane, (uint32_t)bits, 3);
     pos += 3 * num_bfu;
     if (lane < num_bfu && bits)
-        put_bits(s_words, pos + 6 * __popcll(nzmask & ((1ull << lane) - 1ull)), rec->sfi[lane], 6);
+        put_bits(s_words, pos + 6 * __popcll(nzmask & ((1ull << lane) - 1ull)), (uint32_t)my_sfi, 6);
     pos += 6 * __popcll(nzmask);
-    // mantissas: 16 spectral lines per lane (BFU sizes are multiples of 8, so at most two BFUs per lane)
     {
-        const int base = lane * 16;
         uint32_t code[16];
         int sum = 0;
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
-            const int i0 = base + 8 * hlf;
-            const int b = bfu_of_line(i0);
-            const int wl = (b < num_bfu) ? s_alloc[b] : 0;
+            const int wl = wl_h[hlf];
+            const uint2 pk = pk_h[hlf];
             int8_t m8[8];
-            if (wl) {
-                const uint2 pk = *reinterpret_cast<const uint2*>(gmant + (wl - 1) * 1024 + i0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) m8[k] = (int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
-            }
+            for (int k = 0; k < 8; ++k) m8[k] = (int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 uint32_t cl = 0;
@@ -804,25 +842,44 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
                 sum += (int)(cl >> 16);
             }
         }
-        int off = pos + wave_inclusive_scan(sum, lane) - sum;
+        // the lane's codes are strung together in registers (most significant bit first) and reach the shared bit
+        // buffer one 32-bit word at a time: two to four atomic ORs per lane instead of one or two per code
+        const int off = pos + wave_inclusive_scan(sum, lane) - sum;
+        int cur = off >> 5, fill = off & 31;
+        uint64_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int n = (int)(code[k] >> 16);
+            const int n = (int)(code[k] >> 16);   // <= 10
             if (n) {
-                put_bits(s_words, off, code[k] & 0xffffu, n);
-                off += n;
+                acc |= (uint64_t)(code[k] & ((1u << n) - 1u)) << (64 - fill - n);
+                fill += n;
+                if (fill >= 32) {
+                    if (cur < kBitWords) atomicOr(&s_words[cur], (uint32_t)(acc >> 32));
+                    acc <<= 32;
+                    fill -= 32;
+                    ++cur;
+                }
             }
         }
+        if (fill > 0 && cur < kBitWords) atomicOr(&s_words[cur], (uint32_t)(acc >> 32));
     }
     __syncthreads();
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug_stop == 8) return;
+#endif
 
     // ---- frame assembly (atrac3_bitstream.cpp:826-834): ch0 bytes, then ch1 (byte-reversed when JS) ----
     uint8_t* frame = p.out + ((size_t)s * n_out + fo) * p.frame_sz;
     const int dst0 = (ch == 0) ? 0 : half + shift;
-    for (int j = lane; j < nbytes; j += 64) {
-        const int src = (p.js && ch == 1) ? (nbytes - 1 - j) : j;
-        const uint8_t byte = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
-        frame[dst0 + j] = byte;
+    if (!p.js && ((p.frame_sz | half) & 3) == 0) {   // whole big-endian words
+        for (int j = lane; j < (nbytes >> 2); j += 64)
+            *reinterpret_cast<uint32_t*>(frame + dst0 + 4 * j) = (j < kBitWords) ? __builtin_bswap32(s_words[j]) : 0u;
+    } else {
+        for (int j = lane; j < nbytes; j += 64) {
+            const int src = (p.js && ch == 1) ? (nbytes - 1 - j) : j;
+            const uint8_t byte = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
+            frame[dst0 + j] = byte;
+        }
     }
 }
 

@@ -188,43 +188,64 @@ __global__ __launch_bounds__(256) void k_loud_sum(BackParams p, const Tables* T,
     if (chain && c0 + lane < n_cf) p.psy[c0 + lane].loud_ch = l;
 }
 
-// One workgroup per (stream, output frame, channel).
-__global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
+// Flatness, tonal extraction and TScaler::Scale for kPsyCf channel-frames per workgroup. The per-BFU jobs (21 flatness
+// measures, 32 scale/energy chains per channel-frame) are one lane each and cost as many steps as the BFU has lines, so
+// the jobs of the four channel-frames are dealt to the wavefronts BY LENGTH: a wavefront's pass is as long as its
+// longest job, and a pass over 64-line BFUs next to 16-line ones would idle most lanes most of the time.
+constexpr int kPsyCf = 4;
+__device__ __forceinline__ bool psy_flat_job(int wave, int lane, int& k, int& b)
 {
-    __shared__ __attribute__((aligned(16))) float s_spec[1024];
-    __shared__ __attribute__((aligned(16))) float s_e[1024];
-    __shared__ int s_run_start[32];
-    __shared__ int s_run_len[32];
-    __shared__ uint16_t s_tv_pos[112];
-    __shared__ float s_tv_val[112];
-    __shared__ uint8_t s_tv_bfu[112];
-    __shared__ float s_scale[64];          // ScaleTable
-    __shared__ uint32_t s_maxbits[32];     // per BFU: max |x| as its bit pattern (ordered like the value for x >= 0)
-    const int tid = threadIdx.x;
-    const int n_out = p.n_blocks - p.f0;
-    const int ch = blockIdx.x & 1;
-    const int fo = (blockIdx.x >> 1) % n_out;
-    const int s = (blockIdx.x >> 1) / n_out;
-    float* specs = p.specs + (((size_t)s * n_out + fo) * 2 + ch) * 1024;
-    PsyRec* rec = p.psy + ((size_t)s * n_out + fo) * 2 + ch;
+    if (wave == 0) { k = lane / 3; b = 26 + lane % 3; return lane < 12; }      // 64 lines
+    if (wave == 1) { k = lane / 10; b = 16 + lane % 10; return lane < 40; }    // 32 lines
+    if (wave == 2) { k = lane / 8; b = 8 + lane % 8; return lane < 32; }       // 16 lines
+    k = 0; b = 8;
+    return false;
+}
+__device__ __forceinline__ bool psy_scale_job(int wave, int lane, int& k, int& b)
+{
+    if (wave == 0) { k = lane / 6; b = 26 + lane % 6; return lane < 24; }      // 64 and 128 lines
+    if (wave == 1) { k = lane / 10; b = 16 + lane % 10; return lane < 40; }    // 32 lines
+    if (wave == 2) { k = lane / 16; b = lane % 16; return true; }              // 8 and 16 lines
+    k = 0; b = 0;
+    return false;
+}
 
-    // line energies for the flatness measure (the loudness sum of atrac3denc.cpp:811-818 is k_loud_sum's)
+__global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T, int n_cf)
+{
+    __shared__ __attribute__((aligned(16))) float s_spec[kPsyCf][1024];
+    __shared__ int s_run_start[kPsyCf][32];
+    __shared__ int s_run_len[kPsyCf][32];
+    __shared__ uint16_t s_tv_pos[kPsyCf][112];
+    __shared__ float s_tv_val[kPsyCf][112];
+    __shared__ uint8_t s_tv_bfu[kPsyCf][112];
+    __shared__ float s_scale[64];                  // ScaleTable
+    __shared__ uint32_t s_maxbits[kPsyCf][32];     // per BFU: max |x| as its bit pattern (ordered like the value for x >= 0)
+    __shared__ int s_any[kPsyCf];                  // some BFU of the channel-frame has a tonal run
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c0 = blockIdx.x * kPsyCf;
+    const int ncf = (n_cf - c0 < kPsyCf) ? n_cf - c0 : kPsyCf;
+    float* specs0 = p.specs + (size_t)c0 * 1024;
+    PsyRec* rec0 = p.psy + c0;
+
     {
-        const float4 x4 = *reinterpret_cast<const float4*>(specs + 4 * tid);
-        float4 e4;
-        e4.x = x4.x * x4.x; e4.y = x4.y * x4.y; e4.z = x4.z * x4.z; e4.w = x4.w * x4.w;
-        *reinterpret_cast<float4*>(s_spec + 4 * tid) = x4;
-        *reinterpret_cast<float4*>(s_e + 4 * tid) = e4;
+        float4 x4[kPsyCf];
+#pragma unroll
+        for (int k = 0; k < kPsyCf; ++k) x4[k] = (k < ncf) ? *reinterpret_cast<const float4*>(specs0 + (size_t)k * 1024 + 4 * tid) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < kPsyCf; ++k) *reinterpret_cast<float4*>(s_spec[k] + 4 * tid) = x4[k];
     }
-    if (tid < 32) {
-        s_run_len[tid] = 0;
-        s_maxbits[tid] = 0u;
+    if (tid < 32 * kPsyCf) {
+        (&s_run_len[0][0])[tid] = 0;
+        (&s_maxbits[0][0])[tid] = 0u;
     }
-    if (tid >= 64 && tid < 128) s_scale[tid - 64] = T->scale[tid - 64];
+    if (tid < kPsyCf) s_any[tid] = 0;
+    if (tid >= 128 && tid < 192) s_scale[tid - 128] = T->scale[tid - 128];
     __syncthreads();
 
-    if (!p.no_tonal && tid >= 8 && tid < 29) {
-        const int b = tid;
+    int fk, fb;
+    if (!p.no_tonal && psy_flat_job(wave, lane, fk, fb) && fk < ncf) {
+        const int b = fb;
+        const float* sp = s_spec[fk];
         const int start = bfu_start(b), end = bfu_start(b + 1), len = end - start;
         // CalcSpectralFlatnessPerBfu (atrac_psy_common.cpp:158-199) needs mean(log(max(e, floor))). The logarithm of a
         // product is the sum of the logarithms: the lines' f64 mantissas are multiplied (8 .. 64 factors in [0.5, 1),
@@ -235,8 +256,8 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
         int esum = 0;
         const double floor_ = (double)1e-12f;
         for (int i0 = start; i0 < end; i0 += 8) {
-            const float4 ea = *reinterpret_cast<const float4*>(s_e + i0), eb = *reinterpret_cast<const float4*>(s_e + i0 + 4);
-            const float ev[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+            const float4 xa = *reinterpret_cast<const float4*>(sp + i0), xb = *reinterpret_cast<const float4*>(sp + i0 + 4);
+            const float ev[8] = {xa.x * xa.x, xa.y * xa.y, xa.z * xa.z, xa.w * xa.w, xb.x * xb.x, xb.y * xb.y, xb.z * xb.z, xb.w * xb.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const double e = (double)fmaxf(0.0f, ev[k]);
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
                 const int ml = maxLen < end - st ? maxLen : end - st;
                 float score = 0.0f;
                 for (int l = 1; l <= ml; ++l) {
-                    score += fabsf(s_spec[st + l - 1]);
+                    score += fabsf(sp[st + l - 1]);
                     if (score > bestScore) {
                         bestScore = score;
                         bestStart = st;
@@ -271,46 +292,53 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
                 }
             }
             if (bestScore > 0.0f) {
-                s_run_start[b] = bestStart;
-                s_run_len[b] = bestLen;
+                s_run_start[fk][b] = bestStart;
+                s_run_len[fk][b] = bestLen;
+                s_any[fk] = 1;
             }
         }
     }
     __syncthreads();
 
-    if (tid == 0) {
-        int nv = 0;
-        for (int b = 8; b < 29; ++b) {
-            for (int k = 0; k < s_run_len[b]; ++k) {
-                const int pos = s_run_start[b] + k;
-                s_tv_pos[nv] = (uint16_t)pos;
-                s_tv_val[nv] = s_spec[pos];
-                s_tv_bfu[nv] = (uint8_t)b;
-                ++nv;
-                s_spec[pos] = 0.0f;
-                specs[pos] = 0.0f;
-            }
-        }
-        // MapTonalComponents (atrac3denc.cpp:646-662): runs of consecutive positions, at most 7 long
+    if (wave == 3 && lane < ncf) {   // one lane per channel-frame: the extraction order is serial
+        const int k0 = lane;
+        PsyRec* rec = rec0 + k0;
         int nb = 0;
-        for (int i = 0; i < nv;) {
-            const int startPos = i;
-            int curPos;
-            do {
-                curPos = s_tv_pos[i];
-                ++i;
-            } while (i < nv && s_tv_pos[i] == curPos + 1 && i - startPos < 7);
-            const int len = i - startPos;
-            TonalBlock tb;
-            tb.pos = s_tv_pos[startPos];
-            tb.bfu = s_tv_bfu[startPos];
-            tb.len = (uint8_t)len;
-            for (int j = 0; j < 7; ++j) tb.values[j] = 0.0f;
-            for (int j = 0; j < 3; ++j) tb.pad[j] = 0;
-            for (int j = 0; j < 4; ++j) tb.pad2[j] = 0;
-            tb.sfi = (uint8_t)scale_block(s_scale, s_tv_val + startPos, len, tb.values, nullptr);
-            if (nb < kMaxTonal) rec->tonal[nb] = tb;
-            ++nb;
+        if (s_any[k0]) {
+            float* sp = s_spec[k0];
+            float* specs = specs0 + (size_t)k0 * 1024;
+            int nv = 0;
+            for (int b = 8; b < 29; ++b) {
+                for (int k = 0; k < s_run_len[k0][b]; ++k) {
+                    const int pos = s_run_start[k0][b] + k;
+                    s_tv_pos[k0][nv] = (uint16_t)pos;
+                    s_tv_val[k0][nv] = sp[pos];
+                    s_tv_bfu[k0][nv] = (uint8_t)b;
+                    ++nv;
+                    sp[pos] = 0.0f;
+                    specs[pos] = 0.0f;
+                }
+            }
+            // MapTonalComponents (atrac3denc.cpp:646-662): runs of consecutive positions, at most 7 long
+            for (int i = 0; i < nv;) {
+                const int startPos = i;
+                int curPos;
+                do {
+                    curPos = s_tv_pos[k0][i];
+                    ++i;
+                } while (i < nv && s_tv_pos[k0][i] == curPos + 1 && i - startPos < 7);
+                const int len = i - startPos;
+                TonalBlock tb;
+                tb.pos = s_tv_pos[k0][startPos];
+                tb.bfu = s_tv_bfu[k0][startPos];
+                tb.len = (uint8_t)len;
+                for (int j = 0; j < 7; ++j) tb.values[j] = 0.0f;
+                for (int j = 0; j < 3; ++j) tb.pad[j] = 0;
+                for (int j = 0; j < 4; ++j) tb.pad2[j] = 0;
+                tb.sfi = (uint8_t)scale_block(s_scale, s_tv_val[k0] + startPos, len, tb.values, nullptr);
+                if (nb < kMaxTonal) rec->tonal[nb] = tb;
+                ++nb;
+            }
         }
         rec->n_tonal = nb < kMaxTonal ? nb : kMaxTonal;
     }
@@ -319,17 +347,22 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
     // TScaler::Scale per BFU (atrac_scale.cpp:141-172) on the residual spectrum: the maximum is order-free (all
     // work-items, LDS atomic max), the scale factor a binary search, the energy an ordered sum (one lane per BFU)
     {
-        const float4 v = *reinterpret_cast<const float4*>(s_spec + 4 * tid);
-        const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-        atomicMax(&s_maxbits[bfu_of_line(4 * tid)], __float_as_uint(m));
+        const int b = bfu_of_line(4 * tid);
+#pragma unroll
+        for (int k = 0; k < kPsyCf; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(s_spec[k] + 4 * tid);
+            const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+            atomicMax(&s_maxbits[k][b], __float_as_uint(m));
+        }
     }
     __syncthreads();
-    if (tid < 32) {
-        const int start = bfu_start(tid), len = bfu_start(tid + 1) - start;
-        float maxAbs = __uint_as_float(s_maxbits[tid]);
+    int sk, sb;
+    if (psy_scale_job(wave, lane, sk, sb) && sk < ncf) {
+        const int start = bfu_start(sb), len = bfu_start(sb + 1) - start;
+        float maxAbs = __uint_as_float(s_maxbits[sk][sb]);
         if (maxAbs > 1.0f) maxAbs = 1.0f;
         const int sfi = scale_index(s_scale, maxAbs);
-        const float4* x4 = reinterpret_cast<const float4*>(s_spec + start);
+        const float4* x4 = reinterpret_cast<const float4*>(s_spec[sk] + start);
         float e = 0.0f;
         for (int i = 0; i < len / 8; ++i) {
             const float4 a = x4[2 * i], b = x4[2 * i + 1];
@@ -342,8 +375,8 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T)
             e += b.z * b.z;
             e += b.w * b.w;
         }
-        rec->sfi[tid] = (uint8_t)sfi;
-        rec->energy[tid] = e;
+        rec0[sk].sfi[sb] = (uint8_t)sfi;
+        rec0[sk].energy[sb] = e;
     }
 }
 

@@ -29,60 +29,57 @@ struct FrontParams {
     int debug;               // profiling aid (env AT3HIP_DEBUG_FRONT, debug builds): 3 = skip the energy-scale chains
 };
 
-// Modulated new half of one band (TGainProcessor::Modulate, gain_processor.h:93-112) for the eight samples of cell
-// `cell / 8`. Level boundaries and the 8-sample ramps are aligned to these cells, so a cell is untouched, divided by
-// one level (a power of two: multiplying by its reciprocal is the same rounding) or by one running-product ramp.
-// `cv` should be read in place (LDS / global): a private copy indexed in a loop would live in scratch.
-__device__ __forceinline__ void modulate_cell(const Curve& cv, const float* gain_interp, int cell, float (&v)[8])
+// The divisors of the eight samples of cell `cell / 8` under a curve given as its two 8-byte halves (n, level[7] |
+// loc[7], pad): TGainProcessor::Modulate (gain_processor.h:93-112). Level boundaries and the 8-sample ramps are
+// aligned to these cells, so a cell is untouched (1), divided by one level or by one running-product ramp.
+__device__ __forceinline__ void cell_divisors_packed(uint64_t lo, uint64_t hi, const float* gain_interp, int cell, float (&d)[8])
 {
-    int kind = 0;   // 0 untouched, 1 constant level, 2 ramp
-    float lvl = 1.0f, inc = 1.0f, inv = 1.0f;
+    const int n = (int)(lo & 0xffu);
+    int kind = 0;
+    float lvl = 1.0f, inc = 1.0f;
     int pos = 0;
-    for (int q = 0; q < cv.n; ++q) {
-        const int lastPos = (int)cv.loc[q] << 3;
+    for (int q = 0; q < n; ++q) {
+        const int level = (int)((lo >> (8 * (q + 1))) & 0xffu);
+        const int lastPos = (int)((hi >> (8 * q)) & 0xffu) << 3;
         if (cell >= pos && cell < lastPos) {
             kind = 1;
-            inv = __uint_as_float((uint32_t)(127 - 4 + cv.level[q]) << 23);   // 1 / GainLevel
+            lvl = gain_level_of(level);
             break;
         }
         if (lastPos > pos) pos = lastPos;
         if (pos < lastPos + 8) {
             if (cell >= pos && cell < lastPos + 8) {
                 kind = 2;
-                lvl = gain_level_of(cv.level[q]);
-                inc = gain_interp[((q + 1) < cv.n ? (int)cv.level[q + 1] : 4) - (int)cv.level[q] + 15];
+                lvl = gain_level_of(level);
+                const int next = (q + 1) < n ? (int)((lo >> (8 * (q + 2))) & 0xffu) : 4;
+                inc = gain_interp[next - level + 15];
                 break;
             }
             pos = lastPos + 8;
         }
     }
-    if (kind == 1) {
+    float v = (kind == 0) ? 1.0f : lvl;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = v[k] * inv;
-    } else if (kind == 2) {
-        float d = lvl;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[k] = v[k] / d;
-            d *= inc;
-        }
+    for (int k = 0; k < 8; ++k) {
+        d[k] = v;
+        if (kind == 2) v *= inc;
     }
 }
 
 // CalcGainEnergyScale (atrac3denc.cpp:175-224), the `Frame` value the psychoacoustics and the allocator use: ratio of
-// the frame's energy without and with gain modulation. One wavefront per (stream, frame), all eight bands at once. The
-// value is 1 unless this block's or the previous block's curve is non-empty, which is the case for a few per cent of
-// the bands (but then often for several bands of the same frame); those need five strictly ordered 256-term sums: three
-// over this block (carried overlap, windowed original, windowed modulated) and two over the previous one (its "next
-// overlap" scale, which the reference carries forward as PrevOverlapGainScale).
-// Lane (band = lane / 8, slot = lane % 8) produces, in four rounds of 64 samples, the terms of cell 8 round + slot of
-// its band for both blocks; lanes 0..39 = (band, sum) then extend the 40 ordered sums by 64 terms each.
+// the frame's energy without and with gain modulation. One wavefront per (stream, frame). The value is 1 unless this
+// block's or the previous block's curve is non-empty, which is the case for a few per cent of the bands; those need
+// five strictly ordered 256-term sums: three over this block (carried overlap, windowed original, windowed modulated)
+// and two over the previous one (its "next overlap" scale, which the reference carries forward as
+// PrevOverlapGainScale). The frame's modulated bands are taken two at a time: all 64 lanes produce the 2 x 5 x 256
+// terms (four samples each), then ten lanes run the ten ordered sums side by side.
+constexpr int kGesRow = 260;   // row stride of the term lists: the ten chain lanes read ten rows at once, in different banks
 __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const Tables* T, int n_frames_total)
 {
-    __shared__ __attribute__((aligned(16))) float s_terms[1][8][5][64];   // one wavefront per workgroup: 10 KB, so that
-    __shared__ __attribute__((aligned(16))) Curve s_cv[1][8][2];           // every frame of a 4096-frame batch is resident at once
-    __shared__ __attribute__((aligned(16))) float s_win[256];
-    const int wave = 0, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float s_terms[2][5][kGesRow];
+    __shared__ __attribute__((aligned(16))) Curve s_cv[8][2];
+    __shared__ float s_gi[32];
+    const int lane = threadIdx.x;
     const int sf = blockIdx.x;
     if (sf >= n_frames_total) return;
     const int nfr = p.n_blocks - p.f0;
@@ -95,117 +92,112 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
         w_cur = *reinterpret_cast<const uint4*>(p.curves + ((size_t)s * p.n_blocks + f) * 8 + lane);
         w_prev = *reinterpret_cast<const uint4*>((f - 1 < 0) ? &p.state[(size_t)s * 8 + lane].prev_curve
                                                              : p.curves + ((size_t)s * p.n_blocks + (f - 1)) * 8 + lane);
-        *reinterpret_cast<uint4*>(&s_cv[wave][lane][0]) = w_cur;
-        *reinterpret_cast<uint4*>(&s_cv[wave][lane][1]) = w_prev;
+        *reinterpret_cast<uint4*>(&s_cv[lane][0]) = w_cur;
+        *reinterpret_cast<uint4*>(&s_cv[lane][1]) = w_prev;
     }
     const uint32_t active = (uint32_t)__ballot(lane < 8 && (((w_cur.x | w_prev.x) & 0xffu) != 0u));   // Curve::n is the first byte
     float* out8 = p.ges + ((size_t)s * p.n_blocks + f) * 8;
     if (lane < 8 && !((active >> lane) & 1u)) out8[lane] = 1.0f;   // no modulation on either side: every ratio is exactly 1
     if (active == 0u || p.debug == 3) return;
-    // (most frames leave above: the window is fetched only by those that modulate something)
-    *reinterpret_cast<float4*>(s_win + 4 * lane) = *reinterpret_cast<const float4*>(T->enc_win + 4 * lane);
+    // (most frames leave above: the tables are fetched only by those that modulate something)
+    if (lane < 32) s_gi[lane] = T->gain_interp[lane < 31 ? lane : 30];
+    const float4 wn4 = *reinterpret_cast<const float4*>(T->enc_win + 4 * lane);         // EncodeWindow[i], i = 4 lane + k
+    const float4 wr4 = *reinterpret_cast<const float4*>(T->enc_win + 252 - 4 * lane);   // EncodeWindow[255 - i] = wr4[3 - k]
+    const float wn[4] = {wn4.x, wn4.y, wn4.z, wn4.w}, wc[4] = {wr4.w, wr4.z, wr4.y, wr4.x};
     wave_sync();
-    const int c = lane >> 3, slot = lane & 7;
-    const bool on = (active >> c) & 1u;
-    const Curve& cv_cur = s_cv[wave][c][0];
-    const Curve& cv_prev = s_cv[wave][c][1];
-    const bool has_cur = cv_cur.n > 0, has_prev = cv_prev.n > 0;
-    const int ch = c >> 2, band = c & 3;
     const size_t sublen = (size_t)(p.n_blocks + 2) * 256;
-    const float* sb0 = p.sub + ((size_t)s * 8 + band) * sublen + (size_t)(b + 2) * 256;       // left / own channel, current block
-    const float* sb1 = p.sub + ((size_t)s * 8 + 4 + band) * sublen + (size_t)(b + 2) * 256;   // right
-    float acc = 0.0f;
-    const int cc = lane / 5, kk = lane % 5;   // chain lanes: band cc, sum kk
-    const bool chain = lane < 40 && ((active >> cc) & 1u);
-    // all samples this lane will need (four cells of the current and of the previous block), fetched up front
-    float xc[4][8], xp[4][8];
-    if (on) {
+    const int cj = lane / 5, kk = lane % 5;   // chain lanes 0..9: band cj of the pair, sum kk
+    uint32_t todo = active;
+    while (todo) {   // wave-uniform
+        int cpair[2];
+        cpair[0] = __builtin_ctz(todo);
+        todo &= todo - 1u;
+        cpair[1] = todo ? __builtin_ctz(todo) : -1;
+        if (todo) todo &= todo - 1u;
 #pragma unroll
-        for (int rd = 0; rd < 4; ++rd) {
-            const int cell = 8 * (8 * rd + slot);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float* q0 = sb0 + cell + 4 * h;
-                const float* q1 = sb1 + cell + 4 * h;
-                float4 l = *reinterpret_cast<const float4*>(ch ? q1 : q0), lp = *reinterpret_cast<const float4*>((ch ? q1 : q0) - 256);
-                if (p.js) {   // M/S matrixing (atrac3denc.cpp:665-677)
-                    const float4 a0 = *reinterpret_cast<const float4*>(q0), a1 = *reinterpret_cast<const float4*>(q1);
-                    const float4 b0 = *reinterpret_cast<const float4*>(q0 - 256), b1 = *reinterpret_cast<const float4*>(q1 - 256);
-                    if (ch) {
-                        l.x = (a0.x - a1.x) * 0.5f; l.y = (a0.y - a1.y) * 0.5f; l.z = (a0.z - a1.z) * 0.5f; l.w = (a0.w - a1.w) * 0.5f;
-                        lp.x = (b0.x - b1.x) * 0.5f; lp.y = (b0.y - b1.y) * 0.5f; lp.z = (b0.z - b1.z) * 0.5f; lp.w = (b0.w - b1.w) * 0.5f;
-                    } else {
-                        l.x = (a0.x + a1.x) * 0.5f; l.y = (a0.y + a1.y) * 0.5f; l.z = (a0.z + a1.z) * 0.5f; l.w = (a0.w + a1.w) * 0.5f;
-                        lp.x = (b0.x + b1.x) * 0.5f; lp.y = (b0.y + b1.y) * 0.5f; lp.z = (b0.z + b1.z) * 0.5f; lp.w = (b0.w + b1.w) * 0.5f;
-                    }
+        for (int j = 0; j < 2; ++j) {
+            const int c = cpair[j];
+            if (c < 0) continue;
+            const int ch = c >> 2, band = c & 3;
+            const float* q0 = p.sub + ((size_t)s * 8 + band) * sublen + (size_t)(b + 2) * 256 + 4 * lane;       // left / own channel, current block
+            const float* q1 = p.sub + ((size_t)s * 8 + 4 + band) * sublen + (size_t)(b + 2) * 256 + 4 * lane;   // right
+            float4 l = *reinterpret_cast<const float4*>(ch ? q1 : q0), lp = *reinterpret_cast<const float4*>((ch ? q1 : q0) - 256);
+            if (p.js) {   // M/S matrixing (atrac3denc.cpp:665-677)
+                const float4 a0 = *reinterpret_cast<const float4*>(q0), a1 = *reinterpret_cast<const float4*>(q1);
+                const float4 b0 = *reinterpret_cast<const float4*>(q0 - 256), b1 = *reinterpret_cast<const float4*>(q1 - 256);
+                if (ch) {
+                    l.x = (a0.x - a1.x) * 0.5f; l.y = (a0.y - a1.y) * 0.5f; l.z = (a0.z - a1.z) * 0.5f; l.w = (a0.w - a1.w) * 0.5f;
+                    lp.x = (b0.x - b1.x) * 0.5f; lp.y = (b0.y - b1.y) * 0.5f; lp.z = (b0.z - b1.z) * 0.5f; lp.w = (b0.w - b1.w) * 0.5f;
+                } else {
+                    l.x = (a0.x + a1.x) * 0.5f; l.y = (a0.y + a1.y) * 0.5f; l.z = (a0.z + a1.z) * 0.5f; l.w = (a0.w + a1.w) * 0.5f;
+                    lp.x = (b0.x + b1.x) * 0.5f; lp.y = (b0.y + b1.y) * 0.5f; lp.z = (b0.z + b1.z) * 0.5f; lp.w = (b0.w + b1.w) * 0.5f;
                 }
-                xc[rd][4 * h] = l.x; xc[rd][4 * h + 1] = l.y; xc[rd][4 * h + 2] = l.z; xc[rd][4 * h + 3] = l.w;
-                xp[rd][4 * h] = lp.x; xp[rd][4 * h + 1] = lp.y; xp[rd][4 * h + 2] = lp.z; xp[rd][4 * h + 3] = lp.w;
             }
-        }
-    }
-#pragma unroll
-    for (int rd = 0; rd < 4; ++rd) {
-        if (on) {
-            const int cell = 8 * (8 * rd + slot);
-            float mc[8], mp[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                mc[k] = xc[rd][k];
-                mp[k] = xp[rd][k];
+            const float xc[4] = {l.x, l.y, l.z, l.w}, xp[4] = {lp.x, lp.y, lp.z, lp.w};
+            float dc8[8], dp8[8];   // the lane's four samples are one half of cell lane / 2
+            {
+                const uint4 wc4 = *reinterpret_cast<const uint4*>(&s_cv[c][0]), wp4 = *reinterpret_cast<const uint4*>(&s_cv[c][1]);
+                cell_divisors_packed((uint64_t)wc4.x | ((uint64_t)wc4.y << 32), (uint64_t)wc4.z | ((uint64_t)wc4.w << 32), s_gi, 8 * (lane >> 1), dc8);
+                cell_divisors_packed((uint64_t)wp4.x | ((uint64_t)wp4.y << 32), (uint64_t)wp4.z | ((uint64_t)wp4.w << 32), s_gi, 8 * (lane >> 1), dp8);
             }
-            if (has_cur) modulate_cell(cv_cur, T->gain_interp, cell, mc);
-            if (has_prev) modulate_cell(cv_prev, T->gain_interp, cell, mp);
-            float (*terms)[64] = s_terms[wave][c];
+            const bool hi_half = lane & 1;
+            float t[5][4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = cell + k, o = 8 * slot + k;
-                const float wc = s_win[255 - i], wn = s_win[i];
-                const float pv = wn * mp[k];                // the overlap this block inherited: EncodeWindow[i] * modulated sample
-                const float cw = xc[rd][k] * wc, mw = mc[k] * wc, nw = xp[rd][k] * wn, mnw = mp[k] * wn;
-                terms[0][o] = pv * pv;
-                terms[1][o] = cw * cw;
-                terms[2][o] = mw * mw;
-                terms[3][o] = nw * nw;
-                terms[4][o] = mnw * mnw;
+            for (int k = 0; k < 4; ++k) {
+                const float mc = xc[k] / (hi_half ? dc8[4 + k] : dc8[k]);
+                const float mp = xp[k] / (hi_half ? dp8[4 + k] : dp8[k]);
+                const float pv = wn[k] * mp;                // the overlap this block inherited: EncodeWindow[i] * modulated sample
+                const float cw = xc[k] * wc[k], mw = mc * wc[k], nw = xp[k] * wn[k], mnw = mp * wn[k];
+                t[0][k] = pv * pv;
+                t[1][k] = cw * cw;
+                t[2][k] = mw * mw;
+                t[3][k] = nw * nw;
+                t[4][k] = mnw * mnw;
             }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) *reinterpret_cast<float4*>(&s_terms[j][r][4 * lane]) = float4{t[r][0], t[r][1], t[r][2], t[r][3]};
         }
         wave_sync();
+        const int cc = cj == 0 ? cpair[0] : (cj == 1 ? cpair[1] : -1);
+        const bool chain = lane < 10 && cc >= 0;
+        float acc = 0.0f;
         if (chain) {
-            const float4* t4 = reinterpret_cast<const float4*>(s_terms[wave][cc][kk]);
-            float4 v[16];
+            const float4* t4 = reinterpret_cast<const float4*>(s_terms[cj][kk]);
+            for (int q0 = 0; q0 < 64; q0 += 16) {
+                float4 v[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = t4[q];
+                for (int q = 0; q < 16; ++q) v[q] = t4[q0 + q];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                acc += v[q].x;
-                acc += v[q].y;
-                acc += v[q].z;
-                acc += v[q].w;
+                for (int q = 0; q < 16; ++q) {
+                    acc += v[q].x;
+                    acc += v[q].y;
+                    acc += v[q].z;
+                    acc += v[q].w;
+                }
             }
         }
-        wave_sync();   // the term buffers are rewritten by the next round
-    }
-    // the five sums of band cc sit in lanes 5 cc .. 5 cc + 4; the first of them closes the formula
-    const float s1 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 1), (int)__float_as_uint(acc)));
-    const float s2 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 2), (int)__float_as_uint(acc)));
-    const float s3 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 3), (int)__float_as_uint(acc)));
-    const float s4 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 4), (int)__float_as_uint(acc)));
-    if (chain && kk == 0) {
-        const Curve& q_cur = s_cv[wave][cc][0];
-        const bool h_cur = q_cur.n > 0, h_prev = s_cv[wave][cc][1].n > 0;
-        const float s0 = acc;
-        // PrevOverlapGainScale: the previous block's NextOverlapScale, 1 when that block had no curve (equal sums)
-        float ps = h_prev ? safe_energy_scale(s3, s4) : 1.0f;
-        float frame_scale = 1.0f;
-        if (h_cur || ps != 1.0f) {
-            if (!isfinite(ps) || ps <= 0.0f) ps = 1.0f;
-            const float prevDiv = h_cur ? gain_level_of(q_cur.level[0]) : 1.0f;
-            const float prevOrig = s0 * ps;
-            const float prevMod = s0 / (prevDiv * prevDiv);
-            frame_scale = safe_energy_scale(prevOrig + s1, prevMod + s2);
+        // the five sums of a band sit in lanes 5 cj .. 5 cj + 4; the first of them closes the formula
+        const float s1 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 1), (int)__float_as_uint(acc)));
+        const float s2 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 2), (int)__float_as_uint(acc)));
+        const float s3 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 3), (int)__float_as_uint(acc)));
+        const float s4 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 4), (int)__float_as_uint(acc)));
+        if (chain && kk == 0) {
+            const Curve& q_cur = s_cv[cc][0];
+            const bool h_cur = q_cur.n > 0, h_prev = s_cv[cc][1].n > 0;
+            const float s0 = acc;
+            // PrevOverlapGainScale: the previous block's NextOverlapScale, 1 when that block had no curve (equal sums)
+            float ps = h_prev ? safe_energy_scale(s3, s4) : 1.0f;
+            float frame_scale = 1.0f;
+            if (h_cur || ps != 1.0f) {
+                if (!isfinite(ps) || ps <= 0.0f) ps = 1.0f;
+                const float prevDiv = h_cur ? gain_level_of(q_cur.level[0]) : 1.0f;
+                const float prevOrig = s0 * ps;
+                const float prevMod = s0 / (prevDiv * prevDiv);
+                frame_scale = safe_energy_scale(prevOrig + s1, prevMod + s2);
+            }
+            out8[cc] = frame_scale;
         }
-        out8[cc] = frame_scale;
+        wave_sync();   // the term lists are rewritten by the next pair
     }
 }
 

@@ -807,11 +807,6 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
     __shared__ float s_gi4[4][32];    // path (a few items with curves set the kernel's duration) has no dependent global loads
     const int tid = threadIdx.x;
     const int grp = tid >> 5, j = tid & 31, half = grp & 1;
-    {
-        const int wv = tid >> 6, ln = tid & 63;
-        if (ln < 36) reinterpret_cast<double*>(&s_l2[wv])[ln] = (&T->log2f_tab[0][0])[ln];
-        if (ln < 32) s_gi4[wv][ln] = T->gain_interp[ln < 31 ? ln : 30];
-    }
     const Log2fTab* L2 = &s_l2[tid >> 6];
     const float* gi = s_gi4[tid >> 6];
     const int nfr = p.n_blocks - p.f0;
@@ -847,8 +842,9 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
     }
     const float in_next = s_in[grp][j < 31 ? j + 1 : 31];
     s_filt[grp][j] = filt_j;
-    float maxGain = 0.0f;
-    for (int k = 0; k < 32; ++k) maxGain = fmaxf(maxGain, s_in[grp][k]);
+    float maxGain = fmaxf(0.0f, in_j);   // max over the item's 32 lanes (order-free)
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) maxGain = fmaxf(maxGain, __shfl_xor(maxGain, m, 64));
     wave_sync();
 
     // ---- CalcCurve (transient_detector.cpp:299-482) ----
@@ -1005,6 +1001,12 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
     }
 
     // ---- CreateSubbandInfo tail (atrac3denc.cpp:410-577), band < 3 ----
+    {   // (the tables are staged only by the few wavefronts that get here)
+        const int wv = tid >> 6, ln = tid & 63;
+        if (ln < 36) reinterpret_cast<double*>(&s_l2[wv])[ln] = (&T->log2f_tab[0][0])[ln];
+        if (ln < 32) s_gi4[wv][ln] = T->gain_interp[ln < 31 ? ln : 30];
+        wave_sync();
+    }
     if (maxGain < 1e-4f) pts.n = 0;
     if (hfr < 0.3f) pts.n = 0;
     const CurvePts before = pts;

@@ -60,6 +60,7 @@ struct at3hip_ctx {
     int n_cus = 256;
     int wgs_per_cu = 3;        // resident workgroups per CU of the QMF kernel this context uses (k_qmf_sub8 or the fused one)
     int wgs_per_cu_mdct = 3;   // the same of k_mdct_sub
+    int alloc_lds_pad = 0;     // dynamic LDS added to k_alloc_pack's launch: sets how many of its workgroups share a CU
     int dbg_front = 0, dbg_gain = 0, dbg_stop = 0;   // AT3HIP_DEBUG_* (profiling aids), honoured by -DAT3HIP_DEBUG_KNOBS builds only
 
     Tables* d_tables = nullptr;
@@ -240,6 +241,7 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if (const char* e = getenv("AT3HIP_DEBUG_FRONT")) c->dbg_front = atoi(e);
     if (const char* e = getenv("AT3HIP_DEBUG_GAIN")) c->dbg_gain = atoi(e);
     if (const char* e = getenv("AT3HIP_DEBUG_STOP")) c->dbg_stop = atoi(e);
+    if (const char* e = getenv("AT3HIP_ALLOC_PAD")) c->alloc_lds_pad = atoi(e);
 #endif
     {
         // the front half is short, latency-bound kernels; it gets the higher stream priority so that its workgroups are
@@ -537,10 +539,10 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.quant = c->d_quant;
         bp.mant = c->d_mant;
         hipLaunchKernelGGL(k_loud_sum, dim3((unsigned)((S * n_out * 2 + kLoudCf - 1) / kLoudCf)), dim3(256), 0, bk, bp, c->d_tables, S * n_out * 2);
-        hipLaunchKernelGGL(k_psy, dim3(S * n_out * 2), dim3(256), 0, bk, bp, c->d_tables);
+        hipLaunchKernelGGL(k_psy, dim3((S * n_out * 2 + kPsyCf - 1) / kPsyCf), dim3(256), 0, bk, bp, c->d_tables, S * n_out * 2);
         HIPCHK(c, hipEventRecord(ev[6], bk));
         hipLaunchKernelGGL(k_loudness, dim3(S), dim3(64), 0, bk, bp);
-        hipLaunchKernelGGL(k_alloc_pack, dim3(S * n_out * 2), dim3(64), 0, bk, bp, c->d_tables);
+        hipLaunchKernelGGL(k_alloc_pack, dim3(S * n_out * 2), dim3(64), (size_t)c->alloc_lds_pad, bk, bp, c->d_tables);
         HIPCHK(c, hipEventRecord(ev[7], bk));
         if (!(flags & AT3HIP_OUT_ON_DEVICE))
             HIPCHK(c, hipMemcpyAsync(out_frames, c->d_out, (size_t)S * n_out * c->frame_sz, hipMemcpyDeviceToHost, bk));
