@@ -40,7 +40,8 @@ AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_e
                "at1hip_read_tap", "at1hip_host_tables"]
 # include/at3phip.h
 AT3P_SYMBOLS = ["at3phip_create", "at3phip_destroy", "at3phip_last_error", "at3phip_reset", "at3phip_pqf_analyse", "at3phip_mdct",
-                "at3phip_pqf_mdct", "at3phip_get_timings", "at3phip_host_tables"]
+                "at3phip_pqf_mdct", "at3phip_get_timings", "at3phip_host_tables", "at3phip_write_frames", "at3phip_encode_frames",
+                "at3phip_get_write_timing", "at3phip_host_write_tables"]
 
 
 class At1Config(ctypes.Structure):
@@ -126,6 +127,10 @@ def load_library(path=None):
     lib.at3phip_pqf_mdct.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.c_uint32]
     lib.at3phip_get_timings.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     lib.at3phip_host_tables.argtypes = [vp, ctypes.c_size_t]
+    lib.at3phip_write_frames.argtypes = [vp, vp, i32, vp, vp, ctypes.c_uint32]
+    lib.at3phip_encode_frames.argtypes = [vp, vp, i32, vp, ctypes.c_uint32]
+    lib.at3phip_get_write_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.at3phip_host_write_tables.argtypes = [vp, ctypes.c_size_t]
     _lib_cache[path] = lib
     return lib
 
@@ -407,7 +412,32 @@ class At3pHip:
         self._check(self.lib.at3phip_pqf_mdct(self.ctx, ctypes.c_void_p(pcm_ptr), n_frames, None, None, ctypes.c_void_p(specs_ptr),
                                               AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE), "at3phip_pqf_mdct")
 
+    def write_frames(self, specs, win_flags=None):
+        """ScaleFrame + WriteFrame without tonal block: specs [S, F, C, 2048], win_flags uint16 [S, F, C] or None
+        -> frames uint8 [S, F, 2048]."""
+        specs = np.ascontiguousarray(specs, dtype=np.float32)
+        assert specs.ndim == 4 and specs.shape[0] == self.n_streams and specs.shape[2:] == (self.channels, 2048), specs.shape
+        nf = specs.shape[1]
+        fl, flp = self._flags(win_flags, nf)
+        out = np.zeros((self.n_streams, nf, 2048), np.uint8)
+        self._check(self.lib.at3phip_write_frames(self.ctx, _vp(specs), nf, flp, _vp(out), 0), "at3phip_write_frames")
+        return out
+
+    def encode_frames(self, pcm):
+        """pcm float32 [S, F, 2048, C] -> frames uint8 [S, F, 2048] (tonal analysis finding nothing; no look-ahead delay)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        assert pcm.ndim == 4 and pcm.shape[0] == self.n_streams and pcm.shape[2:] == (2048, self.channels), pcm.shape
+        nf = pcm.shape[1]
+        out = np.zeros((self.n_streams, nf, 2048), np.uint8)
+        self._check(self.lib.at3phip_encode_frames(self.ctx, _vp(pcm), nf, _vp(out), 0), "at3phip_encode_frames")
+        return out
+
+    def encode_frames_device(self, pcm_ptr, n_frames, frames_ptr):
+        self._check(self.lib.at3phip_encode_frames(self.ctx, ctypes.c_void_p(pcm_ptr), n_frames, ctypes.c_void_p(frames_ptr),
+                                                   AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE), "at3phip_encode_frames")
+
     def timings(self):
-        a, b = ctypes.c_float(), ctypes.c_float()
+        a, b, w = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
         self._check(self.lib.at3phip_get_timings(self.ctx, ctypes.byref(a), ctypes.byref(b)), "at3phip_get_timings")
-        return {"pqf_ms": a.value, "mdct_ms": b.value}
+        self._check(self.lib.at3phip_get_write_timing(self.ctx, ctypes.byref(w)), "at3phip_get_write_timing")
+        return {"pqf_ms": a.value, "mdct_ms": b.value, "write_ms": w.value}

@@ -8,17 +8,19 @@
 
 #include "../../include/at3phip.h"
 #include "at3p_kernels.hpp"
+#include "at3p_write.hpp"
 #include "at3_host_util.hpp"
 
 using namespace at3p;
 
 static_assert(sizeof(Tables) == AT3PHIP_TABLES_BYTES, "at3phip.h documents the table block's size");
+static_assert(sizeof(WriteTables) == AT3PHIP_WRITE_TABLES_BYTES, "at3phip.h documents the frame writer's table block size");
 
 struct at3phip_ctx {
     at3phip_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {};
+    hipEvent_t ev[4] = {};
     Tables* d_tables = nullptr;
     float* d_pcm_in = nullptr;     // staging for host PCM   [S][F][2048][nch]
     float* d_bands = nullptr;      // subband samples        [S][F][nch][16][128]
@@ -26,7 +28,9 @@ struct at3phip_ctx {
     uint16_t* d_flags = nullptr;   // [S][F][nch]
     float* d_pqf_hist = nullptr;   // [S][nch][368]
     float* d_mdct_hist = nullptr;  // [S][nch][16][128]
-    float pqf_ms = 0.0f, mdct_ms = 0.0f;
+    WriteTables* d_wtables = nullptr;
+    uint8_t* d_frames = nullptr;   // staging for host frames [S][F][2048]
+    float pqf_ms = 0.0f, mdct_ms = 0.0f, write_ms = 0.0f;
     char err[256] = {0};
 };
 
@@ -104,6 +108,22 @@ int launch_mdct(at3phip_ctx* c, const float* d_bands, int n_frames, const uint16
     return AT3HIP_OK;
 }
 
+int launch_write(at3phip_ctx* c, const float* d_specs, int n_frames, const uint16_t* win_flags, uint8_t* d_frames)
+{
+    const size_t S = c->cfg.n_streams, C = c->cfg.channels;
+    if (win_flags) HIPCHK(c, hipMemcpyAsync(c->d_flags, win_flags, S * n_frames * C * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    WriteParams wp;
+    wp.W = c->d_wtables;
+    wp.specs = d_specs;
+    wp.flags = win_flags ? c->d_flags : nullptr;
+    wp.out = d_frames;
+    wp.nch = (int)C;
+    wp.n_items = (int)(S * n_frames);
+    hipLaunchKernelGGL(k_at3p_write, dim3((unsigned)(S * n_frames)), dim3(256), 0, c->stream, wp);
+    HIPCHK(c, hipGetLastError());
+    return AT3HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -145,6 +165,16 @@ int at3phip_create(const at3phip_config* cfg, at3phip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_flags, S * F * C)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_pqf_hist, S * C * kOverlap)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_mdct_hist, S * C * 2048)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_frames, S * F * kFrameBytes)) != AT3HIP_OK) return bail(rc);
+    {
+        WriteTables* wt = new (std::nothrow) WriteTables();
+        if (!wt) return bail(AT3HIP_ENOMEM);
+        build_write_tables(wt);
+        rc = dev_alloc(c, &c->d_wtables, 1);
+        if (rc == AT3HIP_OK && hipMemcpy(c->d_wtables, wt, sizeof(WriteTables), hipMemcpyHostToDevice) != hipSuccess) rc = AT3HIP_EDEVICE;
+        delete wt;
+        if (rc != AT3HIP_OK) return bail(rc);
+    }
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
     *out = c;
     return AT3HIP_OK;
@@ -155,7 +185,7 @@ void at3phip_destroy(at3phip_ctx* c)
     if (!c) return;
     at3host::DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->d_tables, c->d_pcm_in, c->d_bands, c->d_specs, c->d_flags, c->d_pqf_hist, c->d_mdct_hist};
+    void* bufs[] = {c->d_tables, c->d_pcm_in, c->d_bands, c->d_specs, c->d_flags, c->d_pqf_hist, c->d_mdct_hist, c->d_wtables, c->d_frames};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& e : c->ev)
@@ -248,6 +278,75 @@ int at3phip_pqf_mdct(at3phip_ctx* c, const float* pcm, int32_t n_frames, const u
     HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipEventElapsedTime(&c->pqf_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->mdct_ms, c->ev[1], c->ev[2]);
+    return AT3HIP_OK;
+}
+
+int at3phip_write_frames(at3phip_ctx* c, const float* specs, int32_t n_frames, const uint16_t* win_flags, uint8_t* frames, uint32_t flags)
+{
+    if (!c || !specs || !frames || n_frames < 1 || n_frames > c->cfg.max_frames) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
+    const size_t items = (size_t)c->cfg.n_streams * n_frames;
+    const size_t n = items * c->cfg.channels * 2048;
+    const float* d_specs = specs;
+    if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
+        HIPCHK(c, hipMemcpyAsync(c->d_specs, specs, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d_specs = c->d_specs;
+    }
+    uint8_t* d_frames = (flags & AT3HIP_OUT_ON_DEVICE) ? frames : c->d_frames;
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    int rc = launch_write(c, d_specs, n_frames, win_flags, d_frames);
+    if (rc != AT3HIP_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    if (!(flags & AT3HIP_OUT_ON_DEVICE)) HIPCHK(c, hipMemcpyAsync(frames, c->d_frames, items * kFrameBytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipEventElapsedTime(&c->write_ms, c->ev[2], c->ev[3]);
+    c->pqf_ms = c->mdct_ms = 0.0f;
+    return AT3HIP_OK;
+}
+
+int at3phip_encode_frames(at3phip_ctx* c, const float* pcm, int32_t n_frames, uint8_t* frames, uint32_t flags)
+{
+    if (!c || !pcm || !frames || n_frames < 1 || n_frames > c->cfg.max_frames) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
+    const size_t items = (size_t)c->cfg.n_streams * n_frames;
+    const size_t n = items * c->cfg.channels * 2048;
+    const float* d_pcm = pcm;
+    if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
+        HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        d_pcm = c->d_pcm_in;
+    }
+    uint8_t* d_frames = (flags & AT3HIP_OUT_ON_DEVICE) ? frames : c->d_frames;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    int rc = launch_pqf(c, d_pcm, n_frames, c->d_bands);
+    if (rc != AT3HIP_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    rc = launch_mdct(c, c->d_bands, n_frames, nullptr, c->d_specs, AT3PHIP_RESIDUAL_SCALE);   // sine windows: EncodeFrame's default Win
+    if (rc != AT3HIP_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    rc = launch_write(c, c->d_specs, n_frames, nullptr, d_frames);
+    if (rc != AT3HIP_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    if (!(flags & AT3HIP_OUT_ON_DEVICE)) HIPCHK(c, hipMemcpyAsync(frames, c->d_frames, items * kFrameBytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipEventElapsedTime(&c->pqf_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->mdct_ms, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&c->write_ms, c->ev[2], c->ev[3]);
+    return AT3HIP_OK;
+}
+
+int at3phip_get_write_timing(const at3phip_ctx* c, float* write_ms)
+{
+    if (!c) return AT3HIP_EINVAL;
+    if (write_ms) *write_ms = c->write_ms;
+    return AT3HIP_OK;
+}
+
+int at3phip_host_write_tables(void* dst, size_t bytes)
+{
+    if (!dst || bytes != sizeof(WriteTables)) return AT3HIP_EINVAL;
+    build_write_tables((WriteTables*)dst);
     return AT3HIP_OK;
 }
 

@@ -29,6 +29,7 @@
 
 #include "../../include/at1hip.h"
 #include "../../include/at3hip.h"
+#include "../../include/at3phip.h"
 
 namespace NAtracDEncHip {
 
@@ -394,6 +395,93 @@ private:
     const size_t BlockFloats;
     at1hip_ctx* Ctx = nullptr;
     std::vector<float> Pending;
+};
+
+// ---- ATRAC3plus ---------------------------------------------------------------------------------------------------
+// TAt3PEnc (at3p.h, at3p.cpp:37-191) with GHA_PASS_INPUT | GHA_WRITE_RESIUDAL and a tonal analysis that finds nothing
+// (the analysis itself needs libgha, which the reference does not vendor): lambda in - one call per 2048-sample frame of
+// interleaved PCM - and one 2048-byte WriteFrame out per call after the first. The reference looks one frame ahead and
+// encodes the frame BEFORE the current one (PrevBuf, at3p.cpp:115-160), so the first call returns LOOK_AHEAD, the second
+// writes a silent frame and call k >= 2 writes input frame k - 2; this class keeps that schedule. Frames are encoded
+// `batchFrames` at a time like the encoders above and flushed in order.
+class TAt3PEncoder {
+public:
+    TAt3PEncoder(TCompressedOutputPtr&& out, int channels, int batchFrames = 64, int deviceId = 0)
+        : Out(std::move(out)), Channels((size_t)channels), BatchFrames(batchFrames), FrameFloats((size_t)AT3PHIP_FRAME * (size_t)channels)
+    {
+        at3phip_config cfg{};
+        cfg.channels = channels;
+        cfg.n_streams = 1;
+        cfg.max_frames = batchFrames;
+        cfg.device_id = deviceId;
+        const int rc = at3phip_create(&cfg, &Ctx);
+        if (rc != AT3HIP_OK) throw std::runtime_error("at3phip_create failed: " + std::to_string(rc));
+        Pending.reserve((size_t)BatchFrames * FrameFloats);
+    }
+    ~TAt3PEncoder()
+    {
+        try {
+            Flush();
+        } catch (...) {
+        }
+        at3phip_destroy(Ctx);
+    }
+    TAt3PEncoder(const TAt3PEncoder&) = delete;
+    TAt3PEncoder& operator=(const TAt3PEncoder&) = delete;
+
+    TProcessLambda GetLambda()
+    {
+        return [this](float* data, const ProcessMeta&) {
+            const bool first = Calls == 0;
+            ++Calls;
+            Pending.insert(Pending.end(), data, data + FrameFloats);
+            if ((int)(Pending.size() / FrameFloats) == BatchFrames) Flush();
+            return first ? EProcessResult::LOOK_AHEAD : EProcessResult::PROCESSED;
+        };
+    }
+
+    // Encodes what is buffered and writes the frames that are due: after n calls, n - 1 frames have been written.
+    void Flush()
+    {
+        const int nf = (int)(Pending.size() / FrameFloats);
+        if (nf > 0) {
+            std::vector<uint8_t> frames((size_t)nf * AT3PHIP_FRAME_BYTES);
+            Chk(at3phip_encode_frames(Ctx, Pending.data(), nf, frames.data(), 0), "at3phip_encode_frames");
+            Pending.clear();
+            for (int i = 0; i < nf; ++i) Ready.emplace_back(frames.begin() + (size_t)i * AT3PHIP_FRAME_BYTES, frames.begin() + (size_t)(i + 1) * AT3PHIP_FRAME_BYTES);
+        }
+        // call k (0-based) is answered with: nothing (k = 0), silence (k = 1), input frame k - 2
+        while (Written + 1 < Calls) {
+            if (Written == 0) {
+                Out->WriteFrame(SilentFrame());
+            } else {
+                Out->WriteFrame(std::move(Ready.front()));
+                Ready.erase(Ready.begin());
+            }
+            ++Written;
+        }
+    }
+
+private:
+    void Chk(int rc, const char* what)
+    {
+        if (rc != AT3HIP_OK) throw std::runtime_error(std::string(what) + ": " + at3phip_last_error(Ctx));
+    }
+    std::vector<char> SilentFrame()   // an all-zero spectrum through the frame writer (the encoder's PrevBuf starts zeroed)
+    {
+        std::vector<float> specs(FrameFloats, 0.0f);
+        std::vector<uint8_t> frame(AT3PHIP_FRAME_BYTES);
+        Chk(at3phip_write_frames(Ctx, specs.data(), 1, nullptr, frame.data(), 0), "at3phip_write_frames");
+        return std::vector<char>(frame.begin(), frame.end());
+    }
+    TCompressedOutputPtr Out;
+    const size_t Channels;
+    const int BatchFrames;
+    const size_t FrameFloats;
+    at3phip_ctx* Ctx = nullptr;
+    std::vector<float> Pending;
+    std::vector<std::vector<char>> Ready;
+    size_t Calls = 0, Written = 0;
 };
 
 }  // namespace NAtracDEncHip

@@ -1,7 +1,9 @@
-/* at3phip.h - C ABI of the MI355X-native ATRAC3plus front end: the 16-band polyphase analysis
- * filter and the windowed MDCT-256 x 16 that turn PCM into the 2048-line spectrum TAt3PEnc::EncodeFrame scales and packs
- * (at3p.cpp:93-99, 139-159). The tonal (GHA) analysis between them needs libgha, an un-vendored submodule of the
- * reference, and is not part of this row. Same library (libat3hip.so) and error codes as at3hip.h.
+/* at3phip.h - C ABI of the MI355X-native ATRAC3plus path: the 16-band polyphase analysis
+ * filter and the windowed MDCT-256 x 16 that turn PCM into the 2048-line spectrum (at3p.cpp:93-99, 139-159), and the
+ * frame writer that scales and packs it when there is no tonal block (at3p.cpp:159-163: ScaleFrame, then
+ * TAt3PBitStream::WriteFrame(channels, nullptr, sces)). The tonal (GHA) analysis between them needs libgha, an
+ * un-vendored submodule of the reference, and is not part of this row: at3phip_encode_frames is the encoder with that
+ * analysis finding nothing. Same library (libat3hip.so) and error codes as at3hip.h.
  */
 #ifndef AT3PHIP_H
 #define AT3PHIP_H
@@ -51,12 +53,38 @@ int at3phip_mdct(at3phip_ctx* ctx, const float* bands, int32_t n_frames, const u
 int at3phip_pqf_mdct(at3phip_ctx* ctx, const float* pcm, int32_t n_frames, const uint16_t* win_flags, float* bands, float* specs,
                      uint32_t flags);
 
+/* Replaces: per frame, sces[ch].ScaledBlocks = TScaler<NAt3p::TScaleTable>::ScaleFrame(specs) for each channel
+ * (at3p.cpp:159, atrac/atrac_scale.cpp:141-191) and TAt3PBitStream::WriteFrame(channels, nullptr, sces)
+ * (atrac/at3p/at3p_bitstream.cpp:694-726): fixed word lengths per quant unit, the cheapest of eight code tables per unit,
+ * the number of quant units lowered from 32 to 28, 27, ... until the frame fits.
+ *   specs     [n_streams][n_frames][channels][2048] float32 (flags & AT3HIP_PCM_ON_DEVICE: device memory)
+ *   win_flags [n_streams][n_frames][channels] uint16 as in at3phip_mdct (TSubbandInfos::Win); NULL = all sine. Host memory.
+ *   frames    [n_streams][n_frames][2048] bytes, each what ICompressedOutput::WriteFrame receives
+ *             (flags & AT3HIP_OUT_ON_DEVICE: device memory)
+ * Frames do not depend on one another. */
+#define AT3PHIP_FRAME_BYTES 2048
+int at3phip_write_frames(at3phip_ctx* ctx, const float* specs, int32_t n_frames, const uint16_t* win_flags, uint8_t* frames,
+                         uint32_t flags);
+
+/* PCM to frames: at3phip_pqf_mdct with AT3PHIP_RESIDUAL_SCALE and sine windows, then at3phip_write_frames, everything in
+ * between staying in HBM. This is TAt3PEnc::EncodeFrame (at3p.cpp:89-170) with GHA_PASS_INPUT | GHA_WRITE_RESIUDAL and a
+ * tonal analysis that finds nothing; frame f holds input frame f (the reference's two-frame look-ahead delay is the
+ * host's to add, see atracdenc_amd/host/at3hip_host.hpp). pcm as in at3phip_pqf_analyse, frames as above. */
+int at3phip_encode_frames(at3phip_ctx* ctx, const float* pcm, int32_t n_frames, uint8_t* frames, uint32_t flags);
+
+/* Device milliseconds the frame writer took in the last at3phip_write_frames / at3phip_encode_frames call. */
+int at3phip_get_write_timing(const at3phip_ctx* ctx, float* write_ms);
+
 /* Device milliseconds of the last call: {pqf, mdct}. */
 int at3phip_get_timings(const at3phip_ctx* ctx, float* pqf_ms, float* mdct_ms);
 
 /* The constant tables as at3phip_create builds them, on the host (no GPU needed); bytes = AT3PHIP_TABLES_BYTES. */
 #define AT3PHIP_TABLES_BYTES 3456
 int at3phip_host_tables(void* dst, size_t bytes);
+/* The frame writer's tables (code tables, scale table, the spectrum-independent leading bits per channel count and
+ * number of quant units) as at3phip_create builds them; bytes = AT3PHIP_WRITE_TABLES_BYTES. */
+#define AT3PHIP_WRITE_TABLES_BYTES 37252
+int at3phip_host_write_tables(void* dst, size_t bytes);
 
 #ifdef __cplusplus
 }

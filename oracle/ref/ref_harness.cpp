@@ -40,6 +40,8 @@
 #include "raw.h"
 #include "aea.h"
 #include "atrac/at3p/at3p_mdct.h"
+#include "atrac/at3p/at3p_bitstream.h"
+#include "atrac/at3p/at3p_tables.h"
 extern "C" {
 #include "atrac/atrac3plus_pqf/atrac3plus_pqf.h"
 #include "atrac/atrac3plus_pqf/ut/atrac3plusdsp.h"
@@ -413,6 +415,32 @@ void at3pref_mdct(const float* bands, const uint16_t* win_flags, int n_frames, f
             if (win_flags && ((win_flags[f] >> b) & 1)) win.SetSteepWin(b);
         mdct.Do(specs + (size_t)f * 2048, p, hist, win);
     }
+}
+
+// ATRAC3plus frame writer without tonal block: TScaler<NAt3p::TScaleTable>::ScaleFrame per channel, then
+// TAt3PBitStream::WriteFrame(channels, nullptr, sces) as TAt3PEnc::EncodeFrame calls it (at3p.cpp:139-163).
+// specs [n_frames][channels][2048], win_flags [n_frames][channels] or NULL -> out [n_frames][2048]
+int at3pref_write_frames(const float* specs, const uint16_t* win_flags, int channels, int n_frames, uint8_t* out)
+{
+    std::vector<std::vector<char>> frames;
+    TMemOut mem(&frames);
+    TAt3PBitStream bs(&mem, 2048);
+    TScaler<NAt3p::TScaleTable> scaler;
+    for (int f = 0; f < n_frames; ++f) {
+        std::vector<TAt3PBitStream::TSingleChannelElement> sces(channels);
+        for (int ch = 0; ch < channels; ++ch) {
+            const float* x = specs + ((size_t)f * channels + ch) * 2048;
+            std::vector<float> v(x, x + 2048);
+            sces[ch].ScaledBlocks = scaler.ScaleFrame(v, NAt3p::TScaleTable::TBlockSizeMod());
+            for (size_t b = 0; b < 16; ++b)
+                if (win_flags && ((win_flags[(size_t)f * channels + ch] >> b) & 1)) sces[ch].SubbandInfo.Win.SetSteepWin(b);
+        }
+        bs.WriteFrame(channels, nullptr, sces);
+        if (frames.empty() || frames.back().size() != 2048) return -1;
+        memcpy(out + (size_t)f * 2048, frames.back().data(), 2048);
+        frames.clear();
+    }
+    return n_frames;
 }
 
 } // extern "C"

@@ -451,3 +451,40 @@ def at3p_signal(name, n_frames, channel=0, scale=1.0):
     gens["stress"] = pcm_stress
     x = gens[name](2 * n_frames + (32 if name == "stress" else 0)).reshape(-1, 2)[: n_frames * 2048, channel]
     return np.ascontiguousarray((x * np.float32(scale)).astype(np.float32).reshape(n_frames, 2048))
+
+
+AT3P_INFO_DTYPE = np.dtype([("num_quant_units", "<i4"), ("bits_used", "<i4"), ("sfi", "u1", (2, 32)), ("tab", "u1", (2, 32)),
+                            ("qu_bits", "<u2", (2, 32))])
+
+
+def at3p_write_frames(specs, flags=None, which="oracle", info=False):
+    """ScaleFrame + WriteFrame(channels, nullptr, sces): specs float32 [n_frames, channels, 2048], flags uint16
+    [n_frames, channels] (bit b = steep window in subband b) -> frames uint8 [n_frames, 2048] (and the oracle's per-frame
+    record when info=True)."""
+    lib, pre = _at3p_lib(which)
+    specs = np.ascontiguousarray(specs, np.float32)
+    nf, nch, _ = specs.shape
+    out = np.zeros((nf, 2048), np.uint8)
+    fl = None if flags is None else np.ascontiguousarray(flags, np.uint16)
+    fn = getattr(lib, pre + "write_frames")
+    fn.restype = ctypes.c_int
+    if which == "oracle":
+        assert lib.at3po_frame_info_size() == AT3P_INFO_DTYPE.itemsize
+        rec = np.zeros(nf, AT3P_INFO_DTYPE) if info else None
+        rc = fn(_vp(specs), None if fl is None else _vp(fl), nch, nf, _vp(out), _vp(rec) if info else None)
+    else:
+        rec = None
+        rc = fn(_vp(specs), None if fl is None else _vp(fl), nch, nf, _vp(out))
+    assert rc == nf, rc
+    return (out, rec) if info else out
+
+
+def at3p_specs(name, n_frames, channels=2, scale=1.0):
+    """The residual spectra TAt3PEnc::EncodeFrame would scale and pack for a test signal with the tonal analysis out of
+    the way: PQF analysis, division by 32768 / 1.122018 (at3p.cpp:143-147), MDCT with sine windows. [n_frames, channels, 2048]"""
+    out = np.zeros((n_frames, channels, 2048), np.float32)
+    for ch in range(channels):
+        bands = at3p_pqf(at3p_signal(name, n_frames, channel=ch, scale=scale))
+        bands = (bands.astype(np.float64) / (32768.0 / 1.122018)).astype(np.float32)   # float / double, narrowed on the store
+        out[:, ch] = at3p_mdct(bands)
+    return out

@@ -13,6 +13,12 @@
 
 using namespace NAtracDEncHip;
 
+extern "C" {   // oracle/at3p_oracle.c, oracle/at3p_frame_oracle.c
+void at3po_pqf_analyse(const float* in, int n_frames, float* out);
+void at3po_mdct(const float* bands, const uint16_t* win_flags, int n_frames, float* specs);
+int at3po_write_frames(const float* specs, const uint16_t* win_flags, int channels, int n_frames, uint8_t* out, void* info);
+}
+
 struct TMemOut : ICompressedOutput {
     std::vector<std::vector<char>>* Frames;
     explicit TMemOut(std::vector<std::vector<char>>* f) : Frames(f) {}
@@ -131,6 +137,36 @@ int main()
             EXPECT(memcmp(frames.data() + (size_t)s * nf * fsz, exp.data(), (size_t)nf * fsz) == 0);
         }
         printf("TAtrac3EncoderNode (2 contexts) compared\n");
+    }
+    // ---- TAt3PEncoder: 5 stereo frames of 2048 samples through a batch of 2; look-ahead call, silent first frame ----
+    {
+        const int nfr = 5;
+        std::vector<std::vector<char>> frames;
+        {
+            TAt3PEncoder enc(TCompressedOutputPtr(new TMemOut(&frames)), 2, 2);
+            auto lambda = enc.GetLambda();
+            for (int f = 0; f < nfr; ++f) {
+                const auto r = lambda(pcm.data() + (size_t)f * 4096, ProcessMeta{2});
+                EXPECT((f == 0) == (r == EProcessResult::LOOK_AHEAD));
+            }
+        }   // destructor flushes
+        EXPECT((int)frames.size() == nfr - 1);
+        std::vector<float> specs((size_t)(nfr + 1) * 2 * 2048, 0.0f);   // frame 0: silence, frame k + 1: input frame k
+        for (int ch = 0; ch < 2; ++ch) {
+            std::vector<float> mono((size_t)nfr * 2048), bands((size_t)nfr * 2048), sp((size_t)nfr * 2048);
+            for (size_t i = 0; i < mono.size(); ++i) mono[i] = pcm[2 * i + ch];
+            at3po_pqf_analyse(mono.data(), nfr, bands.data());
+            for (auto& v : bands) v = (float)(v / (32768.0 / 1.122018));
+            at3po_mdct(bands.data(), nullptr, nfr, sp.data());
+            for (int f = 0; f < nfr; ++f) memcpy(&specs[((size_t)(f + 1) * 2 + ch) * 2048], &sp[(size_t)f * 2048], 2048 * sizeof(float));
+        }
+        std::vector<uint8_t> exp((size_t)(nfr + 1) * 2048);
+        EXPECT(at3po_write_frames(specs.data(), nullptr, 2, nfr + 1, exp.data(), nullptr) == nfr + 1);
+        for (int i = 0; i < nfr - 1 && i < (int)frames.size(); ++i) {
+            EXPECT(frames[i].size() == 2048);
+            EXPECT(memcmp(frames[i].data(), exp.data() + (size_t)i * 2048, 2048) == 0);
+        }
+        printf("TAt3PEncoder: %d frames compared\n", (int)frames.size());
     }
     printf(fails ? "HOST SHIM TEST FAILED\n" : "HOST SHIM TEST OK\n");
     return fails ? 1 : 0;

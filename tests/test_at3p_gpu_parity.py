@@ -119,3 +119,82 @@ def test_bad_arguments():
     with pytest.raises(At3HipError):
         enc.pqf(np.zeros((1, 3, 2048, 1), np.float32))
     enc.close()
+
+
+# ---- frame writer without tonal block (at3phip_write_frames / at3phip_encode_frames) ---------------------------------
+from at3_testlib import at3p_specs, at3p_write_frames  # noqa: E402
+
+FRAMES_GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "at3p_frames.npz"))
+FRAME_NAMES = sorted(k[:-6] for k in FRAMES_GOLD.files if k.endswith("_specs"))
+
+
+@pytest.mark.parametrize("name", FRAME_NAMES)
+def test_write_frames_golden(name):
+    """Frames written by the real reference (tools/gen_golden_at3p_frames.py), sine windows and mixed window flags."""
+    from atracdenc_amd import At3pHip
+    sp, fl = FRAMES_GOLD[f"{name}_specs"], FRAMES_GOLD[f"{name}_flags"]
+    nf, nch, _ = sp.shape
+    enc = At3pHip(n_streams=1, max_frames=nf, channels=nch)
+    assert np.array_equal(enc.write_frames(sp[None])[0], FRAMES_GOLD[f"{name}_frames_sine"])
+    assert np.array_equal(enc.write_frames(sp[None], fl[None])[0], FRAMES_GOLD[f"{name}_frames_flags"])
+    enc.close()
+
+
+@pytest.mark.parametrize("nch", [1, 2])
+def test_write_frames_vs_oracle(oracle, nch):
+    """One stream per test signal plus white spectra from silence to clipping; random window flags."""
+    from atracdenc_amd import At3pHip
+    nf = 8
+    rng = np.random.RandomState(21 + nch)
+    streams = [at3p_specs(n, nf, nch) for n in ("noise", "tones", "burst", "mix", "silence", "stress")]
+    streams += [(lvl * rng.standard_normal((nf, nch, 2048))).astype(np.float32) for lvl in (1e-7, 1e-3, 0.1, 1.0, 4.0)]
+    specs = np.stack(streams)
+    S = specs.shape[0]
+    flags = rng.randint(0, 65536, (S, nf, nch)).astype(np.uint16)
+    flags[:, 0] = 0
+    flags[:, 1] = 0xFFFF
+    flags[:, 2] = 0x00FF
+    enc = At3pHip(n_streams=S, max_frames=nf, channels=nch)
+    got_sine = enc.write_frames(specs)
+    got_flags = enc.write_frames(specs, flags)
+    enc.close()
+    for s in range(S):
+        assert np.array_equal(got_sine[s], at3p_write_frames(specs[s])), s
+        assert np.array_equal(got_flags[s], at3p_write_frames(specs[s], flags[s])), s
+
+
+@pytest.mark.parametrize("nch", [1, 2])
+def test_encode_frames_in_pieces(oracle, nch):
+    """at3phip_encode_frames fed 3 + 1 + 8 frames: PCM to frames equals the oracle's PQF, residual scale, MDCT, writer."""
+    from atracdenc_amd import At3pHip
+    nf = 12
+    names = ("mix", "noise", "burst", "tones")
+    pcm = np.stack([np.stack([at3p_signal(n, nf, channel=c) for c in range(nch)], axis=-1) for n in names])
+    enc = At3pHip(n_streams=len(names), max_frames=8, channels=nch)
+    got = np.concatenate([enc.encode_frames(pcm[:, a:b]) for a, b in ((0, 3), (3, 4), (4, 12))], axis=1)
+    t = enc.timings()
+    enc.close()
+    assert t["write_ms"] > 0.0
+    for s, n in enumerate(names):
+        assert np.array_equal(got[s], at3p_write_frames(at3p_specs(n, nf, nch))), n
+
+
+def test_write_frames_full_batch(oracle):
+    """A 64-stream x 32-frame batch of stereo spectra at mixed levels: every frame equals the oracle's; every frame starts
+    with the zero bit and the channel-block type, and codes at most 32 quant units."""
+    from atracdenc_amd import At3pHip
+    S, nf = 64, 32
+    rng = np.random.RandomState(77)
+    level = np.exp(rng.uniform(np.log(1e-6), np.log(2.0), size=(S, nf, 1, 1))).astype(np.float32)
+    specs = (level * rng.standard_normal((S, nf, 2, 2048))).astype(np.float32)
+    tilt = np.exp(-np.arange(2048, dtype=np.float32) / rng.uniform(100, 3000, size=(S, 1, 1, 1)).astype(np.float32))
+    specs = (specs * tilt).astype(np.float32)
+    enc = At3pHip(n_streams=S, max_frames=nf, channels=2)
+    got = enc.write_frames(specs)
+    enc.close()
+    exp = at3p_write_frames(specs.reshape(S * nf, 2, 2048)).reshape(S, nf, 2048)
+    bad = (got != exp).any(axis=2)
+    assert not bad.any(), np.argwhere(bad)[:8].tolist()
+    assert np.all(got[:, :, 0] >> 5 == 1)          # 0, then channels - 1 = 1 in two bits
+    units = (got[:, :, 0] & 0x1F) + 1
+    assert units.max() <= 32 and units.min() >= 1 and len(np.unique(units)) > 2
