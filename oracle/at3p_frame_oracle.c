@@ -207,8 +207,8 @@ typedef struct {
 /* One frame: specs [channels][2048], win [channels] (NULL = all sine) -> 2048 bytes */
 static void write_frame(const float* specs, const uint16_t* win, int channels, uint8_t* out, at3po_frame_info* info)
 {
-    static float values[2][2048];
-    static int mant[2][2048];
+    float values[2][2048];
+    int mant[2][2048];
     uint8_t sfi[2][32], tab[2][32];
     int qbits[2][32];
     memset(sfi, 0, sizeof(sfi));
