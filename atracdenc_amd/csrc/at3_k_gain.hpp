@@ -116,19 +116,17 @@ struct Tw32_128 {
     f2 a[3];
     f2 w[4][3];
 };
-__device__ __forceinline__ Tw32_128 irfft_tw_32_128(const cpx* tw, int v)
+__device__ __forceinline__ Tw32_128 irfft_tw_32_128(const cpx (*g)[128], int v)   // g = Tables::gain_tw
 {
-    const int k = v & 31;
     Tw32_128 t;
-    t.a[0] = ld2(tw + 16 * k);   // fstride 16
-    t.a[1] = ld2(tw + 32 * k);
-    t.a[2] = ld2(tw + 48 * k);
+    t.a[0] = ld2(&g[0][v]);   // tw[16 k], tw[32 k], tw[48 k] with k = v % 32 (fstride 16)
+    t.a[1] = ld2(&g[1][v]);
+    t.a[2] = ld2(&g[2][v]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int kk = k + 32 * j;   // fstride 4
-        t.w[j][0] = ld2(tw + 4 * kk);
-        t.w[j][1] = ld2(tw + 8 * kk);
-        t.w[j][2] = ld2(tw + 12 * kk);
+    for (int j = 0; j < 4; ++j) {   // tw[4 kk], tw[8 kk], tw[12 kk] with kk = k + 32 j (fstride 4)
+        t.w[j][0] = ld2(&g[3 + 3 * j][v]);
+        t.w[j][1] = ld2(&g[4 + 3 * j][v]);
+        t.w[j][2] = ld2(&g[5 + 3 * j][v]);
     }
     return t;
 }
@@ -153,15 +151,15 @@ struct Tw512 {
     f2 w[512 / NT][3];
 };
 template <int NT>
-__device__ __forceinline__ Tw512<NT> irfft_tw_512(const cpx* tw, int tid)
+__device__ __forceinline__ Tw512<NT> irfft_tw_512(const cpx (*g)[128], int tid)   // g = Tables::gain_tw; NT == 128
 {
+    static_assert(NT == 128, "Tables::gain_tw is laid out for 128 work-items");
     Tw512<NT> t;
 #pragma unroll
-    for (int u = 0; u < 512 / NT; ++u) {
-        const int k = tid + NT * u;
-        t.w[u][0] = ld2(tw + k);
-        t.w[u][1] = ld2(tw + 2 * k);
-        t.w[u][2] = ld2(tw + 3 * k);
+    for (int u = 0; u < 512 / NT; ++u) {   // tw[k], tw[2 k], tw[3 k] with k = tid + NT u
+        t.w[u][0] = ld2(&g[15 + 3 * u][tid]);
+        t.w[u][1] = ld2(&g[16 + 3 * u][tid]);
+        t.w[u][2] = ld2(&g[17 + 3 * u][tid]);
     }
     return t;
 }
@@ -390,6 +388,9 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
     // below 5 % high-band energy the reference drops the band before the upsampler output is looked at
     // (atrac3denc.cpp:319-327): nothing downstream reads the other fields of such a record
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 11) return;   // launch cost alone
+#endif
     const float hfr = rec->hfr;
     if (hfr < 0.05f) return;
     const cpx* bins = p.bins + item * kGainBins;
@@ -400,8 +401,15 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     const cpx stw_in0 = T->stw2048[k0 - 1];
     const cpx stw_in1 = T->stw2048[k1 - 1 < 1024 ? k1 - 1 : 1023];
     const float hpf1 = T->hpf_w[1], hpf2 = T->hpf_w[2];
-    const Tw32_128 tw_b = irfft_tw_32_128(T->tw2048, tid);
-    const Tw512<128> tw_c = irfft_tw_512<128>(T->tw2048, tid);
+    const Tw32_128 tw_b = irfft_tw_32_128(T->gain_tw, tid);
+    const Tw512<128> tw_c = irfft_tw_512<128>(T->gain_tw, tid);
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 12) {   // launch + the fetches
+        float sink = bin0.r + bin1.i + stw_in0.r + stw_in1.i + hpf1 + hpf2 + tw_b.a[0].x + tw_b.w[3][2].y + tw_c.w[0][0].x + tw_c.w[3][2].y;
+        if (sink == 12345.678f) rec->target = sink;
+        return;
+    }
+#endif
     // 3. kiss_fftri input. Only bins 38..256 survive the high-pass, so tmpbuf is non-zero at k in [38,256] and
     //    [1792,2010]; each of those meets an exact zero in its radix-2 leaf butterfly (x +- 0*w), whose two outputs
     //    are therefore stored directly.

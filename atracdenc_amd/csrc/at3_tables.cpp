@@ -99,6 +99,14 @@ AT3_RUNTIME_LIBM void build_tables(Tables* t)
     fill_twiddles(t->tw2048, 2048, true);
     fill_super_twiddles(t->stw256, 256, false);
     fill_super_twiddles(t->stw2048, 2048, true);
+    for (int tid = 0; tid < 128; ++tid) {   // see at3_k_gain.hpp: irfft_pass_32_128 / irfft_pass_512
+        const int k = tid & 31;
+        for (int q = 0; q < 3; ++q) t->gain_tw[q][tid] = t->tw2048[16 * (q + 1) * k];
+        for (int j = 0; j < 4; ++j)
+            for (int q = 0; q < 3; ++q) t->gain_tw[3 + 3 * j + q][tid] = t->tw2048[4 * (q + 1) * (k + 32 * j)];
+        for (int u = 0; u < 4; ++u)
+            for (int q = 0; q < 3; ++q) t->gain_tw[15 + 3 * u + q][tid] = t->tw2048[(q + 1) * (tid + 128 * u)];
+    }
 
     {   // Planck taper, epsilon 0.15, N = 512
         const float eN = 0.15f * 512.0f;

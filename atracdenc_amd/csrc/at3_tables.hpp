@@ -32,6 +32,10 @@ struct Tables {
     cpx stw2048[1024];      // irfft-4096 super twiddles
     double log2f_tab[16][2];
     double log2f_poly[4];
+    // k_gain_analysis: the 27 twiddles work-item t of a 128-thread workgroup needs for the last three passes of the
+    // irfft-4096 core, as [slot][t] so that a wavefront fetches each slot as one contiguous 512-byte run (picking them out
+    // of tw2048 touched up to 32 cache lines per load). Slots: 0..2 pass m = 32, 3..14 pass m = 128, 15..26 pass m = 512.
+    cpx gain_tw[27][128];
 };
 
 // Fills *t on the host. Pure function of libm.

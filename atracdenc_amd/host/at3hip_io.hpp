@@ -232,6 +232,16 @@ public:
         h[32] = (uint8_t)(word >> 24); h[33] = (uint8_t)(word >> 16); h[34] = (uint8_t)(word >> 8); h[35] = (uint8_t)word;
         Put(h, sizeof(h), "can't write header");
     }
+    // ATRAC3plus (oma.cpp:28-41, liboma.c:190-206): codec id 1, channel id = channel count, (FrameSz - 8) / 8
+    struct TAtrac3Plus {};
+    TOmaOutput(const std::string& filename, TAtrac3Plus, size_t numChannels, uint32_t frameSize) : TFileOutput(filename, numChannels), FrameSize(frameSize)
+    {
+        uint8_t h[96] = {0};
+        h[0] = 'E'; h[1] = 'A'; h[2] = '3'; h[3] = 1; h[5] = 96; h[6] = 0xFF; h[7] = 0xFF;
+        const uint32_t word = (1u << 24) | (1u << 13) | ((numChannels == 1 ? 1u : 2u) << 10) | ((frameSize - 8) / 8);
+        h[32] = (uint8_t)(word >> 24); h[33] = (uint8_t)(word >> 16); h[34] = (uint8_t)(word >> 8); h[35] = (uint8_t)word;
+        Put(h, sizeof(h), "can't write header");
+    }
     void WriteFrame(std::vector<char> data) override
     {
         if (data.size() < FrameSize) throw std::runtime_error("short frame");
@@ -306,6 +316,69 @@ private:
     uint64_t FramesWritten = 0;
 };
 
+// ATRAC3plus in RIFF/WAVE (at3.cpp:273-362): WAVE_FORMAT_EXTENSIBLE with the ATRAC3plus subformat GUID, a 4-byte "fact"
+// chunk, then "data"; 80 header bytes, the length fields corrected on close like TAt3RiffOutput's.
+class TAt3pRiffOutput : public TFileOutput {
+public:
+    TAt3pRiffOutput(const std::string& filename, size_t numChannels, uint32_t numFrames, uint32_t frameSize)
+        : TFileOutput(filename, numChannels), FrameSize(frameSize)
+    {
+        if (frameSize > UINT16_MAX) throw std::runtime_error("ATRAC3plus frame size is too large for WAV block_align");
+        const uint64_t fileSize = kHeader + (uint64_t)numFrames * frameSize;
+        if (fileSize >= UINT32_MAX) throw std::runtime_error("File size is too big for this file format");
+        static const uint8_t guid[16] = {0xBF, 0xAA, 0x23, 0xE9, 0x58, 0xCB, 0x71, 0x44, 0xA1, 0x19, 0xFF, 0xFA, 0x01, 0xE4, 0xCE, 0x62};
+        uint8_t h[kHeader] = {0};
+        memcpy(h, "RIFF", 4);
+        Le32(h + 4, (uint32_t)(fileSize - 8));
+        memcpy(h + 8, "WAVE", 4);
+        memcpy(h + 12, "fmt ", 4);
+        Le32(h + 16, 18 + 22);                       // WAVEFORMATEX + WAVEFORMATEXTENSIBLE tail
+        Le16(h + 20, 0xFFFE);
+        Le16(h + 22, (uint32_t)numChannels);
+        Le32(h + 24, 44100);
+        Le32(h + 28, frameSize * 44100u / 2048u);
+        Le16(h + 32, frameSize);
+        Le16(h + 34, 16);
+        Le16(h + 36, 22);
+        Le16(h + 38, 16);                            // valid bits per sample
+        Le32(h + 40, numChannels == 1 ? 0x4u : numChannels == 2 ? 0x3u : 0u);   // front centre | front left + right
+        memcpy(h + 44, guid, 16);
+        memcpy(h + 60, "fact", 4);
+        Le32(h + 64, 4);
+        Le32(h + 68, numFrames * 2048u);
+        memcpy(h + 72, "data", 4);
+        Le32(h + 76, numFrames * frameSize);
+        Put(h, sizeof(h), "Cannot write WAV header to file");
+    }
+    ~TAt3pRiffOutput() override
+    {
+        const uint64_t fileSize = kHeader + FramesWritten * (uint64_t)FrameSize;
+        if (FramesWritten > 0 && fileSize < UINT32_MAX) {
+            uint8_t v[4];
+            Le32(v, (uint32_t)(fileSize - 8));
+            fseek(Fp, 4, SEEK_SET);
+            fwrite(v, 1, 4, Fp);
+            Le32(v, (uint32_t)FramesWritten * 2048u);
+            fseek(Fp, 68, SEEK_SET);
+            fwrite(v, 1, 4, Fp);
+            Le32(v, (uint32_t)FramesWritten * FrameSize);
+            fseek(Fp, 76, SEEK_SET);
+            fwrite(v, 1, 4, Fp);
+        }
+    }
+    void WriteFrame(std::vector<char> data) override
+    {
+        if (data.size() != FrameSize) throw std::runtime_error("Unexpected ATRAC3plus frame size");
+        Put(data.data(), data.size(), "Cannot write AT3 data to file");
+        ++FramesWritten;
+    }
+
+private:
+    static constexpr size_t kHeader = 80;
+    uint32_t FrameSize;
+    uint64_t FramesWritten = 0;
+};
+
 class TRawOutput : public TFileOutput {
 public:
     TRawOutput(const std::string& filename, size_t numChannels, uint32_t frameSize = 0) : TFileOutput(filename, numChannels), FrameSize(frameSize) {}
@@ -326,6 +399,18 @@ inline TCompressedOutputPtr CreateAtrac3Output(EContainer c, const std::string& 
         case EContainer::RIFF: return TCompressedOutputPtr(new TAt3RiffOutput(outFile, 2, numFrames, frameSize, jointStereo));
         case EContainer::RAW: return TCompressedOutputPtr(new TRawOutput(outFile, numChannels));
         default: return TCompressedOutputPtr(new TOmaOutput(outFile, frameSize, jointStereo));
+    }
+}
+
+// ATRAC3plus: the extension rule is the ATRAC3 one (main.cpp:222-235), the writers are main.cpp:451-463's
+inline EContainer SelectAtrac3PlusContainer(const std::string& outFile) { return SelectAtrac3Container(outFile); }
+inline TCompressedOutputPtr CreateAtrac3PlusOutput(EContainer c, const std::string& outFile, size_t numChannels, uint32_t numFrames,
+                                                   uint32_t frameSize = 2048)
+{
+    switch (c) {
+        case EContainer::RIFF: return TCompressedOutputPtr(new TAt3pRiffOutput(outFile, numChannels, numFrames, frameSize));
+        case EContainer::RAW: return TCompressedOutputPtr(new TRawOutput(outFile, numChannels));
+        default: return TCompressedOutputPtr(new TOmaOutput(outFile, TOmaOutput::TAtrac3Plus{}, numChannels, frameSize));
     }
 }
 

@@ -1,11 +1,14 @@
-// at3hipenc - command-line ATRAC3 / ATRAC1 encoder on libat3hip: the reference tool's
-// `-e atrac3` path (main.cpp:367-425, 659-705) and `-e atrac1` path (main.cpp:292-345, 630-648) with the GPU encoders
+// at3hipenc - command-line ATRAC3 / ATRAC1 / ATRAC3plus encoder on libat3hip: the
+// reference tool's `-e atrac3` path (main.cpp:367-425, 659-705), `-e atrac1` path (main.cpp:292-345, 630-648) and
+// `-e atrac3plus` path (main.cpp:427-483, 679-686; without the tonal analysis, which needs libgha) with the GPU encoders
 // behind the same IProcessor-shaped objects.
 //
 //   at3hipenc -e atrac3 -i in.wav -o out.{oma|at3|wav|raw|dat} [--bitrate kbit] [--bfuidxconst n] [--notonal]
 //             [--nogaincontrol] [--container oma|riff|raw] [--nostdout] [--batch blocks] [--device n]
 //   at3hipenc -e atrac1 -i in.wav -o out.{aea|raw|dat} [--bfuidxconst 1..8] [--notransient[=mask]]
 //             [--container aea|raw] [--nostdout] [--batch blocks] [--device n]
+//   at3hipenc -e atrac3plus -i in.wav -o out.{oma|at3|wav|raw|dat} [--container oma|riff|raw] [--nostdout]
+//             [--batch frames] [--device n]
 //
 // File-level behaviour follows the reference: 44.1 kHz input only, numFrames estimate = samples / 1024 in the
 // container header, the look-ahead first call, the drain call at end of input.
@@ -24,7 +27,8 @@ static int usage()
     std::cerr << "usage: at3hipenc -e atrac3 -i in.wav -o out.oma [--bitrate kbit] [--bfuidxconst n] [--notonal] [--nogaincontrol]\n"
                  "                 [--container oma|riff|raw] [--nostdout] [--batch blocks] [--device n]\n"
                  "       at3hipenc -e atrac1 -i in.wav -o out.aea [--bfuidxconst 1..8] [--notransient[=mask]]\n"
-                 "                 [--container aea|raw] [--nostdout] [--batch blocks] [--device n]\n";
+                 "                 [--container aea|raw] [--nostdout] [--batch blocks] [--device n]\n"
+                 "       at3hipenc -e atrac3plus -i in.wav -o out.oma [--container oma|riff|raw] [--nostdout] [--batch frames] [--device n]\n";
     return 1;
 }
 
@@ -61,7 +65,43 @@ int main(int argc, char** argv)
         else if (a == "--device") device = atoi(need("--device"));
         else return usage();
     }
-    if ((codec != "atrac3" && codec != "atrac1") || inFile.empty() || outFile.empty()) return usage();
+    if ((codec != "atrac3" && codec != "atrac1" && codec != "atrac3plus") || inFile.empty() || outFile.empty()) return usage();
+    if (codec == "atrac3plus") {
+        try {
+            TWavSource wav(inFile);
+            if (wav.GetSampleRate() != 44100) throw std::runtime_error("unsupported sample rate");
+            const size_t numChannels = wav.GetChannelNum();
+            const uint64_t totalSamples = wav.GetTotalSamples();
+            const uint64_t numFrames = totalSamples / 2048;   // main.cpp:440
+            EContainer cont;
+            if (container.empty()) cont = SelectAtrac3PlusContainer(outFile);
+            else if (container == "oma") cont = EContainer::OMA;
+            else if (container == "riff") cont = EContainer::RIFF;
+            else if (container == "raw") cont = EContainer::RAW;
+            else throw std::runtime_error("unrecognized container: " + container);
+            TCompressedOutputPtr out = CreateAtrac3PlusOutput(cont, outFile, numChannels, (uint32_t)numFrames, 2048);
+            if (!noStdOut)
+                std::cout << "Input:\n Filename: " << inFile << "\n Channels: " << numChannels << "\n SampleRate: " << wav.GetSampleRate()
+                          << "\n Duration (sec): " << totalSamples / wav.GetSampleRate() << "\nOutput:\n Filename: " << outFile
+                          << "\n Codec: ATRAC3Plus" << std::endl;
+            TPCMEngine engine(4096, numChannels, [&wav](float* dst, size_t frames) { return wav.Read(dst, frames); });
+            TAt3PEncoder encoder(std::move(out), (int)numChannels, batch > 64 ? 64 : batch, device);
+            auto lambda = encoder.GetLambda();
+            uint64_t processed = 0;
+            try {
+                while (totalSamples > (processed = engine.ApplyProcess(2048, lambda))) {
+                }
+            } catch (const TNoDataToRead&) {
+                std::cerr << "No more data to read from input" << std::endl;
+            }
+            encoder.Flush();
+            if (!noStdOut) std::cout << "\nDone" << std::endl;
+        } catch (const std::exception& ex) {
+            std::cerr << "Fatal error: " << ex.what() << std::endl;
+            return 1;
+        }
+        return 0;
+    }
     if (codec == "atrac1") {
         if (bfuIdxConst > 8) {
             std::cerr << "ATRAC1 mode, --bfuidxconst is a index of max used BFU. Values [1;8] is allowed\n";

@@ -276,6 +276,9 @@ int at3ref_write_container(int kind, const char* path, const uint8_t* frames, in
         else if (kind == 2) out = CreateRawOutput(path, (size_t)nch);
         else if (kind == 3) out = CreateAeaOutput(path, "test", (size_t)nch, (uint32_t)num_frames_hint);
         else if (kind == 4) out = CreateRawOutput(path, (size_t)nch, (uint32_t)frame_sz);   // ATRAC1 raw, main.cpp:323
+        else if (kind == 5) out.reset(new TOma(path, "test", (size_t)nch, (uint32_t)num_frames_hint, OMAC_ID_ATRAC3PLUS, (uint32_t)frame_sz, false));   // main.cpp:456-461
+        else if (kind == 6) out = CreateAt3POutput(path, (size_t)nch, (uint32_t)num_frames_hint, (uint32_t)frame_sz);
+        else if (kind == 7) out = CreateRawOutput(path, (size_t)nch);
         else out.reset(new TOma(path, "test", (size_t)nch, (uint32_t)num_frames_hint, OMAC_ID_ATRAC3, (uint32_t)frame_sz, js != 0));
         for (int i = 0; i < n_frames; ++i)
             out->WriteFrame(std::vector<char>(frames + (size_t)i * frame_sz, frames + (size_t)(i + 1) * frame_sz));

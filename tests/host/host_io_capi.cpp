@@ -14,7 +14,9 @@ int at3host_write_container(int kind, const char* path, const uint8_t* frames, i
                             int num_frames_hint, int nch)
 {
     try {
-        TCompressedOutputPtr out = kind >= 3 ? CreateAtrac1Output(kind == 3 ? EContainer::AEA : EContainer::RAW, path, (size_t)nch, (uint32_t)num_frames_hint)
+        TCompressedOutputPtr out = kind >= 5 ? CreateAtrac3PlusOutput(kind == 6 ? EContainer::RIFF : kind == 7 ? EContainer::RAW : EContainer::OMA, path,
+                                                                      (size_t)nch, (uint32_t)num_frames_hint, (uint32_t)frame_sz)
+                                 : kind >= 3 ? CreateAtrac1Output(kind == 3 ? EContainer::AEA : EContainer::RAW, path, (size_t)nch, (uint32_t)num_frames_hint)
                                              : CreateAtrac3Output(kind == 1 ? EContainer::RIFF : kind == 2 ? EContainer::RAW : EContainer::OMA, path,
                                                       (size_t)nch, (uint32_t)num_frames_hint, (uint32_t)frame_sz, js != 0);
         for (int i = 0; i < n_frames; ++i)

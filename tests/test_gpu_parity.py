@@ -452,3 +452,55 @@ def test_cli_file_parity(oracle, tmp_path, nsamp, ext, opts):
         assert got == exp
     else:
         assert got[-frames.size:] == frames.tobytes()
+
+
+@pytest.mark.parametrize("nsamp,ext,nch", [(20000, "oma", 2), (12288, "at3", 2), (9000, "raw", 1), (2048, "oma", 1), (30000, "wav", 2)])
+def test_cli_atrac3plus_file_parity(oracle, tmp_path, nsamp, ext, nch):
+    """at3hipenc -e atrac3plus (WAV -> container) against the reference's container writer (oracle/_ref) fed with the
+    oracle's frames for the block sequence the reference's frame schedule produces: look-ahead call, then a silent frame,
+    then input frame k - 2 at call k (at3p.cpp:113-160), the drain call after the last read."""
+    import ctypes
+    import os
+    import struct
+    import subprocess
+    from at3_testlib import REF_SO, at3p_mdct, at3p_pqf, at3p_write_frames, have_ref
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "atracdenc_amd", "at3hipenc")
+    if not os.path.exists(exe):
+        pytest.skip("at3hipenc not built")
+    nb1k = (nsamp + 1023) // 1024 + 1
+    s16 = (SIGNALS["mix"](nb1k, seed=13)[:nb1k].reshape(-1, 2)[:nsamp, :nch] * 32768).astype("<i2")
+    body = np.ascontiguousarray(s16).tobytes()
+    wav = str(tmp_path / "in.wav")
+    fmt = struct.pack("<HHIIHH", 1, nch, 44100, 44100 * 2 * nch, 2 * nch, 16)
+    open(wav, "wb").write(b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt +
+                          b"data" + struct.pack("<I", len(body)) + body)
+    out = str(tmp_path / ("out." + ext))
+    r = subprocess.run([exe, "-e", "atrac3plus", "-i", wav, "-o", out, "--nostdout", "--batch", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = open(out, "rb").read()
+
+    so = str(tmp_path / "libhostio.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", os.path.join(root, "include"), "-o", so,
+                           os.path.join(root, "tests", "host", "host_io_capi.cpp")])
+    host = ctypes.CDLL(so)
+    blocks = np.zeros((32, 2048, nch), np.float32)
+    info = (ctypes.c_uint64 * 3)()
+    ncalls = host.at3host_wav_blocks_step(wav.encode(), blocks.ctypes.data_as(ctypes.c_void_p), 32, info, 2048, 1)
+    assert ncalls >= 1 and info[2] == nsamp and info[0] == nch
+    # call k (k >= 1) writes: silence for k == 1, the frame of call k - 2's input otherwise
+    specs = np.zeros((ncalls, nch, 2048), np.float32)          # row k + 1: input of call k; row 0: silence
+    for c in range(nch):
+        bands = at3p_pqf(np.ascontiguousarray(blocks[:ncalls - 1, :, c])) if ncalls > 1 else np.zeros((0, 16, 128), np.float32)
+        if ncalls > 1:
+            specs[1:, c] = at3p_mdct((bands.astype(np.float64) / (32768.0 / 1.122018)).astype(np.float32))
+    frames = at3p_write_frames(specs)[: ncalls - 1]
+    kind = {"oma": 5, "at3": 6, "wav": 6, "raw": 7}[ext]
+    if have_ref():
+        ref = ctypes.CDLL(REF_SO)
+        exp_path = str(tmp_path / "exp.bin")
+        buf = np.ascontiguousarray(frames)
+        assert ref.at3ref_write_container(kind, exp_path.encode(), buf.ctypes.data_as(ctypes.c_void_p), buf.shape[0], 2048, 0, nsamp // 2048, nch) == 0
+        assert got == open(exp_path, "rb").read()
+    else:
+        assert got[len(got) - frames.size:] == frames.tobytes()

@@ -47,6 +47,19 @@ def test_container_bytes(host, reflib, tmp_path, kind, frame_sz, js, n, hint):
     assert len(a) == {0: 96, 1: 76, 2: 0}[kind] + n * frame_sz
 
 
+@pytest.mark.parametrize("kind", [5, 6, 7])
+@pytest.mark.parametrize("nch", [1, 2])
+@pytest.mark.parametrize("n,hint", [(5, 5), (6, 5), (2, 0), (0, 3)])
+def test_atrac3plus_container_bytes(host, reflib, tmp_path, kind, nch, n, hint):
+    """ATRAC3plus sinks of main.cpp:451-463: TOma with OMAC_ID_ATRAC3PLUS, CreateAt3POutput (WAVE_FORMAT_EXTENSIBLE + GUID,
+    lengths back-filled on close), raw; 2048-byte frames."""
+    frames = np.random.RandomState(kind * 10 + nch + n).randint(0, 256, size=(n, 2048)).astype(np.uint8)
+    a = _write(reflib, "at3ref_write_container", kind, str(tmp_path / "ref.bin"), frames, 2048, 0, hint, nch)
+    b = _write(host, "at3host_write_container", kind, str(tmp_path / "own.bin"), frames, 2048, 0, hint, nch)
+    assert a == b
+    assert len(a) == {5: 96, 6: 80, 7: 0}[kind] + n * 2048
+
+
 def test_container_selection(host):
     for name, want in (("x.oma", 0), ("x.OMA", 0), ("x.at3", 1), ("a.b.WAV", 1), ("x.raw", 2), ("x.dat", 2), ("noext", 0), ("x.aa3", 0),
                        ("x.rm", -1)):
@@ -172,6 +185,17 @@ def test_frame_schedule_atrac1(host, reflib, total, nch):
     """ApplyProcess(512, ...) with a lambda that always answers PROCESSED (main.cpp:646, atrac1denc.cpp:253)."""
     a = _trace_step(reflib, "at3ref_engine_trace_step", total, nch, 512, 0)
     b = _trace_step(host, "at3host_engine_trace_step", total, nch, 512, 0)
+    assert a[0] == b[0] and a[1] == b[1]
+    for i in (2, 3, 4):
+        assert np.array_equal(a[i].view(np.uint32), b[i].view(np.uint32))
+
+
+@pytest.mark.parametrize("nch", [1, 2])
+@pytest.mark.parametrize("total", [1, 2047, 2048, 2049, 4095, 4096, 4097, 6144, 8192, 10000, 12288, 20001])
+def test_frame_schedule_atrac3plus(host, reflib, total, nch):
+    """ApplyProcess(2048, ...) with one LOOK_AHEAD answer first (main.cpp:679-686, at3p.cpp:113-115): two calls per read."""
+    a = _trace_step(reflib, "at3ref_engine_trace_step", total, nch, 2048, 1)
+    b = _trace_step(host, "at3host_engine_trace_step", total, nch, 2048, 1)
     assert a[0] == b[0] and a[1] == b[1]
     for i in (2, 3, 4):
         assert np.array_equal(a[i].view(np.uint32), b[i].view(np.uint32))
