@@ -196,10 +196,12 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
             int cnt_u = 0;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const int j = 64 * r + lane, line = start + j;
-                flag[r] = j < n && ((L.code[line >> 2] >> (2 * (line & 3))) & 3u) == want;
+                flag[r] = false;
                 key[r] = 0.0f;
                 recv[r] = 0u;
+                if (r == 1 && n <= 64) continue;   // (uniform) only the two 128-line units have a second round
+                const int j = 64 * r + lane, line = start + j;
+                flag[r] = j < n && ((L.code[line >> 2] >> (2 * (line & 3))) & 3u) == want;
                 const unsigned long long mask = __ballot(flag[r]);
                 if (flag[r]) {
                     const int slot = cnt_u + __popcll(mask & ((1ull << lane) - 1ull));
@@ -217,6 +219,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
             int rank[2] = {0, 0};
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
+                if (r == 1 && n <= 64) continue;
                 if (flag[r]) {
                     const float4* t4 = reinterpret_cast<const float4*>(L.uk);
                     int rr = 0;

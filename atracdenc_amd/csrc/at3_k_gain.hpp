@@ -95,8 +95,18 @@ __device__ __forceinline__ void irfft_pass_2_8(cpx* F, const cpx* tw, int lane)
 {
     cpx* B = F + 33 * lane + KAPPA;
     f2 x[16];
+    // Slot 32 G + KAPPA + 2 i is the leaf of input index r + 256 (i % 4) + 1024 KAPPA with r = the digit reversal of G plus
+    // 64 (i / 4). The caller stores leaves only for inputs 38..256 and 1792..2010 (and their radix-2 partners), i.e. for
+    // r >= 38 at i % 4 == 0, r == 0 at i % 4 == 1 and r <= 218 at i % 4 == 3: every other slot is an exact zero that is
+    // neither stored nor read (the buffer is not cleared between items).
+    const int r0 = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = ld2(B + 2 * i);
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + 64 * (i >> 2);
+        const bool nz = (i & 3) == 0 ? r >= 38 : (i & 3) == 1 ? r == 0 : (i & 3) == 3 ? r <= 218 : false;
+        x[i] = f2{0.0f, 0.0f};
+        if ((i & 3) != 2 && nz) x[i] = ld2(B + 2 * i);
+    }
     const f2 a1 = ld2(tw + 256 * KAPPA), a2 = ld2(tw + 512 * KAPPA), a3 = ld2(tw + 768 * KAPPA);   // k = KAPPA, fstride 256
 #pragma unroll
     for (int g = 0; g < 4; ++g) bfly4<true>(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], a1, a2, a3);
@@ -413,13 +423,6 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     // 3. kiss_fftri input. Only bins 38..256 survive the high-pass, so tmpbuf is non-zero at k in [38,256] and
     //    [1792,2010]; each of those meets an exact zero in its radix-2 leaf butterfly (x +- 0*w), whose two outputs
     //    are therefore stored directly.
-    {
-        float4* z4 = reinterpret_cast<float4*>(L.f);
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-            if (tid + 128 * k < (2048 + 64) / 2) z4[tid + 128 * k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    __syncthreads();
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int k = q ? k1 : k0;
