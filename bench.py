@@ -344,11 +344,18 @@ def main():
     if world > 1:
         # one rank per GPU (torch.distributed.run): CPU-side gloo for the barrier and the MAX only - the data path has no
         # exchange step, and north_star asks for no RCCL
-        if local_rank >= n_visible:
-            raise SystemExit(f"rank {rank}: local_rank {local_rank} but only {n_visible} GPU(s) visible")
-        dist = at3dist.init("gloo")
-        devices = [local_rank]
+        dev = local_rank
         mode = f"{world} ranks x 1 GPU (torch.distributed.run, gloo barrier)"
+        if args.device_map:
+            dmap = [int(x) for x in args.device_map.split(",")]
+            if len(dmap) != world:
+                raise SystemExit("--device-map needs one entry per rank")
+            dev = dmap[local_rank]
+            mode = f"TEST AID --device-map {args.device_map}: {world} ranks on {len(set(dmap))} physical GPU(s) - not an N-GPU measurement"
+        if dev >= n_visible:
+            raise SystemExit(f"rank {rank}: device {dev} but only {n_visible} GPU(s) visible")
+        dist = at3dist.init("gloo")
+        devices = [dev]
     else:
         if args.device_map:
             devices = [int(x) for x in args.device_map.split(",")]
