@@ -184,7 +184,63 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
     int my_nc = 0;   // lane 19 + ub: candidates of its unit
     if (ea_need) {
         uint32_t tie_units = 0;
-        for (uint32_t rem = ea_need >> 19; rem; rem &= rem - 1u) {
+        // BFUs 19..25 are 32 lines wide: two of them share a pass, one per half of the wavefront (same lists, same ranks,
+        // half as many trips through the write / rendezvous / read-back sequence)
+        for (uint32_t rem32 = (ea_need >> 19) & 0x7fu; rem32;) {
+            const int ubA = __builtin_ctz(rem32);
+            rem32 &= rem32 - 1u;
+            int ubB = -1;
+            if (rem32) {
+                ubB = __builtin_ctz(rem32);
+                rem32 &= rem32 - 1u;
+            }
+            const int half = lane >> 5, l = lane & 31;
+            const bool has = half == 0 || ubB >= 0;
+            const int bfu = 19 + ((half && ubB >= 0) ? ubB : ubA);
+            const int start = bfu_start(bfu), ustart = start - kEaLine0, line = start + l;
+            const float e1 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_e1)));
+            const float e2 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_e2)));
+            const uint32_t want = (e2 < e1) ? 1u : (e2 > e1) ? 2u : 3u;
+            const float mul = max_quant(__builtin_amdgcn_ds_bpermute(4 * bfu, bits));
+            const bool flag = has && ((L.code[line >> 2] >> (2 * (line & 3))) & 3u) == want;
+            const unsigned long long mask = __ballot(flag);
+            const uint32_t hm = half ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+            const int cnt = __popc(hm);
+            float* uk = L.uk + 64 * half;
+            float key = 0.0f;
+            uint32_t recv = 0u;
+            if (flag) {
+                const int slot = __popc(hm & ((1u << l) - 1u));
+                const float t = L.val[line] * mul;
+                key = fabsf(t - (truncf(t) + 0.5f));
+                uk[slot] = key;
+                const int m0 = (int)L.bm[line];
+                const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
+                recv = (uint32_t)l | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12);
+            }
+            if (l < 16 && cnt + l < ((cnt + 15) & ~15)) uk[cnt + l] = __builtin_huge_valf();
+            wave_sync();
+            int rr = 0;
+            if (flag) {
+                const float4* t4 = reinterpret_cast<const float4*>(uk);
+                for (int q = 0; q < cnt; q += 16) {
+                    const float4 c0 = t4[(q >> 2)], c1 = t4[(q >> 2) + 1], c2 = t4[(q >> 2) + 2], c3 = t4[(q >> 2) + 3];
+                    rr += (c0.x < key) + (c0.y < key) + (c0.z < key) + (c0.w < key);
+                    rr += (c1.x < key) + (c1.y < key) + (c1.z < key) + (c1.w < key);
+                    rr += (c2.x < key) + (c2.y < key) + (c2.z < key) + (c2.w < key);
+                    rr += (c3.x < key) + (c3.y < key) + (c3.z < key) + (c3.w < key);
+                }
+                L.rec[ustart + rr] = (uint16_t)recv;
+            }
+            wave_sync();
+            const unsigned long long lost = __ballot(flag && L.rec[ustart + rr] != (uint16_t)recv);
+            if ((uint32_t)lost) tie_units |= 1u << ubA;
+            if ((uint32_t)(lost >> 32)) tie_units |= 1u << (ubB >= 0 ? ubB : ubA);
+            if (lane == 19 + ubA) my_nc = __popc((uint32_t)mask);
+            if (ubB >= 0 && lane == 19 + ubB) my_nc = __popc((uint32_t)(mask >> 32));
+            wave_sync();   // the key lists are reused by the next pair
+        }
+        for (uint32_t rem = (ea_need >> 19) & ~0x7fu; rem; rem &= rem - 1u) {
             const int ub = __builtin_ctz(rem), bfu = 19 + ub;
             const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start, ustart = start - kEaLine0;
             const float e1 = readlane_f(my_e1, bfu), e2 = readlane_f(my_e2, bfu);
