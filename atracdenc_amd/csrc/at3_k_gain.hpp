@@ -270,6 +270,9 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
         L.f[fft_leaf_pos<256>(i)] = z;
     }
     wave_sync();
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 21) return;
+#endif
     // 256-point forward core, one butterfly per lane and pass
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
@@ -283,6 +286,9 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
         st2(B + 3 * m, x3);
         wave_sync();
     }
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 22) return;
+#endif
     // 2. kiss_fftr post-processing -> 257 bins (tools/kiss_fftr.c:61-100): lane handles k = lane + 1 and k = lane + 65
     if (lane == 0) {
         const float tr = L.f[0].r, ti = L.f[0].i;
@@ -319,6 +325,9 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
             if (j < 219) bins[j] = L.freq[kLowCutBin + j];
         }
     }
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 23) return;
+#endif
     // highFreqRatio (transient_spectral_upsampler.cpp:99-118): two ordered f64 sums over the 257 bin energies, the second
     // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on). The energies are formed by
     // all lanes and parked (as f64) over the spectrum; after the workgroup's rendezvous lanes 0..7 of the first wavefront
@@ -341,6 +350,9 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
         }
     }
     __syncthreads();
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (p.debug == 24) return;
+#endif
     if (tid < 8) {
         const int it = tid >> 1, kind = tid & 1;
         const double* E = reinterpret_cast<const double*>(s_item[it].freq);
