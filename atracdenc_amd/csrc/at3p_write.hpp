@@ -33,7 +33,13 @@ struct WriteTables {
     uint8_t qu_to_sb[32];
     uint8_t sb_powgrps[16];
     WriteHead head[2][33];          // [channels - 1][quant units]
+    // for the tables the writer prices (word length - 1 + 7 i, i < 8: tables 0..55): per table offset | group_size << 16 |
+    // num_coeffs << 20 | bits << 24 | is_signed << 28, and the code lengths alone, one nibble per symbol - the part of
+    // the table block k_at3p_write keeps in LDS
+    uint32_t info56[56];
+    uint32_t len4[(7812 + 7) / 8];
 };
+constexpr int kLenEntries = 7812;   // symbols of tables 0..55
 
 // TConfigure::Encode's allocTable (at3p_bitstream.cpp:107-112): 7 x 17, 6 x 9, 5, 5, 4, 3, 2, 1
 __host__ __device__ inline int at3p_wordlen(int qu) { return qu < 17 ? 7 : qu < 26 ? 6 : qu < 28 ? 5 : 32 - qu; }
@@ -66,6 +72,10 @@ inline void build_write_tables(WriteTables* w)
     memcpy(w->scale, AT3P_SCALE, sizeof(AT3P_SCALE));
     memcpy(w->qu_to_sb, AT3P_QU_TO_SB, sizeof(AT3P_QU_TO_SB));
     memcpy(w->sb_powgrps, AT3P_SB_POWGRPS, sizeof(AT3P_SB_POWGRPS));
+    for (int t = 0; t < 56; ++t)
+        w->info56[t] = (uint32_t)AT3P_VLC_OFF[t] | ((uint32_t)(AT3P_SPEC_TAB[t][0] & 15) << 16) | ((uint32_t)(AT3P_SPEC_TAB[t][0] >> 4) << 20) |
+                       ((uint32_t)(AT3P_SPEC_TAB[t][1] & 15) << 24) | ((uint32_t)(AT3P_SPEC_TAB[t][1] >> 4) << 28);
+    for (int e = 0; e < AT3P_VLC_OFF[56]; ++e) w->len4[e >> 3] |= (uint32_t)(AT3P_VLC[e] >> 12) << (4 * (e & 7));
     for (int nch = 1; nch <= 2; ++nch) {
         for (int N = 1; N <= 32; ++N) {
             WriteHead& h = w->head[nch - 1][N];
@@ -169,13 +179,16 @@ struct BitRun {
 };
 
 // EncodeQuSpectra (at3p_bitstream.cpp:310-373) over the 16 mantissas of one chunk under code table `ti`: returns the
-// bits, writes them when EMIT. Every table's group (group_size x num_coeffs coefficients) divides 16.
+// bits, writes them when EMIT. Every table's group (group_size x num_coeffs coefficients) divides 16. The table
+// descriptors and the code lengths come from LDS (`info`, `len4`), the codes - wanted for the one chosen table only -
+// from the table block in HBM.
 template <bool EMIT>
-__device__ __forceinline__ int chunk_spectra(const WriteTables* W, const int8_t* m, int ti, BitRun* run)
+__device__ __forceinline__ int chunk_spectra(const WriteTables* W, const uint32_t* info, const uint32_t* len4, const int8_t* m, int ti, BitRun* run)
 {
-    const int group_size = W->tab[ti][0] & 15, num_coeffs = W->tab[ti][0] >> 4;
-    const int bits = W->tab[ti][1] & 15, is_signed = W->tab[ti][1] >> 4;
-    const uint16_t* vlc = W->vlc + W->off[ti];
+    const uint32_t d = info[ti];
+    const int off = (int)(d & 0xffffu), group_size = (int)((d >> 16) & 15u), num_coeffs = (int)((d >> 20) & 15u);
+    const int bits = (int)((d >> 24) & 15u), is_signed = (int)(d >> 28);
+    const uint16_t* vlc = W->vlc + off;
     int total = 0;
     for (int pos = 0; pos < 16;) {
         if (group_size != 1) {
@@ -196,15 +209,43 @@ __device__ __forceinline__ int chunk_spectra(const WriteTables* W, const int8_t*
                 }
                 val |= (uint32_t)t << (bits * i);
             }
-            const uint32_t e = vlc[val & 0xffu];
-            total += (int)(e >> 12) + n_signs;
+            const int e = off + (int)(val & 0xffu);
+            const int len = (int)((len4[e >> 3] >> (4 * (e & 7))) & 15u);
+            total += len + n_signs;
             if (EMIT) {
-                run->add(e & 0xfffu, (int)(e >> 12));
+                run->add(vlc[val & 0xffu] & 0xfffu, len);
                 run->add(sign_bits, n_signs);
             }
         }
     }
     return total;
+}
+
+// The symbols a chunk's 16 mantissas form under a packing (NC coefficients of `bits` bits per symbol, signed or as
+// magnitudes with separate sign bits): statically indexed, so everything stays in registers. The candidate tables of a
+// word length share one to three packings, so the symbols are formed once per packing and only looked up per table.
+template <int NC>
+__device__ __forceinline__ int pack_symbols(const int (&q)[16], int bits, int is_signed, uint32_t (&vals)[16])
+{
+    int n_signs = 0;
+    const int mask = (1 << bits) - 1;
+#pragma unroll
+    for (int sidx = 0; sidx < 16 / NC; ++sidx) {
+        uint32_t val = 0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            int t = q[sidx * NC + i];
+            if (!is_signed && t != 0) {
+                ++n_signs;
+                t = t < 0 ? -t : t;
+            } else {
+                t &= mask;
+            }
+            val |= (uint32_t)t << (bits * i);
+        }
+        vals[sidx] = val & 0xffu;
+    }
+    return n_signs;
 }
 
 __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
@@ -219,6 +260,8 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     __shared__ uint32_t s_best[2][32];
     __shared__ uint32_t s_wsum[4];
     __shared__ int s_n;
+    __shared__ uint32_t s_info[56];
+    __shared__ uint32_t s_len4[(kLenEntries + 7) / 8];
 
     const WriteTables* W = p.W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -237,6 +280,8 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
         (&s_max[0][0])[tid] = 0u;
         s_scale[tid] = W->scale[tid];
     }
+    if (tid >= 64 && tid < 120) s_info[tid - 64] = W->info56[tid - 64];
+    for (int k = tid; k < (kLenEntries + 7) / 8; k += 256) s_len4[k] = W->len4[k];
     float x[16];
     {
         const float4* src = reinterpret_cast<const float4*>(p.specs + (item * nch + (active ? ch : 0)) * 2048 + 16 * c);
@@ -268,6 +313,9 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     }
     __syncthreads();
     // ---- QuantMantisas without the energy pass (atrac_scale.cpp:46-54) at the unit's fixed word length ----
+    int qv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) qv[k] = 0;
     if (active) {
         const float sf = s_scale[s_sfi[ch][qu]];
         const float mul = W->inv_mant[wl];
@@ -277,6 +325,7 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
             float v = x[k] / sf;
             if (fabsf(v) >= 1.0f) v = (v > 0) ? 0.99999f : -0.99999f;
             const int q = __float2int_rn(v * mul);
+            qv[k] = q;
             pk[k >> 2] |= (uint32_t)(uint8_t)(int8_t)q << (8 * (k & 3));
         }
         *reinterpret_cast<uint4*>(&s_mant[ch][16 * c]) = uint4{pk[0], pk[1], pk[2], pk[3]};
@@ -284,9 +333,36 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     __syncthreads();
     // ---- TUnit::GetOrCompute (:387-417): the unit's bits under each of its eight code tables ----
     if (active) {
-        const int8_t* m = &s_mant[ch][16 * c];
+        uint32_t vals[16], prev_packing = 0xffffffffu;
+        int n_signs = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) vals[k] = 0u;
         for (int i = 0; i < 8; ++i) {
-            const int bits = chunk_spectra<false>(W, m, wl - 1 + 7 * i, nullptr);
+            const uint32_t d = s_info[wl - 1 + 7 * i];
+            const int off = (int)(d & 0xffffu), group_size = (int)((d >> 16) & 15u), num_coeffs = (int)((d >> 20) & 15u);
+            if ((d >> 20) != prev_packing) {   // num_coeffs, bits, is_signed
+                prev_packing = d >> 20;
+                const int cbits = (int)((d >> 24) & 15u), is_signed = (int)(d >> 28);
+                if (num_coeffs == 1) n_signs = pack_symbols<1>(qv, cbits, is_signed, vals);
+                else if (num_coeffs == 2) n_signs = pack_symbols<2>(qv, cbits, is_signed, vals);
+                else n_signs = pack_symbols<4>(qv, cbits, is_signed, vals);
+            }
+            const int n_sym = 16 / num_coeffs;
+            int bits = n_signs + (group_size != 1 ? n_sym / group_size : 0);   // one flag bit per group
+            auto len_of = [&](int sidx) {
+                const int e = off + (int)vals[sidx];
+                return (int)((s_len4[e >> 3] >> (4 * (e & 7))) & 15u);
+            };
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) bits += len_of(sidx);
+            if (num_coeffs <= 2) {
+#pragma unroll
+                for (int sidx = 4; sidx < 8; ++sidx) bits += len_of(sidx);
+                if (num_coeffs == 1) {
+#pragma unroll
+                    for (int sidx = 8; sidx < 16; ++sidx) bits += len_of(sidx);
+                }
+            }
             s_cbits[tid][i] = (uint16_t)bits;
             atomicAdd(&s_qbits[ch][qu][i], (uint32_t)bits);
         }
@@ -354,7 +430,7 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     if (coded) {
         BitRun run;
         run.start(s_out, ch_base[ch] + ((wave & 1) ? (int)s_wsum[wave - 1] : 0) + incl - cb);
-        chunk_spectra<true>(W, &s_mant[ch][16 * c], wl - 1 + 7 * my_tab, &run);
+        chunk_spectra<true>(W, s_info, s_len4, &s_mant[ch][16 * c], wl - 1 + 7 * my_tab, &run);
         run.finish();
     }
     if (c == 0 && active) frame_put(s_out, ch_base[ch] + ch_total[ch], (1u << pw) - 1u, pw);   // (15, 4) per power group

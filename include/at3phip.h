@@ -83,7 +83,7 @@ int at3phip_get_timings(const at3phip_ctx* ctx, float* pqf_ms, float* mdct_ms);
 int at3phip_host_tables(void* dst, size_t bytes);
 /* The frame writer's tables (code tables, scale table, the spectrum-independent leading bits per channel count and
  * number of quant units) as at3phip_create builds them; bytes = AT3PHIP_WRITE_TABLES_BYTES. */
-#define AT3PHIP_WRITE_TABLES_BYTES 37252
+#define AT3PHIP_WRITE_TABLES_BYTES 41384
 int at3phip_host_write_tables(void* dst, size_t bytes);
 
 #ifdef __cplusplus

@@ -70,12 +70,12 @@ def test_host_write_tables(oracle):
     bits the oracle writes, and the fixed bit counts add up to the oracle's frame length."""
     from atracdenc_amd.binding import load_library
     lib = load_library()
-    nbytes = 37252
+    nbytes = 41384
     buf = np.zeros(nbytes, np.uint8)
     assert lib.at3phip_host_write_tables(_vp(buf), nbytes) == 0
     assert lib.at3phip_host_write_tables(_vp(buf), nbytes - 4) != 0
     head = np.dtype([("words", "<u4", 8), ("nbits", "<u2"), ("fixed_bits", "<u2")])
-    heads = buf[nbytes - 66 * head.itemsize:].view(head).reshape(2, 33)
+    heads = buf[34876:34876 + 66 * head.itemsize].view(head).reshape(2, 33)   # after the code tables and scalar tables
     for nch in (1, 2):
         frames, info = at3p_write_frames(np.zeros((1, nch, 2048), np.float32), info=True)
         n = int(info["num_quant_units"][0])
