@@ -178,49 +178,6 @@ struct BitRun {
     }
 };
 
-// EncodeQuSpectra (at3p_bitstream.cpp:310-373) over the 16 mantissas of one chunk under code table `ti`: returns the
-// bits, writes them when EMIT. Every table's group (group_size x num_coeffs coefficients) divides 16. The table
-// descriptors and the code lengths come from LDS (`info`, `len4`), the codes - wanted for the one chosen table only -
-// from the table block in HBM.
-template <bool EMIT>
-__device__ __forceinline__ int chunk_spectra(const WriteTables* W, const uint32_t* info, const uint32_t* len4, const int8_t* m, int ti, BitRun* run)
-{
-    const uint32_t d = info[ti];
-    const int off = (int)(d & 0xffffu), group_size = (int)((d >> 16) & 15u), num_coeffs = (int)((d >> 20) & 15u);
-    const int bits = (int)((d >> 24) & 15u), is_signed = (int)(d >> 28);
-    const uint16_t* vlc = W->vlc + off;
-    int total = 0;
-    for (int pos = 0; pos < 16;) {
-        if (group_size != 1) {
-            if (EMIT) run->add(1u, 1);
-            total += 1;
-        }
-        for (int j = 0; j < group_size; ++j) {
-            uint32_t val = 0, sign_bits = 0;
-            int n_signs = 0;
-            for (int i = 0; i < num_coeffs; ++i) {
-                int t = m[pos++];
-                if (!is_signed && t != 0) {
-                    sign_bits = (sign_bits << 1) | (t < 0 ? 1u : 0u);   // 0 for a positive, 1 for a negative coefficient, in order
-                    ++n_signs;
-                    if (t < 0) t = -t;
-                } else {
-                    t &= (1 << bits) - 1;
-                }
-                val |= (uint32_t)t << (bits * i);
-            }
-            const int e = off + (int)(val & 0xffu);
-            const int len = (int)((len4[e >> 3] >> (4 * (e & 7))) & 15u);
-            total += len + n_signs;
-            if (EMIT) {
-                run->add(vlc[val & 0xffu] & 0xfffu, len);
-                run->add(sign_bits, n_signs);
-            }
-        }
-    }
-    return total;
-}
-
 // The symbols a chunk's 16 mantissas form under a packing (NC coefficients of `bits` bits per symbol, signed or as
 // magnitudes with separate sign bits): statically indexed, so everything stays in registers. The candidate tables of a
 // word length share one to three packings, so the symbols are formed once per packing and only looked up per table.
@@ -248,10 +205,54 @@ __device__ __forceinline__ int pack_symbols(const int (&q)[16], int bits, int is
     return n_signs;
 }
 
+// The same with each symbol's sign bits (0 = positive, 1 = negative, in coefficient order) as bits | count << 4: what
+// EncodeQuSpectra appends after the symbol's code (at3p_bitstream.cpp:360-368).
+template <int NC>
+__device__ __forceinline__ void pack_symbols_signs(const int (&q)[16], int bits, int is_signed, uint32_t (&vals)[16], uint32_t (&sgn)[16])
+{
+    const int mask = (1 << bits) - 1;
+#pragma unroll
+    for (int sidx = 0; sidx < 16 / NC; ++sidx) {
+        uint32_t val = 0, sb = 0, ns = 0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            int t = q[sidx * NC + i];
+            if (!is_signed && t != 0) {
+                sb = (sb << 1) | (t < 0 ? 1u : 0u);
+                ++ns;
+                t = t < 0 ? -t : t;
+            } else {
+                t &= mask;
+            }
+            val |= (uint32_t)t << (bits * i);
+        }
+        vals[sidx] = val & 0xffu;
+        sgn[sidx] = sb | (ns << 4);
+    }
+}
+
+// EncodeQuSpectra (at3p_bitstream.cpp:310-373) for the chosen table: all code words are requested first (one memory latency for the chunk), then
+// strung together with the group flags and the sign bits.
+template <int NC>
+__device__ __forceinline__ void emit_chunk(const WriteTables* W, const int (&q)[16], uint32_t d, BitRun* run)
+{
+    const int off = (int)(d & 0xffffu), group_size = (int)((d >> 16) & 15u);
+    const int cbits = (int)((d >> 24) & 15u), is_signed = (int)(d >> 28);
+    uint32_t vals[16], sgn[16], code[16];
+    pack_symbols_signs<NC>(q, cbits, is_signed, vals, sgn);
+#pragma unroll
+    for (int sidx = 0; sidx < 16 / NC; ++sidx) code[sidx] = W->vlc[off + (int)vals[sidx]];
+#pragma unroll
+    for (int sidx = 0; sidx < 16 / NC; ++sidx) {
+        if (group_size != 1 && (sidx % group_size) == 0) run->add(1u, 1);   // group_size is 1, 2 or 4
+        run->add(code[sidx] & 0xfffu, (int)(code[sidx] >> 12));
+        run->add(sgn[sidx] & 15u, (int)(sgn[sidx] >> 4));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
 {
     __shared__ uint32_t s_out[kFrameBytes / 4];
-    __shared__ __attribute__((aligned(16))) int8_t s_mant[2][2048];
     __shared__ uint16_t s_cbits[256][8];     // bits of each 16-line chunk under each of the eight candidate tables
     __shared__ uint32_t s_qbits[2][32][8];   // the same per quant unit
     __shared__ uint32_t s_max[2][32];
@@ -260,6 +261,8 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     __shared__ uint32_t s_best[2][32];
     __shared__ uint32_t s_wsum[4];
     __shared__ int s_n;
+    __shared__ uint16_t s_cb[256];           // the chosen table's bits per chunk, in stream order (channel, chunk)
+    __shared__ uint32_t s_off[256];          // and their exclusive prefix sums per channel
     __shared__ uint32_t s_info[56];
     __shared__ uint32_t s_len4[(kLenEntries + 7) / 8];
 
@@ -267,7 +270,14 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nch = p.nch;
     const size_t item = blockIdx.x;
-    const int ch = tid >> 7, c = tid & 127;       // the thread's chunk: lines 16 c .. 16 c + 15 of channel ch
+    // The thread's chunk (lines 16 c .. 16 c + 15 of channel ch). Threads are dealt by WORD LENGTH, both channels of a
+    // class side by side (7: 2 x 28 chunks, 6: 2 x 52, 5: 2 x 16, 4..1: 2 x 8 each): a wavefront then walks one or two
+    // sets of code tables instead of up to six.
+    int ch, c;
+    if (tid < 56) { ch = tid / 28; c = tid % 28; }
+    else if (tid < 160) { ch = (tid - 56) / 52; c = 28 + (tid - 56) % 52; }
+    else if (tid < 192) { ch = (tid - 160) >> 4; c = 80 + ((tid - 160) & 15); }
+    else { ch = ((tid - 192) >> 3) & 1; c = 96 + 8 * ((tid - 192) >> 4) + ((tid - 192) & 7); }
     const bool active = ch < nch;
     const int qu = at3p_qu_of_line(16 * c);
     const int wl = at3p_wordlen(qu);
@@ -319,16 +329,12 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     if (active) {
         const float sf = s_scale[s_sfi[ch][qu]];
         const float mul = W->inv_mant[wl];
-        uint32_t pk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             float v = x[k] / sf;
             if (fabsf(v) >= 1.0f) v = (v > 0) ? 0.99999f : -0.99999f;
-            const int q = __float2int_rn(v * mul);
-            qv[k] = q;
-            pk[k >> 2] |= (uint32_t)(uint8_t)(int8_t)q << (8 * (k & 3));
+            qv[k] = __float2int_rn(v * mul);
         }
-        *reinterpret_cast<uint4*>(&s_mant[ch][16 * c]) = uint4{pk[0], pk[1], pk[2], pk[3]};
     }
     __syncthreads();
     // ---- TUnit::GetOrCompute (:387-417): the unit's bits under each of its eight code tables ----
@@ -420,17 +426,27 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     if (tid == 64) frame_put(s_out, pos_ct, 1u, 1);   // "use full table"
     const bool coded = active && qu < N;
     const int my_tab = s_tab[active ? ch : 0][qu];
-    const int cb = coded ? (int)s_cbits[tid][my_tab] : 0;
-    const int incl = at3::wave_inclusive_scan(cb, lane);
-    if (lane == 63) s_wsum[wave] = (uint32_t)incl;
+    s_cb[ch * 128 + c] = (uint16_t)(coded ? s_cbits[tid][my_tab] : 0);
+    __syncthreads();
+    {   // prefix sums in stream order: entry u = channel u / 128, chunk u % 128
+        const int v = (int)s_cb[tid];
+        const int incl = at3::wave_inclusive_scan(v, lane);
+        if (lane == 63) s_wsum[wave] = (uint32_t)incl;
+        __syncthreads();
+        s_off[tid] = (uint32_t)(incl - v) + ((wave & 1) ? s_wsum[wave - 1] : 0u);
+    }
     __syncthreads();
     const int ch_total[2] = {(int)(s_wsum[0] + s_wsum[1]), (int)(s_wsum[2] + s_wsum[3])};
     const int pw = 4 * W->sb_powgrps[W->qu_to_sb[N - 1]];
     const int ch_base[2] = {pos_data, pos_data + ch_total[0] + pw};
     if (coded) {
         BitRun run;
-        run.start(s_out, ch_base[ch] + ((wave & 1) ? (int)s_wsum[wave - 1] : 0) + incl - cb);
-        chunk_spectra<true>(W, s_info, s_len4, &s_mant[ch][16 * c], wl - 1 + 7 * my_tab, &run);
+        run.start(s_out, ch_base[ch] + (int)s_off[ch * 128 + c]);
+        const uint32_t d = s_info[wl - 1 + 7 * my_tab];
+        const int num_coeffs = (int)((d >> 20) & 15u);
+        if (num_coeffs == 1) emit_chunk<1>(W, qv, d, &run);
+        else if (num_coeffs == 2) emit_chunk<2>(W, qv, d, &run);
+        else emit_chunk<4>(W, qv, d, &run);
         run.finish();
     }
     if (c == 0 && active) frame_put(s_out, ch_base[ch] + ch_total[ch], (1u << pw) - 1u, pw);   // (15, 4) per power group

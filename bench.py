@@ -311,8 +311,8 @@ def widened_rows(S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: 64 at N=1, 1024 at N>1)")
     ap.add_argument("--frames", type=int, default=0, help="frames per stream per step (default: 64 at N=1, 128 at N>1)")
     ap.add_argument("--bitrate", type=int, default=LP2)
