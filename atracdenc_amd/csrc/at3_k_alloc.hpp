@@ -679,6 +679,14 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         if (num_bfu > lim) num_bfu = lim;
     }
     if (num_bfu < 1) num_bfu = 1;
+    if (!p.bfu_idx_const) {
+        // The reference drops the last BFU and repeats the whole bisection whenever that BFU ends with no bits
+        // (atrac3_bitstream.cpp:646-655). A BFU below the threshold in quiet gets none at any lambda, so every bisection
+        // with such a BFU on top ends that way whatever it converges to: those passes are skipped, not run (a 3 kHz burst
+        // or a handful of sines leaves twenty of them on top, each worth a dozen evaluations).
+        const uint32_t quiet = (uint32_t)__ballot(lane < 32 && gate);
+        while (num_bfu > 1 && ((quiet >> (num_bfu - 1)) & 1u)) --num_bfu;
+    }
     int mode = 1;
     int bits = 0;
     for (;;) {
