@@ -442,6 +442,22 @@ __device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant
     wave_sync();
 }
 
+// CalcBitsAllocation for one BFU (atrac3_bitstream.cpp:272-336) followed by ConsiderEnergyErr's closure `gmap`
+__device__ __forceinline__ int alloc_bits(float A, bool gate, int tcount, uint32_t gmap, float lam)
+{
+    int bits = 0;
+    if (!gate) {
+        const int tmp = (int)(A - lam);
+        if (tmp > 7) bits = 7;
+        else if (tmp < 0) bits = 0;
+        else if (tmp == 0) bits = 1;
+        else bits = tmp;
+    }
+    // one decrement per tonal block in this BFU while the wordlen is above 2 (:325-333)
+    if (bits > 2 && tcount) bits = (bits - tcount > 2) ? bits - tcount : 2;
+    return (int)((gmap >> (3 * bits)) & 7u);
+}
+
 __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) AllocLds L;
@@ -689,6 +705,17 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     }
     int mode = 1;
     int bits = 0;
+    // Evaluations already made, one per lane: lambda -> the CLC | VLC << 13 sums, the count of coded BFUs and the tonal
+    // bits for the CURRENT number of BFUs. The reference repeats the whole bisection with one BFU less whenever the last
+    // BFU ended without bits (three times per channel-frame on white noise, eleven on the burst input), and each repeat
+    // walks the same lambdas until the three header bits it saved tip a comparison: a repeat looks its totals up here -
+    // when a BFU is dropped, its own contribution is taken out of every recorded sum - and only a lambda never seen before
+    // costs a reduction over the BFUs (and possibly new units).
+    float m_lam = 0.0f;
+    uint32_t m_acc = 0u, m_nz = 0u, m_ton = 0u;
+    int memo_n = 0;
+    bool bits_current = false;
+    float final_lam = 0.0f;
     for (;;) {
         float minL = -8.0f, maxL = 20.0f, curL = 0.0f, lastL = 20.0f;
         bool restart = false;
@@ -701,19 +728,18 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
                 curL = (maxL + minL) * 0.5f;
                 lam = curL;
             }
-            bits = 0;
-            if (lane < num_bfu) {
-                if (!gate) {
-                    const int tmp = (int)(A - lam);
-                    if (tmp > 7) bits = 7;
-                    else if (tmp < 0) bits = 0;
-                    else if (tmp == 0) bits = 1;
-                    else bits = tmp;
-                }
-                // one decrement per tonal block in this BFU while the wordlen is above 2 (:325-333)
-                if (bits > 2 && tcount) bits = (bits - tcount > 2) ? bits - tcount : 2;
-                bits = (int)((gmap >> (3 * bits)) & 7u);
-            }
+            uint32_t acc, nz, tonal_bits = 5;
+            int last_alloc;
+            const unsigned long long hit = __ballot(lane < memo_n && m_lam == lam);
+            if (hit) {
+                const int k = __builtin_ctzll(hit);
+                acc = (uint32_t)__builtin_amdgcn_readlane((int)m_acc, k);
+                nz = (uint32_t)__builtin_amdgcn_readlane((int)m_nz, k);
+                tonal_bits = (uint32_t)__builtin_amdgcn_readlane((int)m_ton, k);
+                last_alloc = __builtin_amdgcn_readlane(alloc_bits(A, gate, tcount, gmap, lam), (num_bfu - 1) & 31);
+                bits_current = false;
+            } else {
+            bits = (lane < num_bfu) ? alloc_bits(A, gate, tcount, gmap, lam) : 0;
             // quantise what this allocation asks for and the cache does not hold yet (TEncCache, atrac_enc_cache.cpp)
             {
                 const uint32_t need = (uint32_t)__ballot(lane < 32 && bits != 0 && !((valid >> bits) & 1u));
@@ -731,14 +757,10 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
             }
             const uint32_t mine = (lane < num_bfu && bits) ? (clc_bits(bits, n_i) | ((uint32_t)s_cost[bits * 32 + i] << 13)) : 0u;
             const uint32_t rsum = row_allreduce_add(mine);
-            const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
+            acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
             // the count of non-zero BFUs comes from a ballot: summed as a third field it would need six bits at
             // 32 of 32 (and silently wrapped to zero when every BFU of the frame was coded)
-            const uint32_t clc = acc & 0x1fffu, vlc = (acc >> 13) & 0x3fffu;
-            const uint32_t nz = (uint32_t)__popcll(__ballot(lane < num_bfu && bits != 0));
-            mode = clc <= vlc ? 1 : 0;
-            const uint32_t spec_bits = (uint32_t)num_bfu * 3 + 6 * nz + (mode ? clc : vlc);
-            uint32_t tonal_bits = 5;
+            nz = (uint32_t)__popcll(__ballot(lane < num_bfu && bits != 0));
             if (n_tonal > 0 && tonal_serial) {
                 if (lane < 32) s_alloc[lane] = bits;
                 __syncthreads();
@@ -768,8 +790,22 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
                 const uint32_t group_bands = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
                 if (groups) tonal_bits = 5u + 2u + 10u * groups + 12u * group_bands + members;
             }
+            last_alloc = __builtin_amdgcn_readlane(bits, (num_bfu - 1) & 31);
+            if (memo_n < 64) {
+                if (lane == memo_n) {
+                    m_lam = lam;
+                    m_acc = acc;
+                    m_nz = nz;
+                    m_ton = tonal_bits;
+                }
+                ++memo_n;
+            }
+            bits_current = true;
+            }
+            const uint32_t clc = acc & 0x1fffu, vlc = (acc >> 13) & 0x3fffu;
+            mode = clc <= vlc ? 1 : 0;
+            const uint32_t spec_bits = (uint32_t)num_bfu * 3 + 6 * nz + (mode ? clc : vlc);
             const uint32_t total = spec_bits + tonal_bits;
-            const int last_alloc = __builtin_amdgcn_readlane(bits, (num_bfu - 1) & 31);
             bool done;
             if (exhausted) {
                 done = true;
@@ -784,7 +820,21 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
                 done = true;
             }
             if (!done) continue;
+            final_lam = lam;
             if (!p.bfu_idx_const && num_bfu > 1 && last_alloc == 0) {
+                // the dropped BFU leaves every recorded evaluation: its bits at that lambda, their cost, its place in the count
+                const int t = num_bfu - 1;
+                const int tc_t = __builtin_amdgcn_readlane(tcount, t);
+                if (tc_t > 0) {
+                    memo_n = 0;   // its tonal blocks leave the tonal side information too: nothing recorded stays valid
+                } else {
+                    const int b = alloc_bits(readlane_f(A, t), __builtin_amdgcn_readlane((int)gate, t) != 0, 0,
+                                             (uint32_t)__builtin_amdgcn_readlane((int)gmap, t), m_lam);
+                    if (lane < memo_n && b) {
+                        m_acc -= clc_bits(b, bfu_start(t + 1) - bfu_start(t)) | ((uint32_t)s_cost[b * 32 + t] << 13);
+                        m_nz -= 1u;
+                    }
+                }
                 num_bfu--;
                 restart = true;
             }
@@ -792,6 +842,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         }
         if (!restart) break;
     }
+    if (!bits_current) bits = (lane < num_bfu) ? alloc_bits(A, gate, tcount, gmap, final_lam) : 0;   // (mode is the last evaluation's)
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 3) return;
 #endif
