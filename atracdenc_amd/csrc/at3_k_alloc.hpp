@@ -442,6 +442,85 @@ __device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant
     wave_sync();
 }
 
+// EncodeTonalComponents (atrac3_bitstream.cpp:382-524) for a frame whose (quantiser, length) groups are one sub-group each
+// (the common case, proven per frame by the caller's `tonal_serial` check), written by one lane per tonal block instead of
+// one lane for everything. Stream layout: 5 bits number of groups, 2 zero bits; per group in ascending (quantiser,
+// length): 4 band flags, length - 1 (3), quantiser (3); then for each 64-line block of a flagged band its member count
+// (3) followed by its members, each scale factor (6), position in the block (6) and the VLC codes of its values.
+// Offsets come from one pass over the (at most 24) blocks with cross-lane reads. Returns the bits used (uniform).
+__device__ __forceinline__ int tonal_emit_parallel(const PsyRec* rec, const uint8_t* s_tbits, const uint16_t* s_huff, uint32_t* words, int pos,
+                                                   int lane, int n_tonal, int num_bfu, int bits, int tb_bfu, int tb_len, int tb_blk)
+{
+    const bool live = lane < n_tonal && tb_bfu < num_bfu;
+    const int wl_t = __builtin_amdgcn_ds_bpermute(4 * (tb_bfu & 31), bits);
+    int qn = wl_t + 4;
+    qn = qn > 7 ? 7 : qn;
+    const int g = live ? qn * 8 + tb_len : 0xff;               // group id, ascending = stream order
+    const int sz = live ? 12 + (int)s_tbits[(lane < kMaxTonal ? lane : 0) * 8 + qn] : 0;
+    // my block's payload, requested now
+    TonalBlock tb = {};
+    if (live) tb = rec->tonal[lane];
+    unsigned long long gm = 0ull, gb0 = 0ull, gb1 = 0ull, gb2 = 0ull, gb3 = 0ull;   // groups present; per QMF band
+    int before_members = 0, in_before = 0, same_blk = 0, fb = 0, total_members = 0;
+    bool first_in_group = true, first_in_blk = true;
+    for (int t = 0; t < n_tonal; ++t) {   // uniform
+        const int g2 = __builtin_amdgcn_readlane(g, t);
+        if (g2 == 0xff) continue;
+        const int blk2 = __builtin_amdgcn_readlane(tb_blk, t), sz2 = __builtin_amdgcn_readlane(sz, t);
+        const unsigned long long bit = 1ull << g2;
+        gm |= bit;
+        const int band2 = blk2 >> 2;
+        if (band2 == 0) gb0 |= bit;
+        else if (band2 == 1) gb1 |= bit;
+        else if (band2 == 2) gb2 |= bit;
+        else gb3 |= bit;
+        total_members += sz2;
+        if (g2 < g) before_members += sz2;
+        if (g2 == g) {
+            fb |= 1 << band2;
+            if (t < lane) {
+                first_in_group = false;
+                in_before += sz2;
+                if (blk2 == tb_blk) first_in_blk = false;
+            }
+            if (blk2 == tb_blk) ++same_blk;
+        }
+    }
+    const int groups = __popcll(gm);
+    const int group_bands = __popcll(gb0) + __popcll(gb1) + __popcll(gb2) + __popcll(gb3);
+    if (lane == 0) put_bits(words, pos, (uint32_t)groups, 5);
+    if (groups == 0) return 5;
+    if (live) {
+        const unsigned long long below = (1ull << g) - 1ull;
+        const int groups_before = __popcll(gm & below);
+        const int pairs_before = __popcll(gb0 & below) + __popcll(gb1 & below) + __popcll(gb2 & below) + __popcll(gb3 & below);
+        const int base = pos + 7 + 10 * groups_before + 12 * pairs_before + before_members;
+        const int my_band = tb_blk >> 2;
+        const int counts_upto = 4 * __popc((uint32_t)fb & ((1u << my_band) - 1u)) + (tb_blk & 3) + 1;   // count fields up to my block's
+        const int at = base + 10 + 3 * counts_upto + in_before;
+        if (first_in_group) {
+            const uint32_t flags = ((fb & 1) << 3) | (((fb >> 1) & 1) << 2) | (((fb >> 2) & 1) << 1) | ((fb >> 3) & 1);
+            put_bits(words, base, (flags << 6) | ((uint32_t)(tb_len - 1) << 3) | (uint32_t)qn, 10);
+        }
+        if (first_in_blk) put_bits(words, at - 3, (uint32_t)same_blk, 3);
+        put_bits(words, at, tb.sfi, 6);
+        put_bits(words, at + 6, (uint32_t)tb.pos - (uint32_t)tb_blk * 64u, 6);
+        int bp = at + 12;
+        const float mul = max_quant(qn);
+        const float vals[7] = {tb.values[0], tb.values[1], tb.values[2], tb.values[3], tb.values[4], tb.values[5], tb.values[6]};
+#pragma unroll
+        for (int z = 0; z < 7; ++z) {
+            if (z < tb_len) {
+                const int m = __float2int_rn(vals[z] * mul);
+                const uint32_t e = lds_huff(s_huff, qn, vlc_index(m));
+                put_bits(words, bp, e & 0xffu, (int)(e >> 8));
+                bp += (int)(e >> 8);
+            }
+        }
+    }
+    return 7 + 10 * groups + 12 * group_bands + total_members;
+}
+
 // CalcBitsAllocation for one BFU (atrac3_bitstream.cpp:272-336) followed by ConsiderEnergyErr's closure `gmap`
 __device__ __forceinline__ int alloc_bits(float A, bool gate, int tcount, uint32_t gmap, float lam)
 {
@@ -907,6 +986,8 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     }
     if (n_tonal == 0) {   // EncodeTonalComponents without components: five zero bits (atrac3_bitstream.cpp:382-400)
         pos += 5;
+    } else if (!tonal_serial) {
+        pos += tonal_emit_parallel(rec, s_tbits, s_huff, s_words, pos, lane, n_tonal, num_bfu, bits, tb_bfu, tb_len, tb_blk);
     } else {
         if (lane == 0) s_misc[1] = tonal_encode<true>(rec, s_tbits, s_alloc, num_bfu, s_words, pos);
         __syncthreads();
