@@ -276,20 +276,26 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T, int 
             flat = (float)fmin(1.0, fmax(0.0, ratio));
         }
         if (flat < 0.01f) {  // ExtractTonalComponents search, atrac3denc.cpp:606-625
-            const int maxLen = 5 < len ? 5 : len;
+            // every window of one to five lines, first maximum wins (ascending start, then ascending length); the five
+            // magnitudes a start needs are a shift register fed by one LDS read per start (len >= 16 here)
             float bestScore = -1.0f;
             int bestStart = start, bestLen = 1;
+            float a0 = fabsf(sp[start]), a1 = fabsf(sp[start + 1]), a2 = fabsf(sp[start + 2]), a3 = fabsf(sp[start + 3]), a4 = fabsf(sp[start + 4]);
             for (int st = start; st < end; ++st) {
-                const int ml = maxLen < end - st ? maxLen : end - st;
+                const int ml = 5 < end - st ? 5 : end - st;
+                const float nxt = (st + 5 < end) ? fabsf(sp[st + 5]) : 0.0f;
                 float score = 0.0f;
-                for (int l = 1; l <= ml; ++l) {
-                    score += fabsf(sp[st + l - 1]);
-                    if (score > bestScore) {
-                        bestScore = score;
-                        bestStart = st;
-                        bestLen = l;
-                    }
-                }
+                score += a0;
+                if (score > bestScore) { bestScore = score; bestStart = st; bestLen = 1; }
+                score += a1;
+                if (ml >= 2 && score > bestScore) { bestScore = score; bestStart = st; bestLen = 2; }
+                score += a2;
+                if (ml >= 3 && score > bestScore) { bestScore = score; bestStart = st; bestLen = 3; }
+                score += a3;
+                if (ml >= 4 && score > bestScore) { bestScore = score; bestStart = st; bestLen = 4; }
+                score += a4;
+                if (ml >= 5 && score > bestScore) { bestScore = score; bestStart = st; bestLen = 5; }
+                a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = nxt;
             }
             if (bestScore > 0.0f) {
                 s_run_start[fk][b] = bestStart;
