@@ -241,11 +241,12 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         const int m = 1 << (2 * st), k = lane % m, fs = 64 / m;
-        tw_a[st][0] = ld2(T->tw256 + k * fs);
-        tw_a[st][1] = ld2(T->tw256 + 2 * k * fs);
-        tw_a[st][2] = ld2(T->tw256 + 3 * k * fs);
+        (void)k; (void)fs;   // = tw256[(q + 1) k fs], from the per-lane table (contiguous per fetch)
+        tw_a[st][0] = ld2(&T->spec_tw[3 * st][lane]);
+        tw_a[st][1] = ld2(&T->spec_tw[3 * st + 1][lane]);
+        tw_a[st][2] = ld2(&T->spec_tw[3 * st + 2][lane]);
     }
-    const cpx stw_post0 = T->stw256[lane], stw_post1 = T->stw256[lane + 64];   // bins k = lane + 1, lane + 65
+    const cpx stw_post0 = T->spec_tw[12][lane], stw_post1 = T->spec_tw[13][lane];   // stw256[lane], [lane + 64]: bins k = lane + 1, lane + 65
     const float hpf1 = T->hpf_w[1], hpf2 = T->hpf_w[2];
     // 1. window and pack as 256 complex points in FFT leaf order (4 points per lane)
 #pragma unroll
@@ -264,9 +265,10 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
         } else if (ch == 1) {
             a = *reinterpret_cast<const float2*>(sb1 + 2 * i);
         }
+        const cpx pw = T->planck4[q][lane];
         cpx z;
-        z.r = a.x * T->planck[2 * i];
-        z.i = a.y * T->planck[2 * i + 1];
+        z.r = a.x * pw.r;
+        z.i = a.y * pw.i;
         L.f[fft_leaf_pos<256>(i)] = z;
     }
     wave_sync();

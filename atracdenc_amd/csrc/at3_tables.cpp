@@ -99,6 +99,14 @@ AT3_RUNTIME_LIBM void build_tables(Tables* t)
     fill_twiddles(t->tw2048, 2048, true);
     fill_super_twiddles(t->stw256, 256, false);
     fill_super_twiddles(t->stw2048, 2048, true);
+    for (int l = 0; l < 64; ++l) {   // see at3_k_gain.hpp: k_gain_spec
+        for (int st = 0; st < 4; ++st) {
+            const int m = 1 << (2 * st), k = l % m, fs = 64 / m;
+            for (int q = 0; q < 3; ++q) t->spec_tw[3 * st + q][l] = t->tw256[(q + 1) * k * fs];
+        }
+        t->spec_tw[12][l] = t->stw256[l];
+        t->spec_tw[13][l] = t->stw256[l + 64];
+    }
     for (int tid = 0; tid < 128; ++tid) {   // see at3_k_gain.hpp: irfft_pass_32_128 / irfft_pass_512
         const int k = tid & 31;
         for (int q = 0; q < 3; ++q) t->gain_tw[q][tid] = t->tw2048[16 * (q + 1) * k];
@@ -128,6 +136,13 @@ AT3_RUNTIME_LIBM void build_tables(Tables* t)
         }
         for (int i = 0; i < 3; ++i) t->hpf_w[i] = 0.5f * (1.0f - cosf((float)M_PI * i / 2.0f));
     }
+    for (int l = 0; l < 64; ++l)   // the window in the order k_gain_spec's lanes consume it
+        for (int q = 0; q < 4; ++q) {
+            const int i = l + 64 * q;
+            t->planck4[q][l].r = t->planck[2 * i];
+            t->planck4[q][l].i = t->planck[2 * i + 1];
+        }
+
     for (size_t i = 0; i < 1024; ++i) {
         float f = (float)(i + 3) * 0.5 * 44100 / (float)1024;
         float v = log10f(f) - 3.5;

@@ -36,6 +36,11 @@ struct Tables {
     // irfft-4096 core, as [slot][t] so that a wavefront fetches each slot as one contiguous 512-byte run (picking them out
     // of tw2048 touched up to 32 cache lines per load). Slots: 0..2 pass m = 32, 3..14 pass m = 128, 15..26 pass m = 512.
     cpx gain_tw[27][128];
+    // k_gain_spec: the 12 forward twiddles lane l of a wavefront needs for the four passes of the rfft-512 core
+    // (pass m = 4^st: tw256[(q + 1) (l % m) 64 / m]) and its two super twiddles, as [slot][l]; the Planck window in the
+    // order the lanes consume it: planck4[q][l] = {w[2 i], w[2 i + 1]} for i = l + 64 q
+    cpx spec_tw[14][64];
+    cpx planck4[4][64];
 };
 
 // Fills *t on the host. Pure function of libm.
