@@ -731,6 +731,7 @@ struct StateParams {
     float* sub_tail;        // [S][8][512]: the last two blocks' subbands, the next call's blocks -2 and -1
     int n_blocks;
     int n_streams;
+    int parts;              // 1 = PCM history and subband tail (known once the QMF has run), 2 = last curves, 3 = both
 };
 
 // One-channel input: every sample becomes an (L, R) = (x, x) pair in the layout the stereo pipeline reads.
@@ -751,15 +752,15 @@ __global__ void k_state_update(StateParams p)
     constexpr int kChunks = (kHist + 255) / 256;
     const int s = blockIdx.x / kChunks;
     const int k = (blockIdx.x % kChunks) * blockDim.x + threadIdx.x;
-    if (k < kHist) {
+    if ((p.parts & 1) && k < kHist) {
         const float2* pcm2 = reinterpret_cast<const float2*>(p.pcm) + (size_t)s * p.n_blocks * 1024;
         const float2* hin = reinterpret_cast<const float2*>(p.hist_in) + (size_t)s * kHist;
         float2* hout = reinterpret_cast<float2*>(p.hist_out) + (size_t)s * kHist;
         const int g = p.n_blocks * 1024 - kHist + k;
         hout[k] = (g >= 0) ? pcm2[g] : hin[kHist + g];
     }
-    if (k < 8) p.state[(size_t)s * 8 + k].prev_curve = p.curves[((size_t)s * p.n_blocks + (p.n_blocks - 1)) * 8 + k];
-    if (p.sub && k < 8 * 128) {   // 8 rows x 512 floats as 16-byte words: the tail of every row (its front is the carried part)
+    if ((p.parts & 2) && k < 8) p.state[(size_t)s * 8 + k].prev_curve = p.curves[((size_t)s * p.n_blocks + (p.n_blocks - 1)) * 8 + k];
+    if ((p.parts & 1) && p.sub && k < 8 * 128) {   // 8 rows x 512 floats as 16-byte words: the tail of every row (its front is the carried part)
         const int row = k >> 7, i = k & 127;
         const float4* src = reinterpret_cast<const float4*>(p.sub + ((size_t)s * 8 + row) * ((size_t)(p.n_blocks + 2) * 256) + (size_t)p.n_blocks * 256);
         reinterpret_cast<float4*>(p.sub_tail + ((size_t)s * 8 + row) * 512)[i] = src[i];

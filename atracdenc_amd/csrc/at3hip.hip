@@ -43,6 +43,15 @@ struct at3hip_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;        // front half: QMF, gain control, fused QMF+MDCT, carried state
     hipStream_t back_stream = nullptr;   // back half: psychoacoustics, quantisation, rate loop, packing
+    // With gain control the front half is two stages: the heavy one (QMF, spectra of the gain analysis, upsampled envelopes)
+    // depends only on the PCM, the light one (curve context scan, curves, energy scales, MDCT) on it and on the previous
+    // call's light stage. The light stage is a chain of short latency-bound kernels; on a stream of its own it runs under
+    // the next call's heavy stage and the current call's back half instead of holding the GPU nearly idle between them.
+    hipStream_t mid_stream = nullptr;
+    float* d_sub_b[2] = {nullptr, nullptr};      // subbands, by call parity (the heavy stage runs one call ahead)
+    GainRec* d_rec_b[2] = {nullptr, nullptr};
+    hipEvent_t ev_mid_done[2] = {};              // light stage finished with the parity's subbands and gain records
+    bool mid_done_valid[2] = {false, false};
     // The back half of call N only consumes what the front half of call N produced (spectra, curves, energy scales),
     // and the front half of call N+1 only depends on the front half of call N (carried state): the two halves run on
     // two HIP streams, buffers that cross between them are double-buffered by call parity, and consecutive calls overlap.
@@ -133,6 +142,7 @@ int stage_reserve(at3hip_ctx* c, size_t bytes)
 int drain(at3hip_ctx* c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->mid_stream) HIPCHK(c, hipStreamSynchronize(c->mid_stream));
     HIPCHK(c, hipStreamSynchronize(c->back_stream));
     return AT3HIP_OK;
 }
@@ -250,12 +260,15 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // lo = numerically greatest = lowest priority
         if (hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(AT3HIP_EDEVICE);
         if (hipStreamCreateWithPriority(&c->back_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return bail(AT3HIP_EDEVICE);
+        if (!cfg->no_gain_control && hipStreamCreateWithPriority(&c->mid_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(AT3HIP_EDEVICE);
     }
     c->stream = c->own_stream;
     for (auto& row : c->ev)
         for (auto& e : row)
             if (hipEventCreate(&e) != hipSuccess) return bail(AT3HIP_EDEVICE);
     for (auto& e : c->ev_back_done)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    for (auto& e : c->ev_mid_done)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
 
     const size_t S = cfg->n_streams, B = cfg->max_blocks;
@@ -282,6 +295,10 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     }
     if (!cfg->no_gain_control) {
         if ((rc = dev_alloc(c, &c->d_rec, S * B * 6)) != AT3HIP_OK) return bail(rc);
+        c->d_rec_b[0] = c->d_rec;
+        c->d_sub_b[0] = c->d_sub;
+        if ((rc = dev_alloc(c, &c->d_rec_b[1], S * B * 6)) != AT3HIP_OK) return bail(rc);
+        if ((rc = dev_alloc(c, &c->d_sub_b[1], S * 8 * (B + 2) * 256)) != AT3HIP_OK) return bail(rc);
         if ((rc = dev_alloc(c, &c->d_bins, S * B * 6 * kGainBins)) != AT3HIP_OK) return bail(rc);
         for (int q = 0; q < 2; ++q)
             if ((rc = dev_alloc(c, &c->d_ges[q], S * B * 8)) != AT3HIP_OK) return bail(rc);
@@ -323,7 +340,10 @@ void at3hip_destroy(at3hip_ctx* c)
     // only the context's own streams are waited for: a caller-owned stream (at3hip_set_stream) may already be gone, and
     // everything queued on it is ordered before the back stream's work by events
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->mid_stream) (void)hipStreamSynchronize(c->mid_stream);
     if (c->back_stream) (void)hipStreamSynchronize(c->back_stream);
+    if (c->d_rec_b[1]) (void)hipFree(c->d_rec_b[1]);
+    if (c->d_sub_b[1]) (void)hipFree(c->d_sub_b[1]);
     void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
                     c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
                     c->d_out,       c->d_quant,     c->d_mant,     c->d_pcm_mono,  c->d_stage,    c->d_sub_tail, c->d_bins};
@@ -334,6 +354,9 @@ void at3hip_destroy(at3hip_ctx* c)
             if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_back_done)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_mid_done)
+        if (e) (void)hipEventDestroy(e);
+    if (c->mid_stream) (void)hipStreamDestroy(c->mid_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->back_stream) (void)hipStreamDestroy(c->back_stream);
     delete c;
@@ -414,17 +437,37 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     float* d_specs = c->d_specs[par];
     float* d_ges = c->d_ges[par];
     c->slot_has_frames[slot] = false;
+    auto launch_state = [&](hipStream_t on, int parts) {
+        StateParams sp;
+        sp.pcm = d_pcm;
+        sp.hist_in = hist;
+        sp.hist_out = hist_next;
+        sp.curves = c->d_curves[par];
+        sp.state = c->d_state;
+        sp.sub = (gain || c->js) ? (gain ? c->d_sub_b[par] : c->d_sub) : nullptr;
+        sp.sub_tail = c->d_sub_tail;
+        sp.n_blocks = n_blocks;
+        sp.n_streams = S;
+        sp.parts = parts;
+        hipLaunchKernelGGL(k_state_update, dim3((unsigned)(((kHist + 255) / 256) * S)), dim3(256), 0, on, sp);
+    };
 
-    // the back half of the call before the previous one must be done with this parity's spectra / curves / scales
-    if (c->back_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_back_done[par], 0));
-    HIPCHK(c, hipMemsetAsync(d_curves, 0, (size_t)S * n_blocks * 8 * sizeof(Curve), st));
+    // With gain control: `st` carries the heavy stage, `md` the light one (see at3hip_ctx::mid_stream); otherwise md == st.
+    hipStream_t md = gain ? c->mid_stream : st;
+    float* d_sub = gain ? c->d_sub_b[par] : c->d_sub;
+    GainRec* d_rec = gain ? c->d_rec_b[par] : c->d_rec;
+    // the light stage of the call before the previous one must be done with this parity's subbands and gain records
+    if (gain && c->mid_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_mid_done[par], 0));
     HIPCHK(c, hipEventRecord(ev[0], st));
+    // the back half of the call before the previous one must be done with this parity's spectra / curves / scales
+    if (c->back_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(md, c->ev_back_done[par], 0));
+    HIPCHK(c, hipMemsetAsync(d_curves, 0, (size_t)S * n_blocks * 8 * sizeof(Curve), md));
     if (n_out == 0 && (gain || c->js)) {
         // a call that only primes the look-ahead still has to leave its subbands behind for the next call's look-back
         FrontParams fp = {};
         fp.pcm = d_pcm;
         fp.hist = hist;
-        fp.sub = c->d_sub;
+        fp.sub = d_sub;
         fp.sub_tail = c->d_sub_tail;
         fp.n_blocks = n_blocks;
         fp.f0 = f0;
@@ -441,7 +484,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         fp.state = c->d_state;
         fp.specs = d_specs;
         fp.ges = d_ges;
-        fp.sub = c->d_sub;
+        fp.sub = d_sub;
         fp.sub_tail = c->d_sub_tail;
         fp.n_blocks = n_blocks;
         fp.f0 = f0;
@@ -457,8 +500,8 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         };
         if (gain) {
             GainParams gp;
-            gp.sub = c->d_sub;
-            gp.rec = c->d_rec;
+            gp.sub = d_sub;
+            gp.rec = d_rec;
             gp.bins = c->d_bins;
             gp.state = c->d_state;
             gp.curves = d_curves;
@@ -469,22 +512,24 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.debug = c->dbg_gain;
             launch_qmf_sub();
             HIPCHK(c, hipEventRecord(ev[1], st));
+            launch_state(st, 1);   // PCM history and subband tail: the next call's heavy stage needs nothing else from this one
             hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(256), 0, st, gp, c->d_tables, S * n_out * 6);
             hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), 0, st, gp, c->d_tables);
             HIPCHK(c, hipEventRecord(ev[2], st));
-            hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), 0, st, gp, S);
-            hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), 0, st, gp, c->d_tables, S);
-            hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), 0, st, fp, c->d_tables, S * n_out);
+            HIPCHK(c, hipStreamWaitEvent(md, ev[2], 0));   // the light stage starts when this call's heavy stage is done
+            hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), 0, md, gp, S);
+            hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), 0, md, gp, c->d_tables, S);
+            hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), 0, md, fp, c->d_tables, S * n_out);
         } else {
             HIPCHK(c, hipEventRecord(ev[1], st));
             HIPCHK(c, hipEventRecord(ev[2], st));
         }
-        HIPCHK(c, hipEventRecord(ev[3], st));
+        HIPCHK(c, hipEventRecord(ev[3], md));
         if (split) {
             // with gain control the subbands are in HBM already (k_qmf_sub8 wrote them for the gain analysis)
             if (!gain) launch_qmf_sub();
             MdctSubParams mp;
-            mp.sub = c->d_sub;
+            mp.sub = d_sub;
             mp.curves = gain ? d_curves : nullptr;
             mp.state = c->d_state;
             mp.specs = d_specs;
@@ -493,27 +538,22 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             mp.js = c->js;
             mp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu_mdct, 0.3);
             mp.n_waves = S * 2 * mp.frame_runs;
-            if (c->js) hipLaunchKernelGGL(k_mdct_sub<true>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, st, mp, c->d_tables);
-            else hipLaunchKernelGGL(k_mdct_sub<false>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, st, mp, c->d_tables);
+            if (c->js) hipLaunchKernelGGL(k_mdct_sub<true>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, md, mp, c->d_tables);
+            else hipLaunchKernelGGL(k_mdct_sub<false>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, md, mp, c->d_tables);
         } else {
             const int n_waves = S * 2 * fp.frame_runs;
             hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
         }
-        HIPCHK(c, hipEventRecord(ev[4], st));
+        HIPCHK(c, hipEventRecord(ev[4], md));
         c->slot_k1_launches[slot] = split ? 2 : 1;
     }
-    {
-        StateParams sp;
-        sp.pcm = d_pcm;
-        sp.hist_in = hist;
-        sp.hist_out = hist_next;
-        sp.curves = d_curves;
-        sp.state = c->d_state;
-        sp.sub = (gain || c->js) ? c->d_sub : nullptr;
-        sp.sub_tail = c->d_sub_tail;
-        sp.n_blocks = n_blocks;
-        sp.n_streams = S;
-        hipLaunchKernelGGL(k_state_update, dim3((unsigned)(((kHist + 255) / 256) * S)), dim3(256), 0, st, sp);
+    if (gain) {
+        if (n_out == 0) launch_state(st, 1);   // (with frames it followed the QMF kernel)
+        launch_state(md, 2);                     // last curves: the light stage's own hand-over
+        HIPCHK(c, hipEventRecord(c->ev_mid_done[par], md));
+        c->mid_done_valid[par] = true;
+    } else {
+        launch_state(st, 3);
     }
     if (n_out > 0) {
         // ---- back half, on its own stream, after the fused kernel of THIS call ----
