@@ -433,13 +433,16 @@ def main():
                                    "rocprofv3's kernel durations (profiles/) do not",
                          "limiter": "VALU issue + LDS (FMA-free fp32 arithmetic contract), not HBM: see DESIGN.md section 5; the HBM "
                                     "fraction is reported because it is the roofline north_star names",
-                         "note": "launches of the timed region (device 0); they share the GPU with the previous step's back half "
-                                 "(quantisation / rate loop) running on the context's second stream",
+                         "note": "launches of the timed region (device 0). In the timed region the two kernels run on two of the context's "
+                                 "three streams and share the GPU with the neighbouring steps' gain analysis and rate loop - on purpose: "
+                                 "that overlap is what shortens the step - so each launch takes longer than it does alone; `isolated` is "
+                                 "the same launches with the GPU to themselves",
                          "isolated": {"avg_launch_ms": round(iso_ms, 5), "achieved": ach_iso, "frac": frac_iso,
                                       "note": "same kernel, same batch, launched alone (3 synchronous steps after the timed region)"}},
             "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
-            "pipelining": "front half of step i+1 overlaps the back half of step i (two HIP streams inside the context); "
-                          "stage_ms are per-step HIP-event spans and overlap in time, total_ms is one step's latency",
+            "pipelining": "three HIP streams inside the context: the heavy front stage (QMF, gain spectra, envelopes) of step i+1, the "
+                          "light front stage (curves, energy scales, MDCT) of step i and the back half (psychoacoustics, rate loop, "
+                          "packing) of step i overlap; stage_ms are per-step HIP-event spans and overlap in time, total_ms is one step's latency",
             "checksum": checksum,
         }
         if args.sync_steps:

@@ -53,7 +53,7 @@ typedef struct at3hip_config {
     int32_t device_id;        /* HIP device ordinal */
 } at3hip_config;
 
-/* Per-call device timings in milliseconds (HIP events on the ctx's two streams), filled by the last
+/* Per-call device timings in milliseconds (HIP events on the ctx's streams), filled by the last
  * at3hip_encode / at3hip_qmf_mdct call. total_ms spans the first front-half kernel to the last back-half kernel of ONE
  * call (its latency); with AT3HIP_ASYNC consecutive calls overlap, so throughput is not 1 / total_ms. */
 typedef struct at3hip_timings {
