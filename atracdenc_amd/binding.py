@@ -207,6 +207,11 @@ class At3Hip:
     def sync(self):
         self._check(self.lib.at3hip_sync(self.ctx), "at3hip_sync")
 
+    def set_stream(self, hip_stream):
+        """Queue the front half on the caller's HIP stream (a hipStream_t handle, e.g. torch.cuda.Stream().cuda_stream);
+        0 / None goes back to the context's own stream."""
+        self._check(self.lib.at3hip_set_stream(self.ctx, ctypes.c_void_p(int(hip_stream) if hip_stream else None)), "at3hip_set_stream")
+
     def timings_ago(self, ago):
         t = Timings()
         self._check(self.lib.at3hip_get_timings_ago(self.ctx, int(ago), ctypes.byref(t)), "at3hip_get_timings_ago")

@@ -504,3 +504,38 @@ def test_cli_atrac3plus_file_parity(oracle, tmp_path, nsamp, ext, nch):
         assert got == open(exp_path, "rb").read()
     else:
         assert got[len(got) - frames.size:] == frames.tobytes()
+
+
+def test_caller_stream_and_async_pipeline(hip, oracle):
+    """at3hip_set_stream: PCM produced on the caller's HIP stream (no host synchronisation in between), eight asynchronous
+    calls in flight across the context's three internal streams, one at3hip_sync at the end; then back to the context's
+    own stream. Every call's frames equal the oracle's for the same PCM sequence."""
+    import torch
+    S, nb, calls = 6, 5, 8
+    names = ["noise", "burst", "tones", "mix", "silence", "noise"]
+    whole = np.stack([SIGNALS[n](calls * nb) if n != "mix" else SIGNALS["mix"](calls * nb, seed=21) for n in names])   # [S, calls * nb, 1024, 2]
+    enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2)
+    side = torch.cuda.Stream()
+    enc.set_stream(side.cuda_stream)
+    host = torch.from_numpy(whole)
+    outs = [torch.zeros((S, nb, enc.frame_size), dtype=torch.uint8, device="cuda") for _ in range(calls)]
+    pcms = []
+    counts = []
+    with torch.cuda.stream(side):
+        for k in range(calls):
+            # device-side production of the call's PCM on the SAME stream the encoder will read it from
+            x = host[:, k * nb:(k + 1) * nb].to("cuda", non_blocking=True)
+            x = (x * 2.0 - x).contiguous()          # exact: a real kernel between the copy and the encoder
+            pcms.append(x)
+            counts.append(enc.encode_device(x.data_ptr(), nb, outs[k].data_ptr(), asynchronous=True))
+    enc.sync()
+    # a call's frames are packed [S][frames of this call][frame_size] (the first call yields one frame less: look-ahead)
+    got = np.concatenate([outs[k].cpu().numpy().reshape(-1)[: S * counts[k] * enc.frame_size].reshape(S, counts[k], enc.frame_size)
+                          for k in range(calls)], axis=1)
+    exp = np.stack([oracle.encode(whole[s], LP2)[0] for s in range(S)])
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp)
+    enc.set_stream(None)
+    more = enc.encode(whole[:, :nb] * 0)     # the context still works on its own stream (state continues: silence after the signal)
+    assert more.shape[1] == nb
+    enc.close()
