@@ -54,7 +54,7 @@ struct at3hip_ctx {
     bool mid_done_valid[2] = {false, false};
     // The back half of call N only consumes what the front half of call N produced (spectra, curves, energy scales),
     // and the front half of call N+1 only depends on the front half of call N (carried state): the two halves run on
-    // two HIP streams, buffers that cross between them are double-buffered by call parity, and consecutive calls overlap.
+    // HIP streams of their own (three with gain control, see mid_stream below), buffers that cross between them are double-buffered by call parity, and consecutive calls overlap.
     static constexpr int kSlots = 32;    // timing history (events per call)
     hipEvent_t ev[kSlots][8] = {};
     hipEvent_t ev_back_done[2] = {};     // back half finished with the parity's cross buffers
@@ -138,7 +138,7 @@ int stage_reserve(at3hip_ctx* c, size_t bytes)
     return AT3HIP_OK;
 }
 
-// Waits for everything this context has queued on its two streams.
+// Waits for everything this context has queued on its streams.
 int drain(at3hip_ctx* c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
