@@ -41,7 +41,7 @@ AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_e
 # include/at3phip.h
 AT3P_SYMBOLS = ["at3phip_create", "at3phip_destroy", "at3phip_last_error", "at3phip_reset", "at3phip_pqf_analyse", "at3phip_mdct",
                 "at3phip_pqf_mdct", "at3phip_get_timings", "at3phip_host_tables", "at3phip_write_frames", "at3phip_encode_frames",
-                "at3phip_get_write_timing", "at3phip_host_write_tables"]
+                "at3phip_get_write_timing", "at3phip_host_write_tables", "at3phip_sync"]
 
 
 class At1Config(ctypes.Structure):
@@ -131,6 +131,7 @@ def load_library(path=None):
     lib.at3phip_encode_frames.argtypes = [vp, vp, i32, vp, ctypes.c_uint32]
     lib.at3phip_get_write_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.at3phip_host_write_tables.argtypes = [vp, ctypes.c_size_t]
+    lib.at3phip_sync.argtypes = [vp]
     _lib_cache[path] = lib
     return lib
 
@@ -437,9 +438,14 @@ class At3pHip:
         self._check(self.lib.at3phip_encode_frames(self.ctx, _vp(pcm), nf, _vp(out), 0), "at3phip_encode_frames")
         return out
 
-    def encode_frames_device(self, pcm_ptr, n_frames, frames_ptr):
+    def encode_frames_device(self, pcm_ptr, n_frames, frames_ptr, asynchronous=False):
+        """asynchronous=True only queues the call (AT3HIP_ASYNC): sync() before the frames are read."""
         self._check(self.lib.at3phip_encode_frames(self.ctx, ctypes.c_void_p(pcm_ptr), n_frames, ctypes.c_void_p(frames_ptr),
-                                                   AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE), "at3phip_encode_frames")
+                                                   AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE | (AT3HIP_ASYNC if asynchronous else 0)),
+                    "at3phip_encode_frames")
+
+    def sync(self):
+        self._check(self.lib.at3phip_sync(self.ctx), "at3phip_sync")
 
     def timings(self):
         a, b, w = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()

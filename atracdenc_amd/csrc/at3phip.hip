@@ -20,7 +20,7 @@ struct at3phip_ctx {
     at3phip_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {};
+    hipEvent_t ev[5] = {};
     Tables* d_tables = nullptr;
     float* d_pcm_in = nullptr;     // staging for host PCM   [S][F][2048][nch]
     float* d_bands = nullptr;      // subband samples        [S][F][nch][16][128]
@@ -30,6 +30,13 @@ struct at3phip_ctx {
     float* d_mdct_hist = nullptr;  // [S][nch][16][128]
     WriteTables* d_wtables = nullptr;
     uint8_t* d_frames = nullptr;   // staging for host frames [S][F][2048]
+    // at3phip_encode_frames: the frame writer only needs the spectra of ITS call, so it runs on a stream of its own behind
+    // an event and the next call's filter bank and transform overlap it; the spectra in between are double-buffered
+    hipStream_t write_stream = nullptr;
+    float* d_specs_b[2] = {nullptr, nullptr};
+    hipEvent_t ev_specs[2] = {}, ev_write_done[2] = {};
+    bool write_done_valid[2] = {false, false};
+    long long enc_calls = 0;
     float pqf_ms = 0.0f, mdct_ms = 0.0f, write_ms = 0.0f;
     char err[256] = {0};
 };
@@ -67,6 +74,14 @@ int reset_state(at3phip_ctx* c)
     HIPCHK(c, hipMemsetAsync(c->d_pqf_hist, 0, S * C * kOverlap * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_mdct_hist, 0, S * C * 2048 * sizeof(float), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AT3HIP_OK;
+}
+
+// Entry points other than at3phip_encode_frames work on the context's main stream only: whatever asynchronous calls left
+// on the writer's stream is waited for first.
+int quiesce(at3phip_ctx* c)
+{
+    if (c->write_stream) HIPCHK(c, hipStreamSynchronize(c->write_stream));
     return AT3HIP_OK;
 }
 
@@ -108,10 +123,11 @@ int launch_mdct(at3phip_ctx* c, const float* d_bands, int n_frames, const uint16
     return AT3HIP_OK;
 }
 
-int launch_write(at3phip_ctx* c, const float* d_specs, int n_frames, const uint16_t* win_flags, uint8_t* d_frames)
+int launch_write(at3phip_ctx* c, const float* d_specs, int n_frames, const uint16_t* win_flags, uint8_t* d_frames, hipStream_t on = nullptr)
 {
     const size_t S = c->cfg.n_streams, C = c->cfg.channels;
-    if (win_flags) HIPCHK(c, hipMemcpyAsync(c->d_flags, win_flags, S * n_frames * C * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    if (!on) on = c->stream;
+    if (win_flags) HIPCHK(c, hipMemcpyAsync(c->d_flags, win_flags, S * n_frames * C * sizeof(uint16_t), hipMemcpyHostToDevice, on));
     WriteParams wp;
     wp.W = c->d_wtables;
     wp.specs = d_specs;
@@ -119,7 +135,7 @@ int launch_write(at3phip_ctx* c, const float* d_specs, int n_frames, const uint1
     wp.out = d_frames;
     wp.nch = (int)C;
     wp.n_items = (int)(S * n_frames);
-    hipLaunchKernelGGL(k_at3p_write, dim3((unsigned)(S * n_frames)), dim3(256), 0, c->stream, wp);
+    hipLaunchKernelGGL(k_at3p_write, dim3((unsigned)(S * n_frames)), dim3(256), 0, on, wp);
     HIPCHK(c, hipGetLastError());
     return AT3HIP_OK;
 }
@@ -166,6 +182,13 @@ int at3phip_create(const at3phip_config* cfg, at3phip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_pqf_hist, S * C * kOverlap)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_mdct_hist, S * C * 2048)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_frames, S * F * kFrameBytes)) != AT3HIP_OK) return bail(rc);
+    c->d_specs_b[0] = c->d_specs;
+    if ((rc = dev_alloc(c, &c->d_specs_b[1], S * F * C * 2048)) != AT3HIP_OK) return bail(rc);
+    if (hipStreamCreateWithFlags(&c->write_stream, hipStreamNonBlocking) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    for (int q = 0; q < 2; ++q)
+        if (hipEventCreateWithFlags(&c->ev_specs[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_write_done[q], hipEventDisableTiming) != hipSuccess)
+            return bail(AT3HIP_EDEVICE);
     {
         WriteTables* wt = new (std::nothrow) WriteTables();
         if (!wt) return bail(AT3HIP_ENOMEM);
@@ -185,6 +208,13 @@ void at3phip_destroy(at3phip_ctx* c)
     if (!c) return;
     at3host::DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->write_stream) (void)hipStreamSynchronize(c->write_stream);
+    if (c->d_specs_b[1]) (void)hipFree(c->d_specs_b[1]);
+    for (int q = 0; q < 2; ++q) {
+        if (c->ev_specs[q]) (void)hipEventDestroy(c->ev_specs[q]);
+        if (c->ev_write_done[q]) (void)hipEventDestroy(c->ev_write_done[q]);
+    }
+    if (c->write_stream) (void)hipStreamDestroy(c->write_stream);
     void* bufs[] = {c->d_tables, c->d_pcm_in, c->d_bands, c->d_specs, c->d_flags, c->d_pqf_hist, c->d_mdct_hist, c->d_wtables, c->d_frames};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -201,6 +231,7 @@ int at3phip_reset(at3phip_ctx* c)
     if (!c) return AT3HIP_EINVAL;
     at3host::DeviceGuard guard(c->device);
     HIPCHK(c, guard.error());
+    if (int qrc = quiesce(c)) return qrc;
     return reset_state(c);
 }
 
@@ -209,6 +240,7 @@ int at3phip_pqf_analyse(at3phip_ctx* c, const float* pcm, int32_t n_frames, floa
     if (!c || !pcm || !bands || n_frames < 1 || n_frames > c->cfg.max_frames) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
     at3host::DeviceGuard guard(c->device);
     HIPCHK(c, guard.error());
+    if (int qrc = quiesce(c)) return qrc;
     const size_t n = (size_t)c->cfg.n_streams * n_frames * c->cfg.channels * 2048;
     const float* d_pcm = pcm;
     if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
@@ -232,6 +264,7 @@ int at3phip_mdct(at3phip_ctx* c, const float* bands, int32_t n_frames, const uin
     if (!c || !bands || !specs || n_frames < 1 || n_frames > c->cfg.max_frames) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
     at3host::DeviceGuard guard(c->device);
     HIPCHK(c, guard.error());
+    if (int qrc = quiesce(c)) return qrc;
     const size_t n = (size_t)c->cfg.n_streams * n_frames * c->cfg.channels * 2048;
     const float* d_bands = bands;
     if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
@@ -255,6 +288,7 @@ int at3phip_pqf_mdct(at3phip_ctx* c, const float* pcm, int32_t n_frames, const u
     if (!c || !pcm || !specs || n_frames < 1 || n_frames > c->cfg.max_frames) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
     at3host::DeviceGuard guard(c->device);
     HIPCHK(c, guard.error());
+    if (int qrc = quiesce(c)) return qrc;
     const size_t n = (size_t)c->cfg.n_streams * n_frames * c->cfg.channels * 2048;
     const float* d_pcm = pcm;
     if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
@@ -286,6 +320,7 @@ int at3phip_write_frames(at3phip_ctx* c, const float* specs, int32_t n_frames, c
     if (!c || !specs || !frames || n_frames < 1 || n_frames > c->cfg.max_frames) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
     at3host::DeviceGuard guard(c->device);
     HIPCHK(c, guard.error());
+    if (int qrc = quiesce(c)) return qrc;
     const size_t items = (size_t)c->cfg.n_streams * n_frames;
     const size_t n = items * c->cfg.channels * 2048;
     const float* d_specs = specs;
@@ -318,21 +353,44 @@ int at3phip_encode_frames(at3phip_ctx* c, const float* pcm, int32_t n_frames, ui
         d_pcm = c->d_pcm_in;
     }
     uint8_t* d_frames = (flags & AT3HIP_OUT_ON_DEVICE) ? frames : c->d_frames;
+    const int par = (int)(c->enc_calls & 1);
+    float* d_specs = c->d_specs_b[par];
+    hipStream_t ws = c->write_stream;
+    // the writer of the call before the previous one must be done with this parity's spectra
+    if (c->write_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_write_done[par], 0));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     int rc = launch_pqf(c, d_pcm, n_frames, c->d_bands);
     if (rc != AT3HIP_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    rc = launch_mdct(c, c->d_bands, n_frames, nullptr, c->d_specs, AT3PHIP_RESIDUAL_SCALE);   // sine windows: EncodeFrame's default Win
+    rc = launch_mdct(c, c->d_bands, n_frames, nullptr, d_specs, AT3PHIP_RESIDUAL_SCALE);   // sine windows: EncodeFrame's default Win
     if (rc != AT3HIP_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    rc = launch_write(c, c->d_specs, n_frames, nullptr, d_frames);
+    HIPCHK(c, hipEventRecord(c->ev_specs[par], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(ws, c->ev_specs[par], 0));
+    HIPCHK(c, hipEventRecord(c->ev[4], ws));
+    rc = launch_write(c, d_specs, n_frames, nullptr, d_frames, ws);
     if (rc != AT3HIP_OK) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    if (!(flags & AT3HIP_OUT_ON_DEVICE)) HIPCHK(c, hipMemcpyAsync(frames, c->d_frames, items * kFrameBytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], ws));
+    if (!(flags & AT3HIP_OUT_ON_DEVICE)) HIPCHK(c, hipMemcpyAsync(frames, c->d_frames, items * kFrameBytes, hipMemcpyDeviceToHost, ws));
+    HIPCHK(c, hipEventRecord(c->ev_write_done[par], ws));
+    c->write_done_valid[par] = true;
+    c->enc_calls++;
+    if (flags & AT3HIP_ASYNC) return AT3HIP_OK;   // at3phip_sync is the completion point
+    return at3phip_sync(c);
+}
+
+int at3phip_sync(at3phip_ctx* c)
+{
+    if (!c) return AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipEventElapsedTime(&c->pqf_ms, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&c->mdct_ms, c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&c->write_ms, c->ev[2], c->ev[3]);
+    HIPCHK(c, hipStreamSynchronize(c->write_stream));
+    if (c->enc_calls > 0) {
+        (void)hipEventElapsedTime(&c->pqf_ms, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&c->mdct_ms, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&c->write_ms, c->ev[4], c->ev[3]);
+    }
     return AT3HIP_OK;
 }
 

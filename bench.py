@@ -297,7 +297,14 @@ def widened_rows(S):
         e1.close()
         ep = atracdenc_amd.At3pHip(n_streams=S, max_frames=32)
         op = torch.zeros((S, 32, 2048), dtype=torch.uint8, device="cuda")
-        dt = timed(lambda: ep.encode_frames_device(pcm.data_ptr(), 32, op.data_ptr()))
+        for _ in range(2):
+            ep.encode_frames_device(pcm.data_ptr(), 32, op.data_ptr())
+        t0 = time.perf_counter()
+        for _ in range(10):   # queued calls, one wait: the writer of a call overlaps the next call's filter bank and transform
+            ep.encode_frames_device(pcm.data_ptr(), 32, op.data_ptr(), asynchronous=True)
+        ep.sync()
+        dt = (time.perf_counter() - t0) / 10
+        ep.encode_frames_device(pcm.data_ptr(), 32, op.data_ptr())
         tm = ep.timings()
         out["atrac3plus_encode_no_tonal"] = {"value": round(S * 32 / dt, 1), "unit": "2048-sample stereo frames/s", "ms_per_step": round(dt * 1e3, 4),
                                              "x_realtime": round(S * 65536 / 44100.0 / dt, 1), "device_ms": {k: round(v, 4) for k, v in tm.items()},

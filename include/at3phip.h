@@ -71,6 +71,10 @@ int at3phip_write_frames(at3phip_ctx* ctx, const float* specs, int32_t n_frames,
  * tonal analysis that finds nothing; frame f holds input frame f (the reference's two-frame look-ahead delay is the
  * host's to add, see atracdenc_amd/host/at3hip_host.hpp). pcm as in at3phip_pqf_analyse, frames as above. */
 int at3phip_encode_frames(at3phip_ctx* ctx, const float* pcm, int32_t n_frames, uint8_t* frames, uint32_t flags);
+/* With AT3HIP_ASYNC in `flags` at3phip_encode_frames only queues the call (pcm must stay valid, frames must not be read)
+ * and the frame writer of one call runs beside the filter bank and transform of the next (its own stream, spectra
+ * double-buffered); at3phip_sync waits for everything queued. Without the flag the call waits itself. */
+int at3phip_sync(at3phip_ctx* ctx);
 
 /* Device milliseconds the frame writer took in the last at3phip_write_frames / at3phip_encode_frames call. */
 int at3phip_get_write_timing(const at3phip_ctx* ctx, float* write_ms);

@@ -198,3 +198,34 @@ def test_write_frames_full_batch(oracle):
     assert np.all(got[:, :, 0] >> 5 == 1)          # 0, then channels - 1 = 1 in two bits
     units = (got[:, :, 0] & 0x1F) + 1
     assert units.max() <= 32 and units.min() >= 1 and len(np.unique(units)) > 2
+
+
+def test_encode_frames_async(oracle):
+    """Six asynchronous at3phip_encode_frames calls in flight (the writer of a call on its own stream beside the next
+    call's filter bank and transform), one at3phip_sync: the frames equal the oracle's for the whole PCM sequence; a
+    synchronous entry point right after an asynchronous call waits for it."""
+    import torch
+    from atracdenc_amd import At3pHip
+    nf_call, calls, nch = 4, 6, 2
+    names = ("mix", "noise", "burst")
+    nf = nf_call * calls
+    pcm = np.stack([np.stack([at3p_signal(n, nf, channel=c) for c in range(nch)], axis=-1) for n in names])
+    enc = At3pHip(n_streams=len(names), max_frames=nf_call, channels=nch)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    outs = [torch.zeros((len(names), nf_call, 2048), dtype=torch.uint8, device="cuda") for _ in range(calls)]
+    parts = [d_pcm[:, k * nf_call:(k + 1) * nf_call].contiguous() for k in range(calls)]
+    torch.cuda.synchronize()
+    for k in range(calls):
+        enc.encode_frames_device(parts[k].data_ptr(), nf_call, outs[k].data_ptr(), asynchronous=True)
+    enc.sync()
+    got = np.concatenate([o.cpu().numpy() for o in outs], axis=1)
+    for s, n in enumerate(names):
+        assert np.array_equal(got[s], at3p_write_frames(at3p_specs(n, nf, nch))), n
+    # asynchronous call, then a synchronous entry point without an explicit sync in between
+    enc.reset()
+    enc.encode_frames_device(parts[0].data_ptr(), nf_call, outs[0].data_ptr(), asynchronous=True)
+    again = enc.write_frames(np.zeros((len(names), 1, nch, 2048), np.float32))
+    assert np.array_equal(again[0, 0], at3p_write_frames(np.zeros((1, nch, 2048), np.float32))[0])
+    enc.sync()
+    assert np.array_equal(outs[0].cpu().numpy(), got[:, :nf_call])
+    enc.close()

@@ -31,13 +31,17 @@ def main():
     for _ in range(a.warmup):
         enc.encode_frames_device(d_pcm.data_ptr(), a.frames, d_frames.data_ptr())
     torch.cuda.synchronize()
-    tms = []
+    # the timed region queues the steps (AT3HIP_ASYNC) and waits once: the writer of a step overlaps the next step's
+    # filter bank and transform, as a caller feeding consecutive batches would run it
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        enc.encode_frames_device(d_pcm.data_ptr(), a.frames, d_frames.data_ptr(), asynchronous=True)
+    enc.sync()
+    dt = time.perf_counter() - t0
+    tms = []
+    for _ in range(5):   # per-kernel device times from synchronous calls
         enc.encode_frames_device(d_pcm.data_ptr(), a.frames, d_frames.data_ptr())
         tms.append(enc.timings())
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     units = a.streams * a.frames
     med = {k: float(np.median([t[k] for t in tms])) for k in tms[0]}
     algo = units * 2 * 2048 * 4 * 4   # PCM in, subbands out + in, spectrum out
