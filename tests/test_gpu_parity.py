@@ -539,3 +539,39 @@ def test_caller_stream_and_async_pipeline(hip, oracle):
     more = enc.encode(whole[:, :nb] * 0)     # the context still works on its own stream (state continues: silence after the signal)
     assert more.shape[1] == nb
     enc.close()
+
+
+def test_bench_contract_and_two_context_paths(tmp_path):
+    """bench.py prints ONE JSON line with the contract's fields (N = 1, a short run), and both multi-device code paths -
+    one process driving two contexts from two host threads, and two torch.distributed.run ranks with a gloo barrier - run
+    to completion on this box's single GPU through the --device-map test aid (their lines say so)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+
+    def last_json(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    d = last_json([sys.executable, bench, "--steps", "4", "--warmup", "1", "--no-side-workloads", "--no-cpu-baseline"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["value"] > 1e6
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert "workload" in d["config"]
+
+    d2 = last_json([sys.executable, bench, "--gpus", "2", "--device-map", "0,0", "--steps", "2", "--warmup", "1", "--streams", "64",
+                    "--frames", "16", "--no-side-workloads", "--no-cpu-baseline"])
+    assert d2["n_gpus"] == 2 and "TEST AID" in d2["config"]["launch"] and d2["value"] > 1e5
+
+    d3 = last_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29533", bench, "--gpus", "2", "--device-map", "0,0", "--steps", "2", "--warmup", "1", "--streams", "64",
+                    "--frames", "16", "--no-side-workloads", "--no-cpu-baseline"])
+    assert d3["n_gpus"] == 2 and "ranks" in d3["config"]["launch"] and d3["value"] > 1e5
