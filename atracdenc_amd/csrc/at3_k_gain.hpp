@@ -20,6 +20,7 @@ struct GainParams {
     const float* sub;     // [S][2][4][(n_blocks+2)*256] raw L/R subbands, block b at (b+2)*256
     GainRec* rec;         // [S][n_blocks][2][3] by frame index
     cpx* bins;            // [items][kGainBins] rfft-512 bins 38 .. 256 of every item, k_gain_spec -> k_gain_analysis
+    float* micro;         // [items][256] RMS of the 8-sample micro-chunks of the upsampled band, k_gain_analysis -> k_gain_tail
     BandState* state;     // [S][2][4]
     Curve* curves;        // [S][n_blocks][2][4]
     int n_blocks;
@@ -387,20 +388,13 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
 // allows eight items = 16 wavefronts per CU.
 struct GainLds {
     cpx f[2048 + 64];   // the irfft-4096 core / upsampled samples, padded (irfft_pad)
-    float scratch[352]; // AnalyzeGain scratch
 };
-// AnalyzeGain scratch: float offsets
-constexpr int kGaMicro = 0, kGaGain = 256, kGaFilt = 288, kGaMinv = 320;
 
 __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) GainLds s_item[1];
     const int tid = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     GainLds& L = s_item[0];
-    float* s_micro = L.scratch + kGaMicro;
-    float* s_gain = L.scratch + kGaGain;
-    float* s_filt = L.scratch + kGaFilt;
-    float* s_minv = L.scratch + kGaMinv;
     const int nfr = p.n_blocks - p.f0;
     const bool valid = true;
     int wg = blockIdx.x;
@@ -496,8 +490,11 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
 
 
     // 4. AnalyzeGain over the upsampled samples [1024, 3072): 256 micro-chunks of 8 (4 per lane), 32 sub-frames of 64
-    // complex output j holds the real samples 2j, 2j+1; sample 1024 is complex slot 512 = padded slot 528
+    // complex output j holds the real samples 2j, 2j+1; sample 1024 is complex slot 512 = padded slot 528. The RMS values
+    // leave for HBM; what is made of them (quartiles, plateau target) is a short serial affair of 32 lanes per item and
+    // runs as k_gain_tail on the light stage's stream instead of holding this kernel's 17 KB of LDS for a third of its life.
     const float norm = 1.0f / 4096.0f;
+    float* micro = p.micro + item * 256;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = tid + 128 * q;
@@ -511,7 +508,7 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
             acc += sq.y;
         }
         acc /= 8;
-        s_micro[c] = sqrtf(acc);
+        micro[c] = sqrtf(acc);
     }
     if (tid < 32) {
         const cpx* src = L.f + 528 + 33 * lane;
@@ -527,74 +524,97 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
             acc += sq.y;
         }
         acc /= 64;
-        s_gain[lane] = sqrtf(acc);
+        rec->gain[lane] = sqrtf(acc);
     }
-    __syncthreads();
-    if (wave == 0) {
-        const int j = lane & 31;
-        const float in_j = s_gain[j];
-        // quartiles of the 8 micro-chunk RMS values (transient_detector.cpp:113-133)
-        {
-            const float4 a = *reinterpret_cast<const float4*>(s_micro + j * 8), b = *reinterpret_cast<const float4*>(s_micro + j * 8 + 4);
-            float m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+}
+
+// The rest of AnalyzeGain and CalcCurve's target for one item: quartiles of the 8 micro-chunk RMS values of every
+// sub-frame (transient_detector.cpp:113-133), the plateau target (:178-238, 284-297), the mean gain. 32 lanes per item,
+// eight items per workgroup; items below the 5 % gate have no data and are skipped like k_gain_analysis skipped them.
+__global__ __launch_bounds__(256) void k_gain_tail(GainParams p, int n_items)
+{
+    __shared__ float s_g[8][32], s_f[8][32], s_m[8][32];
+    const int tid = threadIdx.x, grp = tid >> 5, j = tid & 31, half = grp & 1;
+    const int nfr = p.n_blocks - p.f0;
+    int item = blockIdx.x * 8 + grp;
+    const bool valid = item < n_items;
+    if (!valid) item = n_items - 1;
+    int wg = item;
+    const int band = wg % 3; wg /= 3;
+    const int ch = wg % 2; wg /= 2;
+    const int f = p.f0 + wg % nfr;
+    const int s = wg / nfr;
+    GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
+    const bool active = valid && !(rec->hfr < 0.05f);
+    if (__ballot(active) == 0ull) return;
+    float* s_gain = s_g[grp];
+    float* s_filt = s_f[grp];
+    float* s_minv = s_m[grp];
+    float in_j = 0.0f;
+    float m[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (active) {
+        in_j = rec->gain[j];
+        const float4 a = *reinterpret_cast<const float4*>(p.micro + (size_t)item * 256 + j * 8);
+        const float4 b = *reinterpret_cast<const float4*>(p.micro + (size_t)item * 256 + j * 8 + 4);
+        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+    }
+    s_gain[j] = in_j;
 #pragma unroll
-            for (int i = 1; i < 8; ++i) {   // insertion sort, ascending (static indices)
+    for (int i = 1; i < 8; ++i) {   // insertion sort, ascending (static indices)
 #pragma unroll
-                for (int k = i; k > 0; --k) {
-                    const float lo = fminf(m[k - 1], m[k]), hi = fmaxf(m[k - 1], m[k]);
-                    m[k - 1] = lo;
-                    m[k] = hi;
-                }
-            }
-            if (valid && lane < 32) {
-                rec->gain[j] = in_j;
-                rec->lo[j] = m[2];
-                rec->hi[j] = m[6];
-            }
+        for (int k = i; k > 0; --k) {
+            const float lo = fminf(m[k - 1], m[k]), hi = fmaxf(m[k - 1], m[k]);
+            m[k - 1] = lo;
+            m[k] = hi;
         }
-        // plateau target of CalcCurve (transient_detector.cpp:178-238, 284-297) with ballots
-        float filt_j;
-        {
-            const float a = s_gain[j > 0 ? j - 1 : 0], c = s_gain[j < 31 ? j + 1 : 31];
-            if (j == 0) filt_j = fmaxf(in_j, c);
-            else if (j == 31) filt_j = fmaxf(a, in_j);
-            else filt_j = fmaxf(fminf(a, in_j), fminf(fmaxf(a, in_j), c));
+    }
+    if (active) {
+        rec->lo[j] = m[2];
+        rec->hi[j] = m[6];
+    }
+    wave_sync();
+    // plateau target of CalcCurve (transient_detector.cpp:178-238, 284-297) with ballots
+    float filt_j;
+    {
+        const float a = s_gain[j > 0 ? j - 1 : 0], c = s_gain[j < 31 ? j + 1 : 31];
+        if (j == 0) filt_j = fmaxf(in_j, c);
+        else if (j == 31) filt_j = fmaxf(a, in_j);
+        else filt_j = fmaxf(fminf(a, in_j), fminf(fmaxf(a, in_j), c));
+    }
+    s_filt[j] = filt_j;
+    wave_sync();
+    s_minv[j] = (j <= 29) ? fminf(fminf(filt_j, s_filt[j < 30 ? j + 1 : 31]), s_filt[j < 30 ? j + 2 : 31]) : -1.0f;
+    wave_sync();
+    float maxRaw = 0.0f, sum = 0.0f, bestLevel = 0.0f;
+    int bestEnd = -1;
+    for (int k = 0; k < 32; ++k) {
+        const float g = s_gain[k];
+        maxRaw = fmaxf(maxRaw, g);
+        sum += g;
+        const float mv = s_minv[k];
+        if (k <= 29 && mv > bestLevel) {
+            bestLevel = mv;
+            bestEnd = k + 2;
         }
-        if (lane < 32) s_filt[j] = filt_j;
-        wave_sync();
-        if (lane < 32) s_minv[j] = (j <= 29) ? fminf(fminf(filt_j, s_filt[j < 30 ? j + 1 : 31]), s_filt[j < 30 ? j + 2 : 31]) : -1.0f;
-        wave_sync();
-        float maxRaw = 0.0f, sum = 0.0f, bestLevel = 0.0f;
-        int bestEnd = -1;
-        for (int k = 0; k < 32; ++k) {
-            const float g = s_gain[k];
-            maxRaw = fmaxf(maxRaw, g);
-            sum += g;
-            const float mv = s_minv[k];
-            if (k <= 29 && mv > bestLevel) {
-                bestLevel = mv;
-                bestEnd = k + 2;
-            }
+    }
+    const uint32_t ge = (uint32_t)(__ballot(filt_j >= bestLevel) >> (32 * half));
+    const uint32_t high = (uint32_t)(__ballot(in_j >= bestLevel * 0.7f) >> (32 * half));
+    const float last = s_gain[31];
+    float plateau = 0.0f;
+    bool release = false;
+    if (!(bestLevel < 1e-6f)) {
+        plateau = bestLevel;
+        const uint32_t x = (bestEnd + 1 < 32) ? (ge >> (bestEnd + 1)) : 0u;
+        bestEnd += (x == 0xffffffffu) ? 32 : __builtin_ctz(~x);   // extend while filtered stays at plateau level
+        if (bestEnd < 31) {
+            if (last < bestLevel * 0.1f) release = true;
+            else release = ((high >> (bestEnd + 1)) == 0u) && (last < bestLevel * 0.5f);
         }
-        const uint32_t ge = (uint32_t)__ballot(lane < 32 && filt_j >= bestLevel);
-        const uint32_t high = (uint32_t)__ballot(lane < 32 && in_j >= bestLevel * 0.7f);
-        const float last = s_gain[31];
-        float plateau = 0.0f;
-        bool release = false;
-        if (!(bestLevel < 1e-6f)) {
-            plateau = bestLevel;
-            const uint32_t x = (bestEnd + 1 < 32) ? (ge >> (bestEnd + 1)) : 0u;
-            bestEnd += (x == 0xffffffffu) ? 32 : __builtin_ctz(~x);   // extend while filtered stays at plateau level
-            if (bestEnd < 31) {
-                if (last < bestLevel * 0.1f) release = true;
-                else release = ((high >> (bestEnd + 1)) == 0u) && (last < bestLevel * 0.5f);
-            }
-        }
-        const bool usePlateau = plateau > 1e-6f && !release && plateau >= maxRaw * 0.4f;
-        if (valid && lane == 0) {
-            rec->cur_hpf = sum / 32.0f;
-            rec->target = usePlateau ? plateau : last;
-        }
+    }
+    const bool usePlateau = plateau > 1e-6f && !release && plateau >= maxRaw * 0.4f;
+    if (active && j == 0) {
+        rec->cur_hpf = sum / 32.0f;
+        rec->target = usePlateau ? plateau : last;
     }
 }
 
