@@ -106,24 +106,26 @@ __device__ __forceinline__ uint32_t vlc_bits8(int wl, const int (&m)[8])
 __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bits, float my_e1, int lane, int8_t* gmant, int dbg = 0)
 {
     // ---- (1) mantissa = lrint(value * MaxQuant[wl]) for the lines of the needed BFUs; energy-adaptive candidate codes ----
-    int wl_h[2];
+    // Four rounds of four lines per lane, line0 = 256 round + 4 lane: a wavefront's 16-byte LDS accesses are one contiguous
+    // kilobyte (sixteen lines per lane, the first layout, put every fourth lane on the same banks).
+    int wl_h[4];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int line0 = 16 * lane + 8 * h;
+    for (int h = 0; h < 4; ++h) {
+        const int line0 = 256 * h + 4 * lane;
         const int b = bfu_of_line(line0);
         const int wl = __builtin_amdgcn_ds_bpermute(4 * b, bits);
         wl_h[h] = ((need >> b) & 1u) ? wl : 0;
         if (wl_h[h]) {
             const float mul = max_quant(wl), inv2 = inv_mul2(wl);
-            const float4 va = *reinterpret_cast<const float4*>(L.val + line0), vb = *reinterpret_cast<const float4*>(L.val + line0 + 4);
-            const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-            uint32_t pk[2] = {0u, 0u}, code = 0;
-            float tm[8];
+            const float4 va = *reinterpret_cast<const float4*>(L.val + line0);
+            const float v[4] = {va.x, va.y, va.z, va.w};
+            uint32_t pk = 0u, code = 0;
+            float tm[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 const float t = v[k] * mul;
                 const int m = __float2int_rn(t);
-                pk[k >> 2] |= (uint32_t)(uint8_t)m << (8 * (k & 3));
+                pk |= (uint32_t)(uint8_t)m << (8 * k);
                 tm[k] = (float)(m * m) * inv2;
                 // the pass may re-round a line only when it is close to a rounding boundary (|delta| < 0.25) AND lies on the
                 // side the pass moves: rounded towards zero and below the top code (pass taken when e2 < e1) or rounded
@@ -133,10 +135,9 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
                 const uint32_t c = (am < at && am < (mul - 1)) ? 1u : (am > at) ? 2u : 0u;
                 code |= (fabsf(delta) < 0.25f ? c : 0u) << (2 * k);
             }
-            *reinterpret_cast<uint2*>(L.bm + line0) = make_uint2(pk[0], pk[1]);
-            *reinterpret_cast<uint16_t*>(L.code + (line0 >> 2)) = (uint16_t)code;
+            *reinterpret_cast<uint32_t*>(L.bm + line0) = pk;
+            L.code[line0 >> 2] = (uint8_t)code;
             *reinterpret_cast<float4*>(L.term + line0) = make_float4(tm[0], tm[1], tm[2], tm[3]);
-            *reinterpret_cast<float4*>(L.term + line0 + 4) = make_float4(tm[4], tm[5], tm[6], tm[7]);
         }
     }
     if (lane < 32) L.vlc[lane] = 0u;
@@ -385,16 +386,23 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
     wave_sync();
     // ---- (4) VLC cost of the final mantissas; (5) cache entries; (6) mantissas to HBM for the packing step ----
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 4; ++h) {
         const int wl = wl_h[h];
         if (wl) {
-            const int line0 = 16 * lane + 8 * h;
-            const uint2 pk = *reinterpret_cast<const uint2*>(L.bm + line0);
-            int m[8];
+            const int line0 = 256 * h + 4 * lane;
+            const uint32_t pk = *reinterpret_cast<const uint32_t*>(L.bm + line0);
+            int m[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) m[k] = (int)(int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
-            atomicAdd(&L.vlc[bfu_of_line(line0)], vlc_bits8(wl, m));
-            *reinterpret_cast<uint2*>(gmant + (wl - 1) * 1024 + line0) = pk;
+            for (int k = 0; k < 4; ++k) m[k] = (int)(int8_t)((pk >> (8 * k)) & 0xff);
+            uint32_t vb = 0;
+            if (wl > 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vb += vlc_len(wl, m[k]);
+            } else {
+                vb = vlc_pair_len(m[0], m[1]) + vlc_pair_len(m[2], m[3]);
+            }
+            atomicAdd(&L.vlc[bfu_of_line(line0)], vb);
+            *reinterpret_cast<uint32_t*>(gmant + (wl - 1) * 1024 + line0) = pk;
         }
     }
     wave_sync();
