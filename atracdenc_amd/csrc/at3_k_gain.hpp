@@ -209,8 +209,11 @@ __device__ __forceinline__ void irfft_pass_512(cpx* F, const Tw512<NT>& t, int t
 // half, with its sequential chains on two lanes of 128.)
 constexpr int kGainBins = 220;   // bins 38 .. 256 (219), padded to an even count
 
+// rfft-512 core, point i at i + i / 4: the radix-4 passes read and write points 4 m apart (m = 1, 4, 16, 64) with all 64
+// lanes at once, and unpadded every such access landed on an eighth of the banks
+__device__ __forceinline__ int spec_pad(int i) { return i + (i >> 2); }
 struct SpecLds {
-    cpx f[256];       // rfft-512 core
+    cpx f[320];       // rfft-512 core (padded, see spec_pad)
     cpx freq[304];    // 257 bins, then 300 f64 energies (257 + zero padding) over the same bytes
 };
 
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
         cpx z;
         z.r = a.x * pw.r;
         z.i = a.y * pw.i;
-        L.f[fft_leaf_pos<256>(i)] = z;
+        L.f[spec_pad(fft_leaf_pos<256>(i))] = z;
     }
     wave_sync();
 #ifdef AT3HIP_DEBUG_KNOBS
@@ -280,13 +283,17 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         const int m = 1 << (2 * st);
-        cpx* B = L.f + (lane / m) * 4 * m + lane % m;
-        f2 x0 = ld2(B), x1 = ld2(B + m), x2 = ld2(B + 2 * m), x3 = ld2(B + 3 * m);
+        const int b0 = (lane / m) * 4 * m + lane % m;
+        cpx* B0 = L.f + spec_pad(b0);
+        cpx* B1 = L.f + spec_pad(b0 + m);
+        cpx* B2 = L.f + spec_pad(b0 + 2 * m);
+        cpx* B3 = L.f + spec_pad(b0 + 3 * m);
+        f2 x0 = ld2(B0), x1 = ld2(B1), x2 = ld2(B2), x3 = ld2(B3);
         bfly4<false>(x0, x1, x2, x3, tw_a[st][0], tw_a[st][1], tw_a[st][2]);
-        st2(B, x0);
-        st2(B + m, x1);
-        st2(B + 2 * m, x2);
-        st2(B + 3 * m, x3);
+        st2(B0, x0);
+        st2(B1, x1);
+        st2(B2, x2);
+        st2(B3, x3);
         wave_sync();
     }
 #ifdef AT3HIP_DEBUG_KNOBS
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
 #endif
     // 2. kiss_fftr post-processing -> 257 bins (tools/kiss_fftr.c:61-100): lane handles k = lane + 1 and k = lane + 65
     if (lane == 0) {
-        const float tr = L.f[0].r, ti = L.f[0].i;
+        const float tr = L.f[spec_pad(0)].r, ti = L.f[spec_pad(0)].i;
         cpx a, b;
         a.r = tr + ti; a.i = 0.0f;
         b.r = tr - ti; b.i = 0.0f;
@@ -304,10 +311,10 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int k = lane + 1 + 64 * q;
-        const cpx fpk = L.f[k];
+        const cpx fpk = L.f[spec_pad(k)];
         cpx fpnk;
-        fpnk.r = L.f[256 - k].r;
-        fpnk.i = -L.f[256 - k].i;
+        fpnk.r = L.f[spec_pad(256 - k)].r;
+        fpnk.i = -L.f[spec_pad(256 - k)].i;
         cpx f1k, f2k;
         f1k.r = fpk.r + fpnk.r; f1k.i = fpk.i + fpnk.i;
         f2k.r = fpk.r - fpnk.r; f2k.i = fpk.i - fpnk.i;
