@@ -422,7 +422,8 @@ __device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant
     for (int rd = 0; rd < 2; ++rd) {
         const int u = lane + 64 * rd;
         if (u < 70) {
-            const int bfu = u % 10, wl = 1 + u / 10;
+            // the fourteen 16-line units (BFUs 8, 9) first: the second round's six units are then all 8 lines long
+            const int bfu = u < 14 ? 8 + (u & 1) : (u - 14) & 7, wl = u < 14 ? 1 + (u >> 1) : 1 + ((u - 14) >> 3);
             const int start = bfu_start(bfu), n = bfu < 8 ? 8 : 16;
             const float mul = max_quant(wl);
             const float inv2 = inv_mul2(wl);
