@@ -21,20 +21,21 @@
 
 namespace at3 {
 
+constexpr int kTermLine0 = 96;   // BFUs 0..9 (lines 0..95) are quantised by small_units: no batch ever lists their lines
 struct AllocLds {
     float val[1024];                 // scaled spectrum (TScaler::Scale)
     union {
-        float term[1024];            // a batch's energy terms (mantissa / mul)^2, summed in line order by one lane per unit
+        float term[1024 - kTermLine0];   // a batch's energy terms (mantissa / mul)^2 of line i at i - kTermLine0, summed in line order by one lane per unit
         struct {
-            float uk[kEaLines + 4];      // then the energy-adaptive pass: a unit's sort keys (+inf padded); tie-sort scratch
-            uint16_t rec[kEaLines];      // and its candidates ordered by |delta|: line | |m| << 7 | negative << 12
+            float uk[256];               // then the energy-adaptive pass: ONE unit's (or pair's) sort keys (+inf padded); tie-sort scratch
+            uint16_t rec[kEaLines];      // and every unit's candidates ordered by |delta|: line | |m| << 7 | negative << 12
         };
         struct {
             uint32_t words[kBitWords];   // after the rate loop: the sound unit being assembled
             uint16_t huff[130];          // and the code tables
         };
     };
-    float err[8 * 32];               // cache: e1 / e2 per (wordlen, BFU)
+    float err[7 * 16];               // cache: e1 / e2 of (wordlen, BFU < 10) at (wordlen - 1) * 16 + BFU - what ConsiderEnergyErr reads
     uint16_t cost[8 * 32];           // cache: VLC bits (the CLC bits are wordlen x lines)
     int8_t bm[1024];                 // mantissas of the units of the current batch (one wordlen per BFU)
     uint8_t code[256];               // 2 bits per line of the batch: 1 = re-roundable when e2 < e1, 2 = when e2 > e1
@@ -45,7 +46,7 @@ struct AllocLds {
     int misc[4];
     unsigned long long tmask[4];
 };
-static_assert(sizeof(SortItem) * 128 <= sizeof(float) * (kEaLines + 4), "tie-sort scratch must fit in the key lists");
+static_assert(sizeof(SortItem) * 128 <= sizeof(float) * 256, "tie-sort scratch must fit in the key list");
 
 // 1 / MaxQuant[wl]^2 as QuantMantisas forms it (atrac_scale.cpp:61: float(1.0 / double(mul * mul))), folded per wordlen
 __device__ __forceinline__ float inv_mul2(int wl)
@@ -103,7 +104,7 @@ __device__ __forceinline__ uint32_t vlc_bits8(int wl, const int (&m)[8])
 
 // Quantise the units {(b, wl_b) : bit b of `need`}, wl_b = lane b's `bits` (QuantMantisas + CLC/VLC cost,
 // atrac3_bitstream.cpp:154-173, atrac_scale.cpp:40-130). Lane b < 32 passes BFU b's e1 in `my_e1`. Wave-uniform call.
-__device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bits, float my_e1, int lane, int8_t* gmant, int dbg = 0)
+__device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bits, float my_e1, int lane, int8_t* gmant, float* qerr, int dbg = 0)
 {
     // ---- (1) mantissa = lrint(value * MaxQuant[wl]) for the lines of the needed BFUs; energy-adaptive candidate codes ----
     // Four rounds of four lines per lane, line0 = 256 round + 4 lane: a wavefront's 16-byte LDS accesses are one contiguous
@@ -137,7 +138,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
             }
             *reinterpret_cast<uint32_t*>(L.bm + line0) = pk;
             L.code[line0 >> 2] = (uint8_t)code;
-            *reinterpret_cast<float4*>(L.term + line0) = make_float4(tm[0], tm[1], tm[2], tm[3]);
+            *reinterpret_cast<float4*>(L.term + (line0 - kTermLine0)) = make_float4(tm[0], tm[1], tm[2], tm[3]);
         }
     }
     if (lane < 32) L.vlc[lane] = 0u;
@@ -149,7 +150,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
     if (mine) {
         my_mul = max_quant(bits);
         my_inv2 = inv_mul2(bits);
-        const float4* t4 = reinterpret_cast<const float4*>(L.term + my_start);
+        const float4* t4 = reinterpret_cast<const float4*>(L.term + (my_start - kTermLine0));
         float acc = 0.0f;
         float4 c0 = t4[0], c1 = t4[1];
         for (int off = 0; off < my_n; off += 8) {   // eight terms per step, the next eight in flight
@@ -407,7 +408,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
     }
     wave_sync();
     if (mine) {
-        L.err[bits * 32 + lane] = my_e1 / my_e2;
+        if (qerr) qerr[(bits - 1) * 32 + lane] = my_e1 / my_e2;   // BFUs >= 10: nothing but the QUANT tap looks at their energy error
         L.cost[bits * 32 + lane] = (uint16_t)L.vlc[lane];
     }
     wave_sync();
@@ -444,7 +445,7 @@ __device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant
                 vb += vlc_bits8(wl, m);
                 *reinterpret_cast<uint2*>(gmant + (wl - 1) * 1024 + start + off) = make_uint2(pk[0], pk[1]);
             }
-            L.err[wl * 32 + bfu] = L.e1[bfu] / e2;
+            L.err[(wl - 1) * 16 + bfu] = L.e1[bfu] / e2;
             L.cost[wl * 32 + bfu] = (uint16_t)vb;
         }
     }
@@ -546,7 +547,7 @@ __device__ __forceinline__ int alloc_bits(float A, bool gate, int tcount, uint32
     return (int)((gmap >> (3 * bits)) & 7u);
 }
 
-__global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T)
+__global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) AllocLds L;
     uint32_t* s_words = L.words;
@@ -572,11 +573,10 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     const int half = p.frame_sz >> 1;
     const int n_tonal = rec->n_tonal;
 
-    for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
-    for (int i = lane; i < 8 * 32; i += 64) {
-        s_err[i] = 0.0f;
-        s_cost[i] = 0u;
-    }
+    for (int i = lane; i < 8 * 32; i += 64) s_cost[i] = 0u;
+    float* qerr = p.quant ? &p.quant[cf].err[0][0] : nullptr;
+    if (qerr)
+        for (int i = lane; i < 7 * 32; i += 64) qerr[i] = 0.0f;   // (zero = never computed)
 
     // ---- header + gain info bits, joint-stereo byte shift, target bits (WriteSoundUnit :759-810) ----
     // lanes 0..7 hold the frame's eight gain curves (16 bytes each) from here to the emission
@@ -618,6 +618,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     const float loudness = p.loud[(size_t)s * n_out + fo] / 0.006f;
 
     if (p.mono_js && ch == 1) {
+        for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
         // TConfigure / TAlloc with empty ScaledBlocks (atrac3_bitstream.cpp:590-597, 623-626): JS parameters, one subband
         // without gain points, no tonal components, one BFU of precision 0 in coding mode 1 - 33 bits, then zeros
         __syncthreads();
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
         gmap = 7u << 21;
 #pragma unroll
         for (int k = 6; k >= 0; --k) {
-            const float e = s_err[k * 32 + i];
+            const float e = (k > 0 && i < 10) ? s_err[(k - 1) * 16 + i] : 0.0f;
             const bool climbs = i < 10 && k > 0 && ((e > 0 && e < 0.7f) || e > 1.2f);
             g = climbs ? g : k;
             gmap |= (uint32_t)g << (3 * k);
@@ -839,7 +840,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
                 if (need) {
                     if (lane < 32) s_alloc[lane] = bits;
                     wave_sync();
-                    compute_units(L, need, bits, my_e1, lane, gmant, p.debug_stop);
+                    compute_units(L, need, bits, my_e1, lane, gmant, qerr, p.debug_stop);
                     if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
                 }
             }
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(64) void k_alloc_pack(BackParams p, const Tables* T
     if (p.quant) {   // the QUANT tap: what the cache holds at the end (err e1 / e2, cost CLC | VLC << 13; zero = never computed)
         QuantRec* qr = p.quant + cf;
         for (int k = lane; k < 7 * 32; k += 64) {
-            qr->err[k >> 5][k & 31] = s_err[32 + k];
+            if ((k & 31) < 10) qr->err[k >> 5][k & 31] = s_err[(k >> 5) * 16 + (k & 31)];
             const uint32_t vb = s_cost[32 + k];
             qr->cost[k >> 5][k & 31] = vb ? (clc_bits(1 + (k >> 5), bfu_start((k & 31) + 1) - bfu_start(k & 31)) | (vb << 13)) : 0u;
         }

@@ -54,4 +54,6 @@ __device__ __forceinline__ int opaque_lane_value(int v)
 }
 
 }  // namespace at3
+// occupancy hint for a kernel: register allocation for exactly n wavefronts per SIMD
+#define AT3_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif  // AT3_PK_HPP

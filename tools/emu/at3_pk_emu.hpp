@@ -22,4 +22,5 @@ inline f2 pk_sub_ib(f2 a, f2 b) { return mk2(a.x + b.y, a.y - b.x); }
 inline int opaque_lane_value(int v) { return v; }
 
 }  // namespace at3
+#define AT3_WAVES_PER_EU(n)
 #endif
