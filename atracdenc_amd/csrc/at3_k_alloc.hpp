@@ -35,14 +35,12 @@ struct AllocLds {
             uint16_t huff[130];          // and the code tables
         };
     };
-    float err[7 * 16];               // cache: e1 / e2 of (wordlen, BFU < 10) at (wordlen - 1) * 16 + BFU - what ConsiderEnergyErr reads
-    uint16_t cost[8 * 32];           // cache: VLC bits (the CLC bits are wordlen x lines)
+    float err[7 * 10];               // cache: e1 / e2 of (wordlen, BFU < 10) at (wordlen - 1) * 10 + BFU - what ConsiderEnergyErr reads
+    uint16_t cost[7 * 32];           // cache: VLC bits of (wordlen, BFU) at (wordlen - 1) * 32 + BFU (the CLC bits are wordlen x lines)
     int8_t bm[1024];                 // mantissas of the units of the current batch (one wordlen per BFU)
     uint8_t code[256];               // 2 bits per line of the batch: 1 = re-roundable when e2 < e1, 2 = when e2 > e1
-    float e1[32];
-    uint32_t vlc[32];
     int alloc[32];
-    uint8_t tbits[kMaxTonal * 8];
+    uint8_t tbits[kMaxTonal * 8];    // VLC bits of tonal block t at quantiser q: [t * 8 + q]
     int misc[4];
     unsigned long long tmask[4];
 };
@@ -141,7 +139,6 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
             *reinterpret_cast<float4*>(L.term + (line0 - kTermLine0)) = make_float4(tm[0], tm[1], tm[2], tm[3]);
         }
     }
-    if (lane < 32) L.vlc[lane] = 0u;
     wave_sync();
     // ---- (2) e2 = sum of (mantissa / mul)^2, strictly in line order: one lane per unit ----
     const bool mine = lane < 32 && ((need >> lane) & 1u);
@@ -386,6 +383,9 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
     }
     wave_sync();
     // ---- (4) VLC cost of the final mantissas; (5) cache entries; (6) mantissas to HBM for the packing step ----
+    uint32_t* s_vlc = reinterpret_cast<uint32_t*>(L.uk);   // per-BFU bit counts: the key list is free again
+    if (lane < 32) s_vlc[lane] = 0u;
+    wave_sync();
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int wl = wl_h[h];
@@ -402,14 +402,14 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
             } else {
                 vb = vlc_pair_len(m[0], m[1]) + vlc_pair_len(m[2], m[3]);
             }
-            atomicAdd(&L.vlc[bfu_of_line(line0)], vb);
+            atomicAdd(&s_vlc[bfu_of_line(line0)], vb);
             *reinterpret_cast<uint32_t*>(gmant + (wl - 1) * 1024 + line0) = pk;
         }
     }
     wave_sync();
     if (mine) {
         if (qerr) qerr[(bits - 1) * 32 + lane] = my_e1 / my_e2;   // BFUs >= 10: nothing but the QUANT tap looks at their energy error
-        L.cost[bits * 32 + lane] = (uint16_t)L.vlc[lane];
+        L.cost[(bits - 1) * 32 + lane] = (uint16_t)s_vlc[lane];
     }
     wave_sync();
 }
@@ -417,14 +417,22 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
 // The 70 units of BFUs 0..9 (8 or 16 lines each, no energy-adaptive pass below BFU 19), one lane per unit: ConsiderEnergyErr
 // (atrac3_bitstream.cpp:241-257) looks at the first ten BFUs' energy errors at whatever wordlen the allocation gives them,
 // and the whole set costs less than one large unit.
-__device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant)
+__device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant, float my_e1)
 {
+    float e1_of[2];   // e1 of the unit's BFU, from the lane that owns the BFU (all lanes take part in the exchange)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        const int u = lane + 64 * rd;
+        const int bfu = u < 14 ? 8 + (u & 1) : (u - 14) & 7;
+        e1_of[rd] = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (bfu & 31), (int)__float_as_uint(my_e1)));
+    }
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
         const int u = lane + 64 * rd;
         if (u < 70) {
             // the fourteen 16-line units (BFUs 8, 9) first: the second round's six units are then all 8 lines long
             const int bfu = u < 14 ? 8 + (u & 1) : (u - 14) & 7, wl = u < 14 ? 1 + (u >> 1) : 1 + ((u - 14) >> 3);
+            const float e1 = e1_of[rd];
             const int start = bfu_start(bfu), n = bfu < 8 ? 8 : 16;
             const float mul = max_quant(wl);
             const float inv2 = inv_mul2(wl);
@@ -445,8 +453,8 @@ __device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant
                 vb += vlc_bits8(wl, m);
                 *reinterpret_cast<uint2*>(gmant + (wl - 1) * 1024 + start + off) = make_uint2(pk[0], pk[1]);
             }
-            L.err[(wl - 1) * 16 + bfu] = L.e1[bfu] / e2;
-            L.cost[wl * 32 + bfu] = (uint16_t)vb;
+            L.err[(wl - 1) * 10 + bfu] = e1 / e2;
+            L.cost[(wl - 1) * 32 + bfu] = (uint16_t)vb;
         }
     }
     wave_sync();
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     const int half = p.frame_sz >> 1;
     const int n_tonal = rec->n_tonal;
 
-    for (int i = lane; i < 8 * 32; i += 64) s_cost[i] = 0u;
+    for (int i = lane; i < 7 * 32; i += 64) s_cost[i] = 0u;
     float* qerr = p.quant ? &p.quant[cf].err[0][0] : nullptr;
     if (qerr)
         for (int i = lane; i < 7 * 32; i += 64) qerr[i] = 0.0f;   // (zero = never computed)
@@ -676,7 +684,6 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc += term[k];
         }
-        L.e1[lane] = acc;
         my_e1 = acc;
     }
     __syncthreads();
@@ -685,7 +692,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 1) return;
 #endif
-    small_units(L, lane, gmant);
+    small_units(L, lane, gmant, my_e1);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 2) return;
 #endif
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         gmap = 7u << 21;
 #pragma unroll
         for (int k = 6; k >= 0; --k) {
-            const float e = (k > 0 && i < 10) ? s_err[(k - 1) * 16 + i] : 0.0f;
+            const float e = (k > 0 && i < 10) ? s_err[(k - 1) * 10 + i] : 0.0f;
             const bool climbs = i < 10 && k > 0 && ((e > 0 && e < 0.7f) || e > 1.2f);
             g = climbs ? g : k;
             gmap |= (uint32_t)g << (3 * k);
@@ -844,7 +851,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
                 }
             }
-            const uint32_t mine = (lane < num_bfu && bits) ? (clc_bits(bits, n_i) | ((uint32_t)s_cost[bits * 32 + i] << 13)) : 0u;
+            const uint32_t mine = (lane < num_bfu && bits) ? (clc_bits(bits, n_i) | ((uint32_t)s_cost[(bits - 1) * 32 + i] << 13)) : 0u;
             const uint32_t rsum = row_allreduce_add(mine);
             acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
             // the count of non-zero BFUs comes from a ballot: summed as a third field it would need six bits at
@@ -920,7 +927,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     const int b = alloc_bits(readlane_f(A, t), __builtin_amdgcn_readlane((int)gate, t) != 0, 0,
                                              (uint32_t)__builtin_amdgcn_readlane((int)gmap, t), m_lam);
                     if (lane < memo_n && b) {
-                        m_acc -= clc_bits(b, bfu_start(t + 1) - bfu_start(t)) | ((uint32_t)s_cost[b * 32 + t] << 13);
+                        m_acc -= clc_bits(b, bfu_start(t + 1) - bfu_start(t)) | ((uint32_t)s_cost[(b - 1) * 32 + t] << 13);
                         m_nz -= 1u;
                     }
                 }
@@ -938,8 +945,8 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     if (p.quant) {   // the QUANT tap: what the cache holds at the end (err e1 / e2, cost CLC | VLC << 13; zero = never computed)
         QuantRec* qr = p.quant + cf;
         for (int k = lane; k < 7 * 32; k += 64) {
-            if ((k & 31) < 10) qr->err[k >> 5][k & 31] = s_err[(k >> 5) * 16 + (k & 31)];
-            const uint32_t vb = s_cost[32 + k];
+            if ((k & 31) < 10) qr->err[k >> 5][k & 31] = s_err[(k >> 5) * 10 + (k & 31)];
+            const uint32_t vb = s_cost[k];
             qr->cost[k >> 5][k & 31] = vb ? (clc_bits(1 + (k >> 5), bfu_start((k & 31) + 1) - bfu_start(k & 31)) | (vb << 13)) : 0u;
         }
     }
