@@ -210,16 +210,16 @@ __device__ __forceinline__ bool psy_scale_job(int wave, int lane, int& k, int& b
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T, int n_cf)
+__global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, const Tables* T, int n_cf)
 {
     __shared__ __attribute__((aligned(16))) float s_spec[kPsyCf][1024];
-    __shared__ int s_run_start[kPsyCf][32];
-    __shared__ int s_run_len[kPsyCf][32];
-    __shared__ uint16_t s_tv_pos[kPsyCf][112];
+    __shared__ uint16_t s_run_start[kPsyCf][32];
+    __shared__ uint8_t s_run_len[kPsyCf][32];
+    __shared__ __attribute__((aligned(4))) uint16_t s_tv_pos[kPsyCf][112];   // after the tonal mapping: s_maxbits (20 KB in all: eight workgroups per CU, the batch's 2048 in one round)
     __shared__ float s_tv_val[kPsyCf][112];
     __shared__ uint8_t s_tv_bfu[kPsyCf][112];
     __shared__ float s_scale[64];                  // ScaleTable
-    __shared__ uint32_t s_maxbits[kPsyCf][32];     // per BFU: max |x| as its bit pattern (ordered like the value for x >= 0)
+    uint32_t (*s_maxbits)[32] = reinterpret_cast<uint32_t (*)[32]>(&s_tv_pos[0][0]);   // per BFU: max |x| as its bit pattern (ordered like the value for x >= 0); the tonal position list's storage, dead by then
     __shared__ int s_any[kPsyCf];                  // some BFU of the channel-frame has a tonal run
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c0 = blockIdx.x * kPsyCf;
@@ -234,10 +234,7 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T, int 
 #pragma unroll
         for (int k = 0; k < kPsyCf; ++k) *reinterpret_cast<float4*>(s_spec[k] + 4 * tid) = x4[k];
     }
-    if (tid < 32 * kPsyCf) {
-        (&s_run_len[0][0])[tid] = 0;
-        (&s_maxbits[0][0])[tid] = 0u;
-    }
+    if (tid < 32 * kPsyCf) (&s_run_len[0][0])[tid] = 0;
     if (tid < kPsyCf) s_any[tid] = 0;
     if (tid >= 128 && tid < 192) s_scale[tid - 128] = T->scale[tid - 128];
     __syncthreads();
@@ -298,8 +295,8 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T, int 
                 a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = nxt;
             }
             if (bestScore > 0.0f) {
-                s_run_start[fk][b] = bestStart;
-                s_run_len[fk][b] = bestLen;
+                s_run_start[fk][b] = (uint16_t)bestStart;
+                s_run_len[fk][b] = (uint8_t)bestLen;
                 s_any[fk] = 1;
             }
         }
@@ -348,6 +345,8 @@ __global__ __launch_bounds__(256) void k_psy(BackParams p, const Tables* T, int 
         }
         rec->n_tonal = nb < kMaxTonal ? nb : kMaxTonal;
     }
+    __syncthreads();
+    if (tid < 32 * kPsyCf) (&s_maxbits[0][0])[tid] = 0u;   // (the position list is dead: its storage holds the maxima now)
     __syncthreads();
 
     // TScaler::Scale per BFU (atrac_scale.cpp:141-172) on the residual spectrum: the maximum is order-free (all
