@@ -465,10 +465,10 @@ def main():
                 line["cpu_baseline"] = cpu_baseline()
             if not args.no_side_workloads:
                 line["other_workloads"] = [
-                    side_workload("configs[1] shape, 'burst' input (gain-control path busy)", 64, 64, LP2, "burst", 10, 2),
-                    side_workload("configs[1] shape, 'tones' input (tonal extraction busy)", 64, 64, LP2, "tones", 10, 2),
-                    side_workload("configs[3]: LP4 66 kbps joint stereo, configs[1] shape, 'noise'", 64, 64, LP4, "noise", 10, 2),
-                    side_workload("shard_1024x128: per-GPU shard of configs[2] (1024 streams x 128 frames) on one GPU, 'noise'", 1024, 128, LP2, "noise", 6, 2),
+                    side_workload("configs[1] shape, 'burst' input (gain-control path busy)", 64, 64, LP2, "burst", 30, 3),
+                    side_workload("configs[1] shape, 'tones' input (tonal extraction busy)", 64, 64, LP2, "tones", 30, 3),
+                    side_workload("configs[3]: LP4 66 kbps joint stereo, configs[1] shape, 'noise'", 64, 64, LP4, "noise", 30, 3),
+                    side_workload("shard_1024x128: per-GPU shard of configs[2] (1024 streams x 128 frames) on one GPU, 'noise'", 1024, 128, LP2, "noise", 10, 2),
                 ]
                 line["widened_rows"] = widened_rows(64)
         print(json.dumps(line))
