@@ -807,16 +807,32 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     // walks the same lambdas until the three header bits it saved tip a comparison: a repeat looks its totals up here -
     // when a BFU is dropped, its own contribution is taken out of every recorded sum - and only a lambda never seen before
     // costs a reduction over the BFUs (and possibly new units).
-    float m_lam = 0.0f;
+    // A repeat does not even walk the recorded lambdas one by one: each record also keeps the bisection's state before its
+    // evaluation and the way the comparison went, `path` is the set of records the latest pass went through (in lane
+    // order: a pass follows the one before it up to the first comparison that goes another way and appends new records
+    // from there on), so after a drop all records redo their comparison at once and the repeat resumes at the first one
+    // that changed - or at the last one when none did. Anything else (a hit outside that order, a full memo) turns the
+    // shortcut off for the frame and the repeat is walked as before.
+    float m_lam = 0.0f, m_min = 0.0f, m_max = 0.0f, m_last = 0.0f;
     uint32_t m_acc = 0u, m_nz = 0u, m_ton = 0u;
+    int m_dir = 0;   // 0: below the target, 1: above, 2: on it (the pass ended there)
     int memo_n = 0;
+    unsigned long long path = 0ull;
+    bool skip_ok = true;
+    int resume = -1;
     bool bits_current = false;
     float final_lam = 0.0f;
     for (;;) {
         float minL = -8.0f, maxL = 20.0f, curL = 0.0f, lastL = 20.0f;
+        if (resume >= 0) {
+            minL = readlane_f(m_min, resume);
+            maxL = readlane_f(m_max, resume);
+            lastL = readlane_f(m_last, resume);
+        }
         bool restart = false;
         for (;;) {
             const bool exhausted = (maxL <= minL);
+            const float pre_min = minL, pre_max = maxL, pre_last = lastL;
             float lam;
             if (exhausted) {
                 lam = lastL;
@@ -825,14 +841,14 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 lam = curL;
             }
             uint32_t acc, nz, tonal_bits = 5;
-            int last_alloc;
+            int rec_lane = -1;   // the record of this evaluation
             const unsigned long long hit = __ballot(lane < memo_n && m_lam == lam);
             if (hit) {
                 const int k = __builtin_ctzll(hit);
                 acc = (uint32_t)__builtin_amdgcn_readlane((int)m_acc, k);
                 nz = (uint32_t)__builtin_amdgcn_readlane((int)m_nz, k);
                 tonal_bits = (uint32_t)__builtin_amdgcn_readlane((int)m_ton, k);
-                last_alloc = __builtin_amdgcn_readlane(alloc_bits(A, gate, tcount, gmap, lam), (num_bfu - 1) & 31);
+                rec_lane = k;
                 bits_current = false;
             } else {
             bits = (lane < num_bfu) ? alloc_bits(A, gate, tcount, gmap, lam) : 0;
@@ -886,7 +902,6 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 const uint32_t group_bands = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
                 if (groups) tonal_bits = 5u + 2u + 10u * groups + 12u * group_bands + members;
             }
-            last_alloc = __builtin_amdgcn_readlane(bits, (num_bfu - 1) & 31);
             if (memo_n < 64) {
                 if (lane == memo_n) {
                     m_lam = lam;
@@ -894,6 +909,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     m_nz = nz;
                     m_ton = tonal_bits;
                 }
+                rec_lane = memo_n;
                 ++memo_n;
             }
             bits_current = true;
@@ -903,20 +919,39 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             const uint32_t spec_bits = (uint32_t)num_bfu * 3 + 6 * nz + (mode ? clc : vlc);
             const uint32_t total = spec_bits + tonal_bits;
             bool done;
+            int dir = 2;
             if (exhausted) {
                 done = true;
             } else if (total < (uint32_t)target) {
                 lastL = curL;
                 maxL = curL - 0.01f;
                 done = false;
+                dir = 0;
             } else if (total > (uint32_t)target) {
                 minL = curL + 0.01f;
                 done = false;
+                dir = 1;
             } else {
                 done = true;
             }
+            if (skip_ok && !exhausted) {
+                if (rec_lane < 0 || (path >> rec_lane) > 1ull) {   // not recorded, or a record the pass already left behind
+                    skip_ok = false;
+                    path = 0ull;
+                } else {
+                    path |= 1ull << rec_lane;
+                    if (lane == rec_lane) {
+                        m_min = pre_min;
+                        m_max = pre_max;
+                        m_last = pre_last;
+                        m_dir = dir;
+                    }
+                }
+            }
             if (!done) continue;
             final_lam = lam;
+            const int last_alloc = (p.bfu_idx_const || num_bfu <= 1) ? 1
+                                   : __builtin_amdgcn_readlane(bits_current ? bits : alloc_bits(A, gate, tcount, gmap, lam), (num_bfu - 1) & 31);
             if (!p.bfu_idx_const && num_bfu > 1 && last_alloc == 0) {
                 // the dropped BFU leaves every recorded evaluation: its bits at that lambda, their cost, its place in the count
                 const int t = num_bfu - 1;
@@ -933,6 +968,17 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 }
                 num_bfu--;
                 restart = true;
+                resume = -1;
+                if (skip_ok && memo_n > 0 && path) {
+                    const uint32_t c1 = m_acc & 0x1fffu, v1 = (m_acc >> 13) & 0x3fffu;
+                    const uint32_t tot = (uint32_t)num_bfu * 3 + 6 * m_nz + (c1 <= v1 ? c1 : v1) + m_ton;
+                    const int nd = tot < (uint32_t)target ? 0 : tot > (uint32_t)target ? 1 : 2;
+                    const unsigned long long changed = __ballot(nd != m_dir) & path;
+                    resume = changed ? __builtin_ctzll(changed) : 63 - __builtin_clzll(path);
+                    path &= (2ull << resume) - 1ull;
+                } else {
+                    path = 0ull;
+                }
             }
             break;
         }
