@@ -71,9 +71,11 @@ __device__ __forceinline__ uint32_t vlc_pair_index(int m0, int m1) { return (uin
 // stream, atrac3_bitstream.cpp:115-149). A code's length depends on |m| only (the sign is the code's last bit), so each
 // table is a row of 4-bit lengths indexed by |m|, held in one or two 64-bit constants instead of a memory look-up;
 // tests/test_abi.py::test_vlc_length_constants re-derives the constants from the code table in at3_common.hpp.
-__device__ __forceinline__ uint32_t vlc_len(int wl, int m)
+struct VlcRow {
+    unsigned long long lo, hi;   // lengths of |m| = 0..15 and 16..31 (the same row twice below wordlen 7)
+};
+__device__ __forceinline__ VlcRow vlc_row(int wl)
 {
-    const uint32_t a = (uint32_t)(m < 0 ? -m : m);
     unsigned long long k;
     switch (wl) {
         case 2: k = 0x331ull; break;
@@ -81,18 +83,28 @@ __device__ __forceinline__ uint32_t vlc_len(int wl, int m)
         case 4: k = 0x55431ull; break;
         case 5: k = 0x46654432ull; break;
         case 6: k = 0x4777766665554443ull; break;
-        default: k = a < 16 ? 0x7766666666555553ull : 0x4888888888877777ull; break;   // wl 7, |m| <= 31
+        default: k = 0x7766666666555553ull; break;   // wl 7, |m| <= 15
     }
-    return (uint32_t)(k >> (4 * (a & 15u))) & 15u;
+    VlcRow r;
+    r.lo = k;
+    r.hi = wl == 7 ? 0x4888888888877777ull : k;   // wl 7, 16 <= |m| <= 31
+    return r;
 }
+__device__ __forceinline__ uint32_t vlc_len(const VlcRow& r, int m)
+{
+    const uint32_t a = (uint32_t)(m < 0 ? -m : m);
+    return (uint32_t)((a < 16 ? r.lo : r.hi) >> (4 * (a & 15u))) & 15u;
+}
+__device__ __forceinline__ uint32_t vlc_len(int wl, int m) { return vlc_len(vlc_row(wl), m); }
 __device__ __forceinline__ uint32_t vlc_pair_len(int m0, int m1) { return (uint32_t)((0x545313545ull >> (4 * (3 * (m0 + 1) + (m1 + 1)))) & 15ull); }
 
 __device__ __forceinline__ uint32_t vlc_bits8(int wl, const int (&m)[8])
 {
     uint32_t vb = 0;
     if (wl > 1) {
+        const VlcRow row = vlc_row(wl);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) vb += vlc_len(wl, m[k]);
+        for (int k = 0; k < 8; ++k) vb += vlc_len(row, m[k]);
     } else {
 #pragma unroll
         for (int k = 0; k < 8; k += 2) vb += vlc_pair_len(m[k], m[k + 1]);
@@ -129,13 +141,15 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
                 // the pass may re-round a line only when it is close to a rounding boundary (|delta| < 0.25) AND lies on the
                 // side the pass moves: rounded towards zero and below the top code (pass taken when e2 < e1) or rounded
                 // away from zero (e2 > e1), atrac_scale.cpp:66-126; which pass runs is known after the energy sums
-                const float am = fabsf((float)m), at = fabsf(t);
-                const float delta = t - (truncf(t) + 0.5f);
-                const uint32_t c = (am < at && am < (mul - 1)) ? 1u : (am > at) ? 2u : 0u;
-                code |= (fabsf(delta) < 0.25f ? c : 0u) << (2 * k);
+                if (h > 0) {   // (BFU 19, the first one with the pass, starts at line 288)
+                    const float am = fabsf((float)m), at = fabsf(t);
+                    const float delta = t - (truncf(t) + 0.5f);
+                    const uint32_t c = (am < at && am < (mul - 1)) ? 1u : (am > at) ? 2u : 0u;
+                    code |= (fabsf(delta) < 0.25f ? c : 0u) << (2 * k);
+                }
             }
             *reinterpret_cast<uint32_t*>(L.bm + line0) = pk;
-            L.code[line0 >> 2] = (uint8_t)code;
+            if (h > 0) L.code[line0 >> 2] = (uint8_t)code;
             *reinterpret_cast<float4*>(L.term + (line0 - kTermLine0)) = make_float4(tm[0], tm[1], tm[2], tm[3]);
         }
     }
@@ -397,8 +411,9 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
             for (int k = 0; k < 4; ++k) m[k] = (int)(int8_t)((pk >> (8 * k)) & 0xff);
             uint32_t vb = 0;
             if (wl > 1) {
+                const VlcRow row = vlc_row(wl);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) vb += vlc_len(wl, m[k]);
+                for (int k = 0; k < 4; ++k) vb += vlc_len(row, m[k]);
             } else {
                 vb = vlc_pair_len(m[0], m[1]) + vlc_pair_len(m[2], m[3]);
             }
@@ -419,43 +434,54 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
 // and the whole set costs less than one large unit.
 __device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant, float my_e1)
 {
-    float e1_of[2];   // e1 of the unit's BFU, from the lane that owns the BFU (all lanes take part in the exchange)
+    // Unit u = 0..13: the 16-line BFUs 8 and 9 at wordlen 1 + u / 2; u = 14..69: BFU (u - 14) % 8 at wordlen 1 + (u - 14) / 8.
+    // Pass one: lane u takes unit u's first eight lines. Pass two: lanes 0..13 take their unit's second eight lines (the
+    // energy sum goes on in line order) while lanes 14..19 take the six units 64..69 - two passes of eight lines, not three.
+    const int uA = lane, uB = 50 + lane;   // (uB is a unit for lanes 14..19 only)
+    const int bfuA = uA < 14 ? 8 + (uA & 1) : (uA - 14) & 7, wlA = uA < 14 ? 1 + (uA >> 1) : 1 + ((uA - 14) >> 3);
+    const int bfuB = (uB - 14) & 7, wlB = 1 + ((uB - 14) >> 3);
+    const bool second = lane < 14, extra = lane >= 14 && lane < 20;
+    // e1 of the units' BFUs, from the lanes that own the BFUs (all lanes take part in the exchanges)
+    const float e1A = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfuA, (int)__float_as_uint(my_e1)));
+    const float e1B = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfuB, (int)__float_as_uint(my_e1)));
+    float e2A = 0.0f, e2B = 0.0f;
+    uint32_t vbA = 0, vbB = 0;
 #pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        const int u = lane + 64 * rd;
-        const int bfu = u < 14 ? 8 + (u & 1) : (u - 14) & 7;
-        e1_of[rd] = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (bfu & 31), (int)__float_as_uint(my_e1)));
-    }
-#pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-        const int u = lane + 64 * rd;
-        if (u < 70) {
-            // the fourteen 16-line units (BFUs 8, 9) first: the second round's six units are then all 8 lines long
-            const int bfu = u < 14 ? 8 + (u & 1) : (u - 14) & 7, wl = u < 14 ? 1 + (u >> 1) : 1 + ((u - 14) >> 3);
-            const float e1 = e1_of[rd];
-            const int start = bfu_start(bfu), n = bfu < 8 ? 8 : 16;
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool own = pass == 0 || second;   // the lane works on unit A (else, in pass two, on unit B if it has one)
+        if (pass == 0 || second || extra) {
+            const int bfu = own ? bfuA : bfuB, wl = own ? wlA : wlB;
+            const int line0 = bfu_start(bfu) + (pass == 1 && second ? 8 : 0);
             const float mul = max_quant(wl);
             const float inv2 = inv_mul2(wl);
-            float e2 = 0.0f;
-            uint32_t vb = 0;
-            for (int off = 0; off < n; off += 8) {
-                const float4 va = *reinterpret_cast<const float4*>(L.val + start + off), vb4 = *reinterpret_cast<const float4*>(L.val + start + off + 4);
-                const float v[8] = {va.x, va.y, va.z, va.w, vb4.x, vb4.y, vb4.z, vb4.w};
-                int m[8];
-                uint32_t pk[2] = {0u, 0u};
+            const float4 va = *reinterpret_cast<const float4*>(L.val + line0), vb4 = *reinterpret_cast<const float4*>(L.val + line0 + 4);
+            const float v[8] = {va.x, va.y, va.z, va.w, vb4.x, vb4.y, vb4.z, vb4.w};
+            int m[8];
+            uint32_t pk[2] = {0u, 0u};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    m[k] = __float2int_rn(v[k] * mul);
-                    pk[k >> 2] |= (uint32_t)(uint8_t)m[k] << (8 * (k & 3));
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) e2 += (float)(m[k] * m[k]) * inv2;
-                vb += vlc_bits8(wl, m);
-                *reinterpret_cast<uint2*>(gmant + (wl - 1) * 1024 + start + off) = make_uint2(pk[0], pk[1]);
+            for (int k = 0; k < 8; ++k) {
+                m[k] = __float2int_rn(v[k] * mul);
+                pk[k >> 2] |= (uint32_t)(uint8_t)m[k] << (8 * (k & 3));
             }
-            L.err[(wl - 1) * 10 + bfu] = e1 / e2;
-            L.cost[(wl - 1) * 32 + bfu] = (uint16_t)vb;
+            float e2 = own ? e2A : e2B;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e2 += (float)(m[k] * m[k]) * inv2;
+            const uint32_t vb = vlc_bits8(wl, m);
+            if (own) {
+                e2A = e2;
+                vbA += vb;
+            } else {
+                e2B = e2;
+                vbB += vb;
+            }
+            *reinterpret_cast<uint2*>(gmant + (wl - 1) * 1024 + line0) = make_uint2(pk[0], pk[1]);
         }
+    }
+    L.err[(wlA - 1) * 10 + bfuA] = e1A / e2A;
+    L.cost[(wlA - 1) * 32 + bfuA] = (uint16_t)vbA;
+    if (extra) {
+        L.err[(wlB - 1) * 10 + bfuB] = e1B / e2B;
+        L.cost[(wlB - 1) * 32 + bfuB] = (uint16_t)vbB;
     }
     wave_sync();
 }
@@ -1071,49 +1097,73 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         put_bits(s_words, pos + 6 * __popcll(nzmask & ((1ull << lane) - 1ull)), (uint32_t)my_sfi, 6);
     pos += 6 * __popcll(nzmask);
     {
-        uint32_t code[16];
-        int sum = 0;
+        // The lane's codes are strung together in registers, most significant bit first: first into groups of at most 30
+        // bits (four fixed-length codes, or three / three / two Huffman codes per eight lines), then group by group into
+        // a 64-bit window that reaches the shared bit buffer one 32-bit word at a time.
+        uint32_t grp[6], glen[6];
+        int n_grp;
+        if (mode == 1) {
+            // fixed-length codes: clc_len(wl) bits of the mantissa; at wordlen 1 the pair code (m0 & 3) << 2 | (m1 & 3)
+            // (MantissaToCLcIdx {2, 3, 0, 1}[m + 2] == m & 3, atrac3_bitstream.cpp:77-90) is two such codes of two bits
+            n_grp = 4;
 #pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-            const int wl = wl_h[hlf];
-            const uint2 pk = pk_h[hlf];
-            int8_t m8[8];
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int wl = wl_h[hlf];
+                const int nb = wl == 1 ? 2 : clc_len(wl);
+                const uint32_t mask = (1u << nb) - 1u;
+                const uint2 pk = pk_h[hlf];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) m8[k] = (int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
+                for (int q = 0; q < 2; ++q) {
+                    const uint32_t w = q ? pk.y : pk.x;
+                    uint32_t g = w & mask;
+                    g = (g << nb) | ((w >> 8) & mask);
+                    g = (g << nb) | ((w >> 16) & mask);
+                    g = (g << nb) | ((w >> 24) & mask);
+                    grp[2 * hlf + q] = g;
+                    glen[2 * hlf + q] = 4u * (uint32_t)nb;
+                }
+            }
+            grp[4] = grp[5] = glen[4] = glen[5] = 0u;
+        } else {
+            n_grp = 6;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                uint32_t cl = 0;
-                if (wl > 1) {
-                    if (mode == 1) {
-                        const int nb = clc_len(wl);
-                        cl = ((uint32_t)m8[k] & ((1u << nb) - 1u)) | ((uint32_t)nb << 16);
-                    } else {
-                        const uint32_t e = lds_huff(s_huff, wl, vlc_index(m8[k]));
-                        cl = (e & 0xffu) | ((e >> 8) << 16);
-                    }
-                } else if (wl == 1 && (k & 1) == 0) {
-                    if (mode == 1) {
-                        // MantissaToCLcIdx {2, 3, 0, 1}[m + 2] == m & 3 (atrac3_bitstream.cpp:77-90)
-                        cl = ((((uint32_t)m8[k] & 3u) << 2) | ((uint32_t)m8[k + 1] & 3u)) | (4u << 16);
-                    } else {
-                        const uint32_t e = lds_huff(s_huff, 1, vlc_pair_index(m8[k], m8[k + 1]));
-                        cl = (e & 0xffu) | ((e >> 8) << 16);
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int wl = wl_h[hlf];
+                const uint2 pk = pk_h[hlf];
+                const int base = huff_off(wl);
+                int8_t m8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m8[k] = (int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
+                uint32_t g = 0u, gl = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    uint32_t e = 0u;   // code | length << 8
+                    if (wl > 1) e = s_huff[base + vlc_index(m8[k])];
+                    else if (wl == 1 && (k & 1) == 0) e = s_huff[vlc_pair_index(m8[k], m8[k + 1])];
+                    const uint32_t n = e >> 8;   // <= 10
+                    g = (g << n) | (e & 0xffu);
+                    gl += n;
+                    if (k == 2 || k == 5 || k == 7) {
+                        const int gi = 3 * hlf + (k == 2 ? 0 : k == 5 ? 1 : 2);
+                        grp[gi] = g;
+                        glen[gi] = gl;
+                        g = 0u;
+                        gl = 0u;
                     }
                 }
-                code[8 * hlf + k] = cl;
-                sum += (int)(cl >> 16);
             }
         }
-        // the lane's codes are strung together in registers (most significant bit first) and reach the shared bit
-        // buffer one 32-bit word at a time: two to four atomic ORs per lane instead of one or two per code
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sum += (int)glen[k];
         const int off = pos + wave_inclusive_scan(sum, lane) - sum;
         int cur = off >> 5, fill = off & 31;
         uint64_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int n = (int)(code[k] >> 16);   // <= 10
-            if (n) {
-                acc |= (uint64_t)(code[k] & ((1u << n) - 1u)) << (64 - fill - n);
+        for (int k = 0; k < 6; ++k) {
+            if (k < n_grp) {
+                const int n = (int)glen[k];   // <= 30
+                acc |= (uint64_t)grp[k] << ((64 - fill - n) & 63);
                 fill += n;
                 if (fill >= 32) {
                     if (cur < kBitWords) atomicOr(&s_words[cur], (uint32_t)(acc >> 32));

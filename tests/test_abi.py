@@ -67,7 +67,7 @@ def test_vlc_length_constants():
             assert f"case {sel}: k = {hex(k)}ull" in alloc, sel
         else:
             lo, hi = k & ((1 << 64) - 1), k >> 64
-            assert f"a < 16 ? {hex(lo)}ull : {hex(hi)}ull" in alloc
+            assert f"default: k = {hex(lo)}ull" in alloc and f"wl == 7 ? {hex(hi)}ull : k" in alloc
     rt9 = [8, 4, 7, 2, 0, 1, 6, 3, 5]
     kp = sum(bits[rt9[i]] << (4 * i) for i in range(9))
     assert f"({hex(kp)}ull >> (4 * (3 * (m0 + 1) + (m1 + 1))))" in alloc
