@@ -154,6 +154,9 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
         }
     }
     wave_sync();
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (dbg == 9) return;
+#endif
     // ---- (2) e2 = sum of (mantissa / mul)^2, strictly in line order: one lane per unit ----
     const bool mine = lane < 32 && ((need >> lane) & 1u);
     const int my_start = bfu_start(lane & 31), my_n = bfu_start((lane & 31) + 1) - my_start;
@@ -184,6 +187,9 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
         my_e2 = acc;
     }
     wave_sync();   // the terms' storage becomes the key list and the candidate records
+#ifdef AT3HIP_DEBUG_KNOBS
+    if (dbg == 10) return;
+#endif
     // ---- (3) energy-adaptive re-rounding of the new units above BFU 18 (atrac_scale.cpp:66-128) ----
     // A line is a candidate when it passes the side test of the pass that will run (skipped candidates change no state),
     // and the pass visits the candidates by ascending |delta|: the position of a candidate is the number of keys of its unit
