@@ -166,23 +166,37 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
         my_inv2 = inv_mul2(bits);
         const float4* t4 = reinterpret_cast<const float4*>(L.term + (my_start - kTermLine0));
         float acc = 0.0f;
-        float4 c0 = t4[0], c1 = t4[1];
-        for (int off = 0; off < my_n; off += 8) {   // eight terms per step, the next eight in flight
-            float4 n0 = c0, n1 = c1;
-            if (off + 8 < my_n) {
-                n0 = t4[(off >> 2) + 2];
-                n1 = t4[(off >> 2) + 3];
+        // sixteen terms per step (the units here are 16 to 128 lines long), the next sixteen in flight in a second set of
+        // registers: the two sets swap roles from one step to the next instead of being copied
+        float4 a0 = t4[0], a1 = t4[1], a2 = t4[2], a3 = t4[3];
+        float4 b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+        for (int off = 0;;) {
+            const bool more_b = off + 16 < my_n;
+            if (more_b) {
+                b0 = t4[(off >> 2) + 4];
+                b1 = t4[(off >> 2) + 5];
+                b2 = t4[(off >> 2) + 6];
+                b3 = t4[(off >> 2) + 7];
             }
-            acc += c0.x;
-            acc += c0.y;
-            acc += c0.z;
-            acc += c0.w;
-            acc += c1.x;
-            acc += c1.y;
-            acc += c1.z;
-            acc += c1.w;
-            c0 = n0;
-            c1 = n1;
+            acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w;
+            acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w;
+            acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w;
+            acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w;
+            if (!more_b) break;
+            off += 16;
+            const bool more_a = off + 16 < my_n;
+            if (more_a) {
+                a0 = t4[(off >> 2) + 4];
+                a1 = t4[(off >> 2) + 5];
+                a2 = t4[(off >> 2) + 6];
+                a3 = t4[(off >> 2) + 7];
+            }
+            acc += b0.x; acc += b0.y; acc += b0.z; acc += b0.w;
+            acc += b1.x; acc += b1.y; acc += b1.z; acc += b1.w;
+            acc += b2.x; acc += b2.y; acc += b2.z; acc += b2.w;
+            acc += b3.x; acc += b3.y; acc += b3.z; acc += b3.w;
+            if (!more_a) break;
+            off += 16;
         }
         my_e2 = acc;
     }
@@ -734,14 +748,28 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     const int n_i = opaque_lane_value(bfu_start(i + 1) - bfu_start(i));   // (computed once: not re-derived inside the rate loop)
     float spread;
     {
-        float sum = 0.0f;
-        for (int k = 0; k < 32; ++k) sum += (float)__builtin_amdgcn_readlane(my_sfi, k);
-        sum /= 32;
-        float sigma = 0.0f;
-        for (int k = 0; k < 32; ++k) {
-            float t = ((float)__builtin_amdgcn_readlane(my_sfi, k) - sum);
-            t *= t;
-            sigma += t;
+        // The reference's two sequential float sums are sums of exactly representable terms: the 32 indices (integers
+        // below 64) and, with m their total, the squares ((32 sfi - m) / 32)^2 = integer / 1024. While the integer total S2
+        // of the second sum stays below 2^24 no partial sum rounds, so both come out of integer reductions across the
+        // lanes; a frame with a wilder spread (sigma above 22, clamped to 14 anyway) takes the literal loops.
+        const uint32_t r1 = row_allreduce_add(lane < 32 ? (uint32_t)my_sfi : 0u);
+        const int m = (int)((uint32_t)__builtin_amdgcn_readlane((int)r1, 0) + (uint32_t)__builtin_amdgcn_readlane((int)r1, 16));
+        const int d = 32 * my_sfi - m;
+        const uint32_t r2 = row_allreduce_add(lane < 32 ? (uint32_t)(d * d) : 0u);
+        const uint32_t S2 = (uint32_t)__builtin_amdgcn_readlane((int)r2, 0) + (uint32_t)__builtin_amdgcn_readlane((int)r2, 16);
+        float sigma;
+        if (S2 < (1u << 24)) {
+            sigma = (float)S2 / 1024.0f;
+        } else {
+            float sum = 0.0f;
+            for (int k = 0; k < 32; ++k) sum += (float)__builtin_amdgcn_readlane(my_sfi, k);
+            sum /= 32;
+            sigma = 0.0f;
+            for (int k = 0; k < 32; ++k) {
+                float t = ((float)__builtin_amdgcn_readlane(my_sfi, k) - sum);
+                t *= t;
+                sigma += t;
+            }
         }
         sigma /= 32;
         sigma = sqrtf(sigma);
