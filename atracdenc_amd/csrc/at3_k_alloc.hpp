@@ -96,13 +96,41 @@ __device__ __forceinline__ uint32_t vlc_len(const VlcRow& r, int m)
     return (uint32_t)((a < 16 ? r.lo : r.hi) >> (4 * (a & 15u))) & 15u;
 }
 __device__ __forceinline__ uint32_t vlc_len(int wl, int m) { return vlc_len(vlc_row(wl), m); }
+
+// Per-wordlen constants as a table ACROSS the lanes (lane k & 7 holds the entries of wordlen k): the wordlen differs from
+// lane to lane wherever these are needed, where a `switch` is a chain of compares and selects per constant; a cross-lane
+// read (ds_bpermute, no LDS storage, not a vector-ALU instruction) fetches all of them with one address. Every lane must
+// be active at a lookup (an inactive lane's entry reads as zero): lookups stand outside divergent code.
+struct LaneTab {
+    float mq, inv;       // max_quant(k), inv_mul2(k)
+    uint32_t lo0, lo1;   // vlc_row(k).lo
+};
+__device__ __forceinline__ LaneTab lane_tab(int lane)
+{
+    const int k = lane & 7;
+    const VlcRow r = vlc_row(k);
+    LaneTab t;
+    t.mq = max_quant(k);
+    t.inv = inv_mul2(k);
+    t.lo0 = (uint32_t)r.lo;
+    t.lo1 = (uint32_t)(r.lo >> 32);
+    return t;
+}
+__device__ __forceinline__ float tab_f(float v, int wl) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * wl, (int)__float_as_uint(v))); }
+__device__ __forceinline__ VlcRow tab_row(const LaneTab& t, int wl)
+{
+    const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * wl, (int)t.lo0), b = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * wl, (int)t.lo1);
+    VlcRow r;
+    r.lo = (unsigned long long)a | ((unsigned long long)b << 32);
+    r.hi = wl == 7 ? 0x4888888888877777ull : r.lo;
+    return r;
+}
 __device__ __forceinline__ uint32_t vlc_pair_len(int m0, int m1) { return (uint32_t)((0x545313545ull >> (4 * (3 * (m0 + 1) + (m1 + 1)))) & 15ull); }
 
-__device__ __forceinline__ uint32_t vlc_bits8(int wl, const int (&m)[8])
+__device__ __forceinline__ uint32_t vlc_bits8(int wl, const VlcRow& row, const int (&m)[8])
 {
     uint32_t vb = 0;
     if (wl > 1) {
-        const VlcRow row = vlc_row(wl);
 #pragma unroll
         for (int k = 0; k < 8; ++k) vb += vlc_len(row, m[k]);
     } else {
@@ -114,7 +142,7 @@ __device__ __forceinline__ uint32_t vlc_bits8(int wl, const int (&m)[8])
 
 // Quantise the units {(b, wl_b) : bit b of `need`}, wl_b = lane b's `bits` (QuantMantisas + CLC/VLC cost,
 // atrac3_bitstream.cpp:154-173, atrac_scale.cpp:40-130). Lane b < 32 passes BFU b's e1 in `my_e1`. Wave-uniform call.
-__device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bits, float my_e1, int lane, int8_t* gmant, float* qerr, int dbg = 0)
+__device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, uint32_t need, int bits, float my_e1, int lane, int8_t* gmant, float* qerr, int dbg = 0)
 {
     // ---- (1) mantissa = lrint(value * MaxQuant[wl]) for the lines of the needed BFUs; energy-adaptive candidate codes ----
     // Four rounds of four lines per lane, line0 = 256 round + 4 lane: a wavefront's 16-byte LDS accesses are one contiguous
@@ -126,8 +154,8 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
         const int b = bfu_of_line(line0);
         const int wl = __builtin_amdgcn_ds_bpermute(4 * b, bits);
         wl_h[h] = ((need >> b) & 1u) ? wl : 0;
+        const float mul = tab_f(tab.mq, wl), inv2 = tab_f(tab.inv, wl);
         if (wl_h[h]) {
-            const float mul = max_quant(wl), inv2 = inv_mul2(wl);
             const float4 va = *reinterpret_cast<const float4*>(L.val + line0);
             const float v[4] = {va.x, va.y, va.z, va.w};
             uint32_t pk = 0u, code = 0;
@@ -160,10 +188,8 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
     // ---- (2) e2 = sum of (mantissa / mul)^2, strictly in line order: one lane per unit ----
     const bool mine = lane < 32 && ((need >> lane) & 1u);
     const int my_start = bfu_start(lane & 31), my_n = bfu_start((lane & 31) + 1) - my_start;
-    float my_mul = 1.0f, my_inv2 = 1.0f, my_e2 = 0.0f;
+    float my_inv2 = tab_f(tab.inv, bits), my_e2 = 0.0f;
     if (mine) {
-        my_mul = max_quant(bits);
-        my_inv2 = inv_mul2(bits);
         const float4* t4 = reinterpret_cast<const float4*>(L.term + (my_start - kTermLine0));
         float acc = 0.0f;
         // sixteen terms per step (the units here are 16 to 128 lines long), the next sixteen in flight in a second set of
@@ -423,6 +449,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int wl = wl_h[h];
+        const VlcRow row = tab_row(tab, wl);
         if (wl) {
             const int line0 = 256 * h + 4 * lane;
             const uint32_t pk = *reinterpret_cast<const uint32_t*>(L.bm + line0);
@@ -431,7 +458,6 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
             for (int k = 0; k < 4; ++k) m[k] = (int)(int8_t)((pk >> (8 * k)) & 0xff);
             uint32_t vb = 0;
             if (wl > 1) {
-                const VlcRow row = vlc_row(wl);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) vb += vlc_len(row, m[k]);
             } else {
@@ -452,7 +478,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, uint32_t need, int bi
 // The 70 units of BFUs 0..9 (8 or 16 lines each, no energy-adaptive pass below BFU 19), one lane per unit: ConsiderEnergyErr
 // (atrac3_bitstream.cpp:241-257) looks at the first ten BFUs' energy errors at whatever wordlen the allocation gives them,
 // and the whole set costs less than one large unit.
-__device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant, float my_e1)
+__device__ __forceinline__ void small_units(AllocLds& L, const LaneTab& tab, int lane, int8_t* gmant, float my_e1)
 {
     // Unit u = 0..13: the 16-line BFUs 8 and 9 at wordlen 1 + u / 2; u = 14..69: BFU (u - 14) % 8 at wordlen 1 + (u - 14) / 8.
     // Pass one: lane u takes unit u's first eight lines. Pass two: lanes 0..13 take their unit's second eight lines (the
@@ -466,14 +492,21 @@ __device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant
     const float e1B = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfuB, (int)__float_as_uint(my_e1)));
     float e2A = 0.0f, e2B = 0.0f;
     uint32_t vbA = 0, vbB = 0;
+    // the units' constants (lanes without a second unit look up wordlen 0)
+    const float mulA = tab_f(tab.mq, wlA), invA = tab_f(tab.inv, wlA);
+    const VlcRow rowA = tab_row(tab, wlA);
+    const int wlB7 = extra ? wlB : 0;
+    const float mulB = tab_f(tab.mq, wlB7), invB = tab_f(tab.inv, wlB7);
+    const VlcRow rowB = tab_row(tab, wlB7);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const bool own = pass == 0 || second;   // the lane works on unit A (else, in pass two, on unit B if it has one)
         if (pass == 0 || second || extra) {
             const int bfu = own ? bfuA : bfuB, wl = own ? wlA : wlB;
             const int line0 = bfu_start(bfu) + (pass == 1 && second ? 8 : 0);
-            const float mul = max_quant(wl);
-            const float inv2 = inv_mul2(wl);
+            const float mul = own ? mulA : mulB;
+            const float inv2 = own ? invA : invB;
+            const VlcRow row = own ? rowA : rowB;
             const float4 va = *reinterpret_cast<const float4*>(L.val + line0), vb4 = *reinterpret_cast<const float4*>(L.val + line0 + 4);
             const float v[8] = {va.x, va.y, va.z, va.w, vb4.x, vb4.y, vb4.z, vb4.w};
             int m[8];
@@ -486,7 +519,7 @@ __device__ __forceinline__ void small_units(AllocLds& L, int lane, int8_t* gmant
             float e2 = own ? e2A : e2B;
 #pragma unroll
             for (int k = 0; k < 8; ++k) e2 += (float)(m[k] * m[k]) * inv2;
-            const uint32_t vb = vlc_bits8(wl, m);
+            const uint32_t vb = vlc_bits8(wl, row, m);
             if (own) {
                 e2A = e2;
                 vbA += vb;
@@ -738,7 +771,8 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 1) return;
 #endif
-    small_units(L, lane, gmant, my_e1);
+    const LaneTab tab = lane_tab(lane);
+    small_units(L, tab, lane, gmant, my_e1);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 2) return;
 #endif
@@ -923,7 +957,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 if (need) {
                     if (lane < 32) s_alloc[lane] = bits;
                     wave_sync();
-                    compute_units(L, need, bits, my_e1, lane, gmant, qerr, p.debug_stop);
+                    compute_units(L, tab, need, bits, my_e1, lane, gmant, qerr, p.debug_stop);
                     if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
                 }
             }
