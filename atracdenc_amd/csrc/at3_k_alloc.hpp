@@ -104,6 +104,8 @@ __device__ __forceinline__ uint32_t vlc_len(int wl, int m) { return vlc_len(vlc_
 struct LaneTab {
     float mq, inv;       // max_quant(k), inv_mul2(k)
     uint32_t lo0, lo1;   // vlc_row(k).lo
+    uint32_t bfus;       // NOT a table: the BFUs of this lane's four line quads, bfu_of_line(256 h + 4 lane) in byte h
+    uint32_t misc;       // CLC bits per line {0, 2, 3, 3, 4, 4, 5, 6}[k] (a pair's four bits at wordlen 1 are two per line) | huff_off(k) << 8
 };
 __device__ __forceinline__ LaneTab lane_tab(int lane)
 {
@@ -114,9 +116,13 @@ __device__ __forceinline__ LaneTab lane_tab(int lane)
     t.inv = inv_mul2(k);
     t.lo0 = (uint32_t)r.lo;
     t.lo1 = (uint32_t)(r.lo >> 32);
+    t.bfus = (uint32_t)opaque_lane_value(bfu_of_line(4 * lane) | (bfu_of_line(256 + 4 * lane) << 8) | (bfu_of_line(512 + 4 * lane) << 16) |
+                                         (bfu_of_line(768 + 4 * lane) << 24));
+    t.misc = (uint32_t)(k == 1 ? 2 : clc_len(k)) | ((uint32_t)huff_off(k) << 8);
     return t;
 }
 __device__ __forceinline__ float tab_f(float v, int wl) { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * wl, (int)__float_as_uint(v))); }
+__device__ __forceinline__ uint32_t tab_u(uint32_t v, int wl) { return (uint32_t)__builtin_amdgcn_ds_bpermute(4 * wl, (int)v); }
 __device__ __forceinline__ VlcRow tab_row(const LaneTab& t, int wl)
 {
     const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * wl, (int)t.lo0), b = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * wl, (int)t.lo1);
@@ -151,7 +157,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int line0 = 256 * h + 4 * lane;
-        const int b = bfu_of_line(line0);
+        const int b = (int)((tab.bfus >> (8 * h)) & 0xffu);
         const int wl = __builtin_amdgcn_ds_bpermute(4 * b, bits);
         wl_h[h] = ((need >> b) & 1u) ? wl : 0;
         const float mul = tab_f(tab.mq, wl), inv2 = tab_f(tab.inv, wl);
@@ -463,7 +469,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             } else {
                 vb = vlc_pair_len(m[0], m[1]) + vlc_pair_len(m[2], m[3]);
             }
-            atomicAdd(&s_vlc[bfu_of_line(line0)], vb);
+            atomicAdd(&s_vlc[(tab.bfus >> (8 * h)) & 0xffu], vb);
             *reinterpret_cast<uint32_t*>(gmant + (wl - 1) * 1024 + line0) = pk;
         }
     }
@@ -961,7 +967,8 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
                 }
             }
-            const uint32_t mine = (lane < num_bfu && bits) ? (clc_bits(bits, n_i) | ((uint32_t)s_cost[(bits - 1) * 32 + i] << 13)) : 0u;
+            const uint32_t clc_i = (tab_u(tab.misc, bits) & 7u) * (uint32_t)n_i;   // == clc_bits(bits, n_i)
+            const uint32_t mine = (lane < num_bfu && bits) ? (clc_i | ((uint32_t)s_cost[(bits - 1) * 32 + i] << 13)) : 0u;
             const uint32_t rsum = row_allreduce_add(mine);
             acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
             // the count of non-zero BFUs comes from a ballot: summed as a third field it would need six bits at
@@ -1177,7 +1184,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #pragma unroll
             for (int hlf = 0; hlf < 2; ++hlf) {
                 const int wl = wl_h[hlf];
-                const int nb = wl == 1 ? 2 : clc_len(wl);
+                const int nb = (int)(tab_u(tab.misc, wl) & 7u);
                 const uint32_t mask = (1u << nb) - 1u;
                 const uint2 pk = pk_h[hlf];
 #pragma unroll
@@ -1198,7 +1205,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             for (int hlf = 0; hlf < 2; ++hlf) {
                 const int wl = wl_h[hlf];
                 const uint2 pk = pk_h[hlf];
-                const int base = huff_off(wl);
+                const int base = (int)(tab_u(tab.misc, wl) >> 8);
                 int8_t m8[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) m8[k] = (int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
