@@ -73,3 +73,39 @@ def test_vlc_length_constants():
     assert f"({hex(kp)}ull >> (4 * (3 * (m0 + 1) + (m1 + 1))))" in alloc
     ki = sum(rt9[i] << (4 * i) for i in range(9))
     assert f"({hex(ki)}ull >> (4 * (3 * (m0 + 1) + (m1 + 1))))" in alloc
+
+
+def test_spread_integer_shortcut_is_exact():
+    """k_alloc_pack (at3_k_alloc.hpp, TConfigure's spread) replaces the reference's two sequential float sums over the 32
+    scale-factor indices (atrac3_bitstream.cpp:590-621) by integer reductions whenever S2 = sum (32 sfi - m)^2 < 2^24, m the
+    indices' total: then every term and every partial sum of the float loops is exactly representable. Replay both here."""
+    import numpy as np
+    rng = np.random.RandomState(11)
+    f32 = np.float32
+    taken = 0
+    for trial in range(4000):
+        kind = trial % 4
+        if kind == 0:
+            sfi = rng.randint(0, 64, size=32)
+        elif kind == 1:
+            sfi = np.clip(rng.randint(20, 30) + rng.randint(-6, 7, size=32), 0, 63)
+        elif kind == 2:
+            sfi = np.where(rng.rand(32) < rng.rand(), 63, 0)
+        else:
+            sfi = np.clip((rng.randn(32) * rng.uniform(1, 25) + 30).astype(int), 0, 63)
+        s = f32(0)
+        for v in sfi:
+            s = f32(s + f32(v))
+        s = f32(s / f32(32))
+        sigma = f32(0)
+        for v in sfi:
+            t = f32(f32(v) - s)
+            t = f32(t * t)
+            sigma = f32(sigma + t)
+        m = int(sfi.sum())
+        d = 32 * sfi.astype(np.int64) - m
+        S2 = int((d * d).sum())
+        if S2 < (1 << 24):
+            taken += 1
+            assert f32(f32(S2) / f32(1024.0)) == sigma, (sfi, S2)
+    assert 1000 < taken < 4000    # both sides of the guard were visited
