@@ -159,7 +159,10 @@ int at3hip_read_tap(at3hip_ctx* ctx, int32_t kind, void* dst, size_t bytes);
  * Zeroed for calls that produced no frames (the LOOK_AHEAD call). */
 int at3hip_get_timings_ago(at3hip_ctx* ctx, int32_t ago, at3hip_timings* out);
 
-/* Bind all work of this ctx to a caller-provided hipStream_t (NULL = the ctx's own stream). */
+/* Order this ctx's work after a caller-provided hipStream_t (NULL = the ctx's own stream): the first stage of every call
+ * is queued on that stream - behind whatever the caller queued there, e.g. the kernel that produces `pcm` -, the later
+ * stages run on the ctx's own two streams behind HIP events (the rate loop's at the higher priority). Completion is as
+ * before: the call's return, or at3hip_sync() for AT3HIP_ASYNC calls. The stream must outlive its last call's completion. */
 int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
 
 /* Library/ABI version: (major << 16) | minor. */
