@@ -575,3 +575,35 @@ def test_bench_contract_and_two_context_paths(tmp_path):
                     "--master-port", "29533", bench, "--gpus", "2", "--device-map", "0,0", "--steps", "2", "--warmup", "1", "--streams", "64",
                     "--frames", "16", "--no-side-workloads", "--no-cpu-baseline"])
     assert d3["n_gpus"] == 2 and "ranks" in d3["config"]["launch"] and d3["value"] > 1e5
+
+
+def wild_spread_pcm(nb, seed):
+    """Full-scale noise below 3.5 kHz and float rounding dust above it: half of the BFUs scale near the top of the table, the
+    other half at its bottom - a spread of the scale-factor indices that no ordinary material has."""
+    rng = np.random.RandomState(seed)
+    n = nb * 1024
+    x = rng.uniform(-1, 1, size=(n, 2))
+    X = np.fft.rfft(x, axis=0)
+    X[int(3500.0 / 22050.0 * (n // 2)):] = 0
+    y = np.fft.irfft(X, n=n, axis=0)
+    return (0.9 * y / np.abs(y).max()).astype(np.float32).reshape(nb, 1024, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ng", [0, 1])
+def test_wild_scale_factor_spread(hip, oracle, ng):
+    """k_alloc_pack takes TConfigure's spread from two integer reductions while the reference's float sums are provably
+    exact (S2 = sum (32 sfi - m)^2 < 2^24) and runs the literal sequential loops otherwise. Ordinary signals never leave the
+    fast side; this one does (checked on the PSY tap), and the frames still have to match."""
+    from atracdenc_amd import binding as B
+    nb = 9
+    pcm = np.stack([wild_spread_pcm(nb, 5), wild_spread_pcm(nb, 6)])
+    enc = hip.At3Hip(n_streams=2, max_blocks=nb, bitrate=LP2, no_gain=bool(ng))
+    got = enc.encode(pcm)
+    psy = enc.read_tap(B.TAP_PSY, B.At3Hip.PSY_DTYPE, (2, nb - 1, 2))
+    enc.close()
+    sfi = psy["sfi"].astype(np.int64).reshape(-1, 32)
+    d = 32 * sfi - sfi.sum(1, keepdims=True)
+    assert ((d * d).sum(1) >= (1 << 24)).any()
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.encode(pcm[i], LP2, ng, 0)[0]), i
