@@ -12,6 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 AT3HIP_PCM_ON_DEVICE = 1
 AT3HIP_OUT_ON_DEVICE = 2
 AT3HIP_ASYNC = 4
+OPT_RUNS, OPT_FLATNESS_LITERAL = 1, 2
 TAP_SPECTRA, TAP_CURVES, TAP_ENERGY_SCALE, TAP_PSY, TAP_LOUDNESS, TAP_QUANT = 1, 2, 3, 4, 5, 6
 LP2 = 132300
 LP4 = 66150
@@ -34,7 +35,7 @@ class Timings(ctypes.Structure):
 SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint_stereo", "at3hip_last_error",
            "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
            "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago", "at3hip_read_tap",
-           "at3hip_mdct_levels", "at3hip_gain_energy_scale"]
+           "at3hip_mdct_levels", "at3hip_gain_energy_scale", "at3hip_set_option", "at3hip_host_tables"]
 # include/at1hip.h
 AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_encode", "at1hip_reset", "at1hip_get_timings",
                "at1hip_read_tap", "at1hip_host_tables"]
@@ -103,6 +104,8 @@ def load_library(path=None):
     lib.at3hip_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
     lib.at3hip_set_stream.argtypes = [vp, vp]
     lib.at3hip_sync.argtypes = [vp]
+    lib.at3hip_set_option.argtypes = [vp, i32, i32]
+    lib.at3hip_host_tables.argtypes = [vp, ctypes.c_size_t]
     lib.at3hip_read_tap.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.at3hip_get_timings_ago.argtypes = [vp, i32, ctypes.POINTER(Timings)]
     lib.at3hip_version.restype = ctypes.c_uint32
@@ -196,7 +199,7 @@ class At3Hip:
 
     PSY_DTYPE = np.dtype([("loud_ch", "<f4"), ("n_tonal", "<i4"), ("sfi", "u1", 32), ("energy", "<f4", 32),
                           ("tonal", [("pos", "<u2"), ("bfu", "u1"), ("len", "u1"), ("sfi", "u1"), ("pad", "u1", 3),
-                                     ("values", "<f4", 7), ("pad2", "u1", 4)], 24)])
+                                     ("values", "<f4", 7), ("pad2", "u1", 4)], 24), ("flat", "<f4", 32)])
     QUANT_DTYPE = np.dtype([("err", "<f4", (7, 32)), ("cost", "<u4", (7, 32))])
 
     def read_tap(self, kind, dtype, shape):
@@ -207,6 +210,10 @@ class At3Hip:
 
     def sync(self):
         self._check(self.lib.at3hip_sync(self.ctx), "at3hip_sync")
+
+    def set_option(self, option, value):
+        """AT3HIP_OPT_*: work partitioning / equivalent-form switches; results never change."""
+        self._check(self.lib.at3hip_set_option(self.ctx, int(option), int(value)), "at3hip_set_option")
 
     def set_stream(self, hip_stream):
         """Queue the front half on the caller's HIP stream (a hipStream_t handle, e.g. torch.cuda.Stream().cuda_stream);
@@ -262,6 +269,25 @@ class At3Hip:
         t = Timings()
         self._check(self.lib.at3hip_get_timings(self.ctx, ctypes.byref(t)), "at3hip_get_timings")
         return {n: getattr(t, n) for n, _ in Timings._fields_}
+
+
+# atracdenc_amd/csrc/at3_tables.hpp, struct Tables (cpx = two float32)
+AT3_TABLES_DTYPE = np.dtype([("qmf_win", "<f4", 48), ("scale", "<f4", 64), ("enc_win", "<f4", 256), ("gain_level", "<f4", 16),
+                             ("gain_interp", "<f4", 32), ("mdct_sincos", "<f4", 256), ("planck", "<f4", 512), ("hpf_w", "<f4", 4),
+                             ("loud_curve", "<f4", 1024), ("ath_bfu", "<f4", 32), ("tw128", "<f4", (128, 2)), ("tw256", "<f4", (256, 2)),
+                             ("stw256", "<f4", (128, 2)), ("tw2048", "<f4", (2048, 2)), ("stw2048", "<f4", (1024, 2)),
+                             ("log2f_tab", "<f8", (16, 2)), ("log2f_poly", "<f8", 4), ("gain_tw", "<f4", (27, 128, 2)),
+                             ("spec_tw", "<f4", (14, 64, 2)), ("planck4", "<f4", (4, 64, 2)), ("log_c", "<f8", 18),
+                             ("log_tab", "<f8", (128, 2)), ("exp_c", "<f8", 8), ("exp_tab", "<u8", (128, 2))])
+
+
+def at3_host_tables(lib_path=None):
+    """The ATRAC3 constant tables as the library builds them on this host (no GPU involved)."""
+    out = np.zeros((), dtype=AT3_TABLES_DTYPE)
+    rc = load_library(lib_path).at3hip_host_tables(_vp(out), out.nbytes)
+    if rc != 0:
+        raise At3HipError(f"at3hip_host_tables failed ({rc}): table block is {out.nbytes} bytes here")
+    return out
 
 
 AT1_TABLES_DTYPE = np.dtype([("qmf_win", "<f4", 48), ("scale", "<f4", 64), ("sine", "<f4", 32), ("sc512", "<f4", 256),

@@ -56,7 +56,9 @@ struct PsyRec {         // per (stream, frame, channel)
     uint8_t sfi[32];
     float energy[32];
     TonalBlock tonal[kMaxTonal];
+    float flat[32];     // spectral flatness of BFUs 8..28 (the ones ExtractTonalComponents looks at; 0 elsewhere and with NoTonalComponents)
 };
+static_assert(sizeof(PsyRec) == 1256, "PsyRec layout (AT3HIP_TAP_PSY)");
 
 // ---- integer constant tables (atrac/at3/atrac3.h:79-176, atrac3_bitstream.cpp:44-49) ----
 __device__ static const uint16_t c_bfu_start[33] = {

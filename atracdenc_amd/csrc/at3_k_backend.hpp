@@ -33,6 +33,7 @@ struct BackParams {
     int mono_js;             // one input channel in a joint-stereo container: empty second sound unit (atrac3denc.cpp:843-849)
     struct QuantRec* quant;  // [S][n_out][2] the unit cache's final content, for the QUANT tap (zero for units never asked for)
     int8_t* mant;            // [S][n_out][2][7][1024] mantissas of the units k_alloc_pack computed, by wordlen
+    int flat_literal;        // AT3HIP_OPT_FLATNESS_LITERAL: every flatness measure by the literal per-line form (test aid; same results)
     int debug_stop;          // profiling aid (env AT3HIP_DEBUG_STOP, -DAT3HIP_DEBUG_KNOBS builds): stage exits of k_alloc_pack
 };
 
@@ -234,7 +235,11 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
 #pragma unroll
         for (int k = 0; k < kPsyCf; ++k) *reinterpret_cast<float4*>(s_spec[k] + 4 * tid) = x4[k];
     }
-    if (tid < 32 * kPsyCf) (&s_run_len[0][0])[tid] = 0;
+    if (tid < 32 * kPsyCf) {
+        (&s_run_len[0][0])[tid] = 0;
+        const int k = tid >> 5, b = tid & 31;   // the PSY tap's flatness entries nobody measures
+        if (k < ncf && (p.no_tonal || b < 8 || b > 28)) rec0[k].flat[b] = 0.0f;
+    }
     if (tid < kPsyCf) s_any[tid] = 0;
     if (tid >= 128 && tid < 192) s_scale[tid - 128] = T->scale[tid - 128];
     __syncthreads();
@@ -244,11 +249,17 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
         const int b = fb;
         const float* sp = s_spec[fk];
         const int start = bfu_start(b), end = bfu_start(b + 1), len = end - start;
-        // CalcSpectralFlatnessPerBfu (atrac_psy_common.cpp:158-199) needs mean(log(max(e, floor))). The logarithm of a
-        // product is the sum of the logarithms: the lines' f64 mantissas are multiplied (8 .. 64 factors in [0.5, 1),
-        // no underflow), their exponents added, and ONE log per BFU closes the sum - instead of one f64 log per
-        // spectral line, which was a third of this kernel. The result differs from the reference's sum of rounded
-        // logs by a few 1e-16 relative; it is narrowed to f32 and only compared with 0.01.
+        // CalcSpectralFlatnessPerBfu (atrac_psy_common.cpp:158-199): flat = exp(mean(log(max(e, floor)))) / mean(e) in f64
+        // with glibc's log and exp, narrowed to f32. Two forms, same bits:
+        //  * literal: one restated glibc log per line (at3_libm64.hpp), the reference's ordered sums, the restated exp;
+        //  * short:   the logarithm of a product is the sum of the logarithms - the lines' f64 mantissas are multiplied
+        //    (8 .. 64 factors in [0.5, 1), no underflow), their exponents added, ONE log per BFU closes the sum (a log per
+        //    line was a third of this kernel). Its ratio differs from the reference's by rounding only: the reference's mean
+        //    of <= 64 rounded logs (|log| <= 27.7, partial sums below 2048) is within 1.3e-13 of the exact mean, this form's
+        //    (a product of <= 64 factors, one log, exponent sum x ln 2, all in f64) within 4e-14, the two exp / divisions add
+        //    1e-15: relative distance below 2e-13. When BOTH ends of [ratio (1 - 1e-12), ratio (1 + 1e-12)] narrow to the
+        //    same f32 after the clamp, that f32 is the reference's value; otherwise (about 3 in 100 000 BFUs) the literal
+        //    form runs. Any device log / exp within a few hundred ulp serves the short form.
         double arith = 0.0, prod = 1.0;
         int esum = 0;
         const double floor_ = (double)1e-12f;
@@ -266,12 +277,26 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
             }
         }
         arith /= (double)len;
-        const double meanLog = (log(prod) + (double)esum * 0.69314718055994530942) / (double)len;
         float flat = 1.0f;
-        if (!(arith <= (double)1e-12f)) {
+        if (!(arith <= floor_)) {
+            const double meanLog = (log(prod) + (double)esum * 0.69314718055994530942) / (double)len;
             const double ratio = exp(meanLog) / arith;
-            flat = (float)fmin(1.0, fmax(0.0, ratio));
+            const float f_lo = (float)fmin(1.0, fmax(0.0, ratio * (1.0 - 1e-12)));
+            const float f_hi = (float)fmin(1.0, fmax(0.0, ratio * (1.0 + 1e-12)));
+            flat = f_lo;
+            if (f_lo != f_hi || p.flat_literal) {
+                const Libm64* M = &T->libm;
+                double ml = 0.0;
+                for (int i = start; i < end; ++i) {
+                    const float x = sp[i];
+                    const double e = (double)fmaxf(0.0f, x * x);
+                    ml += at3_log(M, e > floor_ ? e : floor_);
+                }
+                ml /= (double)len;
+                flat = (float)fmin(1.0, fmax(0.0, at3_exp(M, ml) / arith));
+            }
         }
+        rec0[fk].flat[b] = flat;
         if (flat < 0.01f) {  // ExtractTonalComponents search, atrac3denc.cpp:606-625
             // every window of one to five lines, first maximum wins (ascending start, then ascending length); the five
             // magnitudes a start needs are a shift register fed by one LDS read per start (len >= 16 here)

@@ -24,6 +24,8 @@ const float kTapHalf[24] = {
 
 namespace {
 
+#include "at3_libm64.inc"
+
 // Threshold in quiet, millibel re 20 uPa, 4 steps per third starting at 10 Hz (Musepack table used by
 // atrac/atrac_psy_common.cpp:43-83).
 const short kAthMilliBel[] = {
@@ -180,6 +182,11 @@ AT3_RUNTIME_LIBM void build_tables(Tables* t)
                                    0x1.715475f35c8b8p+0};
     memcpy(t->log2f_tab, tab, sizeof(tab));
     memcpy(t->log2f_poly, poly, sizeof(poly));
+    // f64 log / exp of the same glibc (std::log, std::exp in CalcSpectralFlatnessPerBfu, atrac_psy_common.cpp:184,194)
+    memcpy(t->libm.log_c, kLogData, sizeof(t->libm.log_c));
+    memcpy(t->libm.log_tab, kLogData + 18, sizeof(t->libm.log_tab));
+    memcpy(t->libm.exp_c, kExpData, sizeof(t->libm.exp_c));
+    memcpy(t->libm.exp_tab, kExpTab, sizeof(t->libm.exp_tab));
 }
 
 }  // namespace at3

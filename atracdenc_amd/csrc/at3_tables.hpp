@@ -8,6 +8,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "at3_libm64.hpp"
+
 namespace at3 {
 
 struct cpx {
@@ -41,6 +43,8 @@ struct Tables {
     // order the lanes consume it: planck4[q][l] = {w[2 i], w[2 i + 1]} for i = l + 64 q
     cpx spec_tw[14][64];
     cpx planck4[4][64];
+    // glibc 2.35's f64 log / exp data (at3_libm64.hpp): the literal form of CalcSpectralFlatnessPerBfu in k_psy
+    Libm64 libm;
 };
 
 // Fills *t on the host. Pure function of libm.

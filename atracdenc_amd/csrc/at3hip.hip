@@ -58,6 +58,8 @@ struct at3hip_ctx {
     // HIP streams of their own (three with gain control, see mid_stream below), buffers that cross between them are double-buffered by call parity, and consecutive calls overlap.
     static constexpr int kSlots = 32;    // timing history (events per call)
     hipEvent_t ev[kSlots][8] = {};
+    hipEvent_t ev_front_done = nullptr;  // everything the most recent call queued on `stream` (which may be the caller's)
+    bool front_done_valid = false;
     hipEvent_t ev_back_done[2] = {};     // back half finished with the parity's cross buffers
     bool back_done_valid[2] = {false, false};
     long long enc_calls = 0;             // at3hip_encode calls so far
@@ -66,7 +68,8 @@ struct at3hip_ctx {
     int slot_k1_launches[kSlots] = {};   // kernels the QMF + MDCT work of the slot's call was spread over (1 = fused, 2)
     char err[256] = {0};
     long long blocks_fed = 0;   // per stream
-    int runs_override = 0;   // AT3HIP_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
+    int runs_override = 0;   // AT3HIP_OPT_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
+    int flat_literal = 0;    // AT3HIP_OPT_FLATNESS_LITERAL
     int n_cus = 256;
     int wgs_per_cu = 3;        // resident workgroups per CU of the QMF kernel this context uses (k_qmf_sub8 or the fused one)
     int wgs_per_cu_mdct = 3;   // the same of k_mdct_sub
@@ -180,7 +183,8 @@ int pick_runs(const at3hip_ctx* c, int items, int wgs_per_cu, double prologue)
     int best = 1;
     double best_t = 1e300;
     const int r_min = (items + 31) / 32;
-    for (int r = r_min; r <= items && r <= 128; ++r) {
+    const int r_max = r_min > 128 ? r_min + 16 : 128;   // (a run holds at most 32 items: long calls need more than 128 runs)
+    for (int r = r_min; r <= items && r <= r_max; ++r) {
         const long long waves = pairs * r;
         const long long per_simd = (waves + simds - 1) / simds;   // the fullest SIMD
         const double work = (double)((items + r - 1) / r) + prologue;   // the longest run
@@ -269,6 +273,7 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     for (auto& row : c->ev)
         for (auto& e : row)
             if (hipEventCreate(&e) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    if (hipEventCreateWithFlags(&c->ev_front_done, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
     for (auto& e : c->ev_back_done)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
     for (auto& e : c->ev_mid_done)
@@ -320,8 +325,6 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_quant, S * B * 2)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_mant, S * B * 2 * 7168)) != AT3HIP_OK) return bail(rc);
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
-    const char* runs_env = getenv("AT3HIP_RUNS");
-    c->runs_override = (runs_env && atoi(runs_env) > 0) ? atoi(runs_env) : 0;   // 0 = choose per call
     hipDeviceProp_t prop;
     c->n_cus = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     {
@@ -342,8 +345,10 @@ void at3hip_destroy(at3hip_ctx* c)
 {
     if (!c) return;
     at3host::DeviceGuard guard(c->device);
-    // only the context's own streams are waited for: a caller-owned stream (at3hip_set_stream) may already be gone, and
-    // everything queued on it is ordered before the back stream's work by events
+    // only the context's own streams are waited for: a caller-owned stream (at3hip_set_stream) may already be gone. What
+    // the last call queued there (the carried-state update writes buffers freed below) is covered by an event, which
+    // outlives the stream
+    if (c->front_done_valid) (void)hipEventSynchronize(c->ev_front_done);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->mid_stream) (void)hipStreamSynchronize(c->mid_stream);
     if (c->back_stream) (void)hipStreamSynchronize(c->back_stream);
@@ -359,6 +364,7 @@ void at3hip_destroy(at3hip_ctx* c)
     for (auto& row : c->ev)
         for (auto& e : row)
             if (e) (void)hipEventDestroy(e);
+    if (c->ev_front_done) (void)hipEventDestroy(c->ev_front_done);
     for (auto& e : c->ev_back_done)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_mid_done)
@@ -382,6 +388,28 @@ int at3hip_set_stream(at3hip_ctx* c, void* hip_stream)
     if (rc != AT3HIP_OK) return rc;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return AT3HIP_OK;
+}
+
+int at3hip_host_tables(void* dst, size_t bytes)
+{
+    if (!dst || bytes != sizeof(Tables)) return AT3HIP_EINVAL;
+    build_tables((Tables*)dst);
+    return AT3HIP_OK;
+}
+
+int at3hip_set_option(at3hip_ctx* c, int32_t option, int32_t value)
+{
+    if (!c) return AT3HIP_EINVAL;
+    switch (option) {
+        case AT3HIP_OPT_RUNS:
+            if (value < 0) return fail(c, AT3HIP_EINVAL, "runs must be >= 0");
+            c->runs_override = value;
+            return AT3HIP_OK;
+        case AT3HIP_OPT_FLATNESS_LITERAL:
+            c->flat_literal = value != 0;
+            return AT3HIP_OK;
+        default: return fail(c, AT3HIP_EINVAL, "unknown option");
+    }
 }
 
 int at3hip_reset(at3hip_ctx* c)
@@ -530,13 +558,13 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), 0, md, gp, c->d_tables, S);
             hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), 0, md, fp, c->d_tables, S * n_out);
         } else {
+            if (split) launch_qmf_sub();   // joint stereo without gain control: the QMF kernel, timed as qmf_ms
             HIPCHK(c, hipEventRecord(ev[1], st));
             HIPCHK(c, hipEventRecord(ev[2], st));
         }
         HIPCHK(c, hipEventRecord(ev[3], md));
         if (split) {
-            // with gain control the subbands are in HBM already (k_qmf_sub8 wrote them for the gain analysis)
-            if (!gain) launch_qmf_sub();
+            // the subbands are in HBM (k_qmf_sub8 wrote them: for the gain analysis, or for the M/S matrixing)
             MdctSubParams mp;
             mp.sub = d_sub;
             mp.curves = gain ? d_curves : nullptr;
@@ -584,6 +612,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.frame_sz = c->frame_sz;
         bp.bfu_idx_const = c->cfg.bfu_idx_const;
         bp.mono_js = (c->cfg.channels == 1 && c->js) ? 1 : 0;
+        bp.flat_literal = c->flat_literal;
         bp.debug_stop = c->dbg_stop;
         bp.quant = c->d_quant;
         bp.mant = c->d_mant;
@@ -600,6 +629,8 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         c->slot_has_frames[slot] = true;
         c->last_slot = slot;
     }
+    HIPCHK(c, hipEventRecord(c->ev_front_done, st));
+    c->front_done_valid = true;
     HIPCHK(c, hipGetLastError());
     c->hist_cur ^= 1;
     c->blocks_fed += n_blocks;

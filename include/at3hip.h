@@ -143,8 +143,9 @@ int at3hip_sync(at3hip_ctx* ctx);
  *   SPECTRA       float [n_streams][F][2][1024]   spectra after Mdct, tonal lines zeroed        (T3)
  *   CURVES        16-byte records [n_streams][n][2][4]: n, level[7], loc[7], pad - by frame index (T2)
  *   ENERGY_SCALE  float [n_streams][n][2][4] GainEnergyScale.Frame by frame index (gain control only)
- *   PSY           1128-byte records [n_streams][F][2]: float loud_ch, int32 n_tonal, u8 sfi[32], float energy[32],
- *                 tonal blocks 24 x {u16 pos, u8 bfu, len, sfi, pad[3], float values[7], pad[4]}    (T4, T5, T6)
+ *   PSY           1256-byte records [n_streams][F][2]: float loud_ch, int32 n_tonal, u8 sfi[32], float energy[32],
+ *                 tonal blocks 24 x {u16 pos, u8 bfu, len, sfi, pad[3], float values[7], pad[4]}, float flat[32] =
+ *                 CalcSpectralFlatnessPerBfu of BFUs 8..28 (0 elsewhere and with NoTonalComponents)  (T4, T5, T6)
  *   LOUDNESS      float [n_streams][F] tracked loudness                                             (T6)
  *   QUANT         1792-byte records [n_streams][F][2]: float err[7][32] (e1/e2), u32 cost[7][32] (CLC | VLC << 13) */
 #define AT3HIP_TAP_SPECTRA 1
@@ -164,6 +165,23 @@ int at3hip_get_timings_ago(at3hip_ctx* ctx, int32_t ago, at3hip_timings* out);
  * stages run on the ctx's own two streams behind HIP events (the rate loop's at the higher priority). Completion is as
  * before: the call's return, or at3hip_sync() for AT3HIP_ASYNC calls. The stream must outlive its last call's completion. */
 int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
+
+/* Options that never change a result: how the work is cut up, or which of two equivalent forms computes it.
+ *   AT3HIP_OPT_RUNS              wavefronts ("runs" of consecutive blocks) per (stream, channel) of the QMF / MDCT kernels;
+ *                                0 = chosen per call from the batch geometry (default). A run re-derives its FIR history and
+ *                                overlap from the samples before its first block, so any cut gives the same bytes.
+ *   AT3HIP_OPT_FLATNESS_LITERAL  1 = every spectral-flatness measure (CalcSpectralFlatnessPerBfu,
+ *                                atrac_psy_common.cpp:158-199) by the literal per-line form; 0 (default) = the short form
+ *                                with the literal one as fall-back where rounding could matter. Same values either way. */
+#define AT3HIP_OPT_RUNS 1
+#define AT3HIP_OPT_FLATNESS_LITERAL 2
+int at3hip_set_option(at3hip_ctx* ctx, int32_t option, int32_t value);
+
+/* The constant tables exactly as at3hip_create builds them on this host (libm expressions of the reference's static
+ * initialisers, atrac3.h:178-198, qmf.cpp:36-45, atrac_psy_common.cpp:126-156, ...) - no GPU involved. `bytes` must be the
+ * size of the table block (see atracdenc_amd/csrc/at3_tables.hpp; the ctypes stub mirrors the layout). Lets a parity
+ * suite prove, on the machine that runs the encoder, that the tables equal the reference's. */
+int at3hip_host_tables(void* dst, size_t bytes);
 
 /* Library/ABI version: (major << 16) | minor. */
 uint32_t at3hip_version(void);

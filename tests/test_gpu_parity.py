@@ -125,21 +125,67 @@ def test_stage_taps(hip, oracle, br):
                 assert np.array_equal(curves[i, f + 1, ch, b, 8:8 + n], tap["loc"][f, ch, b, :n].astype(np.uint8))
 
 
-def test_flatness_threshold_adversarial(hip, oracle):
-    """The one documented arithmetic deviation of the device path (one f64 log of the product of the lines' mantissas
-    instead of the reference's sum of per-line logs) sits in front of the `flat < 0.01` tonal
-    decision. This walks the decision boundary: ~150 inputs that close in on a threshold crossing of four different
-    BFUs from both sides, down to neighbouring f32 PCM inputs whose flatness lies within 1e-7 of 0.01 - the device has to
-    take the reference's side every time (frame bytes and tonal-block counts)."""
+def _raw_spectra(hip, pcm, br=LP2):
+    """Spectra BEFORE the tonal lines are removed: the same stream with NoTonalComponents (the spectra tap is untouched)."""
+    from atracdenc_amd import binding as B
+    S, nb = pcm.shape[0], pcm.shape[1]
+    enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=br, no_gain=True, no_tonal=True)
+    enc.encode(pcm)
+    specs = enc.read_tap(B.TAP_SPECTRA, np.float32, (S, nb - 1, 2, 1024))
+    enc.close()
+    return specs
+
+
+def _check_flat_values(oracle, psy, specs):
+    """PSY tap flat[8..28] == CalcSpectralFlatnessPerBfu of the same spectra (oracle = glibc's log / exp), as bit patterns."""
+    n = 0
+    for idx in np.ndindex(specs.shape[:3]):
+        exp = oracle.flatness(specs[idx] * specs[idx])
+        got = psy[idx]["flat"]
+        assert np.array_equal(got[8:29].view(np.uint32), exp[8:29].view(np.uint32)), (idx, got[8:29], exp[8:29])
+        assert not got[:8].any() and not got[29:].any()
+        n += 21
+    return n
+
+
+@pytest.mark.parametrize("literal", [0, 1])
+def test_flatness_values(hip, oracle, literal):
+    """CalcSpectralFlatnessPerBfu (atrac_psy_common.cpp:158-199) by VALUE: the f32 the device hands to `flat < 0.01f` equals
+    the reference's for every BFU the extraction looks at - in the default form (one log of the lines' mantissa product,
+    guarded by an error bound, literal fall-back) and with AT3HIP_OPT_FLATNESS_LITERAL (a restated glibc log per line, the
+    reference's ordered sums, the restated exp: atracdenc_amd/csrc/at3_libm64.hpp). Frames equal either way."""
+    from atracdenc_amd import binding as B
+    nb = 12
+    names = sorted(SIGNALS)
+    pcm = np.stack([SIGNALS[n](nb) for n in names] + [pcm_stress(nb, seed=2)])
+    S = pcm.shape[0]
+    specs = _raw_spectra(hip, pcm)
+    enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2, no_gain=True)
+    enc.set_option(B.OPT_FLATNESS_LITERAL, literal)
+    got = enc.encode(pcm)
+    psy = enc.read_tap(B.TAP_PSY, B.At3Hip.PSY_DTYPE, (S, nb - 1, 2))
+    enc.close()
+    assert _check_flat_values(oracle, psy, specs) == S * (nb - 1) * 2 * 21
+    assert np.array_equal(got, oracle_frames(oracle, pcm, LP2, 1, 0))
+
+
+@pytest.mark.parametrize("literal", [0, 1])
+def test_flatness_threshold_adversarial(hip, oracle, literal):
+    """The `flat < 0.01` tonal decision (atrac3denc.cpp:606) on ~150 inputs that close in on a threshold crossing of four
+    different BFUs from both sides, down to neighbouring f32 PCM inputs whose flatness lies within 1e-7 of 0.01: flatness
+    VALUES equal the oracle's bit for bit, and so do tonal-block counts and frame bytes - in both forms of the measure."""
     from atracdenc_amd import binding as B
     from at3_testlib import flatness_threshold_walk
     pcm, closest = flatness_threshold_walk(oracle)
     assert max(closest) < 1e-7, closest            # the walk really ends at the threshold (relative distance < 1e-5)
     S, nb = pcm.shape[0], pcm.shape[1]
+    specs = _raw_spectra(hip, pcm)
     enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2, no_gain=True)
+    enc.set_option(B.OPT_FLATNESS_LITERAL, literal)
     got = enc.encode(pcm)
     psy = enc.read_tap(B.TAP_PSY, B.At3Hip.PSY_DTYPE, (S, nb - 1, 2))
     enc.close()
+    _check_flat_values(oracle, psy, specs)
     for i in range(S):
         frames, tap = oracle.encode(pcm[i], LP2, 1, 0, taps=True)
         assert np.array_equal(psy[i]["n_tonal"], tap["n_tonal"]), i
@@ -198,18 +244,33 @@ def test_streaming_pieces_equal_one_shot(hip, oracle, br):
 
 
 @pytest.mark.parametrize("br,ng", [(LP2, 0), (LP2, 1), (LP4, 0), (LP4, 1)])
-def test_run_length_invariance(hip, oracle, monkeypatch, br, ng):
+def test_run_length_invariance(hip, oracle, br, ng):
     """The front-end kernels cut every (stream, channel) into runs of blocks, one wavefront each, with recomputed FIR
-    histories and overlap priming at every cut (AT3HIP_RUNS overrides the automatic choice): any cut gives the same bytes."""
+    histories and overlap priming at every cut (AT3HIP_OPT_RUNS overrides the automatic choice): any cut gives the same bytes."""
+    from atracdenc_amd import binding as B
     nb = 13
     pcm = np.stack([SIGNALS["mix"](nb, seed=9), SIGNALS["burst"](nb, phase=700)])
     exp = oracle_frames(oracle, pcm, br, ng)
-    for runs in ("1", "2", "5", "12", "64"):
-        monkeypatch.setenv("AT3HIP_RUNS", runs)
+    for runs in (1, 2, 5, 12, 64):
         enc = hip.At3Hip(n_streams=2, max_blocks=nb, bitrate=br, no_gain=ng)
+        enc.set_option(B.OPT_RUNS, runs)
         got = np.concatenate([enc.encode(pcm[:, :6]), enc.encode(pcm[:, 6:])], axis=1)
         enc.close()
         assert np.array_equal(got, exp), runs
+
+
+@pytest.mark.parametrize("ng", [0, 1])
+def test_one_long_call(hip, oracle, ng):
+    """More than 4096 blocks of one stream in ONE call: a run holds at most 32 blocks, so the automatic choice needs more
+    than 128 runs per (stream, channel) (it used to fall back to a single wavefront walking the whole call)."""
+    nb = 4200
+    pcm = SIGNALS["mix"](nb, seed=3)[None]
+    enc = hip.At3Hip(n_streams=1, max_blocks=nb, bitrate=LP2, no_gain=ng)
+    got = enc.encode(pcm)
+    tm = enc.timings()
+    enc.close()
+    assert np.array_equal(got[0], oracle.encode(pcm[0], LP2, ng)[0])
+    assert tm["qmf_ms"] + tm["qmf_mdct_ms"] < 5.0, tm    # a single wavefront per channel took tens of milliseconds
 
 
 def test_mdct_api(hip, oracle, golden_stages):

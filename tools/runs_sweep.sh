@@ -3,7 +3,7 @@
 # usage: tools/runs_sweep.sh "<runs values>" [bench args]
 VALS=$1; shift
 for R in $VALS; do
-  AT3HIP_RUNS=$R python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-side-workloads --sync-steps "$@" 2>/dev/null | python3 -c "
+  python bench.py --runs $R --steps 10 --warmup 3 --no-cpu-baseline --no-side-workloads --sync-steps "$@" 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 st=d['stage_ms_per_step']

@@ -66,3 +66,27 @@ if parts:
     }
     json.dump(out, open(os.path.join(root, "k1_traffic.json"), "w"), indent=1)
     print("== k1 traffic ==", json.dumps(out))
+
+# ---- whole-pipeline traffic per frame and the vector-instruction counts of the QMF + MDCT kernels -> pipeline_traffic.json ----
+def per_kernel(sub, counter):
+    res = {}
+    for f in dbs(sub):
+        db = sqlite3.connect(f)
+        for k, v, n in db.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? group by kernel_name", (counter,)):
+            res[short(k)] = v
+    return res
+
+fetch, write, valu = per_kernel("pmc_fetch", "FETCH_SIZE"), per_kernel("pmc_write", "WRITE_SIZE"), per_kernel("pmc_sq", "SQ_INSTS_VALU")
+ours = [k for k in fetch if k.startswith("k_") and k in write]
+if ours:
+    frames = 4096
+    # launches per step (k_state_update runs twice per step)
+    rows = {k: {"FETCH_SIZE_KiB_raw": fetch[k], "WRITE_SIZE_KiB": write[k], "bytes_per_launch": (2.0 * fetch[k] + write[k]) * 1024.0} for k in sorted(ours)}
+    mult = {k: (2 if k.startswith("k_state_update") else 1) for k in rows}
+    total = sum(rows[k]["bytes_per_launch"] * mult[k] for k in rows)
+    out = {"workload": "64 streams x 64 frames (4096 frames per step), synchronous steps", "kernels": rows,
+           "bytes_per_step": total, "pipeline_bytes_per_frame": total / frames, "algorithmic_bytes_per_frame": 8192 + 384,
+           "correction": "FETCH_SIZE x2 + WRITE_SIZE per kernel (MI355X_MICROARCH.md, HBM section), separate --pmc passes",
+           "valu_wave_insts_per_launch": {k: v for k, v in valu.items() if k.startswith(("k_qmf", "k_mdct_sub"))}}
+    json.dump(out, open(os.path.join(root, "pipeline_traffic.json"), "w"), indent=1)
+    print("== pipeline traffic == %.1f KB per frame (%.1f MB per step)" % (total / frames / 1024.0, total / 1e6))
