@@ -22,6 +22,7 @@
 namespace at3 {
 
 constexpr int kTermLine0 = 96;   // BFUs 0..9 (lines 0..95) are quantised by small_units: no batch ever lists their lines
+constexpr int kChgWords = kEaLines / 32;   // 23: one bit per line from BFU 19 on (every such BFU covers whole words)
 struct AllocLds {
     float val[1024];                 // scaled spectrum (TScaler::Scale)
     union {
@@ -35,15 +36,23 @@ struct AllocLds {
             uint16_t huff[130];          // and the code tables
         };
     };
-    float err[7 * 10];               // cache: e1 / e2 of (wordlen, BFU < 10) at (wordlen - 1) * 10 + BFU - what ConsiderEnergyErr reads
-    uint16_t cost[7 * 32];           // cache: VLC bits of (wordlen, BFU) at (wordlen - 1) * 32 + BFU (the CLC bits are wordlen x lines)
-    int8_t bm[1024];                 // mantissas of the units of the current batch (one wordlen per BFU)
-    uint8_t code[256];               // 2 bits per line of the batch: 1 = re-roundable when e2 < e1, 2 = when e2 > e1
-    int alloc[32];
-    uint8_t tbits[kMaxTonal * 8];    // VLC bits of tonal block t at quantiser q: [t * 8 + q]
-    int misc[4];
     unsigned long long tmask[4];
+    union {
+        float err[7 * 10];               // e1 / e2 of (wordlen, BFU < 10) at (wordlen - 1) * 10 + BFU: read once, for ConsiderEnergyErr's map
+        // from then on: which lines the energy-adaptive pass re-rounded, per wordlen - with plain rounding everything the
+        // emission needs to form the chosen units' mantissas again (they never go to memory): bit (line - 288) of row wordlen - 1
+        uint32_t chg[7 * kChgWords];
+    };
+    uint16_t cost[7 * 32];           // cache: VLC bits of (wordlen, BFU) at (wordlen - 1) * 32 + BFU (the CLC bits are wordlen x lines)
+    int misc[4];
+    int8_t bm[1024 - kTermLine0];    // mantissas of the units of the current batch (one wordlen per BFU), line i at i - kTermLine0
+    uint8_t code[kEaLines / 4];      // 2 bits per line of the batch from BFU 19 on: 1 = re-roundable when e2 < e1, 2 = when e2 > e1
+    uint8_t alloc[32];
+    uint8_t tbits[kMaxTonal * 6];    // VLC bits of tonal block t at quantiser q = 2..7: [t * 6 + q - 2]
 };
+static_assert(sizeof(AllocLds) <= 10240, "sixteen workgroups per CU");
+static_assert(sizeof(float) * 256 + sizeof(uint16_t) * kEaLines + 72 * sizeof(int) <= sizeof(float) * (1024 - kTermLine0), "tie-sort stack behind the candidate records");
+static_assert(sizeof(uint32_t) * kBitWords + sizeof(uint16_t) * 132 + 5 * kMaxTonal + 24 <= sizeof(float) * (1024 - kTermLine0), "tonal walk scratch behind the code tables");
 static_assert(sizeof(SortItem) * 128 <= sizeof(float) * 256, "tie-sort scratch must fit in the key list");
 
 // 1 / MaxQuant[wl]^2 as QuantMantisas forms it (atrac_scale.cpp:61: float(1.0 / double(mul * mul))), folded per wordlen
@@ -148,7 +157,7 @@ __device__ __forceinline__ uint32_t vlc_bits8(int wl, const VlcRow& row, const i
 
 // Quantise the units {(b, wl_b) : bit b of `need`}, wl_b = lane b's `bits` (QuantMantisas + CLC/VLC cost,
 // atrac3_bitstream.cpp:154-173, atrac_scale.cpp:40-130). Lane b < 32 passes BFU b's e1 in `my_e1`. Wave-uniform call.
-__device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, uint32_t need, int bits, float my_e1, int lane, int8_t* gmant, float* qerr, int dbg = 0)
+__device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, uint32_t need, int bits, float my_e1, int lane, float* qerr, int dbg = 0)
 {
     // ---- (1) mantissa = lrint(value * MaxQuant[wl]) for the lines of the needed BFUs; energy-adaptive candidate codes ----
     // Four rounds of four lines per lane, line0 = 256 round + 4 lane: a wavefront's 16-byte LDS accesses are one contiguous
@@ -175,15 +184,15 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                 // the pass may re-round a line only when it is close to a rounding boundary (|delta| < 0.25) AND lies on the
                 // side the pass moves: rounded towards zero and below the top code (pass taken when e2 < e1) or rounded
                 // away from zero (e2 > e1), atrac_scale.cpp:66-126; which pass runs is known after the energy sums
-                if (h > 0) {   // (BFU 19, the first one with the pass, starts at line 288)
+                if (h > 0) {   // (BFU 19, the first one with the pass, starts at line 288: round 1's lanes 0..7 form codes nobody stores)
                     const float am = fabsf((float)m), at = fabsf(t);
                     const float delta = t - (truncf(t) + 0.5f);
                     const uint32_t c = (am < at && am < (mul - 1)) ? 1u : (am > at) ? 2u : 0u;
                     code |= (fabsf(delta) < 0.25f ? c : 0u) << (2 * k);
                 }
             }
-            *reinterpret_cast<uint32_t*>(L.bm + line0) = pk;
-            if (h > 0) L.code[line0 >> 2] = (uint8_t)code;
+            *reinterpret_cast<uint32_t*>(L.bm + (line0 - kTermLine0)) = pk;
+            if (h > 0 && line0 >= kEaLine0) L.code[(line0 - kEaLine0) >> 2] = (uint8_t)code;
             *reinterpret_cast<float4*>(L.term + (line0 - kTermLine0)) = make_float4(tm[0], tm[1], tm[2], tm[3]);
         }
     }
@@ -195,7 +204,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
     const bool mine = lane < 32 && ((need >> lane) & 1u);
     const int my_start = bfu_start(lane & 31), my_n = bfu_start((lane & 31) + 1) - my_start;
     float my_inv2 = tab_f(tab.inv, bits), my_e2 = 0.0f;
-    if (mine) {
+    if (mine && (lane > 18 || qerr)) {   // below BFU 19 nothing but the QUANT tap reads a unit's quantised energy
         const float4* t4 = reinterpret_cast<const float4*>(L.term + (my_start - kTermLine0));
         float acc = 0.0f;
         // sixteen terms per step (the units here are 16 to 128 lines long), the next sixteen in flight in a second set of
@@ -267,7 +276,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             const float e2 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_e2)));
             const uint32_t want = (e2 < e1) ? 1u : (e2 > e1) ? 2u : 3u;
             const float mul = max_quant(__builtin_amdgcn_ds_bpermute(4 * bfu, bits));
-            const bool flag = has && ((L.code[line >> 2] >> (2 * (line & 3))) & 3u) == want;
+            const bool flag = has && ((L.code[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;
             const unsigned long long mask = __ballot(flag);
             const uint32_t hm = half ? (uint32_t)(mask >> 32) : (uint32_t)mask;
             const int cnt = __popc(hm);
@@ -279,7 +288,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                 const float t = L.val[line] * mul;
                 key = fabsf(t - (truncf(t) + 0.5f));
                 uk[slot] = key;
-                const int m0 = (int)L.bm[line];
+                const int m0 = (int)L.bm[line - kTermLine0];
                 const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
                 recv = (uint32_t)l | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12);
             }
@@ -322,14 +331,14 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                 recv[r] = 0u;
                 if (r == 1 && n <= 64) continue;   // (uniform) only the two 128-line units have a second round
                 const int j = 64 * r + lane, line = start + j;
-                flag[r] = j < n && ((L.code[line >> 2] >> (2 * (line & 3))) & 3u) == want;
+                flag[r] = j < n && ((L.code[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;
                 const unsigned long long mask = __ballot(flag[r]);
                 if (flag[r]) {
                     const int slot = cnt_u + __popcll(mask & ((1ull << lane) - 1ull));
                     const float t = L.val[line] * mul;
                     key[r] = fabsf(t - (truncf(t) + 0.5f));   // sort key |delta|
                     L.uk[slot] = key[r];
-                    const int m0 = (int)L.bm[line];
+                    const int m0 = (int)L.bm[line - kTermLine0];
                     const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
                     recv[r] = (uint32_t)j | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12);
                 }
@@ -382,7 +391,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                         ++nall;
                     }
                 }
-                std_sort_abs(s_items, nall);
+                std_sort_abs(s_items, nall, reinterpret_cast<int*>(reinterpret_cast<char*>(L.term) + sizeof(float) * 256 + sizeof(uint16_t) * kEaLines));   // the union's bytes behind the key list and the records
                 const int dir = (e2 < e1) ? 1 : (e2 > e1) ? -1 : 0;
                 uint16_t* sorted = L.rec + (start - kEaLine0);
                 int nc = 0;
@@ -411,7 +420,8 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             const bool grow = e2 < e1;
             float dist = fabsf(e2 - e1);
             const uint16_t* rp = L.rec + (my_start - kEaLine0);
-            int8_t* mant = L.bm + my_start;
+            int8_t* mant = L.bm + (my_start - kTermLine0);
+            unsigned long long ch_lo = 0ull, ch_hi = 0ull;   // the lines re-rounded below (bit = line in the unit)
             uint2 r4 = *reinterpret_cast<const uint2*>(rp);
             for (int c0 = 0; c0 < my_nc; c0 += 4) {
                 uint2 n4 = r4;
@@ -437,6 +447,8 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                         const float nd = fabsf(ex - e1);
                         if (nd < dist) {
                             mant[idx[k]] = (int8_t)mnew[k];
+                            if (idx[k] < 64) ch_lo |= 1ull << idx[k];
+                            else ch_hi |= 1ull << (idx[k] - 64);
                             e2 = ex;
                             dist = nd;
                         }
@@ -445,10 +457,21 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                 r4 = n4;
             }
             my_e2 = e2;
+            // what the emission needs to form this unit's mantissas again: plain rounding plus these lines moved by one (a
+            // unit is quantised once per wordlen and its rows were cleared before the rate loop: untouched units stay zero)
+            uint32_t* cw = L.chg + (bits - 1) * kChgWords + ((my_start - kEaLine0) >> 5);
+            if (ch_lo | ch_hi) {
+                cw[0] = (uint32_t)ch_lo;
+                if (my_n > 32) cw[1] = (uint32_t)(ch_lo >> 32);
+                if (my_n > 64) {
+                    cw[2] = (uint32_t)ch_hi;
+                    cw[3] = (uint32_t)(ch_hi >> 32);
+                }
+            }
         }
     }
     wave_sync();
-    // ---- (4) VLC cost of the final mantissas; (5) cache entries; (6) mantissas to HBM for the packing step ----
+    // ---- (4) VLC cost of the final mantissas; (5) cache entries ----
     uint32_t* s_vlc = reinterpret_cast<uint32_t*>(L.uk);   // per-BFU bit counts: the key list is free again
     if (lane < 32) s_vlc[lane] = 0u;
     wave_sync();
@@ -458,7 +481,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
         const VlcRow row = tab_row(tab, wl);
         if (wl) {
             const int line0 = 256 * h + 4 * lane;
-            const uint32_t pk = *reinterpret_cast<const uint32_t*>(L.bm + line0);
+            const uint32_t pk = *reinterpret_cast<const uint32_t*>(L.bm + (line0 - kTermLine0));
             int m[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) m[k] = (int)(int8_t)((pk >> (8 * k)) & 0xff);
@@ -470,7 +493,6 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                 vb = vlc_pair_len(m[0], m[1]) + vlc_pair_len(m[2], m[3]);
             }
             atomicAdd(&s_vlc[(tab.bfus >> (8 * h)) & 0xffu], vb);
-            *reinterpret_cast<uint32_t*>(gmant + (wl - 1) * 1024 + line0) = pk;
         }
     }
     wave_sync();
@@ -484,7 +506,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
 // The 70 units of BFUs 0..9 (8 or 16 lines each, no energy-adaptive pass below BFU 19), one lane per unit: ConsiderEnergyErr
 // (atrac3_bitstream.cpp:241-257) looks at the first ten BFUs' energy errors at whatever wordlen the allocation gives them,
 // and the whole set costs less than one large unit.
-__device__ __forceinline__ void small_units(AllocLds& L, const LaneTab& tab, int lane, int8_t* gmant, float my_e1)
+__device__ __forceinline__ void small_units(AllocLds& L, const LaneTab& tab, int lane, float my_e1)
 {
     // Unit u = 0..13: the 16-line BFUs 8 and 9 at wordlen 1 + u / 2; u = 14..69: BFU (u - 14) % 8 at wordlen 1 + (u - 14) / 8.
     // Pass one: lane u takes unit u's first eight lines. Pass two: lanes 0..13 take their unit's second eight lines (the
@@ -516,12 +538,8 @@ __device__ __forceinline__ void small_units(AllocLds& L, const LaneTab& tab, int
             const float4 va = *reinterpret_cast<const float4*>(L.val + line0), vb4 = *reinterpret_cast<const float4*>(L.val + line0 + 4);
             const float v[8] = {va.x, va.y, va.z, va.w, vb4.x, vb4.y, vb4.z, vb4.w};
             int m[8];
-            uint32_t pk[2] = {0u, 0u};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                m[k] = __float2int_rn(v[k] * mul);
-                pk[k >> 2] |= (uint32_t)(uint8_t)m[k] << (8 * (k & 3));
-            }
+            for (int k = 0; k < 8; ++k) m[k] = __float2int_rn(v[k] * mul);
             float e2 = own ? e2A : e2B;
 #pragma unroll
             for (int k = 0; k < 8; ++k) e2 += (float)(m[k] * m[k]) * inv2;
@@ -533,7 +551,6 @@ __device__ __forceinline__ void small_units(AllocLds& L, const LaneTab& tab, int
                 e2B = e2;
                 vbB += vb;
             }
-            *reinterpret_cast<uint2*>(gmant + (wl - 1) * 1024 + line0) = make_uint2(pk[0], pk[1]);
         }
     }
     L.err[(wlA - 1) * 10 + bfuA] = e1A / e2A;
@@ -559,7 +576,7 @@ __device__ __forceinline__ int tonal_emit_parallel(const PsyRec* rec, const uint
     int qn = wl_t + 4;
     qn = qn > 7 ? 7 : qn;
     const int g = live ? qn * 8 + tb_len : 0xff;               // group id, ascending = stream order
-    const int sz = live ? 12 + (int)s_tbits[(lane < kMaxTonal ? lane : 0) * 8 + qn] : 0;
+    const int sz = live ? 12 + (int)s_tbits[(lane < kMaxTonal ? lane : 0) * 6 + qn - 2] : 0;
     // my block's payload, requested now
     TonalBlock tb = {};
     if (live) tb = rec->tonal[lane];
@@ -644,13 +661,15 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 {
     __shared__ __attribute__((aligned(16))) AllocLds L;
     uint32_t* s_words = L.words;
-    int* s_alloc = L.alloc;
+    uint8_t* s_alloc = L.alloc;
     uint8_t* s_tbits = L.tbits;
     uint16_t* s_huff = L.huff;
     int* s_misc = L.misc;
     uint16_t* s_cost = L.cost;
     float* s_err = L.err;
     unsigned long long* s_tmask = L.tmask;
+    // scratch of the serial tonal walk: the union's bytes behind the bit buffer and the code tables (free whenever it runs)
+    uint8_t* tonal_scr = reinterpret_cast<uint8_t*>(L.term) + sizeof(uint32_t) * kBitWords + sizeof(uint16_t) * 132;
 
     const int lane = threadIdx.x;
     const int n_out = p.n_blocks - p.f0;
@@ -662,7 +681,6 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     const PsyRec* recs = p.psy + (cf & ~(size_t)1);
     const PsyRec* rec = recs + ch;
     const Curve* curves = p.curves + ((size_t)s * p.n_blocks + f) * 8;
-    int8_t* gmant = p.mant + cf * 7168;
     const int half = p.frame_sz >> 1;
     const int n_tonal = rec->n_tonal;
 
@@ -673,11 +691,10 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 
     // ---- header + gain info bits, joint-stereo byte shift, target bits (WriteSoundUnit :759-810) ----
     // lanes 0..7 hold the frame's eight gain curves (16 bytes each) from here to the emission
-    uint4 cw = {0u, 0u, 0u, 0u};
-    if (lane < 8) cw = *reinterpret_cast<const uint4*>(curves + lane);
-    const int curve_n = (int)(cw.x & 0xffu);
-    // the code tables the emission will want in LDS (their storage is the key lists' until then)
-    const uint32_t huff_a = c_huff[lane], huff_b = c_huff[64 + lane], huff_c = lane < 2 ? c_huff[128 + lane] : 0u;
+    // (only the point counts are needed before the emission: the curves themselves are fetched again there rather than
+    // held in four registers across the whole rate loop)
+    int curve_n = 0;
+    if (lane < 8) curve_n = (int)(*reinterpret_cast<const uint32_t*>(curves + lane) & 0xffu);
     int hdr[2];
     for (int c2 = 0; c2 < 2; ++c2) {
         int bits = (p.js && c2 == 1) ? 14 : 6;
@@ -778,7 +795,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     if (p.debug_stop == 1) return;
 #endif
     const LaneTab tab = lane_tab(lane);
-    small_units(L, tab, lane, gmant, my_e1);
+    small_units(L, tab, lane, my_e1);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 2) return;
 #endif
@@ -823,7 +840,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         const float mul = max_quant(qq);
         int bits = 0;
         for (int z = 0; z < tb.len; ++z) bits += (int)(huff_entry(qq, vlc_index(__float2int_rn(tb.values[z] * mul))) >> 8);
-        s_tbits[t * 8 + qq] = (uint8_t)bits;
+        s_tbits[t * 6 + qq - 2] = (uint8_t)bits;
     }
     // Lane t < n_tonal also owns tonal block t (its BFU, length and 64-line block): the cost of the tonal side
     // information is evaluated by these lanes in parallel inside the rate loop (inside the bisection below).
@@ -882,6 +899,13 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             gmap |= (uint32_t)g << (3 * k);
         }
     }
+    if (p.quant) {   // the QUANT tap's energy errors (BFUs 0..9, every wordlen): their storage is about to be reused
+        QuantRec* qr = p.quant + cf;
+        for (int k = lane; k < 70; k += 64) qr->err[k / 10][k % 10] = s_err[k];
+    }
+    wave_sync();
+    for (int k = lane; k < 7 * kChgWords; k += 64) L.chg[k] = 0u;   // (same bytes as the energy errors, dead from here on)
+    wave_sync();
     // ---- rate loop: TConfigure / TAlloc under the bisection driver (uniform control flow) ----
     int num_bfu = p.bfu_idx_const ? p.bfu_idx_const : 32;
     if (target < 101) {
@@ -961,9 +985,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 } else
 #endif
                 if (need) {
-                    if (lane < 32) s_alloc[lane] = bits;
-                    wave_sync();
-                    compute_units(L, tab, need, bits, my_e1, lane, gmant, qerr, p.debug_stop);
+                    compute_units(L, tab, need, bits, my_e1, lane, qerr, p.debug_stop);
                     if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
                 }
             }
@@ -975,9 +997,9 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             // 32 of 32 (and silently wrapped to zero when every BFU of the frame was coded)
             nz = (uint32_t)__popcll(__ballot(lane < num_bfu && bits != 0));
             if (n_tonal > 0 && tonal_serial) {
-                if (lane < 32) s_alloc[lane] = bits;
+                if (lane < 32) s_alloc[lane] = (uint8_t)bits;
                 __syncthreads();
-                if (lane == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0);
+                if (lane == 0) s_misc[0] = tonal_encode<false>(rec, s_tbits, s_alloc, num_bfu, nullptr, 0, tonal_scr);
                 __syncthreads();
                 tonal_bits = (uint32_t)(s_misc[0] & 0xffff);
             } else if (n_tonal > 0) {
@@ -993,7 +1015,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 uint32_t member = 0;
                 if (live) {
                     atomicOr(&s_tmask[tb_blk >> 2], 1ull << ((qn - 2) * 7 + (tb_len - 1)));
-                    member = 12u + s_tbits[lane * 8 + qn];
+                    member = 12u + s_tbits[lane * 6 + qn - 2];
                 }
                 const uint32_t msum = row_allreduce_add(member);
                 const uint32_t members = (uint32_t)__builtin_amdgcn_readlane((int)msum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)msum, 16);
@@ -1092,31 +1114,54 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     if (p.quant) {   // the QUANT tap: what the cache holds at the end (err e1 / e2, cost CLC | VLC << 13; zero = never computed)
         QuantRec* qr = p.quant + cf;
         for (int k = lane; k < 7 * 32; k += 64) {
-            if ((k & 31) < 10) qr->err[k >> 5][k & 31] = s_err[(k >> 5) * 10 + (k & 31)];
             const uint32_t vb = s_cost[k];
             qr->cost[k >> 5][k & 31] = vb ? (clc_bits(1 + (k >> 5), bfu_start((k & 31) + 1) - bfu_start(k & 31)) | (vb << 13)) : 0u;
         }
     }
-    if (lane < 32) s_alloc[lane] = bits;
+    // requested now, wanted after the mantissas below have been formed: the frame's curves (lanes 0..7, for the header) and
+    // the code tables (their LDS storage was the key lists' until here)
+    uint4 cw = {0u, 0u, 0u, 0u};
+    if (lane < 8) cw = *reinterpret_cast<const uint4*>(curves + lane);
+    const uint32_t huff_a = c_huff[lane], huff_b = c_huff[64 + lane], huff_c = lane < 2 ? c_huff[128 + lane] : 0u;
+    if (lane < 32) s_alloc[lane] = (uint8_t)bits;
     for (int k = lane; k < kBitWords; k += 64) s_words[k] = 0;   // the key lists are dead: their storage becomes the bit buffer
-    s_huff[lane] = (uint16_t)huff_a;
-    s_huff[64 + lane] = (uint16_t)huff_b;
-    if (lane < 2) s_huff[128 + lane] = (uint16_t)huff_c;
-    __syncthreads();
 
     // ---- emission (WriteSoundUnit header, EncodeSpecs) ----
-    // mantissas: 16 spectral lines per lane (BFU sizes are multiples of 8, so at most two BFUs per lane), requested
-    // from HBM before lane 0 writes the header
+    // mantissas: 16 spectral lines per lane (BFU sizes are multiples of 8, so at most two BFUs per lane), formed AGAIN from
+    // the scaled values instead of being kept for every unit the rate loop ever asked for: plain rounding, and from BFU 19
+    // on the lines the energy-adaptive pass moved by one (its record, one bit per line and wordlen). Which way a recorded
+    // line went can be read off the line itself: the pass that adds lists only lines rounded towards zero, the pass that
+    // takes away only lines rounded away from it (atrac_scale.cpp:86-118; the side tests of compute_units' codes).
     int wl_h[2];
-    uint2 pk_h[2];
+    int m_h[2][8];
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
         const int i0 = lane * 16 + 8 * hlf;
         const int b = bfu_of_line(i0);
-        wl_h[hlf] = (b < num_bfu) ? s_alloc[b] : 0;
-        pk_h[hlf] = make_uint2(0u, 0u);
-        if (wl_h[hlf]) pk_h[hlf] = *reinterpret_cast<const uint2*>(gmant + (wl_h[hlf] - 1) * 1024 + i0);
+        const int wl = __builtin_amdgcn_ds_bpermute(4 * b, bits);   // (zero from num_bfu on)
+        wl_h[hlf] = wl;
+        const float mul = tab_f(tab.mq, wl);
+        const float4 va = *reinterpret_cast<const float4*>(L.val + i0), vb = *reinterpret_cast<const float4*>(L.val + i0 + 4);
+        const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        uint32_t moved = 0u;
+        if (i0 >= kEaLine0 && wl) moved = (L.chg[(wl - 1) * kChgWords + ((i0 - kEaLine0) >> 5)] >> ((i0 - kEaLine0) & 31)) & 0xffu;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float t = v[k] * mul;
+            int m = __float2int_rn(t);
+            if ((moved >> k) & 1u) {
+                const int a0 = m < 0 ? -m : m;
+                const int a1 = ((float)a0 < fabsf(t)) ? a0 + 1 : a0 - 1;
+                const bool neg = m < 0 || (m == 0 && !(t > 0));
+                m = neg ? -a1 : a1;
+            }
+            m_h[hlf][k] = wl ? m : 0;
+        }
     }
+    s_huff[lane] = (uint16_t)huff_a;
+    s_huff[64 + lane] = (uint16_t)huff_b;
+    if (lane < 2) s_huff[128 + lane] = (uint16_t)huff_c;
+    __syncthreads();
     int pos = (p.js && ch == 1) ? 14 : 6;
     if (lane == 0) {
         if (p.js && ch == 1) {
@@ -1153,7 +1198,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     } else if (!tonal_serial) {
         pos += tonal_emit_parallel(rec, s_tbits, s_huff, s_words, pos, lane, n_tonal, num_bfu, bits, tb_bfu, tb_len, tb_blk);
     } else {
-        if (lane == 0) s_misc[1] = tonal_encode<true>(rec, s_tbits, s_alloc, num_bfu, s_words, pos);
+        if (lane == 0) s_misc[1] = tonal_encode<true>(rec, s_tbits, s_alloc, num_bfu, s_words, pos, tonal_scr);
         __syncthreads();
         pos += s_misc[1];
     }
@@ -1186,14 +1231,12 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 const int wl = wl_h[hlf];
                 const int nb = (int)(tab_u(tab.misc, wl) & 7u);
                 const uint32_t mask = (1u << nb) - 1u;
-                const uint2 pk = pk_h[hlf];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const uint32_t w = q ? pk.y : pk.x;
-                    uint32_t g = w & mask;
-                    g = (g << nb) | ((w >> 8) & mask);
-                    g = (g << nb) | ((w >> 16) & mask);
-                    g = (g << nb) | ((w >> 24) & mask);
+                    uint32_t g = (uint32_t)m_h[hlf][4 * q] & mask;
+                    g = (g << nb) | ((uint32_t)m_h[hlf][4 * q + 1] & mask);
+                    g = (g << nb) | ((uint32_t)m_h[hlf][4 * q + 2] & mask);
+                    g = (g << nb) | ((uint32_t)m_h[hlf][4 * q + 3] & mask);
                     grp[2 * hlf + q] = g;
                     glen[2 * hlf + q] = 4u * (uint32_t)nb;
                 }
@@ -1204,11 +1247,8 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #pragma unroll
             for (int hlf = 0; hlf < 2; ++hlf) {
                 const int wl = wl_h[hlf];
-                const uint2 pk = pk_h[hlf];
                 const int base = (int)(tab_u(tab.misc, wl) >> 8);
-                int8_t m8[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) m8[k] = (int8_t)(((k < 4 ? pk.x : pk.y) >> (8 * (k & 3))) & 0xff);
+                const int (&m8)[8] = m_h[hlf];
                 uint32_t g = 0u, gl = 0u;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {

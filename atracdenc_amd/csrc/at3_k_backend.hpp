@@ -31,8 +31,7 @@ struct BackParams {
     int frame_sz;
     int bfu_idx_const;
     int mono_js;             // one input channel in a joint-stereo container: empty second sound unit (atrac3denc.cpp:843-849)
-    struct QuantRec* quant;  // [S][n_out][2] the unit cache's final content, for the QUANT tap (zero for units never asked for)
-    int8_t* mant;            // [S][n_out][2][7][1024] mantissas of the units k_alloc_pack computed, by wordlen
+    struct QuantRec* quant;  // [S][n_out][2] the unit cache's final content, for the QUANT tap (zero for units never asked for); null unless AT3HIP_OPT_QUANT_TAP
     int flat_literal;        // AT3HIP_OPT_FLATNESS_LITERAL: every flatness measure by the literal per-line form (test aid; same results)
     int debug_stop;          // profiling aid (env AT3HIP_DEBUG_STOP, -DAT3HIP_DEBUG_KNOBS builds): stage exits of k_alloc_pack
 };
@@ -211,6 +210,22 @@ __device__ __forceinline__ bool psy_scale_job(int wave, int lane, int& k, int& b
     return false;
 }
 
+// The literal form of CalcSpectralFlatnessPerBfu's geometric mean (atrac_psy_common.cpp:180-198) for one BFU: a restated
+// glibc log per line, the reference's ordered sum, the restated exp. Rarely called (see k_psy) and kept out of line: inlined,
+// its forty f64 temporaries cost the common path a third of its speed.
+__device__ __attribute__((noinline)) float flatness_literal(const Libm64* M, const float* sp, int len, double arith)
+{
+    const double floor_ = (double)1e-12f;
+    double ml = 0.0;
+    for (int i = 0; i < len; ++i) {
+        const float x = sp[i];
+        const double e = (double)fmaxf(0.0f, x * x);
+        ml += at3_log(M, e > floor_ ? e : floor_);
+    }
+    ml /= (double)len;
+    return (float)fmin(1.0, fmax(0.0, at3_exp(M, ml) / arith));
+}
+
 __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, const Tables* T, int n_cf)
 {
     __shared__ __attribute__((aligned(16))) float s_spec[kPsyCf][1024];
@@ -284,17 +299,7 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
             const float f_lo = (float)fmin(1.0, fmax(0.0, ratio * (1.0 - 1e-12)));
             const float f_hi = (float)fmin(1.0, fmax(0.0, ratio * (1.0 + 1e-12)));
             flat = f_lo;
-            if (f_lo != f_hi || p.flat_literal) {
-                const Libm64* M = &T->libm;
-                double ml = 0.0;
-                for (int i = start; i < end; ++i) {
-                    const float x = sp[i];
-                    const double e = (double)fmaxf(0.0f, x * x);
-                    ml += at3_log(M, e > floor_ ? e : floor_);
-                }
-                ml /= (double)len;
-                flat = (float)fmin(1.0, fmax(0.0, at3_exp(M, ml) / arith));
-            }
+            if (f_lo != f_hi || p.flat_literal) flat = flatness_literal(&T->libm, sp + start, len, arith);
         }
         rec0[fk].flat[b] = flat;
         if (flat < 0.01f) {  // ExtractTonalComponents search, atrac3denc.cpp:606-625
@@ -356,15 +361,16 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
                     ++i;
                 } while (i < nv && s_tv_pos[k0][i] == curPos + 1 && i - startPos < 7);
                 const int len = i - startPos;
-                TonalBlock tb;
-                tb.pos = s_tv_pos[k0][startPos];
-                tb.bfu = s_tv_bfu[k0][startPos];
-                tb.len = (uint8_t)len;
-                for (int j = 0; j < 7; ++j) tb.values[j] = 0.0f;
-                for (int j = 0; j < 3; ++j) tb.pad[j] = 0;
-                for (int j = 0; j < 4; ++j) tb.pad2[j] = 0;
-                tb.sfi = (uint8_t)scale_block(s_scale, s_tv_val[k0] + startPos, len, tb.values, nullptr);
-                if (nb < kMaxTonal) rec->tonal[nb] = tb;
+                if (nb < kMaxTonal) {   // the block is assembled in place (a local copy with run-time indices would live in scratch memory)
+                    TonalBlock* tb = &rec->tonal[nb];
+                    tb->pos = s_tv_pos[k0][startPos];
+                    tb->bfu = s_tv_bfu[k0][startPos];
+                    tb->len = (uint8_t)len;
+                    for (int j = 0; j < 3; ++j) tb->pad[j] = 0;
+                    for (int j = 0; j < 4; ++j) tb->pad2[j] = 0;
+                    for (int j = len; j < 7; ++j) tb->values[j] = 0.0f;
+                    tb->sfi = (uint8_t)scale_block(s_scale, s_tv_val[k0] + startPos, len, tb->values, nullptr);
+                }
                 ++nb;
             }
         }
@@ -552,13 +558,14 @@ __device__ inline void s_insertion_sort(SortItem* a, int first, int last)
     }
 }
 
-__device__ __attribute__((noinline)) void std_sort_abs(SortItem* a, int n)
+// `stk`: 72 ints of scratch (LDS), the explicit stack of the introsort loop.
+__device__ __attribute__((noinline)) void std_sort_abs(SortItem* a, int n, int* stk)
 {
     if (n <= 0) return;
     int lg = 0;
     for (int t = n; t > 1; t >>= 1) ++lg;
     // introsort loop with an explicit stack instead of recursion on the right partition
-    int stk_first[24], stk_last[24], stk_depth[24];
+    int *stk_first = stk, *stk_last = stk + 24, *stk_depth = stk + 48;
     int sp = 0;
     stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = 2 * lg; sp = 1;
     while (sp > 0) {
@@ -616,12 +623,16 @@ __device__ __attribute__((noinline)) void std_sort_abs(SortItem* a, int n)
 // Tonal component side information: grouping (GroupTonalComponents, atrac3_bitstream.cpp:338-380) and
 // cost / emission (EncodeTonalComponents :382-524). Serial (one lane). With EMIT the bits go to `words`
 // starting at bit `pos`; returns the number of bits.
+// `scr`: 5 * kMaxTonal + 24 bytes of scratch (LDS): the serial walk's small arrays (private arrays would live in scratch memory).
 template <bool EMIT>
-__device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const uint8_t* tbits /* [kMaxTonal][8] */, const int* alloc,
-                                   int n_alloc, uint32_t* words, int pos)
+__device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const uint8_t* tbits /* [kMaxTonal][6]: quantisers 2..7 */, const uint8_t* alloc,
+                                   int n_alloc, uint32_t* words, int pos, uint8_t* scr)
 {
     const int nt = rec->n_tonal;
-    uint8_t grp_of[kMaxTonal];
+    uint8_t* grp_of = scr;                    // [kMaxTonal]
+    uint8_t* mem = scr + kMaxTonal;           // [kMaxTonal]
+    uint8_t* sg_start = scr + 2 * kMaxTonal;  // [kMaxTonal]
+    uint8_t* cnt = scr + 3 * kMaxTonal;       // [16]
     int tcsgn = 0;
     for (int t = 0; t < nt; ++t) {
         const int bfu = rec->tonal[t].bfu;
@@ -629,17 +640,16 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
             grp_of[t] = 0xff;
             continue;
         }
-        int quant = alloc[bfu] + 4;
+        int quant = (int)alloc[bfu] + 4;
         if (quant > 7) quant = 7;
         if (quant < 2) quant = 2;
         grp_of[t] = (uint8_t)(quant * 8 + rec->tonal[t].len);
     }
     // first pass: count sub-groups (needed up front for the 5-bit header)
     for (int g = 16; g < 64; ++g) {
-        int mem[kMaxTonal];
         int nm = 0;
         for (int t = 0; t < nt; ++t)
-            if (grp_of[t] == g) mem[nm++] = t;
+            if (grp_of[t] == g) mem[nm++] = (uint8_t)t;
         int cur = 0;
         while (cur < nm) {
             int start = cur;
@@ -663,19 +673,17 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
     if (EMIT) put_bits(words, pos + used, 0, 2);
     used += 2;
     for (int g = 16; g < 64; ++g) {
-        int mem[kMaxTonal];
         int nm = 0;
         for (int t = 0; t < nt; ++t)
-            if (grp_of[t] == g) mem[nm++] = t;
+            if (grp_of[t] == g) mem[nm++] = (uint8_t)t;
         if (nm == 0) continue;
         // sub-group boundaries
-        int sg_start[kMaxTonal];
         int nsg = 0;
         {
             int cur = 0;
             while (cur < nm) {
                 int start = cur;
-                sg_start[nsg++] = cur;
+                sg_start[nsg++] = (uint8_t)cur;
                 int limiter = 0;
                 do {
                     ++cur;
@@ -694,13 +702,10 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
         for (int sg = 0; sg < nsg; ++sg) {
             const int sgStart = sg_start[sg];
             const int sgEnd = (sg < nsg - 1) ? sg_start[sg + 1] : nm;
-            uint8_t cnt[16];
             for (int j = 0; j < 16; ++j) cnt[j] = 0;
             for (int j = sgStart; j < sgEnd; ++j) cnt[rec->tonal[mem[j]].pos >> 6]++;
-            int bandFlag[4];
-            for (int b = 0; b < 4; ++b) bandFlag[b] = cnt[4 * b] | cnt[4 * b + 1] | cnt[4 * b + 2] | cnt[4 * b + 3];
             if (EMIT)
-                for (int b = 0; b < 4; ++b) put_bits(words, pos + used + b, bandFlag[b] != 0, 1);
+                for (int b = 0; b < 4; ++b) put_bits(words, pos + used + b, (cnt[4 * b] | cnt[4 * b + 1] | cnt[4 * b + 2] | cnt[4 * b + 3]) != 0, 1);
             used += 4;
             if (EMIT) put_bits(words, pos + used, (uint32_t)codedValues - 1, 3);
             used += 3;
@@ -708,7 +713,8 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
             used += 3;
             int lastPos = sgStart;
             for (int j = 0; j < 16; ++j) {
-                if (!bandFlag[j >> 2]) continue;
+                const int b4 = j & ~3;
+                if (!(cnt[b4] | cnt[b4 + 1] | cnt[b4 + 2] | cnt[b4 + 3])) continue;
                 const int coded = cnt[j];
                 if (EMIT) put_bits(words, pos + used, (uint32_t)coded, 3);
                 used += 3;
@@ -727,7 +733,7 @@ __device__ __attribute__((noinline)) int tonal_encode(const PsyRec* rec, const u
                             bp += (int)(e >> 8);
                         }
                     }
-                    used += 12 + tbits[mem[k] * 8 + q];
+                    used += 12 + tbits[mem[k] * 6 + q - 2];
                 }
                 lastPos = k;
             }

@@ -93,8 +93,7 @@ struct at3hip_ctx {
     float* d_loud = nullptr;
     float* d_loud_state = nullptr;
     uint8_t* d_out = nullptr;
-    QuantRec* d_quant = nullptr;
-    int8_t* d_mant = nullptr;
+    QuantRec* d_quant = nullptr;     // allocated by AT3HIP_OPT_QUANT_TAP
     at3hip_timings tm = {};
     // grow-only device staging of the stage-level entry points (at3hip_mdct, at3hip_gain_energy_scale) for host buffers
     void* d_stage = nullptr;
@@ -322,8 +321,6 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_loud, S * B)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_loud_state, S)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_out, S * B * (size_t)c->frame_sz)) != AT3HIP_OK) return bail(rc);
-    if ((rc = dev_alloc(c, &c->d_quant, S * B * 2)) != AT3HIP_OK) return bail(rc);
-    if ((rc = dev_alloc(c, &c->d_mant, S * B * 2 * 7168)) != AT3HIP_OK) return bail(rc);
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
     hipDeviceProp_t prop;
     c->n_cus = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -358,7 +355,7 @@ void at3hip_destroy(at3hip_ctx* c)
         if (c->d_micro_b[q]) (void)hipFree(c->d_micro_b[q]);
     void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
                     c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
-                    c->d_out,       c->d_quant,     c->d_mant,     c->d_pcm_mono,  c->d_stage,    c->d_sub_tail, c->d_bins};
+                    c->d_out,       c->d_quant,     c->d_pcm_mono,  c->d_stage,    c->d_sub_tail, c->d_bins};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& row : c->ev)
@@ -408,6 +405,18 @@ int at3hip_set_option(at3hip_ctx* c, int32_t option, int32_t value)
         case AT3HIP_OPT_FLATNESS_LITERAL:
             c->flat_literal = value != 0;
             return AT3HIP_OK;
+        case AT3HIP_OPT_QUANT_TAP: {
+            at3host::DeviceGuard guard(c->device);
+            HIPCHK(c, guard.error());
+            const int rc = drain(c);
+            if (rc != AT3HIP_OK) return rc;
+            if (value && !c->d_quant) return dev_alloc(c, &c->d_quant, (size_t)c->cfg.n_streams * c->cfg.max_blocks * 2);
+            if (!value && c->d_quant) {
+                (void)hipFree(c->d_quant);
+                c->d_quant = nullptr;
+            }
+            return AT3HIP_OK;
+        }
         default: return fail(c, AT3HIP_EINVAL, "unknown option");
     }
 }
@@ -615,7 +624,6 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.flat_literal = c->flat_literal;
         bp.debug_stop = c->dbg_stop;
         bp.quant = c->d_quant;
-        bp.mant = c->d_mant;
         hipLaunchKernelGGL(k_loud_sum, dim3((unsigned)((S * n_out * 2 + kLoudCf - 1) / kLoudCf)), dim3(256), 0, bk, bp, c->d_tables, S * n_out * 2);
         hipLaunchKernelGGL(k_psy, dim3((S * n_out * 2 + kPsyCf - 1) / kPsyCf), dim3(256), 0, bk, bp, c->d_tables, S * n_out * 2);
         HIPCHK(c, hipEventRecord(ev[6], bk));
@@ -673,7 +681,7 @@ int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
         case AT3HIP_TAP_ENERGY_SCALE: src = c->d_ges[par]; cap = c->d_ges[par] ? S * B * 8 * sizeof(float) : 0; break;
         case AT3HIP_TAP_PSY: src = c->d_psy; cap = S * B * 2 * sizeof(PsyRec); break;
         case AT3HIP_TAP_LOUDNESS: src = c->d_loud; cap = S * B * sizeof(float); break;
-        case AT3HIP_TAP_QUANT: src = c->d_quant; cap = S * B * 2 * sizeof(QuantRec); break;
+        case AT3HIP_TAP_QUANT: src = c->d_quant; cap = c->d_quant ? S * B * 2 * sizeof(QuantRec) : 0; break;
         default: return fail(c, AT3HIP_EINVAL, "unknown tap");
     }
     if (!src || bytes > cap) return fail(c, AT3HIP_EINVAL, "tap not available or request too large");

@@ -456,7 +456,7 @@ def main():
     k1_ms, stage_ms = j0.k1_stats(min(region_steps, 28), 0)      # the last region's launches
     iso_ms = j0.isolated_k1()                       # 3 synchronous steps after the timed regions
     parity = None
-    if rank == 0 and not args.no_parity:
+    if rank == 0 and not args.no_parity and not args.sync_steps:
         # (1) the whole timed sequence again from start of stream: same final frames (determinism); (2) the start of that
         # sequence against the CPU oracle. Both after the timing, on the buffers the timed regions used.
         same = None

@@ -147,7 +147,8 @@ int at3hip_sync(at3hip_ctx* ctx);
  *                 tonal blocks 24 x {u16 pos, u8 bfu, len, sfi, pad[3], float values[7], pad[4]}, float flat[32] =
  *                 CalcSpectralFlatnessPerBfu of BFUs 8..28 (0 elsewhere and with NoTonalComponents)  (T4, T5, T6)
  *   LOUDNESS      float [n_streams][F] tracked loudness                                             (T6)
- *   QUANT         1792-byte records [n_streams][F][2]: float err[7][32] (e1/e2), u32 cost[7][32] (CLC | VLC << 13) */
+ *   QUANT         1792-byte records [n_streams][F][2]: float err[7][32] (e1/e2), u32 cost[7][32] (CLC | VLC << 13) of the
+ *                 quantised units the rate loop asked for (zero = never computed); only with AT3HIP_OPT_QUANT_TAP */
 #define AT3HIP_TAP_SPECTRA 1
 #define AT3HIP_TAP_CURVES 2
 #define AT3HIP_TAP_ENERGY_SCALE 3
@@ -172,9 +173,11 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
  *                                overlap from the samples before its first block, so any cut gives the same bytes.
  *   AT3HIP_OPT_FLATNESS_LITERAL  1 = every spectral-flatness measure (CalcSpectralFlatnessPerBfu,
  *                                atrac_psy_common.cpp:158-199) by the literal per-line form; 0 (default) = the short form
- *                                with the literal one as fall-back where rounding could matter. Same values either way. */
+ *                                with the literal one as fall-back where rounding could matter. Same values either way.
+ *   AT3HIP_OPT_QUANT_TAP         1 = keep the AT3HIP_TAP_QUANT records (3.5 KB written per frame; off by default). */
 #define AT3HIP_OPT_RUNS 1
 #define AT3HIP_OPT_FLATNESS_LITERAL 2
+#define AT3HIP_OPT_QUANT_TAP 3
 int at3hip_set_option(at3hip_ctx* ctx, int32_t option, int32_t value);
 
 /* The constant tables exactly as at3hip_create builds them on this host (libm expressions of the reference's static

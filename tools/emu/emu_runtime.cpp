@@ -164,7 +164,7 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body)
                         swapcontext(&g_main, &f.ctx);
                         if (!f.done) ++alive;
                     }
-                    if (++spins > 2000000ull) { fprintf(stderr, "emu: deadlock (divergent barrier?)\n"); abort(); }
+                    if (++spins > 20000000ull) { fprintf(stderr, "emu: deadlock (divergent barrier?)\n"); abort(); }
                 }
             }
 }
