@@ -35,7 +35,8 @@ class Timings(ctypes.Structure):
 SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint_stereo", "at3hip_last_error",
            "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
            "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago", "at3hip_read_tap",
-           "at3hip_mdct_levels", "at3hip_gain_energy_scale", "at3hip_set_option", "at3hip_host_tables"]
+           "at3hip_mdct_levels", "at3hip_gain_energy_scale", "at3hip_set_option", "at3hip_host_tables", "at3hip_host_alloc",
+           "at3hip_host_free", "at3hip_wait_input", "at3hip_wait_frames"]
 # include/at1hip.h
 AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_encode", "at1hip_reset", "at1hip_get_timings",
                "at1hip_read_tap", "at1hip_host_tables"]
@@ -106,6 +107,10 @@ def load_library(path=None):
     lib.at3hip_sync.argtypes = [vp]
     lib.at3hip_set_option.argtypes = [vp, i32, i32]
     lib.at3hip_host_tables.argtypes = [vp, ctypes.c_size_t]
+    lib.at3hip_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.at3hip_host_free.argtypes = [vp, vp]
+    lib.at3hip_wait_input.argtypes = [vp, i32]
+    lib.at3hip_wait_frames.argtypes = [vp, i32]
     lib.at3hip_read_tap.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.at3hip_get_timings_ago.argtypes = [vp, i32, ctypes.POINTER(Timings)]
     lib.at3hip_version.restype = ctypes.c_uint32
@@ -210,6 +215,34 @@ class At3Hip:
 
     def sync(self):
         self._check(self.lib.at3hip_sync(self.ctx), "at3hip_sync")
+
+    def host_alloc(self, shape, dtype):
+        """Page-locked host array (at3hip_host_alloc); free it with host_free(array) before close()."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        self._check(self.lib.at3hip_host_alloc(self.ctx, n, ctypes.byref(p)), "at3hip_host_alloc")
+        buf = (ctypes.c_char * n).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def host_free(self, a):
+        p = self._pinned.pop(a.ctypes.data)
+        self._check(self.lib.at3hip_host_free(self.ctx, p), "at3hip_host_free")
+
+    def encode_host_async(self, pcm, out):
+        """Queues one call on host arrays (pinned ones overlap copies and kernels); returns frames per stream. `out` is valid
+        after wait_frames(ago) / sync(), `pcm` may be refilled after wait_input(ago)."""
+        nf = ctypes.c_int32()
+        self._check(self.lib.at3hip_encode(self.ctx, _vp(pcm), pcm.shape[1], _vp(out), ctypes.byref(nf), AT3HIP_ASYNC), "at3hip_encode")
+        return nf.value
+
+    def wait_input(self, ago=0):
+        self._check(self.lib.at3hip_wait_input(self.ctx, int(ago)), "at3hip_wait_input")
+
+    def wait_frames(self, ago=0):
+        self._check(self.lib.at3hip_wait_frames(self.ctx, int(ago)), "at3hip_wait_frames")
 
     def set_option(self, option, value):
         """AT3HIP_OPT_*: work partitioning / equivalent-form switches; results never change."""

@@ -210,17 +210,26 @@ __device__ __forceinline__ bool psy_scale_job(int wave, int lane, int& k, int& b
     return false;
 }
 
-// The literal form of CalcSpectralFlatnessPerBfu's geometric mean (atrac_psy_common.cpp:180-198) for one BFU: a restated
-// glibc log per line, the reference's ordered sum, the restated exp. Rarely called (see k_psy) and kept out of line: inlined,
-// its forty f64 temporaries cost the common path a third of its speed.
-__device__ __attribute__((noinline)) float flatness_literal(const Libm64* M, const float* sp, int len, double arith)
+// The literal form of CalcSpectralFlatnessPerBfu's geometric mean (atrac_psy_common.cpp:180-198) for ONE BFU, run by a
+// whole wavefront: lane i takes line i's restated glibc log (at3_libm64.hpp; the table look-ups of all lines are in flight
+// together), the reference's ordered sum walks the lanes' values as scalars, the restated exp closes it. Rarely needed
+// (see k_psy): one lane doing it alone - up to 64 dependent table look-ups in global memory - held its workgroup for
+// several times the kernel's normal duration. Wave-uniform call; `sp`, `len`, `arith` are uniform. Returns the flatness.
+__device__ __attribute__((noinline)) float flatness_literal_wave(const Libm64* M, const float* sp, int len, double arith, int lane)
 {
     const double floor_ = (double)1e-12f;
+    double lg = 0.0;
+    if (lane < len) {
+        const float x = sp[lane];
+        const double e = (double)fmaxf(0.0f, x * x);
+        lg = at3_log(M, e > floor_ ? e : floor_);
+    }
+    const uint64_t lb = (uint64_t)__double_as_longlong(lg);
+    const int lo = (int)(uint32_t)lb, hi = (int)(uint32_t)(lb >> 32);
     double ml = 0.0;
     for (int i = 0; i < len; ++i) {
-        const float x = sp[i];
-        const double e = (double)fmaxf(0.0f, x * x);
-        ml += at3_log(M, e > floor_ ? e : floor_);
+        const uint64_t v = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(lo, i) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(hi, i) << 32);
+        ml += __longlong_as_double((long long)v);
     }
     ml /= (double)len;
     return (float)fmin(1.0, fmax(0.0, at3_exp(M, ml) / arith));
@@ -260,7 +269,11 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
     __syncthreads();
 
     int fk, fb;
-    if (!p.no_tonal && psy_flat_job(wave, lane, fk, fb) && fk < ncf) {
+    const bool flat_job = !p.no_tonal && psy_flat_job(wave, lane, fk, fb) && fk < ncf;
+    float flat = 1.0f;
+    double arith = 0.0;
+    bool want_literal = false;
+    if (flat_job) {
         const int b = fb;
         const float* sp = s_spec[fk];
         const int start = bfu_start(b), end = bfu_start(b + 1), len = end - start;
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
         //    1e-15: relative distance below 2e-13. When BOTH ends of [ratio (1 - 1e-12), ratio (1 + 1e-12)] narrow to the
         //    same f32 after the clamp, that f32 is the reference's value; otherwise (about 3 in 100 000 BFUs) the literal
         //    form runs. Any device log / exp within a few hundred ulp serves the short form.
-        double arith = 0.0, prod = 1.0;
+        double prod = 1.0;
         int esum = 0;
         const double floor_ = (double)1e-12f;
         for (int i0 = start; i0 < end; i0 += 8) {
@@ -292,15 +305,30 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
             }
         }
         arith /= (double)len;
-        float flat = 1.0f;
         if (!(arith <= floor_)) {
             const double meanLog = (log(prod) + (double)esum * 0.69314718055994530942) / (double)len;
             const double ratio = exp(meanLog) / arith;
             const float f_lo = (float)fmin(1.0, fmax(0.0, ratio * (1.0 - 1e-12)));
             const float f_hi = (float)fmin(1.0, fmax(0.0, ratio * (1.0 + 1e-12)));
             flat = f_lo;
-            if (f_lo != f_hi || p.flat_literal) flat = flatness_literal(&T->libm, sp + start, len, arith);
+            want_literal = f_lo != f_hi || p.flat_literal;
         }
+    }
+    // the literal form for the lanes that asked for it, one after the other, by the whole wavefront (uniform)
+    for (unsigned long long rem = __ballot(want_literal); rem; rem &= rem - 1ull) {
+        const int src = __builtin_ctzll(rem);
+        const int jk = __builtin_amdgcn_readlane(fk, src), jb = __builtin_amdgcn_readlane(fb, src);
+        const uint64_t ab = (uint64_t)__double_as_longlong(arith);
+        const uint64_t as = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ab, src) |
+                            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ab >> 32), src) << 32);
+        const int jstart = bfu_start(jb);
+        const float r = flatness_literal_wave(&T->libm, s_spec[jk] + jstart, bfu_start(jb + 1) - jstart, __longlong_as_double((long long)as), lane);
+        if (lane == src) flat = r;
+    }
+    if (flat_job) {
+        const int b = fb;
+        const float* sp = s_spec[fk];
+        const int start = bfu_start(b), end = bfu_start(b + 1);
         rec0[fk].flat[b] = flat;
         if (flat < 0.01f) {  // ExtractTonalComponents search, atrac3denc.cpp:606-625
             // every window of one to five lines, first maximum wins (ascending start, then ascending length); the five

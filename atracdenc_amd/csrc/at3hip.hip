@@ -60,6 +60,14 @@ struct at3hip_ctx {
     hipEvent_t ev[kSlots][8] = {};
     hipEvent_t ev_front_done = nullptr;  // everything the most recent call queued on `stream` (which may be the caller's)
     bool front_done_valid = false;
+    // Host PCM: staged through a copy stream into device staging that is double-buffered by call parity, so that the
+    // H2D copy of call N+1 runs beside the kernels of call N (pinned host memory: at3hip_host_alloc).
+    hipStream_t h2d_stream = nullptr;
+    float* d_pcm_in_b[2] = {nullptr, nullptr};      // [S][max_blocks][1024][channels]
+    hipEvent_t ev_h2d[2] = {};                      // the parity's PCM has arrived
+    hipEvent_t ev_pcm_free[2] = {};                 // the parity's staging has been consumed (front half done with it)
+    bool pcm_free_valid[2] = {false, false};
+    bool h2d_valid[2] = {false, false};
     hipEvent_t ev_back_done[2] = {};     // back half finished with the parity's cross buffers
     bool back_done_valid[2] = {false, false};
     long long enc_calls = 0;             // at3hip_encode calls so far
@@ -77,8 +85,7 @@ struct at3hip_ctx {
     int dbg_front = 0, dbg_gain = 0, dbg_stop = 0;   // AT3HIP_DEBUG_* (profiling aids), honoured by -DAT3HIP_DEBUG_KNOBS builds only
 
     Tables* d_tables = nullptr;
-    float* d_pcm_in = nullptr;       // staging for host PCM [S][max_blocks][1024][2]
-    float* d_pcm_mono = nullptr;     // one-channel contexts: staging for host PCM [S][max_blocks][1024]
+    float* d_pcm_in = nullptr;       // one-channel contexts: the samples as (x, x) pairs [S][max_blocks][1024][2]
     float* d_hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
     float* d_sub = nullptr;
@@ -144,6 +151,7 @@ int stage_reserve(at3hip_ctx* c, size_t bytes)
 // Waits for everything this context has queued on its streams.
 int drain(at3hip_ctx* c)
 {
+    if (c->h2d_stream) HIPCHK(c, hipStreamSynchronize(c->h2d_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->mid_stream) HIPCHK(c, hipStreamSynchronize(c->mid_stream));
     HIPCHK(c, hipStreamSynchronize(c->back_stream));
@@ -268,6 +276,11 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
         if (hipStreamCreateWithPriority(&c->back_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(AT3HIP_EDEVICE);
         if (!cfg->no_gain_control && hipStreamCreateWithPriority(&c->mid_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return bail(AT3HIP_EDEVICE);
     }
+    if (hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    for (int q = 0; q < 2; ++q)
+        if (hipEventCreateWithFlags(&c->ev_h2d[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_pcm_free[q], hipEventDisableTiming) != hipSuccess)
+            return bail(AT3HIP_EDEVICE);
     c->stream = c->own_stream;
     for (auto& row : c->ev)
         for (auto& e : row)
@@ -290,8 +303,8 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     delete host_tables;
     if (rc != AT3HIP_OK) return bail(rc);
 
-    if ((rc = dev_alloc(c, &c->d_pcm_in, S * B * 2048)) != AT3HIP_OK) return bail(rc);
-    if (cfg->channels == 1 && (rc = dev_alloc(c, &c->d_pcm_mono, S * B * 1024)) != AT3HIP_OK) return bail(rc);
+    if (cfg->channels == 1 && (rc = dev_alloc(c, &c->d_pcm_in, S * B * 2048)) != AT3HIP_OK) return bail(rc);
+    // (the host-PCM staging pair is allocated by the first call that hands over host memory)
     if ((rc = dev_alloc(c, &c->d_hist[0], S * kHist * 2)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_hist[1], S * kHist * 2)) != AT3HIP_OK) return bail(rc);
     // subbands go through HBM when gain control analyses them, and for joint stereo (the M/S matrixing needs both channels'
@@ -355,12 +368,19 @@ void at3hip_destroy(at3hip_ctx* c)
         if (c->d_micro_b[q]) (void)hipFree(c->d_micro_b[q]);
     void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
                     c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
-                    c->d_out,       c->d_quant,     c->d_pcm_mono,  c->d_stage,    c->d_sub_tail, c->d_bins};
+                    c->d_out,       c->d_quant,     c->d_stage,    c->d_sub_tail, c->d_bins};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& row : c->ev)
         for (auto& e : row)
             if (e) (void)hipEventDestroy(e);
+    if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
+    for (int q = 0; q < 2; ++q) {
+        if (c->d_pcm_in_b[q]) (void)hipFree(c->d_pcm_in_b[q]);
+        if (c->ev_h2d[q]) (void)hipEventDestroy(c->ev_h2d[q]);
+        if (c->ev_pcm_free[q]) (void)hipEventDestroy(c->ev_pcm_free[q]);
+    }
+    if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
     if (c->ev_front_done) (void)hipEventDestroy(c->ev_front_done);
     for (auto& e : c->ev_back_done)
         if (e) (void)hipEventDestroy(e);
@@ -384,6 +404,49 @@ int at3hip_set_stream(at3hip_ctx* c, void* hip_stream)
     const int rc = drain(c);
     if (rc != AT3HIP_OK) return rc;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return AT3HIP_OK;
+}
+
+int at3hip_host_alloc(at3hip_ctx* c, size_t bytes, void** out)
+{
+    if (!c || !out || bytes == 0) return AT3HIP_EINVAL;
+    *out = nullptr;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, AT3HIP_ENOMEM, "hipHostMalloc", e);
+    *out = p;
+    return AT3HIP_OK;
+}
+
+int at3hip_host_free(at3hip_ctx* c, void* p)
+{
+    if (!c) return AT3HIP_EINVAL;
+    if (!p) return AT3HIP_OK;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
+    HIPCHK(c, hipHostFree(p));
+    return AT3HIP_OK;
+}
+
+int at3hip_wait_input(at3hip_ctx* c, int32_t ago)
+{
+    if (!c || ago < 0 || ago > 1 || ago >= c->enc_calls) return AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
+    const int par = (int)((c->enc_calls - 1 - ago) & 1);
+    if (c->h2d_valid[par]) HIPCHK(c, hipEventSynchronize(c->ev_h2d[par]));
+    return AT3HIP_OK;
+}
+
+int at3hip_wait_frames(at3hip_ctx* c, int32_t ago)
+{
+    if (!c || ago < 0 || ago > 1 || ago >= c->enc_calls) return AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
+    const int par = (int)((c->enc_calls - 1 - ago) & 1);
+    if (c->back_done_valid[par]) HIPCHK(c, hipEventSynchronize(c->ev_back_done[par]));
     return AT3HIP_OK;
 }
 
@@ -451,30 +514,39 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     hipStream_t st = c->stream;
     const bool gain = !c->cfg.no_gain_control;
 
+    const int par = (int)(c->enc_calls & 1);
     const float* d_pcm = pcm;
+    const size_t n_in = (size_t)S * n_blocks * 1024 * c->cfg.channels;
+    const float* d_staged = pcm;   // the call's PCM in device memory, [S][n_blocks][1024][channels]
+    if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
+        // host memory: the copy runs on its own stream into this parity's staging buffer - beside the previous call's
+        // kernels when the memory is pinned - and the front half waits for its arrival
+        if (!c->d_pcm_in_b[par]) {
+            const int rc = dev_alloc(c, &c->d_pcm_in_b[par], (size_t)S * c->cfg.max_blocks * 1024 * c->cfg.channels);
+            if (rc != AT3HIP_OK) return rc;
+        }
+        if (c->pcm_free_valid[par]) HIPCHK(c, hipStreamWaitEvent(c->h2d_stream, c->ev_pcm_free[par], 0));
+        HIPCHK(c, hipMemcpyAsync(c->d_pcm_in_b[par], pcm, n_in * sizeof(float), hipMemcpyHostToDevice, c->h2d_stream));
+        HIPCHK(c, hipEventRecord(c->ev_h2d[par], c->h2d_stream));
+        c->h2d_valid[par] = true;
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_h2d[par], 0));
+        d_staged = c->d_pcm_in_b[par];
+    }
+    d_pcm = d_staged;
     if (c->cfg.channels == 1) {
         // "No mono mode for atrac3, just make duplicate of first channel" (atrac3_bitstream.cpp:836-843): the one-channel
         // frame is two identical sound units, i.e. the discrete-stereo frame of L = R (TrackLoudness' 0.02 l equals
         // 0.01 (l + l) exactly). The samples are duplicated in HBM and the stereo pipeline runs unchanged.
         // Joint-stereo containers: M = (x + x) / 2 = x exactly, so the M unit is the mono unit (gain analysis, loudness
         // with 0.02 l and all); the rate/pack kernel replaces the S unit by the empty element of atrac3denc.cpp:843-849.
-        const float* d_mono = pcm;
         const size_t n = (size_t)S * n_blocks * 1024;
-        if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
-            HIPCHK(c, hipMemcpyAsync(c->d_pcm_mono, pcm, n * sizeof(float), hipMemcpyHostToDevice, st));
-            d_mono = c->d_pcm_mono;
-        }
-        hipLaunchKernelGGL(k_mono_to_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_mono, c->d_pcm_in, n);
-        d_pcm = c->d_pcm_in;
-    } else if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
-        HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, (size_t)S * n_blocks * 2048 * sizeof(float), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_mono_to_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_staged, c->d_pcm_in, n);
         d_pcm = c->d_pcm_in;
     }
     uint8_t* d_out = (flags & AT3HIP_OUT_ON_DEVICE) ? out_frames : c->d_out;
     const float* hist = c->d_hist[c->hist_cur];
     float* hist_next = c->d_hist[c->hist_cur ^ 1];
     hipStream_t bk = c->back_stream;
-    const int par = (int)(c->enc_calls & 1);
     const int slot = (int)(c->enc_calls % at3hip_ctx::kSlots);
     hipEvent_t* ev = c->ev[slot];
     Curve* d_curves = c->d_curves[par];
@@ -639,6 +711,10 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     }
     HIPCHK(c, hipEventRecord(c->ev_front_done, st));
     c->front_done_valid = true;
+    if (!(flags & AT3HIP_PCM_ON_DEVICE)) {   // (the PCM is read by the first stage and by the carried-state update, both on `st`)
+        HIPCHK(c, hipEventRecord(c->ev_pcm_free[par], st));
+        c->pcm_free_valid[par] = true;
+    }
     HIPCHK(c, hipGetLastError());
     c->hist_cur ^= 1;
     c->blocks_fed += n_blocks;

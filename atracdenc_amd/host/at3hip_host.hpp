@@ -17,6 +17,7 @@
 // throws from its sinks and aborts on impossible states; it never returns error codes).
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstring>
@@ -195,6 +196,51 @@ public:
     void Reset() { Check(at3hip_reset(Ctx), Ctx, "at3hip_reset"); }
     at3hip_ctx* Handle() { return Ctx; }
 
+    // A long input fed call by call with the copies hidden: two page-locked PCM buffers and two frame buffers alternate, the
+    // calls are asynchronous, so while the GPU encodes call k the host thread fills call k + 1's buffer (`fill`), the copy
+    // engine moves it, and call k - 1's frames come back and are handed to `drain` - what TPCMEngine::ApplyProcess
+    // (pcmengin.h:152-192) and ICompressedOutput::WriteFrame do around the reference's lambda, batched.
+    //   fill(float* dst, int maxBlocks) -> blocks written, [nStreams][blocks][1024][channels]; 0 ends the input
+    //   drain(const uint8_t* frames, int nFrames): [nStreams][nFrames][FrameSize()], in call order
+    // Returns the number of frames per stream.
+    template <class TFill, class TDrain>
+    long long EncodePipelined(int blocksPerCall, int channels, TFill fill, TDrain drain)
+    {
+        struct TPinned {
+            at3hip_ctx* Ctx;
+            void* P = nullptr;
+            TPinned(at3hip_ctx* c, size_t bytes) : Ctx(c) { Check(at3hip_host_alloc(c, bytes, &P), c, "at3hip_host_alloc"); }
+            ~TPinned() { at3hip_host_free(Ctx, P); }
+        };
+        const size_t inFloats = (size_t)NStreams * blocksPerCall * 1024 * channels, outBytes = (size_t)NStreams * blocksPerCall * FrameSz;
+        TPinned in0(Ctx, inFloats * sizeof(float)), in1(Ctx, inFloats * sizeof(float)), out0(Ctx, outBytes), out1(Ctx, outBytes);
+        float* in[2] = {(float*)in0.P, (float*)in1.P};
+        uint8_t* out[2] = {(uint8_t*)out0.P, (uint8_t*)out1.P};
+        int32_t nf[2] = {0, 0};
+        long long total = 0;
+        int call = 0;
+        for (;; ++call) {
+            const int q = call & 1;
+            if (call >= 2) Check(at3hip_wait_input(Ctx, 1), Ctx, "at3hip_wait_input");   // call - 2 read in[q]: gone to the device by now?
+            const int nb = fill(in[q], blocksPerCall);
+            if (nb <= 0) break;
+            // frames of call - 2 (same output buffer) were drained after call - 1 was queued: out[q] is free
+            Check(at3hip_encode(Ctx, in[q], nb, out[q], &nf[q], AT3HIP_ASYNC), Ctx, "at3hip_encode");
+            if (call >= 1) {   // while this call runs: the previous call's frames
+                Check(at3hip_wait_frames(Ctx, 1), Ctx, "at3hip_wait_frames");
+                if (nf[q ^ 1] > 0) drain(out[q ^ 1], (int)nf[q ^ 1]);
+                total += nf[q ^ 1];
+            }
+        }
+        if (call >= 1) {
+            Check(at3hip_sync(Ctx), Ctx, "at3hip_sync");
+            const int q = (call - 1) & 1;
+            if (nf[q] > 0) drain(out[q], (int)nf[q]);
+            total += nf[q];
+        }
+        return total;
+    }
+
 private:
     at3hip_ctx* Ctx = nullptr;
     int NStreams;
@@ -255,6 +301,47 @@ public:
     void Reset()
     {
         for (auto& p : Parts) p->Reset();
+    }
+
+    // The same for a long input: pcm [nStreams][nBlocksTotal][1024][SourceChannels] is cut into calls of `blocksPerCall`
+    // blocks; every device's host thread runs TAtrac3EncoderBatch::EncodePipelined on its slice (page-locked staging, copies
+    // and kernels of consecutive calls overlapping). frames [nStreams][nFrames][FrameSize()]; returns nFrames per stream.
+    int EncodePipelined(const float* pcm, int nBlocksTotal, int blocksPerCall, std::vector<uint8_t>& frames)
+    {
+        const size_t blockFloats = (size_t)1024 * Channels;
+        const int nfTotal = nBlocksTotal - 1;   // (fresh streams: the first block is the look-ahead)
+        frames.assign((size_t)NStreams * (nfTotal > 0 ? nfTotal : 0) * FrameSz, 0);
+        std::vector<std::string> err(Parts.size());
+        std::vector<long long> got(Parts.size(), 0);
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < Parts.size(); ++i)
+            th.emplace_back([&, i] {
+                try {
+                    int fed = 0, written = 0;
+                    got[i] = Parts[i]->EncodePipelined(
+                        blocksPerCall, Channels,
+                        [&](float* dst, int maxBlocks) {
+                            const int nb = std::min(maxBlocks, nBlocksTotal - fed);
+                            for (int s = 0; s < Count[i] && nb > 0; ++s)
+                                memcpy(dst + (size_t)s * nb * blockFloats, pcm + ((size_t)(First[i] + s) * nBlocksTotal + fed) * blockFloats,
+                                       (size_t)nb * blockFloats * sizeof(float));
+                            fed += nb > 0 ? nb : 0;
+                            return nb;
+                        },
+                        [&](const uint8_t* fr, int nf) {
+                            for (int s = 0; s < Count[i]; ++s)
+                                memcpy(frames.data() + ((size_t)(First[i] + s) * nfTotal + written) * FrameSz, fr + (size_t)s * nf * FrameSz,
+                                       (size_t)nf * FrameSz);
+                            written += nf;
+                        });
+                } catch (const std::exception& e) {
+                    err[i] = e.what();
+                }
+            });
+        for (auto& t : th) t.join();
+        for (size_t i = 0; i < Parts.size(); ++i)
+            if (!err[i].empty()) throw std::runtime_error("TAtrac3EncoderNode device " + std::to_string(i) + ": " + err[i]);
+        return (int)got[0];
     }
 
 private:

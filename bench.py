@@ -309,6 +309,64 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup):
     return out
 
 
+def host_pipeline_workload(S, F, steps=160, warmup=8):
+    """configs[1] fed from HOST memory the way the reference's caller hands it over (pcmengin.h:152-192), PCIe included: two
+    page-locked PCM buffers and two frame buffers alternate, the calls are asynchronous, so the H2D copy of call k + 1, the
+    kernels of call k and the D2H copy of call k - 1 overlap (at3hip_host_alloc / at3hip_wait_*). Never part of `value`."""
+    out = {"workload": f"configs[1] from host memory: {S} x {F} frames per call, pinned double-buffered staging, H2D + kernels + D2H overlapped"}
+    try:
+        import torch
+        import atracdenc_amd
+        enc = atracdenc_amd.At3Hip(n_streams=S, max_blocks=F + 1, bitrate=LP2, device_id=0)
+        ins = [enc.host_alloc((S, F, 1024, 2), np.float32) for _ in range(2)]
+        outs = [enc.host_alloc((S, F, enc.frame_size), np.uint8) for _ in range(2)]
+        rng = np.random.RandomState(5)
+        for a in ins:
+            a[...] = rng.randint(-8192, 8192, size=a.shape).astype(np.float32) / np.float32(32768.0)
+        prime = synth_pcm(S, 1, 99)
+        enc.encode(prime)                      # LOOK_AHEAD call
+        for i in range(warmup):
+            enc.encode_host_async(ins[i & 1], outs[i & 1])
+        enc.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if i >= 2:
+                enc.wait_input(1)      # where the caller refills ins[i & 1]
+            enc.encode_host_async(ins[i & 1], outs[i & 1])
+            if i >= 1:
+                enc.wait_frames(1)     # where the caller consumes the previous call's frames: at most two calls in flight
+        enc.sync()
+        dt = (time.perf_counter() - t0) / steps
+        # the same calls one at a time (copy, kernels, copy back, then the next): what the overlap buys
+        t0 = time.perf_counter()
+        for i in range(8):
+            enc.encode_host_async(ins[i & 1], outs[i & 1])
+            enc.sync()
+        dt_serial = (time.perf_counter() - t0) / 8
+        # the PCIe bound measured here: the same 32 MiB from page-locked memory, copies only
+        nbytes = ins[0].nbytes
+        x = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        d = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        d.copy_(x, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            d.copy_(x, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d = (time.perf_counter() - t0) / 10
+        for a in ins + outs:
+            enc.host_free(a)
+        enc.close()
+        out.update({"value": round(S * F / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4),
+                    "serial_calls_ms_per_step": round(dt_serial * 1e3, 4),
+                    "h2d_bytes_per_step": nbytes, "d2h_bytes_per_step": outs[0].nbytes,
+                    "h2d_copy_alone_ms": round(h2d * 1e3, 4), "h2d_GBps": round(nbytes / h2d / 1e9, 2),
+                    "pcie_bound_frames_per_s": round(S * F / h2d, 1), "frac_of_pcie_bound": round(h2d / dt, 4)})
+    except Exception as ex:   # noqa: BLE001 - the headline line must not depend on this
+        out["error"] = repr(ex)
+    return out
+
+
 def widened_rows(S):
     """SURVEY 8(f) rows f3 / f4 measured in the same process, after the headline (not part of `value`): the ATRAC1 encode
     path and ATRAC3plus PCM-to-frames (no tonal block) on the same audio shape (S stereo streams x 65536 samples, PCM resident in HBM)."""
@@ -549,6 +607,7 @@ def main():
                     side_workload("configs[3]: LP4 66 kbps joint stereo, configs[1] shape, 'noise'", 64, 64, LP4, "noise", 30, 3),
                     side_workload("shard_1024x128: per-GPU shard of configs[2] (1024 streams x 128 frames) on one GPU, 'noise'", 1024, 128, LP2, "noise", 10, 2),
                 ]
+                line["host_pipeline"] = host_pipeline_workload(64, 64)
                 line["widened_rows"] = widened_rows(64)
         print(json.dumps(line))
     for j in jobs:

@@ -180,6 +180,20 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
 #define AT3HIP_OPT_QUANT_TAP 3
 int at3hip_set_option(at3hip_ctx* ctx, int32_t option, int32_t value);
 
+/* Host-buffer pipeline. The reference's caller hands host floats (TPCMEngine::ApplyProcess, pcmengin.h:152-192): with
+ * page-locked buffers from at3hip_host_alloc and AT3HIP_ASYNC calls that alternate between two input and two output
+ * buffers, the H2D copy of call N+1 (on a copy stream of the ctx, into device staging double-buffered by call parity), the
+ * kernels of call N and the D2H copy of call N-1's frames overlap. `ago` = 0 for the most recent at3hip_encode call, 1
+ * for the one before it.
+ *   at3hip_wait_input   returns once that call's PCM has left the host buffer (it may be refilled)
+ *   at3hip_wait_frames  returns once that call's frames are in out_frames (the completion point of ONE call; at3hip_sync
+ *                       waits for all of them)
+ * Pageable host memory works too (the copies then block the calling thread, as hipMemcpyAsync does for such memory). */
+int at3hip_host_alloc(at3hip_ctx* ctx, size_t bytes, void** out);
+int at3hip_host_free(at3hip_ctx* ctx, void* p);
+int at3hip_wait_input(at3hip_ctx* ctx, int32_t ago);
+int at3hip_wait_frames(at3hip_ctx* ctx, int32_t ago);
+
 /* The constant tables exactly as at3hip_create builds them on this host (libm expressions of the reference's static
  * initialisers, atrac3.h:178-198, qmf.cpp:36-45, atrac_psy_common.cpp:126-156, ...) - no GPU involved. `bytes` must be the
  * size of the table block (see atracdenc_amd/csrc/at3_tables.hpp; the ctypes stub mirrors the layout). Lets a parity

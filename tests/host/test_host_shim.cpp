@@ -137,6 +137,13 @@ int main()
             EXPECT(memcmp(frames.data() + (size_t)s * nf * fsz, exp.data(), (size_t)nf * fsz) == 0);
         }
         printf("TAtrac3EncoderNode (2 contexts) compared\n");
+        // the same input through the page-locked, double-buffered pipeline: calls of 2 blocks, copies and kernels overlapping
+        node.Reset();
+        std::vector<uint8_t> piped;
+        const int nfp = node.EncodePipelined(batch.data(), n, 2, piped);
+        EXPECT(nfp == nf && piped.size() == frames.size());
+        EXPECT(memcmp(piped.data(), frames.data(), frames.size()) == 0);
+        printf("TAtrac3EncoderNode::EncodePipelined (pinned staging, 5 calls of <= 2 blocks) compared\n");
     }
     // ---- TAt3PEncoder: 5 stereo frames of 2048 samples through a batch of 2; look-ahead call, silent first frame ----
     {

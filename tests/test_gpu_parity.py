@@ -668,3 +668,38 @@ def test_wild_scale_factor_spread(hip, oracle, ng):
     assert ((d * d).sum(1) >= (1 << 24)).any()
     for i in range(2):
         assert np.array_equal(got[i], oracle.encode(pcm[i], LP2, ng, 0)[0]), i
+
+
+@pytest.mark.parametrize("br", [LP2, LP4])
+def test_host_buffer_pipeline(hip, oracle, br):
+    """Host PCM through the copy stream and the parity-double-buffered device staging (include/at3hip.h, "Host-buffer
+    pipeline"): page-locked buffers from at3hip_host_alloc, asynchronous calls alternating between two input and two output
+    buffers that are REFILLED / read as soon as at3hip_wait_input / at3hip_wait_frames allow - any missing ordering between
+    the copy stream, the three compute streams and the host shows up as a wrong frame."""
+    nb, piece, S = 41, 5, 3
+    pcm = np.stack([SIGNALS["mix"](nb, seed=31), SIGNALS["burst"](nb, phase=300), SIGNALS["noise"](nb, seed=32)])
+    enc = hip.At3Hip(n_streams=S, max_blocks=piece, bitrate=br)
+    ins = [enc.host_alloc((S, piece, 1024, 2), np.float32) for _ in range(2)]
+    outs = [enc.host_alloc((S, piece, enc.frame_size), np.uint8) for _ in range(2)]
+    got, counts = [], []
+    calls = [(pos, min(piece, nb - pos)) for pos in range(0, nb, piece)]
+    for k, (pos, n) in enumerate(calls):
+        q = k & 1
+        if k >= 2:
+            enc.wait_input(1)                       # call k - 2 has left ins[q]
+        ins[q][:, :n] = pcm[:, pos:pos + n]
+        ins[q][:, n:] = np.nan                      # (never read)
+        counts.append(enc.encode_host_async(ins[q][:, :n] if n == piece else np.ascontiguousarray(ins[q][:, :n]), outs[q]))
+        if k >= 1:
+            enc.wait_frames(1)                      # call k - 1's frames are in outs[q ^ 1]
+            c = counts[k - 1]
+            got.append(outs[q ^ 1].reshape(-1)[: S * c * enc.frame_size].reshape(S, c, enc.frame_size).copy())
+            outs[q ^ 1][...] = 0xEE
+    enc.sync()
+    c = counts[-1]
+    got.append(outs[(len(calls) - 1) & 1].reshape(-1)[: S * c * enc.frame_size].reshape(S, c, enc.frame_size).copy())
+    for a in ins + outs:
+        enc.host_free(a)
+    enc.close()
+    assert sum(counts) == nb - 1
+    assert np.array_equal(np.concatenate(got, axis=1), oracle_frames(oracle, pcm, br))
