@@ -200,33 +200,43 @@ __device__ __forceinline__ void irfft_pass_512(cpx* F, const Tw512<NT>& t, int t
 
 // The analysis of one (stream, frame, channel, band < 3) item is two kernels:
 //   k_gain_spec      Planck window, rFFT-512, the two ordered f64 energy sums and the high-frequency ratio; the 219 bins
-//                    that survive the high-pass go to HBM. One wavefront per item (the 256-point complex core is 64
-//                    butterflies per pass), four items per workgroup, 4.4 KB of LDS per item: a CU holds 32 items, and
-//                    the eight 257-term f64 chains of a workgroup run side by side in eight lanes of one wavefront.
+//                    that survive the high-pass go to HBM. The 256-point complex core of an item lives in the SIXTEEN LANES
+//                    of one DPP row with sixteen points per lane (below): four items per wavefront.
 //   k_gain_analysis  x8 zero-padded irFFT-4096 (2048-point complex core, 17 KB of LDS), AnalyzeGain, plateau target - only for
 //                    items whose ratio reaches 5 % (atrac3denc.cpp:319-327), two wavefronts per item.
 // (One kernel did both at first: its cheap first half then ran at the 8-items-per-CU occupancy of the LDS-hungry second
 // half, with its sequential chains on two lanes of 128.)
 constexpr int kGainBins = 220;   // bins 38 .. 256 (219), padded to an even count
 
-// rfft-512 core, point i at i + i / 4: the radix-4 passes read and write points 4 m apart (m = 1, 4, 16, 64) with all 64
-// lanes at once, and unpadded every such access landed on an eighth of the banks
-__device__ __forceinline__ int spec_pad(int i) { return i + (i >> 2); }
-struct SpecLds {
-    cpx f[320];       // rfft-512 core (padded, see spec_pad)
-    cpx freq[304];    // 257 bins, then 300 f64 energies (257 + zero padding) over the same bytes
+// ---- rfft-512 of one item in a 16-lane row --------------------------------------------------------------------------
+// kissfft factors 256 as 4 x 4 x 4 x 4 (kiss_fft.c:357-363): input i = q1 + 4 q2 + 16 q3 + 64 q4 enters the recombination at
+// position 64 q1 + 16 q2 + 4 q3 + q4, pass m (= 1, 4, 16, 64) combines positions m apart with twiddles tw[q k 64 / m].
+// Lane L = q1 + 4 q2 of the row loads its sixteen inputs i = L + 16 t straight from the subbands (for a given t the row reads
+// 128 contiguous bytes) and runs passes m = 1 and m = 4 on them in registers - the sixteen positions 64 q1 + 16 q2 + r are
+// exactly its own. One transposition through LDS (sixteen 8-byte stores, eight 16-byte loads per lane, conflict free) hands
+// lane K position r = K of every sixteen-block; passes m = 16 (butterfly k = K) and m = 64 (k = K + 16 j) are again
+// in-lane and leave F[K + 16 jj] in it. kiss_fftr's post-processing (tools/kiss_fftr.c:61-100) pairs F[k] with F[256 - k],
+// which sits in lane (16 - K) % 16: sixteen cross-lane reads (ds_bpermute: the LDS crossbar, no storage). The first
+// version walked all four passes through LDS with one butterfly per lane and pass: 4.3 k lane accesses per item, now 1.4 k.
+constexpr int kSpecRowStride = 18;                    // 8-byte slots per transposed position: 144 bytes, 16-byte aligned rows
+constexpr int kSpecItemBytes = 2432;                  // per item: the transposition (16 x 18 x 8 = 2304 B), later 300 f64 energies (2400 B)
+struct SpecItemLds {
+    union {
+        cpx x[16 * kSpecRowStride];
+        double e[304];
+    };
 };
+static_assert(sizeof(SpecItemLds) == kSpecItemBytes, "SpecItemLds layout");
 
-__global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T, int n_items)
+__global__ __launch_bounds__(64) void k_gain_spec(GainParams p, const Tables* T, int n_items)
 {
-    __shared__ __attribute__((aligned(16))) SpecLds s_item[4];
-    __shared__ double s_hsum[4][2];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    SpecLds& L = s_item[wave];
+    __shared__ __attribute__((aligned(16))) SpecItemLds s_item[4];
+    const int lane = threadIdx.x, row = lane >> 4, L = lane & 15;
+    SpecItemLds& S = s_item[row];
     const int nfr = p.n_blocks - p.f0;
-    int item = blockIdx.x * 4 + wave;
+    int item = blockIdx.x * 4 + row;
     const bool valid = item < n_items;
-    if (!valid) item = n_items - 1;   // keep the workgroup's barriers uniform; nothing is stored
+    if (!valid) item = n_items - 1;   // (keeps the wavefront uniform; nothing is stored)
     int wg = item;
     const int band = wg % 3; wg /= 3;
     const int ch = wg % 2; wg /= 2;
@@ -239,135 +249,147 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
     GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
     cpx* bins = p.bins + (size_t)item * kGainBins;
 
-    // Table entries this lane will need depend on its index only: all fetched now, so that the kernel pays one
-    // global-memory latency instead of one per pass.
-    f2 tw_a[4][3];                     // forward 256-point core: pass m = 4^st, k = lane % m, fstride 64 / m
+    // 1. window and pack: complex input i = L + 16 t is samples (2 i, 2 i + 1); a[4 q3 + q4] = input t = q3 + 4 q4
+    f2 a[16];
+    {
+        f2 raw[16], rb[16];
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        const int m = 1 << (2 * st), k = lane % m, fs = 64 / m;
-        (void)k; (void)fs;   // = tw256[(q + 1) k fs], from the per-lane table (contiguous per fetch)
-        tw_a[st][0] = ld2(&T->spec_tw[3 * st][lane]);
-        tw_a[st][1] = ld2(&T->spec_tw[3 * st + 1][lane]);
-        tw_a[st][2] = ld2(&T->spec_tw[3 * st + 2][lane]);
-    }
-    const cpx stw_post0 = T->spec_tw[12][lane], stw_post1 = T->spec_tw[13][lane];   // stw256[lane], [lane + 64]: bins k = lane + 1, lane + 65
-    const float hpf1 = T->hpf_w[1], hpf2 = T->hpf_w[2];
-    // 1. window and pack as 256 complex points in FFT leaf order (4 points per lane)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = lane + 64 * q;
-        float2 a = *reinterpret_cast<const float2*>(sb0 + 2 * i);
-        if (p.js) {
-            const float2 b = *reinterpret_cast<const float2*>(sb1 + 2 * i);
-            if (ch == 0) {
-                a.x = (a.x + b.x) * 0.5f;
-                a.y = (a.y + b.y) * 0.5f;
-            } else {
-                a.x = (a.x - b.x) * 0.5f;
-                a.y = (a.y - b.y) * 0.5f;
-            }
-        } else if (ch == 1) {
-            a = *reinterpret_cast<const float2*>(sb1 + 2 * i);
+        for (int t = 0; t < 16; ++t) {
+            const int i = L + 16 * t;
+            raw[t] = *reinterpret_cast<const f2*>((p.js || ch == 0 ? sb0 : sb1) + 2 * i);
+            if (p.js) rb[t] = *reinterpret_cast<const f2*>(sb1 + 2 * i);
         }
-        const cpx pw = T->planck4[q][lane];
-        cpx z;
-        z.r = a.x * pw.r;
-        z.i = a.y * pw.i;
-        L.f[spec_pad(fft_leaf_pos<256>(i))] = z;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            f2 v = raw[t];
+            if (p.js) v = (ch == 0) ? (v + rb[t]) * mk2(0.5f, 0.5f) : (v - rb[t]) * mk2(0.5f, 0.5f);
+            const f2 w = ld2(&T->spec16_win[t][L]);
+            a[4 * (t & 3) + (t >> 2)] = v * w;
+        }
     }
-    wave_sync();
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug == 21) return;
 #endif
-    // 256-point forward core, one butterfly per lane and pass
+    // passes m = 1 (all twiddles tw[0]) and m = 4 (butterfly k: tw[16 k], tw[32 k], tw[48 k], the same in every lane)
+    {
+        const f2 w0 = ld2(&T->tw256[0]);
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        const int m = 1 << (2 * st);
-        const int b0 = (lane / m) * 4 * m + lane % m;
-        cpx* B0 = L.f + spec_pad(b0);
-        cpx* B1 = L.f + spec_pad(b0 + m);
-        cpx* B2 = L.f + spec_pad(b0 + 2 * m);
-        cpx* B3 = L.f + spec_pad(b0 + 3 * m);
-        f2 x0 = ld2(B0), x1 = ld2(B1), x2 = ld2(B2), x3 = ld2(B3);
-        bfly4<false>(x0, x1, x2, x3, tw_a[st][0], tw_a[st][1], tw_a[st][2]);
-        st2(B0, x0);
-        st2(B1, x1);
-        st2(B2, x2);
-        st2(B3, x3);
-        wave_sync();
+        for (int q3 = 0; q3 < 4; ++q3) bfly4<false>(a[4 * q3], a[4 * q3 + 1], a[4 * q3 + 2], a[4 * q3 + 3], w0, w0, w0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            bfly4<false>(a[k], a[k + 4], a[k + 8], a[k + 12], ld2(&T->tw256[16 * k]), ld2(&T->tw256[32 * k]), ld2(&T->tw256[48 * k]));
     }
+    // transposition: lane K takes position r = K of every lane's block; b[l] = position 64 q1 + 16 q2 + K of lane l = q1 + 4 q2
+    f2 b[16];
+    {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st2(&S.x[r * kSpecRowStride + L], a[r]);
+        wave_sync();
+        const float4* src = reinterpret_cast<const float4*>(&S.x[L * kSpecRowStride]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const float4 v = src[m];
+            b[2 * m] = mk2(v.x, v.y);
+            b[2 * m + 1] = mk2(v.z, v.w);
+        }
+        wave_sync();   // (the item's storage is reused for the energies)
+    }
+    // passes m = 16 (butterfly k = L over q2, for every q1) and m = 64 (butterfly k = L + 16 j over q1)
+    {
+        const f2 u1 = ld2(&T->spec16_tw[0][L]), u2 = ld2(&T->spec16_tw[1][L]), u3 = ld2(&T->spec16_tw[2][L]);
+#pragma unroll
+        for (int q1 = 0; q1 < 4; ++q1) bfly4<false>(b[q1], b[q1 + 4], b[q1 + 8], b[q1 + 12], u1, u2, u3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            bfly4<false>(b[4 * j], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3], ld2(&T->spec16_tw[3 + 3 * j][L]), ld2(&T->spec16_tw[4 + 3 * j][L]),
+                         ld2(&T->spec16_tw[5 + 3 * j][L]));
+    }
+    // now b[q + 4 j] = F[L + 16 (j + 4 q)]: F[L + 16 jj] = b[(jj >> 2) + 4 (jj & 3)]
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug == 22) return;
 #endif
-    // 2. kiss_fftr post-processing -> 257 bins (tools/kiss_fftr.c:61-100): lane handles k = lane + 1 and k = lane + 65
-    if (lane == 0) {
-        const float tr = L.f[spec_pad(0)].r, ti = L.f[spec_pad(0)].i;
-        cpx a, b;
-        a.r = tr + ti; a.i = 0.0f;
-        b.r = tr - ti; b.i = 0.0f;
-        L.freq[0] = a;
-        L.freq[256] = b;
-    }
+    // 2. kiss_fftr post-processing -> 257 bins: this lane's k = L + 16 jj, jj = 0..7, each with its partner 256 - k, whose F
+    // is element 15 - jj of lane (16 - L) % 16 - for L = 0 element 16 - jj of the lane itself
+    f2 fa[8], fb[8];   // freq[k], freq[256 - k]
+    f2 f128 = mk2(0.0f, 0.0f);
+    {
+        const int partner = 4 * ((lane & 48) | ((16 - L) & 15));
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int k = lane + 1 + 64 * q;
-        const cpx fpk = L.f[spec_pad(k)];
-        cpx fpnk;
-        fpnk.r = L.f[spec_pad(256 - k)].r;
-        fpnk.i = -L.f[spec_pad(256 - k)].i;
-        cpx f1k, f2k;
-        f1k.r = fpk.r + fpnk.r; f1k.i = fpk.i + fpnk.i;
-        f2k.r = fpk.r - fpnk.r; f2k.i = fpk.i - fpnk.i;
-        const cpx tw = cmul(f2k, q ? stw_post1 : stw_post0);
-        cpx a, b;
-        a.r = (f1k.r + tw.r) * 0.5f; a.i = (f1k.i + tw.i) * 0.5f;
-        b.r = (f1k.r - tw.r) * 0.5f; b.i = (tw.i - f1k.i) * 0.5f;
-        if (k != 128) L.freq[k] = a;   // k == 128: the second store wins in the reference
-        L.freq[256 - k] = b;
+        for (int jj = 0; jj < 8; ++jj) {
+            const int je = 15 - jj;                                  // partner's element (L != 0)
+            const f2 pe = b[(je >> 2) + 4 * (je & 3)];
+            f2 other;
+            other.x = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)__float_as_uint(pe.x)));
+            other.y = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)__float_as_uint(pe.y)));
+            if (jj > 0) {
+                const int j0 = 16 - jj;                              // L == 0: own element 16 - jj
+                const f2 own = b[(j0 >> 2) + 4 * (j0 & 3)];
+                if (L == 0) other = own;
+            }
+            const f2 fpk = b[(jj >> 2) + 4 * (jj & 3)];
+            const cpx stw = T->spec16_stw[jj][L];
+            const float fnr = other.x, fni = -other.y;               // fpnk = conj(F[256 - k])
+            const float f1r = fpk.x + fnr, f1i = fpk.y + fni;
+            const float f2r = fpk.x - fnr, f2i = fpk.y - fni;
+            const float twr = f2r * stw.r - f2i * stw.i, twi = f2r * stw.i + f2i * stw.r;
+            fa[jj] = mk2((f1r + twr) * 0.5f, (f1i + twi) * 0.5f);
+            fb[jj] = mk2((f1r - twr) * 0.5f, (twi - f1i) * 0.5f);
+        }
+        // k = 0 (lane 0, jj = 0): freq[0] = (F0.r + F0.i, 0), freq[256] = (F0.r - F0.i, 0)
+        if (L == 0) {
+            const f2 f0 = b[0];
+            fa[0] = mk2(f0.x + f0.y, 0.0f);
+            fb[0] = mk2(f0.x - f0.y, 0.0f);
+        }
+        // k = 128 (lane 0, element 8): paired with itself; the reference's second store (freq[256 - k]) is the one that stays
+        {
+            const f2 fpk = b[2];   // jj = 8 -> (8 >> 2) + 4 (8 & 3) = 2
+            const cpx stw = T->spec16_stw[8][L];
+            const float fnr = fpk.x, fni = -fpk.y;
+            const float f1r = fpk.x + fnr, f1i = fpk.y + fni;
+            const float f2r = fpk.x - fnr, f2i = fpk.y - fni;
+            const float twr = f2r * stw.r - f2i * stw.i, twi = f2r * stw.i + f2i * stw.r;
+            f128 = mk2((f1r - twr) * 0.5f, (twi - f1i) * 0.5f);
+        }
     }
-    wave_sync();
     // the bins that survive the high-pass (38 .. 256) go to HBM for k_gain_analysis; whether it will want them is known
     // only after the energy sums, and the stores cost less than waiting for that
     if (valid) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = lane + 64 * q;
-            if (j < 219) bins[j] = L.freq[kLowCutBin + j];
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = L + 16 * jj;
+            if (k >= kLowCutBin) st2(&bins[k - kLowCutBin], fa[jj]);
+            st2(&bins[256 - k - kLowCutBin], fb[jj]);
         }
+        if (L == 0) st2(&bins[128 - kLowCutBin], f128);
     }
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug == 23) return;
 #endif
     // highFreqRatio (transient_spectral_upsampler.cpp:99-118): two ordered f64 sums over the 257 bin energies, the second
-    // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on). The energies are formed by
-    // all lanes and parked (as f64) over the spectrum; after the workgroup's rendezvous lanes 0..7 of the first wavefront
-    // add them up - item lane / 2: even lanes e[0..256], odd lanes the two weighted terms followed by e[40..256] (the
-    // skipped terms of the reference are exact zeros and the padding read past bin 256 is zero).
+    // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on). The energies are parked (as f64)
+    // in the item's storage; lanes 0..7 of the wavefront add them up - item lane / 2: even lanes e[0..256], odd lanes the
+    // two weighted terms followed by e[40..256] (the skipped terms of the reference are exact zeros and the padding read
+    // past bin 256 is zero).
     {
-        double e[5];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const int k = lane + 64 * t;
-            const cpx z = L.freq[k < 257 ? k : 256];
-            e[t] = (k < 257) ? (double)z.r * z.r + (double)z.i * z.i : 0.0;
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = L + 16 * jj;
+            S.e[k] = (double)fa[jj].x * fa[jj].x + (double)fa[jj].y * fa[jj].y;
+            S.e[256 - k] = (double)fb[jj].x * fb[jj].x + (double)fb[jj].y * fb[jj].y;
         }
-        wave_sync();
-        double* E = reinterpret_cast<double*>(L.freq);
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            const int k = lane + 64 * t;
-            if (k < 300) E[k] = e[t];
-        }
+        if (L == 0) S.e[128] = (double)f128.x * f128.x + (double)f128.y * f128.y;
+        for (int k = 257 + L; k < 304; k += 16) S.e[k] = 0.0;
     }
-    __syncthreads();
+    wave_sync();
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug == 24) return;
 #endif
-    if (tid < 8) {
-        const int it = tid >> 1, kind = tid & 1;
-        const double* E = reinterpret_cast<const double*>(s_item[it].freq);
-        const double h1 = (double)hpf1, h2 = (double)hpf2;
-        double acc = 0.0;
+    double acc = 0.0;
+    if (lane < 8) {
+        const int it = lane >> 1, kind = lane & 1;
+        const double* E = s_item[it].e;
+        const double h1 = (double)T->hpf_w[1], h2 = (double)T->hpf_w[2];
         if (kind == 1) {
             acc += E[kLowCutBin] * h1 * h1;
             acc += E[kLowCutBin + 1] * h2 * h2;
@@ -381,11 +403,16 @@ __global__ __launch_bounds__(256) void k_gain_spec(GainParams p, const Tables* T
             for (int i = 0; i < 16; ++i) acc += v[i];
         }
         acc += src[256];
-        s_hsum[it][kind] = acc;
     }
-    __syncthreads();
-    if (valid && lane == 0) {
-        const double totalE = s_hsum[wave][0], filtE = s_hsum[wave][1];
+    // lane 2 it holds the item's total energy, lane 2 it + 1 the filtered one
+    const uint64_t ab = (uint64_t)__double_as_longlong(acc);
+    const int alo = (int)(uint32_t)ab, ahi = (int)(uint32_t)(ab >> 32);
+    const uint64_t fb64 = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(4 * (2 * row + 1), alo) |
+                          ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(4 * (2 * row + 1), ahi) << 32);
+    const uint64_t tb64 = (uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(4 * (2 * row), alo) |
+                          ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(4 * (2 * row), ahi) << 32);
+    if (valid && L == 0) {
+        const double totalE = __longlong_as_double((long long)tb64), filtE = __longlong_as_double((long long)fb64);
         rec->hfr = (totalE > 0.0) ? (float)(filtE / totalE) : 0.0f;
     }
 }

@@ -101,13 +101,16 @@ AT3_RUNTIME_LIBM void build_tables(Tables* t)
     fill_twiddles(t->tw2048, 2048, true);
     fill_super_twiddles(t->stw256, 256, false);
     fill_super_twiddles(t->stw2048, 2048, true);
-    for (int l = 0; l < 64; ++l) {   // see at3_k_gain.hpp: k_gain_spec
-        for (int st = 0; st < 4; ++st) {
-            const int m = 1 << (2 * st), k = l % m, fs = 64 / m;
-            for (int q = 0; q < 3; ++q) t->spec_tw[3 * st + q][l] = t->tw256[(q + 1) * k * fs];
+    for (int L = 0; L < 16; ++L) {   // see at3_k_gain.hpp: k_gain_spec (a 256-point transform in a 16-lane row)
+        for (int q = 1; q <= 3; ++q) t->spec16_tw[q - 1][L] = t->tw256[4 * q * L];
+        for (int j = 0; j < 4; ++j)
+            for (int q = 1; q <= 3; ++q) t->spec16_tw[3 + 3 * j + q - 1][L] = t->tw256[q * (L + 16 * j)];
+        for (int jj = 0; jj < 9; ++jj) {
+            const int k = L + 16 * jj;
+            cpx z = {0.0f, 0.0f};
+            if (k >= 1 && k <= 128 && (jj < 8 || L == 0)) z = t->stw256[k - 1];
+            t->spec16_stw[jj][L] = z;
         }
-        t->spec_tw[12][l] = t->stw256[l];
-        t->spec_tw[13][l] = t->stw256[l + 64];
     }
     for (int tid = 0; tid < 128; ++tid) {   // see at3_k_gain.hpp: irfft_pass_32_128 / irfft_pass_512
         const int k = tid & 31;
@@ -138,11 +141,11 @@ AT3_RUNTIME_LIBM void build_tables(Tables* t)
         }
         for (int i = 0; i < 3; ++i) t->hpf_w[i] = 0.5f * (1.0f - cosf((float)M_PI * i / 2.0f));
     }
-    for (int l = 0; l < 64; ++l)   // the window in the order k_gain_spec's lanes consume it
-        for (int q = 0; q < 4; ++q) {
-            const int i = l + 64 * q;
-            t->planck4[q][l].r = t->planck[2 * i];
-            t->planck4[q][l].i = t->planck[2 * i + 1];
+    for (int L = 0; L < 16; ++L)   // the window in the order k_gain_spec's lanes consume it
+        for (int tt = 0; tt < 16; ++tt) {
+            const int i = L + 16 * tt;
+            t->spec16_win[tt][L].r = t->planck[2 * i];
+            t->spec16_win[tt][L].i = t->planck[2 * i + 1];
         }
 
     for (size_t i = 0; i < 1024; ++i) {

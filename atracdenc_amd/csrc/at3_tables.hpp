@@ -38,11 +38,14 @@ struct Tables {
     // irfft-4096 core, as [slot][t] so that a wavefront fetches each slot as one contiguous 512-byte run (picking them out
     // of tw2048 touched up to 32 cache lines per load). Slots: 0..2 pass m = 32, 3..14 pass m = 128, 15..26 pass m = 512.
     cpx gain_tw[27][128];
-    // k_gain_spec: the 12 forward twiddles lane l of a wavefront needs for the four passes of the rfft-512 core
-    // (pass m = 4^st: tw256[(q + 1) (l % m) 64 / m]) and its two super twiddles, as [slot][l]; the Planck window in the
-    // order the lanes consume it: planck4[q][l] = {w[2 i], w[2 i + 1]} for i = l + 64 q
-    cpx spec_tw[14][64];
-    cpx planck4[4][64];
+    // k_gain_spec: a 256-point transform lives in the 16 lanes of a DPP row, position L = lane & 15 (see at3_k_gain.hpp):
+    //   spec16_win[t][L]  Planck window pair {w[2 i], w[2 i + 1]} of complex input i = L + 16 t
+    //   spec16_tw[s][L]   s = 0..2: tw256[4 (s + 1) L] (pass m = 16, butterfly k = L);
+    //                     s = 3 + 3 j + q - 1: tw256[q (L + 16 j)], j = 0..3, q = 1..3 (pass m = 64, butterfly k = L + 16 j)
+    //   spec16_stw[jj][L] super twiddle stw256[k - 1] of bin k = L + 16 jj, jj = 0..7 (k = 0: unused); [8][0] = stw256[127] (bin 128)
+    cpx spec16_win[16][16];
+    cpx spec16_tw[15][16];
+    cpx spec16_stw[9][16];
     // glibc 2.35's f64 log / exp data (at3_libm64.hpp): the literal form of CalcSpectralFlatnessPerBfu in k_psy
     Libm64 libm;
 };

@@ -630,7 +630,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             launch_qmf_sub();
             HIPCHK(c, hipEventRecord(ev[1], st));
             launch_state(st, 1);   // PCM history and subband tail: the next call's heavy stage needs nothing else from this one
-            hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(256), 0, st, gp, c->d_tables, S * n_out * 6);
+            hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(64), 0, st, gp, c->d_tables, S * n_out * 6);
             hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), 0, st, gp, c->d_tables);
             HIPCHK(c, hipEventRecord(ev[2], st));
             HIPCHK(c, hipStreamWaitEvent(md, ev[2], 0));   // the light stage starts when this call's heavy stage is done

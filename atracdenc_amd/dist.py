@@ -1,5 +1,5 @@
 """Multi-GPU plumbing: streams are independent, so a node scales by sharding streams across one process per
-GPU. There is no data-path collective; torch.distributed (RCCL on GPUs, gloo on CPU in the tests) is used
+GPU. There is no data-path collective; torch.distributed (gloo, CPU side) is used
 only for the start/stop barrier, the MAX of the per-rank elapsed time and - in tests - gathering checksums."""
 import os
 
@@ -19,13 +19,10 @@ def shard_streams(n_streams_total, world, rank):
     return first, base + (1 if rank < rem else 0)
 
 
-def init(backend, local_rank=0):
-    import torch
+def init(backend="gloo"):
+    """CPU-side process group (gloo): the data path has no exchange step, so nothing ever runs over RCCL."""
     import torch.distributed as dist
-    if backend == "nccl":
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(backend=backend)
+    dist.init_process_group(backend=backend)
     return dist
 
 

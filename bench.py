@@ -541,6 +541,28 @@ def main():
                                 "this workload, collected separately as the guide prescribes) - not measured in this run")
             except Exception:
                 traffic = None
+        # whole-pipeline HBM traffic and the vector-instruction counts of the QMF + MDCT kernels: PMC passes cannot run inside
+        # the timed region, so these come from the committed profile of the same workload (tools/profile_gpu.sh) and say so
+        pipe_traffic, valu_floor_ms, valu_note = None, None, "not available"
+        pt = os.path.join(ROOT, "profiles", "pipeline_traffic.json")
+        if os.path.exists(pt) and (S, F) == (64, 64) and not args.no_gain and fsz == 384:
+            try:
+                pj = json.load(open(pt))
+                pipe_traffic = {"pipeline_bytes_per_frame": round(pj["pipeline_bytes_per_frame"], 1),
+                                "algorithmic_bytes_per_frame": pj["algorithmic_bytes_per_frame"],
+                                "source": "profiles/pipeline_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE summed over the pipeline's "
+                                          "kernels, separate passes, this workload - not measured in this run"}
+                insts = sum(pj.get("valu_wave_insts_per_launch", {}).values())
+                if insts > 0:
+                    # tools/ubench (profiles/r02_ubench_instruction_rates.txt): one plain fp32 wave-instruction per 1.29 ns and SIMD
+                    # at full issue, a packed one per 2.37 ns; the FIR's are packed, so the true floor lies above this figure
+                    n_simd = 1024
+                    valu_floor_ms = insts / n_simd * 1.29e-6
+                    valu_note = (f"{int(insts)} vector wave-instructions per launch pair (SQ_INSTS_VALU, profiles/pipeline_traffic.json) / "
+                                 f"{n_simd} SIMDs x 1.29 ns, the measured issue cost of a PLAIN fp32 instruction (a packed one costs 2.37 ns: "
+                                 "the arithmetic contract forbids FMA, so the multiply-add pairs of the FIR are two packed instructions each)")
+            except Exception:
+                pipe_traffic = None
         cfgname = {384: "LP2 132 kbps", 192: "LP4 66 kbps joint stereo"}.get(fsz, f"{fsz} B/frame")
         line = {
             "metric": "ATRAC3 1024-sample stereo frames/sec", "value": round(value, 1), "unit": "frames/s",
@@ -572,8 +594,12 @@ def main():
                                  "three streams and share the GPU with the neighbouring steps' gain analysis and rate loop - on purpose: "
                                  "that overlap is what shortens the step - so each launch takes longer than it does alone; `isolated` is "
                                  "the same launches with the GPU to themselves",
+                         "valu_floor_ms": None if valu_floor_ms is None else round(valu_floor_ms, 5),
+                         "valu_frac": None if valu_floor_ms is None else round(valu_floor_ms / iso_ms, 4),
+                         "valu_floor_note": valu_note + "; valu_frac = valu_floor_ms / isolated.avg_launch_ms",
                          "isolated": {"avg_launch_ms": round(iso_ms, 5), "achieved": ach_iso, "frac": frac_iso,
                                       "note": "same kernel, same batch, launched alone (3 synchronous steps after the timed region)"}},
+            "pipeline_traffic": pipe_traffic,
             "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
             "pipelining": "three HIP streams inside the context: the heavy front stage (QMF, gain spectra, envelopes) of step i+1, the "
                           "light front stage (curves, energy scales, MDCT) of step i and the back half (psychoacoustics, rate loop, "
