@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 REPO=$(pwd)
 cd /tmp
 rm -rf /tmp/tl
-rocprofv3 --kernel-trace --stats -d /tmp/tl -o tl -- python $REPO/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-side-workloads "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/tl -o tl -- python $REPO/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-side-workloads --regions 0 --no-parity "$@" > /dev/null 2>&1
 python3 - <<'PY'
 import glob, sqlite3
 for f in glob.glob("/tmp/tl/**/*.db", recursive=True):
