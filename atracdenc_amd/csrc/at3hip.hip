@@ -274,7 +274,11 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // lo = numerically greatest = lowest priority
         if (hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return bail(AT3HIP_EDEVICE);
         if (hipStreamCreateWithPriority(&c->back_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(AT3HIP_EDEVICE);
-        if (!cfg->no_gain_control && hipStreamCreateWithPriority(&c->mid_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return bail(AT3HIP_EDEVICE);
+        // The light front stage (curve context, curves, energy scales, MDCT) sits on the step's critical path - the next rate
+        // loop waits for its spectra - while the heavy stage it shares the chip with (the NEXT step's spectra and envelopes,
+        // whose workgroups fill the LDS) has a whole rate loop of slack: high priority lets its short kernels take the
+        // slots the heavy stage's workgroups free (+3 % on the step; a middle priority does nothing).
+        if (!cfg->no_gain_control && hipStreamCreateWithPriority(&c->mid_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(AT3HIP_EDEVICE);
     }
     if (hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess) return bail(AT3HIP_EDEVICE);
     for (int q = 0; q < 2; ++q)
