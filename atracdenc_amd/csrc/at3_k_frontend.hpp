@@ -134,18 +134,22 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
                 }
             }
             const float xc[4] = {l.x, l.y, l.z, l.w}, xp[4] = {lp.x, lp.y, lp.z, lp.w};
-            float dc8[8], dp8[8];   // the lane's four samples are one half of cell lane / 2
+            const bool hi_half = lane & 1;
+            float dc4[4], dp4[4];   // the lane's four samples are one half of cell lane / 2: that half's divisors
             {
+                float dc8[8], dp8[8];
                 const uint4 wc4 = *reinterpret_cast<const uint4*>(&s_cv[c][0]), wp4 = *reinterpret_cast<const uint4*>(&s_cv[c][1]);
                 cell_divisors_packed((uint64_t)wc4.x | ((uint64_t)wc4.y << 32), (uint64_t)wc4.z | ((uint64_t)wc4.w << 32), s_gi, 8 * (lane >> 1), dc8);
                 cell_divisors_packed((uint64_t)wp4.x | ((uint64_t)wp4.y << 32), (uint64_t)wp4.z | ((uint64_t)wp4.w << 32), s_gi, 8 * (lane >> 1), dp8);
+                // (selected with static indices: `d[4 hi_half + k]` is a run-time index and sends the arrays to scratch memory)
+                dc4[0] = hi_half ? dc8[4] : dc8[0]; dc4[1] = hi_half ? dc8[5] : dc8[1]; dc4[2] = hi_half ? dc8[6] : dc8[2]; dc4[3] = hi_half ? dc8[7] : dc8[3];
+                dp4[0] = hi_half ? dp8[4] : dp8[0]; dp4[1] = hi_half ? dp8[5] : dp8[1]; dp4[2] = hi_half ? dp8[6] : dp8[2]; dp4[3] = hi_half ? dp8[7] : dp8[3];
             }
-            const bool hi_half = lane & 1;
             float t[5][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float mc = xc[k] / (hi_half ? dc8[4 + k] : dc8[k]);
-                const float mp = xp[k] / (hi_half ? dp8[4 + k] : dp8[k]);
+                const float mc = xc[k] / dc4[k];
+                const float mp = xp[k] / dp4[k];
                 const float pv = wn[k] * mp;                // the overlap this block inherited: EncodeWindow[i] * modulated sample
                 const float cw = xc[k] * wc[k], mw = mc * wc[k], nw = xp[k] * wn[k], mnw = mp * wn[k];
                 t[0][k] = pv * pv;
