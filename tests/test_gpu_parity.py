@@ -703,3 +703,34 @@ def test_host_buffer_pipeline(hip, oracle, br):
     enc.close()
     assert sum(counts) == nb - 1
     assert np.array_equal(np.concatenate(got, axis=1), oracle_frames(oracle, pcm, br))
+
+
+def test_options_and_quant_tap(hip, oracle):
+    """at3hip_set_option: the QUANT tap is off by default (at3hip_read_tap refuses it), on request it holds the unit cache of
+    the rate loop - every (wordlen, BFU < 10) unit (the seventy small units are always quantised) with a finite energy error and
+    a CLC | VLC cost - and switching it on, off or asking for another work partitioning never changes a frame."""
+    from atracdenc_amd import binding as B
+    nb = 9
+    pcm = np.stack([SIGNALS["mix"](nb, seed=2), SIGNALS["noise"](nb, seed=3)])
+    exp = oracle_frames(oracle, pcm, LP2)
+    enc = hip.At3Hip(n_streams=2, max_blocks=nb, bitrate=LP2)
+    assert np.array_equal(enc.encode(pcm), exp)
+    with pytest.raises(hip.At3HipError):
+        enc.read_tap(B.TAP_QUANT, B.At3Hip.QUANT_DTYPE, (2, nb - 1, 2))
+    enc.reset()
+    enc.set_option(B.OPT_QUANT_TAP, 1)
+    enc.set_option(B.OPT_RUNS, 3)
+    assert np.array_equal(enc.encode(pcm), exp)
+    q = enc.read_tap(B.TAP_QUANT, B.At3Hip.QUANT_DTYPE, (2, nb - 1, 2))
+    err, cost = q["err"][..., :10], q["cost"][..., :10]
+    assert np.isfinite(err).all() and (err > 0).all()
+    lines = np.array([8] * 8 + [16] * 2)
+    clc = np.array([2, 3, 3, 4, 4, 5, 6])[:, None] * lines[None, :]          # CLC bits per unit: clc_len(wordlen) x lines (pairs of 4 bits at wordlen 1)
+    assert ((cost & 0x1fff) == clc).all() and ((cost >> 13) > 0).all()
+    enc.reset()
+    enc.set_option(B.OPT_QUANT_TAP, 0)
+    enc.set_option(B.OPT_RUNS, 0)
+    assert np.array_equal(enc.encode(pcm), exp)
+    with pytest.raises(hip.At3HipError):
+        enc.set_option(99, 1)
+    enc.close()
