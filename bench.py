@@ -309,7 +309,7 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup):
     return out
 
 
-def host_pipeline_workload(S, F, steps=160, warmup=8):
+def host_pipeline_workload(S, F, steps=400, warmup=8):
     """configs[1] fed from HOST memory the way the reference's caller hands it over (pcmengin.h:152-192), PCIe included: two
     page-locked PCM buffers and two frame buffers alternate, the calls are asynchronous, so the H2D copy of call k + 1, the
     kernels of call k and the D2H copy of call k - 1 overlap (at3hip_host_alloc / at3hip_wait_*). Never part of `value`."""
