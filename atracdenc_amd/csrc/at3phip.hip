@@ -37,6 +37,7 @@ struct at3phip_ctx {
     hipEvent_t ev_specs[2] = {}, ev_write_done[2] = {};
     bool write_done_valid[2] = {false, false};
     long long enc_calls = 0;
+    bool ev_from_encode = false;   // the timing events were last recorded by at3phip_encode_frames (at3phip_sync may read all of them)
     float pqf_ms = 0.0f, mdct_ms = 0.0f, write_ms = 0.0f;
     char err[256] = {0};
 };
@@ -249,6 +250,7 @@ int at3phip_pqf_analyse(at3phip_ctx* c, const float* pcm, int32_t n_frames, floa
     }
     float* d_bands = (flags & AT3HIP_OUT_ON_DEVICE) ? bands : c->d_bands;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    c->ev_from_encode = false;
     int rc = launch_pqf(c, d_pcm, n_frames, d_bands);
     if (rc != AT3HIP_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -273,6 +275,7 @@ int at3phip_mdct(at3phip_ctx* c, const float* bands, int32_t n_frames, const uin
     }
     float* d_specs = (flags & AT3HIP_OUT_ON_DEVICE) ? specs : c->d_specs;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    c->ev_from_encode = false;
     int rc = launch_mdct(c, d_bands, n_frames, win_flags, d_specs, flags);
     if (rc != AT3HIP_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -299,6 +302,7 @@ int at3phip_pqf_mdct(at3phip_ctx* c, const float* pcm, int32_t n_frames, const u
     float* d_bands = (out_dev && bands) ? bands : c->d_bands;
     float* d_specs = out_dev ? specs : c->d_specs;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    c->ev_from_encode = false;
     int rc = launch_pqf(c, d_pcm, n_frames, d_bands);
     if (rc != AT3HIP_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -337,6 +341,7 @@ int at3phip_write_frames(at3phip_ctx* c, const float* specs, int32_t n_frames, c
     HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipEventElapsedTime(&c->write_ms, c->ev[2], c->ev[3]);
     c->pqf_ms = c->mdct_ms = 0.0f;
+    c->ev_from_encode = false;   // ev[2], ev[3] now belong to this call: a later at3phip_sync must not mix them with an older encode's
     return AT3HIP_OK;
 }
 
@@ -375,6 +380,7 @@ int at3phip_encode_frames(at3phip_ctx* c, const float* pcm, int32_t n_frames, ui
     HIPCHK(c, hipEventRecord(c->ev_write_done[par], ws));
     c->write_done_valid[par] = true;
     c->enc_calls++;
+    c->ev_from_encode = true;
     if (flags & AT3HIP_ASYNC) return AT3HIP_OK;   // at3phip_sync is the completion point
     return at3phip_sync(c);
 }
@@ -386,10 +392,14 @@ int at3phip_sync(at3phip_ctx* c)
     HIPCHK(c, guard.error());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->write_stream));
-    if (c->enc_calls > 0) {
-        (void)hipEventElapsedTime(&c->pqf_ms, c->ev[0], c->ev[1]);
-        (void)hipEventElapsedTime(&c->mdct_ms, c->ev[1], c->ev[2]);
-        (void)hipEventElapsedTime(&c->write_ms, c->ev[4], c->ev[3]);
+    if (c->ev_from_encode) {
+        float a = 0.0f, b = 0.0f, w = 0.0f;
+        if (hipEventElapsedTime(&a, c->ev[0], c->ev[1]) == hipSuccess && hipEventElapsedTime(&b, c->ev[1], c->ev[2]) == hipSuccess &&
+            hipEventElapsedTime(&w, c->ev[4], c->ev[3]) == hipSuccess) {
+            c->pqf_ms = a;
+            c->mdct_ms = b;
+            c->write_ms = w;
+        }
     }
     return AT3HIP_OK;
 }
