@@ -271,11 +271,11 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             const int half = lane >> 5, l = lane & 31;
             const bool has = half == 0 || ubB >= 0;
             const int bfu = 19 + ((half && ubB >= 0) ? ubB : ubA);
-            const int start = bfu_start(bfu), ustart = start - kEaLine0, line = start + l;
+            const int start = kEaLine0 + 32 * (bfu - 19), ustart = start - kEaLine0, line = start + l;   // == bfu_start(bfu) for BFUs 19..25
             const float e1 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_e1)));
             const float e2 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_e2)));
             const uint32_t want = (e2 < e1) ? 1u : (e2 > e1) ? 2u : 3u;
-            const float mul = max_quant(__builtin_amdgcn_ds_bpermute(4 * bfu, bits));
+            const float mul = tab_f(tab.mq, __builtin_amdgcn_ds_bpermute(4 * bfu, bits));   // == max_quant(wordlen of the unit)
             const bool flag = has && ((L.code[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;
             const unsigned long long mask = __ballot(flag);
             const uint32_t hm = half ? (uint32_t)(mask >> 32) : (uint32_t)mask;
@@ -292,17 +292,16 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                 const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
                 recv = (uint32_t)l | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12);
             }
-            if (l < 16 && cnt + l < ((cnt + 15) & ~15)) uk[cnt + l] = __builtin_huge_valf();
+            if (l < 8 && cnt + l < ((cnt + 7) & ~7)) uk[cnt + l] = __builtin_huge_valf();   // pad the list to eight
             wave_sync();
             int rr = 0;
             if (flag) {
+                // eight keys per step: most units list eight candidates or fewer (5.5 on average on white noise)
                 const float4* t4 = reinterpret_cast<const float4*>(uk);
-                for (int q = 0; q < cnt; q += 16) {
-                    const float4 c0 = t4[(q >> 2)], c1 = t4[(q >> 2) + 1], c2 = t4[(q >> 2) + 2], c3 = t4[(q >> 2) + 3];
+                for (int q = 0; q < cnt; q += 8) {
+                    const float4 c0 = t4[(q >> 2)], c1 = t4[(q >> 2) + 1];
                     rr += (c0.x < key) + (c0.y < key) + (c0.z < key) + (c0.w < key);
                     rr += (c1.x < key) + (c1.y < key) + (c1.z < key) + (c1.w < key);
-                    rr += (c2.x < key) + (c2.y < key) + (c2.z < key) + (c2.w < key);
-                    rr += (c3.x < key) + (c3.y < key) + (c3.z < key) + (c3.w < key);
                 }
                 L.rec[ustart + rr] = (uint16_t)recv;
             }
