@@ -219,6 +219,7 @@ public:
         int32_t nf[2] = {0, 0};
         long long total = 0;
         int call = 0;
+        try {
         for (;; ++call) {
             const int q = call & 1;
             if (call >= 2) Check(at3hip_wait_input(Ctx, 1), Ctx, "at3hip_wait_input");   // call - 2 read in[q]: gone to the device by now?
@@ -237,6 +238,10 @@ public:
             const int q = (call - 1) & 1;
             if (nf[q] > 0) drain(out[q], (int)nf[q]);
             total += nf[q];
+        }
+        } catch (...) {
+            at3hip_sync(Ctx);   // the page-locked buffers are released on the way out: no copy may still be in flight
+            throw;
         }
         return total;
     }
