@@ -444,14 +444,20 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
     __syncthreads();
     if (tid == 0) {
         // per-channel loudness (atrac1denc.cpp:235-240): one running sum over the 512 lines
+        // (sixteen 16-byte reads in flight per step: a read per four additions left the chain waiting for the LDS every time)
         float l = 0.0f;
         const float4* q = reinterpret_cast<const float4*>(s_tmp);
-        for (int i = 0; i < 128; ++i) {
-            const float4 v = q[i];
-            l += v.x;
-            l += v.y;
-            l += v.z;
-            l += v.w;
+        for (int i0 = 0; i0 < 128; i0 += 16) {
+            float4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = q[i0 + i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                l += v[i].x;
+                l += v[i].y;
+                l += v[i].z;
+                l += v[i].w;
+            }
         }
         p.loud_ch[item] = l;
         p.mask[item] = mask;
@@ -464,11 +470,18 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         const int src0 = sh ? bf_short : bf_long;
         const float* in = s_specs + src0;
         float max_abs = 0.0f, e = 0.0f;
-        for (int i = 0; i < bf_len; ++i) {
-            const float xv = in[i];
-            const float a = fabsf(xv);
-            if (a > max_abs) max_abs = a;
-            e += xv * xv;
+        {
+            float xv[20];   // a BFU has 4 .. 20 lines: all of them requested before the ordered sum starts
+#pragma unroll
+            for (int i = 0; i < 20; ++i) xv[i] = i < bf_len ? in[i] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                if (i < bf_len) {
+                    const float a = fabsf(xv[i]);
+                    if (a > max_abs) max_abs = a;
+                    e += xv[i] * xv[i];
+                }
+            }
         }
         if (max_abs > 1.0f) max_abs = 1.0f;
         int lo = 0, hi = 63;
