@@ -205,6 +205,44 @@ int pick_runs(const at3hip_ctx* c, int items, int wgs_per_cu, double prologue)
     return best;
 }
 
+// Dynamic LDS added to k_gain_analysis' launch: it decides how many of its 17 KB workgroups share a CU (nine without). A
+// launch of few rounds wants WHOLE rounds - 24 576 workgroups (4096 frames) are 10.67 rounds of 256 x 9 but exactly 16 of
+// 256 x 6 - and fewer, fatter slots leave the light stage's and the back half's kernels room beside it: measured on the
+// step at 4096 frames 0.333 ms (nine per CU), 0.329 (eight), 0.333 (seven), 0.326 (six), 0.357 (five); at the 1024 x 128
+// shard (342 rounds, nothing to round) any padding costs 3 %.
+struct LdsChoice {
+    int per_cu;
+    size_t pad;
+};
+size_t whole_rounds_pad(const at3hip_ctx* c, long long n_wgs, const LdsChoice* choice, int n_choices, bool ties_to_fewer)
+{
+    const long long cus = c->n_cus > 0 ? c->n_cus : 256;
+    if (n_wgs >= 32 * choice[0].per_cu * cus) return 0;
+    double best_waste = 1e30;
+    size_t best_pad = 0;
+    for (int i = 0; i < n_choices; ++i) {
+        const long long slots = cus * choice[i].per_cu;
+        const double waste = (double)(((n_wgs + slots - 1) / slots) * slots) / (double)n_wgs;
+        if (ties_to_fewer ? waste <= best_waste + 0.005 : waste < best_waste - 0.005) {
+            best_waste = waste < best_waste ? waste : best_waste;
+            best_pad = choice[i].pad;
+        }
+    }
+    return best_pad;
+}
+size_t analysis_lds_pad(const at3hip_ctx* c, long long n_wgs)
+{
+    static const LdsChoice kChoice[3] = {{9, 0}, {8, 3328}, {6, 8704}};
+    return whole_rounds_pad(c, n_wgs, kChoice, 3, true);   // (equally whole rounds: the fewer, fatter slots measured better)
+}
+// The same for k_gain_spec (9.5 KB per one-wavefront workgroup, sixteen per CU without padding): the 6144 workgroups of
+// 4096 frames are one and a half rounds of 256 x 16 and exactly two of 256 x 12 (+0.8 % on the step).
+size_t spec_lds_pad(const at3hip_ctx* c, long long n_wgs)
+{
+    static const LdsChoice kChoice[2] = {{16, 0}, {12, 3584}};
+    return whole_rounds_pad(c, n_wgs, kChoice, 2, false);   // (only when it removes a partial round: 16384 frames are six whole rounds as they are)
+}
+
 int reset_state(at3hip_ctx* c)
 {
     const size_t S = c->cfg.n_streams;
@@ -634,8 +672,8 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             launch_qmf_sub();
             HIPCHK(c, hipEventRecord(ev[1], st));
             launch_state(st, 1);   // PCM history and subband tail: the next call's heavy stage needs nothing else from this one
-            hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(64), 0, st, gp, c->d_tables, S * n_out * 6);
-            hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), 0, st, gp, c->d_tables);
+            hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(64), spec_lds_pad(c, ((long long)S * n_out * 6 + 3) / 4), st, gp, c->d_tables, S * n_out * 6);
+            hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), analysis_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);
             HIPCHK(c, hipEventRecord(ev[2], st));
             HIPCHK(c, hipStreamWaitEvent(md, ev[2], 0));   // the light stage starts when this call's heavy stage is done
             hipLaunchKernelGGL(k_gain_tail, dim3((unsigned)((S * n_out * 6 + 7) / 8)), dim3(256), 0, md, gp, S * n_out * 6);
