@@ -91,6 +91,29 @@ __device__ inline float curve_target(const float* in, const float* filtered)
 // pass 4m that combine exactly those points, and stores them - same butterflies, same operands, half the LDS traffic.
 __device__ __forceinline__ int irfft_pad(int i) { return i + (i >> 5); }
 
+// kf_bfly4 (inverse) whose third input is an exact zero and - with Z1 - whose second one is too: the products and sums a
+// zero takes part in are dropped (x + 0 w = x exactly; a zero result keeps its magnitude, only its sign may differ, and no
+// sign of a zero survives the squares the transform's output ends in).
+template <bool Z1>
+__device__ __forceinline__ void bfly4_inv_sparse(f2& x0, f2& x1, f2& x2, f2& x3, f2 w1, f2 w3)
+{
+    const f2 s2 = pk_cmul(x3, w3);
+    const f2 f0 = x0;
+    if (Z1) {
+        x2 = f0 - s2;
+        x0 = f0 + s2;
+        x1 = pk_sub_ib(f0, s2);   // s5 + i s4 with s4 = -s2
+        x3 = pk_add_ib(f0, s2);
+    } else {
+        const f2 s0 = pk_cmul(x1, w1);
+        const f2 s3 = s0 + s2, s4 = s0 - s2;
+        x2 = f0 - s3;
+        x0 = f0 + s3;
+        x1 = pk_add_ib(f0, s4);
+        x3 = pk_sub_ib(f0, s4);
+    }
+}
+
 template <int KAPPA>   // passes m = 2 and m = 8: unit = (32-block G = lane, parity KAPPA), points 32 G + KAPPA + 2 i
 __device__ __forceinline__ void irfft_pass_2_8(cpx* F, const cpx* tw, int lane)
 {
@@ -108,9 +131,11 @@ __device__ __forceinline__ void irfft_pass_2_8(cpx* F, const cpx* tw, int lane)
         x[i] = f2{0.0f, 0.0f};
         if ((i & 3) != 2 && nz) x[i] = ld2(B + 2 * i);
     }
-    const f2 a1 = ld2(tw + 256 * KAPPA), a2 = ld2(tw + 512 * KAPPA), a3 = ld2(tw + 768 * KAPPA);   // k = KAPPA, fstride 256
+    const f2 a1 = ld2(tw + 256 * KAPPA), a3 = ld2(tw + 768 * KAPPA);   // k = KAPPA, fstride 256 (tw[512 KAPPA] only ever meets a zero)
+    // pass m = 2: the third input of every butterfly is a zero leaf, the second one too except for input 256 (g = 0, lane 0)
+    bfly4_inv_sparse<false>(x[0], x[1], x[2], x[3], a1, a3);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bfly4<true>(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], a1, a2, a3);
+    for (int g = 1; g < 4; ++g) bfly4_inv_sparse<true>(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], a1, a3);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k = KAPPA + 2 * j;   // fstride 64
