@@ -89,31 +89,35 @@ __device__ inline int scale_block(const float* scale_tab, const float* in, int l
 // them out per channel-frame in LDS, one 64-line chunk ahead of the consumer.
 // A channel-frame's 64 terms of a chunk are a row of kLoudRow floats: 16-byte aligned, and rows 4 banks apart, so that
 // the sixteen lanes a 16-byte LDS read serves together hit sixteen different bank quads.
-constexpr int kLoudRow = 68;
+constexpr int kLoudLines = 128;                    // lines per chunk (64 at first: half as many workgroup rendezvous now, -3 us)
+constexpr int kLoudRowWords = kLoudLines / 4;      // 16-byte words of a channel-frame's chunk
+constexpr int kLoudRow = kLoudLines + 4;
+constexpr int kLoudChunks = 1024 / kLoudLines;
 constexpr int kLoudCf = 32;                        // channel-frames per workgroup
-constexpr int kLoudWords = kLoudCf * 16;           // 16-byte words of a chunk
+constexpr int kLoudWords = kLoudCf * kLoudRowWords;   // 16-byte words of a chunk
 constexpr int kLoudPer = (kLoudWords + 191) / 192; // words per producer thread
+static_assert(192 % kLoudRowWords == 0, "a producer thread keeps its place in the row from word to word");
 
 // (free functions: array arguments of lambdas end up in scratch memory)
 __device__ __forceinline__ void loud_request(const float* specs, int c0, int n_cf, int u, int k, float4 (&xr)[kLoudPer])
 {
 #pragma unroll
     for (int i = 0; i < kLoudPer; ++i) {
-        const int w = u + 192 * i, c = c0 + (w >> 4);
-        xr[i] = (w < kLoudWords && c < n_cf) ? *reinterpret_cast<const float4*>(specs + (size_t)c * 1024 + 64 * k + 4 * (w & 15))
+        const int w = u + 192 * i, c = c0 + w / kLoudRowWords;
+        xr[i] = (w < kLoudWords && c < n_cf) ? *reinterpret_cast<const float4*>(specs + (size_t)c * 1024 + kLoudLines * k + 4 * (w % kLoudRowWords))
                                              : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
 __device__ __forceinline__ void loud_produce(float* tile, const float* s_curve, const float* s_ges, int u, int k, const float4 (&xr)[kLoudPer])
 {
-    const float4 cv = *reinterpret_cast<const float4*>(s_curve + 64 * k + 4 * (u & 15));   // (u + 192 i) & 15 == u & 15
+    const float4 cv = *reinterpret_cast<const float4*>(s_curve + kLoudLines * k + 4 * (u % kLoudRowWords));   // (u + 192 i) % kLoudRowWords == u % kLoudRowWords
 #pragma unroll
     for (int i = 0; i < kLoudPer; ++i) {
         const int w = u + 192 * i;
         if (w < kLoudWords) {
-            const float gg = s_ges[4 * (w >> 4) + (k >> 2)];
+            const float gg = s_ges[4 * (w / kLoudRowWords) + (kLoudLines * k) / 256];
             const float4 x = xr[i];
-            *reinterpret_cast<float4*>(tile + (w >> 4) * kLoudRow + 4 * (w & 15)) =
+            *reinterpret_cast<float4*>(tile + (w / kLoudRowWords) * kLoudRow + 4 * (w % kLoudRowWords)) =
                 make_float4(x.x * x.x * gg * cv.x, x.y * x.y * gg * cv.y, x.z * x.z * gg * cv.z, x.w * x.w * gg * cv.w);
         }
     }
@@ -122,7 +126,7 @@ __device__ __forceinline__ void loud_consume(const float* row, float& l)
 {
     const float4* r4 = reinterpret_cast<const float4*>(row);
 #pragma unroll
-    for (int q = 0; q < 16; q += 4) {
+    for (int q = 0; q < kLoudRowWords; q += 4) {
         const float4 a = r4[q], b = r4[q + 1], c = r4[q + 2], d = r4[q + 3];
         l += a.x; l += a.y; l += a.z; l += a.w;
         l += b.x; l += b.y; l += b.z; l += b.w;
@@ -151,8 +155,8 @@ __global__ __launch_bounds__(256) void k_loud_sum(BackParams p, const Tables* T,
         *reinterpret_cast<float4*>(s_ges + 4 * tid) = gv;
     }
     // producer role: thread u = tid - 64 of 192 forms the terms of the 16-byte words w = u + 192 i of a chunk (word w =
-    // lines 4 (w & 15) .. + 3 of channel-frame w >> 4). The spectra of chunk k + 2 are requested while chunk k + 1 is turned
-    // into terms: a producer never waits for a load it has just issued.
+    // lines 4 (w % words per row) .. + 3 of channel-frame w / words per row). The spectra of chunk k + 2 are requested while
+    // chunk k + 1 is turned into terms: a producer never waits for a load it has just issued.
     const int u = tid - 64;
     const bool chain = wave == 0 && lane < kLoudCf;
     float4 xa[kLoudPer], xb[kLoudPer];
@@ -167,18 +171,18 @@ __global__ __launch_bounds__(256) void k_loud_sum(BackParams p, const Tables* T,
     }
     __syncthreads();
     float l = 0.0f;
-    for (int k = 0; k < 16; k += 2) {   // chunk k + 1 comes from xb, chunk k + 2 from xa
+    for (int k = 0; k < kLoudChunks; k += 2) {   // chunk k + 1 comes from xb, chunk k + 2 from xa
         if (wave > 0) {
             loud_produce(s_t[(k + 1) & 1], s_curve, s_ges, u, k + 1, xb);
-            if (k + 3 < 16) loud_request(p.specs, c0, n_cf, u, k + 3, xb);
+            if (k + 3 < kLoudChunks) loud_request(p.specs, c0, n_cf, u, k + 3, xb);
         } else if (chain) {
             loud_consume(s_t[k & 1] + lane * kLoudRow, l);
         }
         __syncthreads();
         if (wave > 0) {
-            if (k + 2 < 16) {
+            if (k + 2 < kLoudChunks) {
                 loud_produce(s_t[k & 1], s_curve, s_ges, u, k + 2, xa);
-                if (k + 4 < 16) loud_request(p.specs, c0, n_cf, u, k + 4, xa);
+                if (k + 4 < kLoudChunks) loud_request(p.specs, c0, n_cf, u, k + 4, xa);
             }
         } else if (chain) {
             loud_consume(s_t[(k + 1) & 1] + lane * kLoudRow, l);
