@@ -604,7 +604,13 @@ __global__ __launch_bounds__(256) void k_gain_tail(GainParams p, int n_items)
     const int f = p.f0 + wg % nfr;
     const int s = wg / nfr;
     GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
-    const bool active = valid && !(rec->hfr < 0.05f);
+    // (the item's values are requested together with its gate: an item below the gate has stale numbers there, which are
+    // fetched and dropped - two dependent global-memory latencies would cost this short kernel more)
+    const float hfr = rec->hfr;
+    const float g_j = rec->gain[j];
+    const float4 ma = *reinterpret_cast<const float4*>(p.micro + (size_t)item * 256 + j * 8);
+    const float4 mb = *reinterpret_cast<const float4*>(p.micro + (size_t)item * 256 + j * 8 + 4);
+    const bool active = valid && !(hfr < 0.05f);
     if (__ballot(active) == 0ull) return;
     float* s_gain = s_g[grp];
     float* s_filt = s_f[grp];
@@ -612,10 +618,8 @@ __global__ __launch_bounds__(256) void k_gain_tail(GainParams p, int n_items)
     float in_j = 0.0f;
     float m[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     if (active) {
-        in_j = rec->gain[j];
-        const float4 a = *reinterpret_cast<const float4*>(p.micro + (size_t)item * 256 + j * 8);
-        const float4 b = *reinterpret_cast<const float4*>(p.micro + (size_t)item * 256 + j * 8 + 4);
-        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+        in_j = g_j;
+        m[0] = ma.x; m[1] = ma.y; m[2] = ma.z; m[3] = ma.w; m[4] = mb.x; m[5] = mb.y; m[6] = mb.z; m[7] = mb.w;
     }
     s_gain[j] = in_j;
 #pragma unroll
@@ -734,11 +738,9 @@ __global__ __launch_bounds__(64) void k_gain_scan(GainParams p, int n_streams)
     }
 }
 
-__device__ inline uint32_t first_set_bit(uint32_t x)
+__device__ inline uint32_t first_set_bit(uint32_t x)   // index of the highest set bit, 0 for x < 2 (the reference's shift loop)
 {
-    uint32_t r = 0;
-    while (x >>= 1) ++r;
-    return r;
+    return x ? 31u - (uint32_t)__builtin_clz(x) : 0u;
 }
 
 // transient_detector.cpp:141-149
