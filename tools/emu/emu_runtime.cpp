@@ -123,7 +123,7 @@ int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool
     return (int)all[row * 16 + srcpos];
 }
 
-void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body)
+void emu_launch(const char* name, dim3 grid, dim3 block, const std::function<void()>& body)
 {
     const unsigned nthr = block.x * block.y * block.z;
     if (g_fibers.size() < nthr) {
@@ -164,7 +164,7 @@ void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body)
                         swapcontext(&g_main, &f.ctx);
                         if (!f.done) ++alive;
                     }
-                    if (++spins > 20000000ull) { fprintf(stderr, "emu: deadlock (divergent barrier?)\n"); abort(); }
+                    if (++spins > 3000000ull) { fprintf(stderr, "emu: deadlock (divergent barrier?) in %s, workgroup %u of %u\n", name, bx, grid.x); abort(); }
                 }
             }
 }

@@ -121,6 +121,6 @@ static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 
-void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void emu_launch(const char* name, dim3 grid, dim3 block, const std::function<void()>& body);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    emu_launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+    emu_launch(#kernel, (grid), (block), [&]() { kernel(__VA_ARGS__); })
