@@ -854,8 +854,9 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     // 64-line block. A 64-line block holds at most four tonal BFUs (BFUs 8..28 are 16 lines or wider, one run each), so
     // that never happens and every (quantiser, length) group is exactly one sub-group; the check below proves it for this
     // frame (blocks are ordered by position) and sends anything else down the literal, serial path.
-    const bool tonal_serial = __ballot(lane + 7 < n_tonal &&
-                                       __builtin_amdgcn_ds_bpermute(4 * ((lane + 7) & 63), tb_blk) == tb_blk) != 0ull;
+    // (the cross-lane read stands in front of the condition: inside a short-circuit it would run with some lanes switched off)
+    const int blk_7_on = __builtin_amdgcn_ds_bpermute(4 * ((lane + 7) & 63), tb_blk);
+    const bool tonal_serial = __ballot(lane + 7 < n_tonal && blk_7_on == tb_blk) != 0ull;
     // per-BFU constants of CalcBitsAllocation (atrac3_bitstream.cpp:272-336)
     float A;
     bool gate;

@@ -1,5 +1,6 @@
 // DEVELOPMENT HARNESS ONLY - see hip/hip_runtime.h in this directory.
 #include "hip/hip_runtime.h"
+#include <dlfcn.h>
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 
@@ -8,6 +9,10 @@ struct Fiber {
     ucontext_t ctx;
     char* stack = nullptr;
     bool done = false;
+    const char* wait = "";   // what the work-item waits in, and where it was called from (deadlock report)
+    void* wait_pc = nullptr;
+    void* hist[16] = {};   // the last call sites, newest at hist_n % 16
+    unsigned long long hist_n = 0;
 };
 constexpr size_t kStack = 256 * 1024;
 std::vector<Fiber> g_fibers;
@@ -22,6 +27,7 @@ unsigned g_live = 0, g_bar_arrived = 0, g_bar_gen = 0;
 struct Wave {
     unsigned live = 0, arrived = 0, gen = 0;
     unsigned slot[64];
+    void* site[64];
     bool present[64];
     unsigned snap[64];
     bool snap_present[64];
@@ -48,8 +54,11 @@ void trampoline()
 }
 }  // namespace
 
-void emu_syncthreads()
+#define EMU_WAIT(what) do { Fiber& f_ = g_fibers[g_cur]; f_.wait = what; f_.wait_pc = __builtin_return_address(0); f_.hist[++f_.hist_n % 16] = f_.wait_pc; } while (0)
+
+__attribute__((noinline)) void emu_syncthreads()
 {
+    EMU_WAIT("__syncthreads");
     const unsigned gen = g_bar_gen;
     if (++g_bar_arrived == g_live) { g_bar_arrived = 0; ++g_bar_gen; return; }
     while (g_bar_gen == gen) yield_to_scheduler();
@@ -62,8 +71,21 @@ unsigned emu_wave_exchange(unsigned value, unsigned* all64)
     const int lane = g_cur % 64;
     w.slot[lane] = value;
     w.present[lane] = true;
+    w.site[lane] = g_fibers[g_cur].wait_pc;
     const unsigned gen = w.gen;
     if (++w.arrived == w.live) {
+        // every lane of a rendezvous must come from the same call: lanes that meet from two different ones have
+        // taken different paths through code this harness can only run convergently
+        // (EMU_STRICT=1, for -O0 builds: an optimiser may duplicate one call into two places)
+        static const bool strict = getenv("EMU_STRICT") != nullptr;
+        for (int i = 0; strict && i < 64; ++i)
+            if (w.present[i] && w.site[i] != w.site[lane]) {
+                Dl_info di;
+                const bool ok = dladdr(w.site[lane], &di) != 0;
+                char* base = ok ? (char*)di.dli_fbase : (char*)0;
+                fprintf(stderr, "emu: divergent rendezvous: lane %d called from +0x%zx, lane %d from +0x%zx\n", lane, (size_t)((char*)w.site[lane] - base), i, (size_t)((char*)w.site[i] - base));
+                abort();
+            }
         memcpy(w.snap, w.slot, sizeof(w.slot)); memcpy(w.snap_present, w.present, sizeof(w.present));
         memset(w.present, 0, sizeof(w.present)); w.arrived = 0; ++w.gen;
     } else {
@@ -73,14 +95,16 @@ unsigned emu_wave_exchange(unsigned value, unsigned* all64)
     return 0;
 }
 
-void emu_wave_barrier()
+__attribute__((noinline)) void emu_wave_barrier()
 {
+    EMU_WAIT("wave_sync");
     unsigned all[64];
     emu_wave_exchange(0u, all);
 }
 
-unsigned long long emu_ballot(bool pred)
+__attribute__((noinline)) unsigned long long emu_ballot(bool pred)
 {
+    EMU_WAIT("ballot");
     unsigned all[64];
     emu_wave_exchange(pred ? 1u : 0u, all);
     unsigned long long m = 0;
@@ -88,22 +112,25 @@ unsigned long long emu_ballot(bool pred)
     return m;
 }
 
-int emu_readlane(int v, int lane)
+__attribute__((noinline)) int emu_readlane(int v, int lane)
 {
+    EMU_WAIT("readlane");
     unsigned all[64];
     emu_wave_exchange((unsigned)v, all);
     return (int)all[lane & 63];
 }
 
-int emu_bpermute(int addr, int v)
+__attribute__((noinline)) int emu_bpermute(int addr, int v)
 {
+    EMU_WAIT("bpermute");
     unsigned all[64];
     emu_wave_exchange((unsigned)v, all);
     return (int)all[(addr >> 2) & 63];
 }
 
-int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+__attribute__((noinline)) int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
+    EMU_WAIT("dpp");
     unsigned all[64];
     emu_wave_exchange((unsigned)src, all);
     const int lane = g_cur % 64, row = lane / 16, pos = lane % 16;
@@ -143,7 +170,7 @@ void emu_launch(const char* name, dim3 grid, dim3 block, const std::function<voi
                 g_waves.assign((nthr + 63) / 64, Wave());
                 for (unsigned t = 0; t < nthr; ++t) {
                     Fiber& f = g_fibers[t];
-                    f.done = false;
+                    f.done = false; f.hist_n = 0;
                     g_waves[t / 64].live++;
                     getcontext(&f.ctx);
                     f.ctx.uc_stack.ss_sp = f.stack;
@@ -164,7 +191,18 @@ void emu_launch(const char* name, dim3 grid, dim3 block, const std::function<voi
                         swapcontext(&g_main, &f.ctx);
                         if (!f.done) ++alive;
                     }
-                    if (++spins > 3000000ull) { fprintf(stderr, "emu: deadlock (divergent barrier?) in %s, workgroup %u of %u\n", name, bx, grid.x); abort(); }
+                    if (++spins > 300000ull) { fprintf(stderr, "emu: deadlock (divergent barrier?) in %s, workgroup %u of %u\n", name, bx, grid.x);
+                        for (unsigned t = 0; t < nthr; ++t)
+                            if (!g_fibers[t].done) {
+                                Dl_info di;   // offset in the shared object: addr2line -e <lib> <offset>
+                                const bool ok = dladdr(g_fibers[t].wait_pc, &di) != 0;
+                                fprintf(stderr, "  work-item %u waits in %s called from +0x%zx; %llu rendezvous so far, the last ones from", t, g_fibers[t].wait, ok ? (size_t)((char*)g_fibers[t].wait_pc - (char*)di.dli_fbase) : (size_t)g_fibers[t].wait_pc, g_fibers[t].hist_n);
+                                for (unsigned h = 0; h < 16 && h < g_fibers[t].hist_n; ++h)
+                                    fprintf(stderr, " +0x%zx", (size_t)((char*)g_fibers[t].hist[(g_fibers[t].hist_n - h) % 16] - (ok ? (char*)di.dli_fbase : (char*)0)));
+                                fprintf(stderr, "\n");
+                            }
+                        abort();
+                    }
                 }
             }
 }

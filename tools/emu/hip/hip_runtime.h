@@ -104,15 +104,15 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 // ---- wave-level (64 lanes) cross-lane primitives: implemented with a wave-wide rendezvous ----
 unsigned emu_wave_exchange(unsigned value, unsigned* all64);   // deposit `value`, returns active mask lo; all64 = values
 unsigned long long emu_ballot(bool pred);
-static inline unsigned long long __ballot(bool pred) { return emu_ballot(pred); }
+#define __ballot(pred) emu_ballot(pred)
 int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl);
 int emu_bpermute(int addr, int v);
 #define __builtin_amdgcn_ds_bpermute(addr, v) emu_bpermute((int)(addr), (int)(v))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((int)(old), (int)(src), (ctrl), (rm), (bm), (bc))
 int emu_readlane(int v, int lane);
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((int)(v), (lane))
-static inline float __shfl(float v, int lane, int = 64) { float r; int i; memcpy(&i, &v, 4); i = emu_readlane(i, lane); memcpy(&r, &i, 4); return r; }
-static inline float __shfl_xor(float v, int mask, int = 64) { return __shfl(v, (int)((threadIdx.x & 63u) ^ (unsigned)mask)); }
+static inline __attribute__((always_inline)) float __shfl(float v, int lane, int = 64) { float r; int i; memcpy(&i, &v, 4); i = emu_readlane(i, lane); memcpy(&r, &i, 4); return r; }
+static inline __attribute__((always_inline)) float __shfl_xor(float v, int mask, int = 64) { return __shfl(v, (int)((threadIdx.x & 63u) ^ (unsigned)mask)); }
 void emu_wave_barrier();
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)

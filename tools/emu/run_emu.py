@@ -5,13 +5,16 @@ import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from at3_testlib import SIGNALS, LP2, LP4, oracle
+from at3_testlib import SIGNALS, LP2, LP4, oracle, pcm_stress
+SIGNALS = dict(SIGNALS, stress=lambda nb: pcm_stress(nb, seed=7))
 from atracdenc_amd.binding import At3Hip
 
 EMU = os.path.join(ROOT, "tools", "emu", "libat3hip_emu.so")
 
-def build():
-    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
+def build(strict=False):
+    # --strict: -O0 (every cross-lane call keeps one address) + EMU_STRICT=1: the harness aborts when the lanes of a wavefront
+    # meet in a rendezvous from two different calls, i.e. when a cross-lane read sits inside divergent control flow
+    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O0" if strict else "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off", "-x", "c++",
                            "-I", os.path.join(ROOT, "tools", "emu"), "-include", os.path.join(ROOT, "tools", "emu", "at3_pk_emu.hpp"), "-o", EMU,
                            os.path.join(ROOT, "atracdenc_amd/csrc/at3hip.hip"),
                            os.path.join(ROOT, "atracdenc_amd/csrc/at1hip.hip"),
@@ -20,8 +23,10 @@ def build():
                            os.path.join(ROOT, "tools/emu/emu_runtime.cpp")])
 
 if __name__ == "__main__":
-    if "--nobuild" not in sys.argv: build()
-    names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["noise", "burst", "tones", "silence", "mix"]
+    strict = "--strict" in sys.argv
+    if strict: os.environ["EMU_STRICT"] = "1"
+    if "--nobuild" not in sys.argv: build(strict)
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["noise", "burst", "tones", "silence", "mix", "stress"]
     nb = 6
     o = oracle()
     for name in names:
