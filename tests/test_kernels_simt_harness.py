@@ -1,0 +1,59 @@
+"""The kernel SOURCES of the product, compiled for the host and run lane by lane through the SIMT harness of tools/emu,
+against the oracle - the parity gate that exists without a GPU (the `-m gpu` tests are the parity tests proper).
+
+The harness is test infrastructure like the oracle: the product library never contains or loads it. It is built in its
+strict form here (-O0 + EMU_STRICT): besides comparing results it aborts when the lanes of a wavefront reach a cross-lane
+exchange (ballot, readlane, ds_bpermute, DPP, wave-level rendezvous) from two DIFFERENT calls, i.e. when such a read
+sits inside divergent control flow - a class of mistake the GPU tolerates until the compiler or the data change.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs ROCm's clang++ to compile the kernel sources for the host")
+
+
+def _run(script, *args, timeout=900):
+    env = dict(os.environ, EMU_STRICT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu", script), *args], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    return out
+
+
+def _assert_clean(out, min_cases):
+    counts = re.findall(r"(?:mismatching frames|bad) (\d+)", out)
+    assert len(counts) >= min_cases, out[-4000:]
+    assert all(c == "0" for c in counts), out[-4000:]
+
+
+@pytest.fixture(scope="module")
+def harness():
+    sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
+    import run_emu
+    run_emu.build(strict=True)
+    return run_emu.EMU
+
+
+def test_atrac3_kernels(harness):
+    """Six signals x LP2 / LP4 x (all tools, no gain, no gain + no tonal), two streams, two calls (carried state)."""
+    _assert_clean(_run("run_emu.py", "--strict", "--nobuild"), 36)
+
+
+def test_atrac1_kernels(harness):
+    _assert_clean(_run("run_emu_at1.py", "--nobuild"), 24 * 4)
+
+
+def test_atrac3plus_front_kernels(harness):
+    _assert_clean(_run("run_emu_at3p.py", "--nobuild"), 12)
+
+
+def test_atrac3plus_frame_kernels(harness):
+    _assert_clean(_run("run_emu_at3p_write.py", "--nobuild"), 26)
