@@ -543,7 +543,7 @@ def main():
                 traffic = None
         # whole-pipeline HBM traffic and the vector-instruction counts of the QMF + MDCT kernels: PMC passes cannot run inside
         # the timed region, so these come from the committed profile of the same workload (tools/profile_gpu.sh) and say so
-        pipe_traffic, valu_floor_ms, valu_note = None, None, "not available"
+        pipe_traffic, valu_floor_ms, valu_note, pipe_valu = None, None, "not available", None
         pt = os.path.join(ROOT, "profiles", "pipeline_traffic.json")
         if os.path.exists(pt) and (S, F) == (64, 64) and not args.no_gain and fsz == 384:
             try:
@@ -552,15 +552,34 @@ def main():
                                 "algorithmic_bytes_per_frame": pj["algorithmic_bytes_per_frame"],
                                 "source": "profiles/pipeline_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE summed over the pipeline's "
                                           "kernels, separate passes, this workload - not measured in this run"}
-                insts = sum(pj.get("valu_wave_insts_per_launch", {}).values())
-                if insts > 0:
-                    # tools/ubench (profiles/r02_ubench_instruction_rates.txt): one plain fp32 wave-instruction per 1.29 ns and SIMD
-                    # at full issue, a packed one per 2.37 ns; the FIR's are packed, so the true floor lies above this figure
-                    n_simd = 1024
-                    valu_floor_ms = insts / n_simd * 1.29e-6
-                    valu_note = (f"{int(insts)} vector wave-instructions per launch pair (SQ_INSTS_VALU, profiles/pipeline_traffic.json) / "
-                                 f"{n_simd} SIMDs x 1.29 ns, the measured issue cost of a PLAIN fp32 instruction (a packed one costs 2.37 ns: "
-                                 "the arithmetic contract forbids FMA, so the multiply-add pairs of the FIR are two packed instructions each)")
+                # Issue floors. SQ_INSTS_VALU per kernel (profiles/pipeline_traffic.json) priced with the measured issue costs
+                # (tools/ubench, profiles/r02_ubench_instruction_rates.txt): 1.29 ns per plain wave-instruction and SIMD, 2.37 ns
+                # per packed fp32 one; the packed share of a kernel comes from the compiler's assembly (profiles/valu_mix.json)
+                mix = {}
+                mp = os.path.join(ROOT, "profiles", "valu_mix.json")
+                if os.path.exists(mp):
+                    mix = {k: v.get("packed_share", 0.0) for k, v in json.load(open(mp)).get("kernels", {}).items()}
+                n_simd = 1024
+
+                def floor_ms(counts):
+                    return sum(n * (mix.get(k, 0.0) * 2.37e-6 + (1.0 - mix.get(k, 0.0)) * 1.29e-6) for k, n in counts.items()) / n_simd
+
+                k1_counts = pj.get("valu_wave_insts_per_launch", {})
+                if k1_counts:
+                    valu_floor_ms = floor_ms(k1_counts)
+                    valu_note = (f"{int(sum(k1_counts.values()))} vector wave-instructions per launch pair (SQ_INSTS_VALU, profiles/pipeline_traffic.json) / "
+                                 f"{n_simd} SIMDs, a plain fp32 instruction priced at its measured 1.29 ns of issue and a packed one at 2.37 ns "
+                                 "(packed share per kernel from the compiler's assembly, profiles/valu_mix.json; the arithmetic contract "
+                                 "forbids FMA, so the multiply-add pairs of the FIR are two packed instructions each)")
+                all_counts = pj.get("valu_wave_insts_per_launch_all", {})
+                if all_counts:
+                    step_floor = floor_ms(all_counts)
+                    pipe_valu = {"floor_ms_per_step": round(step_floor, 4), "frac": round(step_floor / med_ms, 4),
+                                 "vector_wave_instructions_per_step": int(sum(all_counts.values())),
+                                 "note": "the whole step against the issue floor of its own vector instruction streams (every kernel of the pipeline, "
+                                         "same pricing as roofline.valu_floor_ms; f64 instructions priced as plain ones, so the true floor is "
+                                         "slightly higher): frac = floor / ms_per_step. This, not HBM, is the roofline that bounds the encoder "
+                                         "under the FMA-free arithmetic contract"}
             except Exception:
                 pipe_traffic = None
         cfgname = {384: "LP2 132 kbps", 192: "LP4 66 kbps joint stereo"}.get(fsz, f"{fsz} B/frame")
@@ -600,6 +619,7 @@ def main():
                          "isolated": {"avg_launch_ms": round(iso_ms, 5), "achieved": ach_iso, "frac": frac_iso,
                                       "note": "same kernel, same batch, launched alone (3 synchronous steps after the timed region)"}},
             "pipeline_traffic": pipe_traffic,
+            "pipeline_valu": pipe_valu,
             "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
             "pipelining": "three HIP streams inside the context: the heavy front stage (QMF, gain spectra, envelopes) of step i+1, the "
                           "light front stage (curves, energy scales, MDCT) of step i and the back half (psychoacoustics, rate loop, "

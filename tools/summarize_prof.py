@@ -87,6 +87,8 @@ if ours:
     out = {"workload": "64 streams x 64 frames (4096 frames per step), synchronous steps", "kernels": rows,
            "bytes_per_step": total, "pipeline_bytes_per_frame": total / frames, "algorithmic_bytes_per_frame": 8192 + 384,
            "correction": "FETCH_SIZE x2 + WRITE_SIZE per kernel (MI355X_MICROARCH.md, HBM section), separate --pmc passes",
-           "valu_wave_insts_per_launch": {k: v for k, v in valu.items() if k.startswith(("k_qmf", "k_mdct_sub"))}}
+           "valu_wave_insts_per_launch": {k: v for k, v in valu.items() if k.startswith(("k_qmf", "k_mdct_sub"))},
+           # every kernel of the pipeline, for the whole-step issue floor (bench.py prices them with profiles/valu_mix.json)
+           "valu_wave_insts_per_launch_all": {k: v * mult.get(k, 1) for k, v in sorted(valu.items()) if k.startswith("k_")}}
     json.dump(out, open(os.path.join(root, "pipeline_traffic.json"), "w"), indent=1)
     print("== pipeline traffic == %.1f KB per frame (%.1f MB per step)" % (total / frames / 1024.0, total / 1e6))
