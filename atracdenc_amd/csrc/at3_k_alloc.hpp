@@ -471,34 +471,53 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
     }
     wave_sync();
     // ---- (4) VLC cost of the final mantissas; (5) cache entries ----
-    uint32_t* s_vlc = reinterpret_cast<uint32_t*>(L.uk);   // per-BFU bit counts: the key list is free again
-    if (lane < 32) s_vlc[lane] = 0u;
-    wave_sync();
+    // A unit's lines sit in 4, 8, 16 or 32 NEIGHBOURING lanes of one round (16-, 32-, 64-, 128-line BFUs from line 96 on, all
+    // aligned to their own size), so its bit count is a sum over a quad, a half row, a row or two rows: DPP adds, no
+    // LDS traffic (the first version added every lane's count to a per-BFU LDS counter: up to 32 lanes on one address).
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int wl = wl_h[h];
         const VlcRow row = tab_row(tab, wl);
+        uint32_t vb = 0;
         if (wl) {
             const int line0 = 256 * h + 4 * lane;
             const uint32_t pk = *reinterpret_cast<const uint32_t*>(L.bm + (line0 - kTermLine0));
             int m[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) m[k] = (int)(int8_t)((pk >> (8 * k)) & 0xff);
-            uint32_t vb = 0;
             if (wl > 1) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) vb += vlc_len(row, m[k]);
             } else {
                 vb = vlc_pair_len(m[0], m[1]) + vlc_pair_len(m[2], m[3]);
             }
-            atomicAdd(&s_vlc[(tab.bfus >> (8 * h)) & 0xffu], vb);
         }
+        vb += (uint32_t)AT3_DPP(vb, 0xB1, false);   // quad_perm [1, 0, 3, 2]
+        vb += (uint32_t)AT3_DPP(vb, 0x4E, false);   // quad_perm [2, 3, 0, 1]: every lane of a quad holds the quad's 16 lines
+        bool lead = (lane & 3) == 0;
+        if (h == 0) {   // lines 96..191: 16-line BFUs, lines 192..255: two 32-line BFUs
+            const uint32_t v8 = vb + (uint32_t)AT3_DPP(vb, 0x141, false);   // row_half_mirror
+            if (lane >= 48) {
+                vb = v8;
+                lead = (lane & 7) == 0;
+            }
+        } else {
+            vb += (uint32_t)AT3_DPP(vb, 0x141, false);
+            lead = (lane & 7) == 0;
+            if (h >= 2) {   // 64-line BFUs: a row each
+                vb += (uint32_t)AT3_DPP(vb, 0x140, false);   // row_mirror
+                lead = (lane & 15) == 0;
+            }
+            if (h == 3) {   // 128-line BFUs: two rows each
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)vb, 0) + (uint32_t)__builtin_amdgcn_readlane((int)vb, 16);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)vb, 32) + (uint32_t)__builtin_amdgcn_readlane((int)vb, 48);
+                vb = lane < 32 ? lo : hi;
+                lead = (lane & 31) == 0;
+            }
+        }
+        if (wl && lead) L.cost[(wl - 1) * 32 + (int)((tab.bfus >> (8 * h)) & 0xffu)] = (uint16_t)vb;
     }
-    wave_sync();
-    if (mine) {
-        if (qerr) qerr[(bits - 1) * 32 + lane] = my_e1 / my_e2;   // BFUs >= 10: nothing but the QUANT tap looks at their energy error
-        L.cost[(bits - 1) * 32 + lane] = (uint16_t)s_vlc[lane];
-    }
+    if (mine && qerr) qerr[(bits - 1) * 32 + lane] = my_e1 / my_e2;   // BFUs >= 10: nothing but the QUANT tap looks at their energy error
     wave_sync();
 }
 
