@@ -175,7 +175,6 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
     float* const s_specs = s_region_a;                                   // after the first QMF stage
     float* const s_filt = s_region_b;                                    // detector high-pass output: low/mid [-16,128), hi [-16,256)
     at3::cpx* const s_f = reinterpret_cast<at3::cpx*>(s_region_b);       // 256 points, after the detector
-    float* const s_tmp = s_region_b;                                     // e * LoudnessCurve, after the post-rotation
     __shared__ __attribute__((aligned(16))) float s_lo1[480];            // m  in [-118, 256)   first-stage lower band, padded (qmf_pad)
     __shared__ float s_up1[332];                                         // m  in [-75, 256)    first-stage upper band; hi[i] = up1[i - 39]
     __shared__ float s_low[166], s_mid[164];                             // q  in [-36, 128); s_low[164] = 0 for the detector
@@ -186,7 +185,6 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
     __shared__ LogfTab s_logf;
     __shared__ __attribute__((aligned(16))) at3::cpx s_tw[208];          // tw128 | tw64 | tw16
     __shared__ float s_cs[416];                                          // sc512 | sc256 | sc64
-    __shared__ float s_loud[512];
     __shared__ float s_sf[kMaxBfus];
     __shared__ int s_srcoff[kMaxBfus];
     __shared__ int s_mask;
@@ -207,15 +205,12 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
                  : t >= 0   ? p.pcm[((size_t)s * p.n_frames * 512 + t) * nch + ch]
                             : p.hist[((size_t)s * 512 + (512 + t)) * nch + ch];
         }
-        const float l0 = T->loud[tid], l1 = T->loud[tid + 256];
         const float c0 = (&T->sc512[0])[tid], c1 = tid < 160 ? (&T->sc512[0])[tid + 256] : 0.0f;   // sc512 | sc256 | sc64 are contiguous
         at3::cpx w = {0.0f, 0.0f};
         if (tid < 208) w = tid < 128 ? T->tw128[tid] : tid < 192 ? T->tw64[tid - 128] : T->tw16[tid - 192];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (tid + 256 * r < 800) s_pcm[qmf_pad(tid + 256 * r)] = v[r];
-        s_loud[tid] = l0;
-        s_loud[tid + 256] = l1;
         s_cs[tid] = c0;
         if (tid < 160) s_cs[tid + 256] = c1;
         if (tid < 208) s_tw[tid] = w;
@@ -435,33 +430,11 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
 
     if (p.debug == 7) return;
     {
-        const float v0 = s_specs[tid], v1 = s_specs[tid + 256];
-        s_tmp[tid] = (v0 * v0) * s_loud[tid];
-        s_tmp[tid + 256] = (v1 * v1) * s_loud[tid + 256];
-        p.specs[item * 512 + tid] = v0;
-        p.specs[item * 512 + tid + 256] = v1;
+        // the spectrum leaves for HBM; the per-channel loudness (an ordered sum over its 512 lines) is k_at1_loud's
+        p.specs[item * 512 + tid] = s_specs[tid];
+        p.specs[item * 512 + tid + 256] = s_specs[tid + 256];
     }
-    __syncthreads();
-    if (tid == 0) {
-        // per-channel loudness (atrac1denc.cpp:235-240): one running sum over the 512 lines
-        // (sixteen 16-byte reads in flight per step: a read per four additions left the chain waiting for the LDS every time)
-        float l = 0.0f;
-        const float4* q = reinterpret_cast<const float4*>(s_tmp);
-        for (int i0 = 0; i0 < 128; i0 += 16) {
-            float4 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = q[i0 + i];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                l += v[i].x;
-                l += v[i].y;
-                l += v[i].z;
-                l += v[i].w;
-            }
-        }
-        p.loud_ch[item] = l;
-        p.mask[item] = mask;
-    }
+    if (tid == 0) p.mask[item] = mask;
     if (tid >= 64 && tid < 64 + kMaxBfus) {
         // TScaler<TAtrac1Data>::Scale / ScaleFrame (atrac/atrac_scale.cpp:141-188), one lane per BFU: the scale factor and
         // the in-order energy sum; the divisions are spread over the whole workgroup below
@@ -505,6 +478,104 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
         p.values[item * 512 + tid] = v0;
         p.values[item * 512 + tid + 256] = v1;
     }
+}
+
+// Per-channel loudness of a sound unit (atrac1denc.cpp:235-240): l = sum over the 512 lines, IN ORDER, of specs[i]^2 *
+// LoudnessCurve[i]. A 512-step chain whatever the hardware: in k_at1_front it was one lane of 256 holding the workgroup's
+// slot for the length of the chain. Here a lane runs one unit's chain and a wavefront kAt1LoudUnits of them side by side,
+// fed by the workgroup's three other wavefronts (coalesced 16-byte loads of the spectra k_at1_front has just written,
+// products laid out per unit in LDS one chunk ahead of the chains) - the ATRAC3 k_loud_sum scheme.
+constexpr int kAt1LoudUnits = 32;                       // units per workgroup
+constexpr int kAt1LoudLines = 128;                      // lines per chunk
+constexpr int kAt1LoudRow = kAt1LoudLines + 4;          // floats per unit and chunk: rows 4 banks apart, 16-byte aligned
+constexpr int kAt1LoudChunks = 512 / kAt1LoudLines;
+constexpr int kAt1LoudWords = kAt1LoudUnits * kAt1LoudLines / 4;   // 16-byte words of a chunk
+constexpr int kAt1LoudPer = (kAt1LoudWords + 191) / 192;           // words per producer thread
+static_assert(192 % (kAt1LoudLines / 4) == 0, "a producer thread keeps its place in the row from word to word");
+
+struct LoudParams {
+    const Tables* T;
+    const float* specs;   // [units][512]
+    float* loud_ch;       // [units]
+    int32_t n_units;
+};
+
+__device__ __forceinline__ void at1_loud_request(const float* specs, int u0, int n_units, int u, int k, float4 (&xr)[kAt1LoudPer])
+{
+#pragma unroll
+    for (int i = 0; i < kAt1LoudPer; ++i) {
+        const int w = u + 192 * i, unit = u0 + w / (kAt1LoudLines / 4);
+        xr[i] = (w < kAt1LoudWords && unit < n_units)
+                    ? *reinterpret_cast<const float4*>(specs + (size_t)unit * 512 + kAt1LoudLines * k + 4 * (w % (kAt1LoudLines / 4)))
+                    : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+__device__ __forceinline__ void at1_loud_produce(float* tile, const float* s_curve, int u, int k, const float4 (&xr)[kAt1LoudPer])
+{
+    const float4 cv = *reinterpret_cast<const float4*>(s_curve + kAt1LoudLines * k + 4 * (u % (kAt1LoudLines / 4)));
+#pragma unroll
+    for (int i = 0; i < kAt1LoudPer; ++i) {
+        const int w = u + 192 * i;
+        if (w < kAt1LoudWords) {
+            const float4 x = xr[i];
+            *reinterpret_cast<float4*>(tile + (w / (kAt1LoudLines / 4)) * kAt1LoudRow + 4 * (w % (kAt1LoudLines / 4))) =
+                make_float4((x.x * x.x) * cv.x, (x.y * x.y) * cv.y, (x.z * x.z) * cv.z, (x.w * x.w) * cv.w);
+        }
+    }
+}
+__device__ __forceinline__ void at1_loud_consume(const float* row, float& l)
+{
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int q = 0; q < kAt1LoudLines / 4; q += 4) {
+        const float4 a = r4[q], b = r4[q + 1], c = r4[q + 2], d = r4[q + 3];
+        l += a.x; l += a.y; l += a.z; l += a.w;
+        l += b.x; l += b.y; l += b.z; l += b.w;
+        l += c.x; l += c.y; l += c.z; l += c.w;
+        l += d.x; l += d.y; l += d.z; l += d.w;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_at1_loud(LoudParams p)
+{
+    __shared__ __attribute__((aligned(16))) float s_t[2][kAt1LoudUnits * kAt1LoudRow];   // [buffer][unit][line in chunk]
+    __shared__ __attribute__((aligned(16))) float s_curve[512];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < 128) *reinterpret_cast<float4*>(s_curve + 4 * tid) = *reinterpret_cast<const float4*>(p.T->loud + 4 * tid);
+    const int u0 = blockIdx.x * kAt1LoudUnits;
+    const int u = tid - 64;   // producer index 0..191
+    const bool chain = wave == 0 && lane < kAt1LoudUnits;
+    float4 xa[kAt1LoudPer], xb[kAt1LoudPer];
+    if (wave > 0) {
+        at1_loud_request(p.specs, u0, p.n_units, u, 0, xa);
+        at1_loud_request(p.specs, u0, p.n_units, u, 1, xb);
+    }
+    __syncthreads();   // the curve is in LDS
+    if (wave > 0) {
+        at1_loud_produce(s_t[0], s_curve, u, 0, xa);
+        at1_loud_request(p.specs, u0, p.n_units, u, 2, xa);
+    }
+    __syncthreads();
+    float l = 0.0f;
+    for (int k = 0; k < kAt1LoudChunks; k += 2) {   // chunk k + 1 comes from xb, chunk k + 2 from xa
+        if (wave > 0) {
+            at1_loud_produce(s_t[(k + 1) & 1], s_curve, u, k + 1, xb);
+            if (k + 3 < kAt1LoudChunks) at1_loud_request(p.specs, u0, p.n_units, u, k + 3, xb);
+        } else if (chain) {
+            at1_loud_consume(s_t[k & 1] + lane * kAt1LoudRow, l);
+        }
+        __syncthreads();
+        if (wave > 0) {
+            if (k + 2 < kAt1LoudChunks) {
+                at1_loud_produce(s_t[k & 1], s_curve, u, k + 2, xa);
+                if (k + 4 < kAt1LoudChunks) at1_loud_request(p.specs, u0, p.n_units, u, k + 4, xa);
+            }
+        } else if (chain) {
+            at1_loud_consume(s_t[(k + 1) & 1] + lane * kAt1LoudRow, l);
+        }
+        __syncthreads();
+    }
+    if (chain && u0 + lane < p.n_units) p.loud_ch[u0 + lane] = l;
 }
 
 struct ScanParams {

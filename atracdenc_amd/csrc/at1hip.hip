@@ -197,6 +197,13 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     fp.loud_ch = c->d_loud_ch;
     hipLaunchKernelGGL(k_at1_front, dim3((unsigned)F, (unsigned)(S * C)), dim3(256), 0, st, fp);
     HIPCHK(c, hipGetLastError());
+    LoudParams lp;
+    lp.T = c->d_tables;
+    lp.specs = c->d_specs;
+    lp.loud_ch = c->d_loud_ch;
+    lp.n_units = (int32_t)(S * F * C);
+    hipLaunchKernelGGL(k_at1_loud, dim3((unsigned)((S * F * C + kAt1LoudUnits - 1) / kAt1LoudUnits)), dim3(256), 0, st, lp);
+    HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_at1_state, dim3((unsigned)((S * 512 * C + 255) / 256)), dim3(256), 0, st, d_pcm, c->d_hist, n_blocks, (int)C,
                        (int)S);
     HIPCHK(c, hipEventRecord(c->ev[1], st));

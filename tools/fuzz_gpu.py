@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity hunt (run on the GPU box): many short streams of varied synthetic material, all
-option sets; prints every mismatching (family, seed, stream, frame). Usage: fuzz_gpu.py [rounds] [streams] [blocks]"""
+option sets; prints every mismatching (family, seed, stream, frame). Usage: fuzz_gpu.py [rounds] [streams] [blocks] [first round]
+(round r draws its material from seed 1000 + r: a later run continues where an earlier one stopped)"""
 import os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -72,11 +73,12 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 192
     nb = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+    first = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     o = oracle()
     pool = ThreadPoolExecutor(min(64, os.cpu_count() or 8))
     total = bad_total = 0
     t0 = time.time()
-    for rd in range(rounds):
+    for rd in range(first, first + rounds):
         rng = np.random.RandomState(1000 + rd)
         items = [gen(rng, nb) for _ in range(S)]
         pcm = np.stack([p for _, p in items])
