@@ -1,8 +1,9 @@
 // ATRAC1 encode kernels (gfx950), SURVEY.md 8(f) row f3: the body of TAtrac1Encoder::GetLambda (atrac1denc.cpp:180-255)
 // for a batch of streams. Nothing in the path carries a recursion across sound units except the loudness tracker, so
 // the work splits into
-//   k_at1_front      one workgroup per (stream, sound unit, channel): QMF tree, transient detection, block-switched
-//                    MDCT, per-channel loudness, scale factors
+//   k_at1_front      one wavefront per (stream, sound unit, channel): QMF tree, transient detection, block-switched
+//                    MDCT, scale factors
+//   k_at1_loud       per-channel loudness: the ordered 512-line sums, a lane per sound unit
 //   k_at1_loud_scan  one lane per stream: TrackLoudness over the call's sound units
 //   k_at1_alloc_pack one wave per (stream, sound unit, channel): shift bisection, BFU-count reduction, bit boost, packing
 // Every float operation is the reference's, in its order, without contraction; integer work is free to reassociate.
@@ -58,6 +59,7 @@ struct LogfTab {
     double poly[3];
 };
 static_assert(offsetof(Tables, logf_poly) - offsetof(Tables, logf_tab) == sizeof(double) * 33, "Tables keeps the logf data together");
+static_assert(512 + 166 + 164 + 166 <= 1008, "the second QMF stage's outputs fit behind the spectrum");
 static_assert(offsetof(Tables, sc256) - offsetof(Tables, sc512) == 256 * 4 && offsetof(Tables, sc64) - offsetof(Tables, sc512) == 384 * 4,
               "the three MDCT rotation tables are staged as one block");
 
@@ -164,146 +166,160 @@ __device__ __forceinline__ float mdct_in(const float* src, const float* sine, in
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
+// One WAVEFRONT per (stream, sound unit, channel). The first version gave a sound unit 256 threads and separated its
+// phases by workgroup barriers; no phase has 256 independent jobs (the first QMF stage has 94, the second 41, the
+// detector's level comparison 35), so most of a workgroup's wavefronts spent most of its life parked at a barrier while
+// occupying registers and LDS. Here the 64 lanes walk every phase's jobs in rounds, phases are separated by wave-level
+// rendezvous only (the LDS pipeline executes one wavefront's instructions in order), the rotation tables, the window and
+// the logarithm's table are read where they are used (they stay in the L1 of a CU that runs nothing else) and the
+// scale-factor table lives in the lanes: 11 KB of LDS per unit, fourteen units per CU.
+__global__ __launch_bounds__(64) void k_at1_front(FrontParams p)
 {
-    // window of band signals kept per workgroup, indices relative to the sound unit's first sample of each rate.
-    // Two regions are reused once their first tenant is dead: the PCM window becomes the spectrum, the detector's
-    // filter output becomes the FFT buffer and then the loudness products (18.3 KB in all: 8 workgroups per CU).
+    // Two regions are reused once their first tenant is dead: the PCM window becomes the spectrum; the first QMF stage's
+    // lower band becomes the detector's filter output and then the FFT buffer.
     __shared__ __attribute__((aligned(16))) float s_region_a[1008];
     __shared__ __attribute__((aligned(16))) float s_region_b[560];
     float* const s_pcm = s_region_a;                                     // t  in [-288, 512), padded (qmf_pad)
     float* const s_specs = s_region_a;                                   // after the first QMF stage
+    float* const s_lo1 = s_region_b;                                     // m  in [-118, 256)   first-stage lower band, padded (qmf_pad): 480 floats
     float* const s_filt = s_region_b;                                    // detector high-pass output: low/mid [-16,128), hi [-16,256)
     at3::cpx* const s_f = reinterpret_cast<at3::cpx*>(s_region_b);       // 256 points, after the detector
-    __shared__ __attribute__((aligned(16))) float s_lo1[480];            // m  in [-118, 256)   first-stage lower band, padded (qmf_pad)
     __shared__ float s_up1[332];                                         // m  in [-75, 256)    first-stage upper band; hi[i] = up1[i - 39]
-    __shared__ float s_low[166], s_mid[164];                             // q  in [-36, 128); s_low[164] = 0 for the detector
-    __shared__ float s_dmid[166], s_dhi[294];                            // InvertSpectr'ed mid [-36,128] / high [-36,256] band, last = 0
+    // the second stage's outputs live behind the spectrum's 512 floats in the PCM window's storage (dead after the first stage)
+    float* const s_low = s_region_a + 512;                               // q  in [-36, 128); s_low[164] = 0 for the detector
+    float* const s_mid = s_region_a + 512 + 166;                         // 164 floats
+    float* const s_dmid = s_region_a + 512 + 166 + 164;                  // InvertSpectr'ed mid band [-36,128], last = 0: 166 floats
+    __shared__ float s_dhi[294];                                         // InvertSpectr'ed high band [-36,256], last = 0
     __shared__ float s_rms[3][17];
-    __shared__ float s_scale[64], s_sine[32];
-    __shared__ __attribute__((aligned(8))) float s_fir[10];
-    __shared__ LogfTab s_logf;
-    __shared__ __attribute__((aligned(16))) at3::cpx s_tw[208];          // tw128 | tw64 | tw16
-    __shared__ float s_cs[416];                                          // sc512 | sc256 | sc64
     __shared__ float s_sf[kMaxBfus];
     __shared__ int s_srcoff[kMaxBfus];
-    __shared__ int s_mask;
+    __shared__ float s_sine[32];
+    __shared__ LogfTab s_logf;
 
     const Tables* T = p.T;
     const int f = blockIdx.x, sc = blockIdx.y;
     const int nch = p.nch, s = sc / nch, ch = sc - s * nch;
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const size_t item = ((size_t)s * p.n_frames + f) * nch + ch;
 
     {
-        float v[4];
+        float v[13];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = tid + 256 * r;
+        for (int r = 0; r < 13; ++r) {
+            const int j = lane + 64 * r;
             const int t = 512 * f - 288 + j;
             v[r] = j >= 800 ? 0.0f
                  : t >= 0   ? p.pcm[((size_t)s * p.n_frames * 512 + t) * nch + ch]
                             : p.hist[((size_t)s * 512 + (512 + t)) * nch + ch];
         }
-        const float c0 = (&T->sc512[0])[tid], c1 = tid < 160 ? (&T->sc512[0])[tid + 256] : 0.0f;   // sc512 | sc256 | sc64 are contiguous
-        at3::cpx w = {0.0f, 0.0f};
-        if (tid < 208) w = tid < 128 ? T->tw128[tid] : tid < 192 ? T->tw64[tid - 128] : T->tw16[tid - 192];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (tid + 256 * r < 800) s_pcm[qmf_pad(tid + 256 * r)] = v[r];
-        s_cs[tid] = c0;
-        if (tid < 160) s_cs[tid + 256] = c1;
-        if (tid < 208) s_tw[tid] = w;
+        for (int r = 0; r < 13; ++r)
+            if (lane + 64 * r < 800) s_pcm[qmf_pad(lane + 64 * r)] = v[r];
     }
-    if (tid < 48) {
-    } else if (tid < 112) s_scale[tid - 48] = T->scale[tid - 48];
-    else if (tid < 144) s_sine[tid - 112] = T->sine[tid - 112];
-    else if (tid < 154) s_fir[tid - 144] = T->fir[tid - 144];
-    else if (tid < 154 + 36) (&s_logf.tab[0][0])[tid - 154] = (&T->logf_tab[0][0])[tid - 154];
-    const int pos_bfu0 = c_bfu_of_pos[tid], pos_bfu1 = c_bfu_of_pos[tid + 256];
+    const float my_scale = T->scale[lane];   // ScaleTable has 64 entries: looked up across the lanes
+    // everything the later phases read from tables at indices that are known now is requested now, behind the PCM window:
+    // a global load issued where its value is needed costs a wavefront a microsecond of its 24
+    if (lane < 32) s_sine[lane] = T->sine[lane];
+    if (lane < 36) (&s_logf.tab[0][0])[lane] = (&T->logf_tab[0][0])[lane];   // 16 x 2 table entries, ln 2, three coefficients
+    // rotation factors of the lane's point in the four pre- / post-rotation rounds, long window (index 2 c), and of its
+    // point in a short block (index 2 (c & 15), the same in every round); sc512 | sc256 | sc64 are contiguous
+    f2 cs_long[4];
+#pragma unroll
+    for (int round = 0; round < 4; ++round)
+        cs_long[round] = *reinterpret_cast<const f2*>(&T->sc512[0] + (round < 2 ? 256 : 0) + 2 * (lane + (round == 3 ? 64 : 0)));
+    const f2 cs_short = *reinterpret_cast<const f2*>(&T->sc512[0] + 384 + 2 * (lane & 15));
+    const uint32_t pos_bfu4[2] = {*reinterpret_cast<const uint32_t*>(c_bfu_of_pos + 4 * lane), *reinterpret_cast<const uint32_t*>(c_bfu_of_pos + 4 * (lane + 64))};
     int bf_long = 0, bf_short = 0, bf_len = 0;
-    if (tid >= 64 && tid < 64 + kMaxBfus) {
-        bf_long = c_start_long[tid - 64];
-        bf_short = c_start_short[tid - 64];
-        bf_len = c_spb[tid - 64];
+    if (lane < kMaxBfus) {
+        bf_long = c_start_long[lane];
+        bf_short = c_start_short[lane];
+        bf_len = c_spb[lane];
     }
-    if (tid == 255) {
-        s_mask = 0;
-        s_low[164] = 0.0f;   // HPFBuffer[BlockSz + 20] is never written: the sample after the block reads as 0
-        s_dmid[164] = 0.0f;
-        s_dhi[292] = 0.0f;
-    }
-    __syncthreads();
+    if (lane == 63) s_dhi[292] = 0.0f;   // HPFBuffer[BlockSz + 20] is never written: the sample after the block reads as 0
+    wave_sync();
 
     if (p.debug == 1) return;
     // Atrac1AnalysisFilterBank::Analysis (atrac/at1/atrac1_qmf.h:37-43): Qmf1 over the PCM ...
-    if (tid < 94) {
-        // outputs m = -118 + 4 tid + r; the first pair read is PCM index 2 m - 46 = 8 tid - 282, window index 8 tid + 6
-        float lo[4], up[4];
-        qmf_quad<6>(T->qmf_win, s_pcm + qmf_pad(8 * tid + 6), lo, up);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = 4 * tid + r, m = j - 118;
-            if (j < 374) {
-                s_lo1[qmf_pad(j)] = lo[r];
-                if (m >= -75) {
-                    s_up1[m + 75] = up[r];
-                    if (m < 217) s_dhi[m + 75] = (m & 1) ? -up[r] : up[r];   // hi[i] = up1[i - 39]: i even <=> m odd (InvertSpectr, util.h:51-63)
+    for (int round = 0; round < 2; ++round) {
+        const int tt = lane + 64 * round;
+        if (tt < 94) {
+            // outputs m = -118 + 4 tt + r; the first pair read is PCM index 2 m - 46 = 8 tt - 282, window index 8 tt + 6
+            float lo[4], up[4];
+            qmf_quad<6>(T->qmf_win, s_pcm + qmf_pad(8 * tt + 6), lo, up);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 4 * tt + r, m = j - 118;
+                if (j < 374) {
+                    s_lo1[qmf_pad(j)] = lo[r];
+                    if (m >= -75) {
+                        s_up1[m + 75] = up[r];
+                        if (m < 217) s_dhi[m + 75] = (m & 1) ? -up[r] : up[r];   // hi[i] = up1[i - 39]: i even <=> m odd (InvertSpectr, util.h:51-63)
+                    }
                 }
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     if (p.debug == 2) return;
     // ... Qmf2 over its lower half; the upper half is delayed by 39 samples
-    if (tid < 41) {
-        // outputs q = -36 + 4 tid + r; the first pair read is lower-band index 2 q - 46 = 8 tid - 118, buffer index 8 tid
+    if (lane < 41) {
+        // outputs q = -36 + 4 lane + r; the first pair read is lower-band index 2 q - 46 = 8 lane - 118, buffer index 8 lane
         float lo[4], up[4];
-        qmf_quad<0>(T->qmf_win, s_lo1 + qmf_pad(8 * tid), lo, up);
+        qmf_quad<0>(T->qmf_win, s_lo1 + qmf_pad(8 * lane), lo, up);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int j = 4 * tid + r, q = j - 36;
+            const int j = 4 * lane + r, q = j - 36;
             s_low[j] = lo[r];
             s_mid[j] = up[r];
             s_dmid[j] = (q & 1) ? up[r] : -up[r];
         }
     }
-    __syncthreads();
+    if (lane == 63) {
+        s_low[164] = 0.0f;   // (as s_dhi[292] above)
+        s_dmid[164] = 0.0f;
+    }
+    wave_sync();
     if (p.debug == 3) return;
     int mask = p.window_mask;
     if (p.window_auto) {
-        // TTransientDetector::HPFilter (transient_detector.cpp:48-66) for this unit (512 outputs: each wave stays inside one
-        // band) and for the last short block of the previous unit (its LastEnergy, 48 outputs). The two running sums of the
-        // reference loop are independent and ride in the halves of packed fp32 operations.
-        const f2* firp = reinterpret_cast<const f2*>(s_fir);
-        for (int j = tid; j < 560; j += 256) {
+        // TTransientDetector::HPFilter (transient_detector.cpp:48-66) for this unit (512 outputs: a round of 64 stays inside
+        // one band) and for the last short block of the previous unit (its LastEnergy, 48 outputs). The two running sums
+        // of the reference loop are independent and ride in the halves of packed fp32 operations.
+        f2 fir[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) fir[q] = at3::mk2(T->fir[2 * q], T->fir[2 * q + 1]);   // wave-uniform: scalar registers
+#pragma unroll
+        for (int round = 0; round < 9; ++round) {
+            const int j = lane + 64 * round;
             int b, i;
-            if (j < 512) {
-                b = j < 128 ? 0 : j < 256 ? 1 : 2;
+            if (round < 8) {
+                b = round < 2 ? 0 : round < 4 ? 1 : 2;
                 i = j - (b == 0 ? 0 : b == 1 ? 128 : 256);
             } else {
-                if (j >= 512 + 48) break;
-                b = (j - 512) >> 4;
-                i = ((j - 512) & 15) - 16;
+                b = lane >> 4;
+                i = (lane & 15) - 16;
             }
-            const float* d = (b == 0 ? s_low : b == 1 ? s_dmid : s_dhi) + 36;
-            // the previous unit's own last output saw 0 after its block, not this unit's first sample
-            const float nxt = i == -1 ? 0.0f : d[i + 1];
-            f2 acc = at3::mk2(d[i - 10], 0.0f);
-            acc += firp[0] * (at3::mk2(d[i - 20], d[i - 19]) + at3::mk2(nxt, d[i]));
+            if (round < 8 || lane < 48) {
+                const float* d = (b == 0 ? s_low : b == 1 ? s_dmid : s_dhi) + 36;
+                // the previous unit's own last output saw 0 after its block, not this unit's first sample
+                const float nxt = i == -1 ? 0.0f : d[i + 1];
+                f2 acc = at3::mk2(d[i - 10], 0.0f);
+                acc += fir[0] * (at3::mk2(d[i - 20], d[i - 19]) + at3::mk2(nxt, d[i]));
 #pragma unroll
-            for (int jj = 2; jj < 9; jj += 2)
-                acc += firp[jj >> 1] * (at3::mk2(d[i - 20 + jj], d[i - 19 + jj]) + at3::mk2(d[i + 1 - jj], d[i - jj]));
-            s_filt[(b == 0 ? 0 : b == 1 ? 144 : 288) + 16 + i] = (acc.x + acc.y) / 2;
+                for (int jj = 2; jj < 9; jj += 2)
+                    acc += fir[jj >> 1] * (at3::mk2(d[i - 20 + jj], d[i - 19 + jj]) + at3::mk2(d[i + 1 - jj], d[i - jj]));
+                s_filt[(b == 0 ? 0 : b == 1 ? 144 : 288) + 16 + i] = (acc.x + acc.y) / 2;
+            }
         }
-        __syncthreads();
+        wave_sync();
         // calculateRMS over the 16-sample short blocks, 19 log10, the +16 / -20 jumps (transient_detector.cpp:40-46, 76-88):
-        // 35 lanes of wave 0, exchanged inside the wave
-        if (tid < 64) {
-            const int b = tid < 9 ? 0 : tid < 18 ? 1 : 2;
-            const int k = tid - (b == 0 ? 0 : b == 1 ? 9 : 18);
+        // 35 lanes, exchanged inside the wave
+        {
+            const int b = lane < 9 ? 0 : lane < 18 ? 1 : 2;
+            const int k = lane - (b == 0 ? 0 : b == 1 ? 9 : 18);
             float r = 0.0f;
-            if (tid < 35) {
+            if (lane < 35) {
                 const float* fl = s_filt + (b == 0 ? 0 : b == 1 ? 144 : 288) + 16 * k;
                 float acc = 0.0f;
 #pragma unroll
@@ -315,23 +331,45 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
             }
             wave_sync();
             bool jump = false;
-            if (tid < 35 && k > 0) {
+            if (lane < 35 && k > 0) {
                 const float r0 = s_rms[b][k - 1];
                 jump = r - r0 > 16 || r0 - r > 20;
             }
             const unsigned long long jl = __ballot(jump && b == 0), jm = __ballot(jump && b == 1), jh = __ballot(jump && b == 2);
-            if (tid == 0) s_mask = (jl ? 1 : 0) | (jm ? 2 : 0) | (jh ? 4 : 0);
+            mask = (jl ? 1 : 0) | (jm ? 2 : 0) | (jh ? 4 : 0);
         }
-        __syncthreads();
-        mask = s_mask;
+        wave_sync();   // the filter output is dead: its storage becomes the FFT buffer
     }
 
     if (p.debug == 4) return;
+    // the lane's FFT twiddles (their indices depend on the window mask only) are requested before the pre-rotation
+    const at3::cpx* tw128 = T->tw128;   // tw128 | tw64 | tw16 are contiguous
+    const int f_bsel = lane < 32 ? 2 : lane < 48 ? 0 : 1;
+    const int f_j = lane < 32 ? lane : (lane - 32) & 15;
+    const bool f_sh = (mask >> f_bsel) & 1;
+    const int f_N = f_sh ? 16 : (f_bsel == 2 ? 128 : 64);
+    const int f_r = f_j % (f_N >> 2);
+    f2 f_tw[3][3];
+    const f2 f_tw0 = at3::ld2(tw128);
+    {
+        const at3::cpx* tw = tw128 + (f_sh ? 192 : f_bsel == 2 ? 0 : 128);
+        int m = f_N == 128 ? 2 : 1;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+            const int mm = m < f_N ? m : 1;   // (a stage the transform does not have: any valid index)
+            const int fstride = f_N / (4 * mm), k = f_r % mm;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) f_tw[st][q] = at3::ld2(tw + (q + 1) * k * fstride);
+            m <<= 2;
+        }
+    }
     // TAtrac1MDCT::Mdct (atrac1denc.cpp:70-102): TMDCT<N>::operator() pre-rotation (lib/mdct/mdct.h:51-87) straight into
     // the FFT's leaf order; the windowed input buffer of the reference is evaluated where it is read (mdct_in).
-    {
-        const int b = tid < 64 ? 0 : tid < 128 ? 1 : 2;
-        const int c = tid - (b == 0 ? 0 : b == 1 ? 64 : 128);
+    // Round 0 is the low band's 64 points, round 1 the middle band's, rounds 2 and 3 the high band's 128.
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const int b = round < 2 ? round : 2;
+        const int c = lane + (round == 3 ? 64 : 0);
         const bool sh = (mask >> b) & 1;
         const int B = b == 2 ? 256 : 128;
         const int N = sh ? 64 : 2 * B;
@@ -349,46 +387,39 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
             r0 = in(n34 - 1 - n) - in(n - n4);
             i0 = in(n4 + n) + in(n54 - 1 - n);
         }
-        const float* cs = s_cs + (sh ? 384 : b == 2 ? 0 : 256);
-        const float cc = cs[n], ss = cs[n + 1];
+        const f2 csv = sh ? cs_short : cs_long[round];
+        const float cc = csv.x, ss = csv.y;
         at3::cpx v;
         v.r = r0 * cc + i0 * ss;
         v.i = i0 * cc - r0 * ss;
         const int leaf = sh ? fft_leaf_pos<16>(pidx) : (b == 2 ? fft_leaf_pos<128>(pidx) : fft_leaf_pos<64>(pidx));
         s_f[(b == 0 ? 0 : b == 1 ? 64 : 128) + 16 * k + leaf] = v;
     }
-    __syncthreads();
+    wave_sync();
     if (p.debug == 5) return;
-    if (tid < 64) {
-        // All three bands' transforms in ONE wave: a radix-4 stage has 32 butterflies in the high band (one 128-point or
+    {
+        // All three bands' transforms at once: a radix-4 stage has 32 butterflies in the high band (one 128-point or
         // eight 16-point transforms) and 16 each in the low and middle bands (one 64-point or four 16-point) - 64 lanes.
         // Lanes 0..31 own the high band, 32..47 the low, 48..63 the middle band; the 128-point transform's radix-2
-        // leaves (64 butterflies) take all lanes first. Stages are separated by wave-level rendezvous only.
-        const int lane = tid;
+        // leaves (64 butterflies) take all lanes first.
         if (!(mask & 4)) {
             at3::cpx* a = s_f + 128 + 2 * lane;
             f2 a0 = at3::ld2(a), a1 = at3::ld2(a + 1);
-            at3::bfly2(a0, a1, at3::ld2(s_tw));
+            at3::bfly2(a0, a1, f_tw0);
             at3::st2(a, a0);
             at3::st2(a + 1, a1);
         }
         wave_sync();
-        const int bsel = lane < 32 ? 2 : lane < 48 ? 0 : 1;
-        const int j = lane < 32 ? lane : (lane - 32) & 15;
-        const bool sh = (mask >> bsel) & 1;
-        const int N = sh ? 16 : (bsel == 2 ? 128 : 64);
-        at3::cpx* F = s_f + (bsel == 0 ? 0 : bsel == 1 ? 64 : 128);
-        const at3::cpx* tw = s_tw + (sh ? 192 : bsel == 2 ? 0 : 128);
-        const int f = j / (N >> 2), r = j % (N >> 2);   // transform inside the band, butterfly inside the transform
-        int m = N == 128 ? 2 : 1;
+        at3::cpx* F = s_f + (f_bsel == 0 ? 0 : f_bsel == 1 ? 64 : 128);
+        const int ft = f_j / (f_N >> 2);   // transform inside the band; f_r: butterfly inside the transform
+        int m = f_N == 128 ? 2 : 1;
 #pragma unroll
         for (int st = 0; st < 3; ++st) {
-            if (m < N) {
-                const int fstride = N / (4 * m);
-                const int g = r / m, k = r % m;
-                at3::cpx* B = F + f * N + g * 4 * m + k;
+            if (m < f_N) {
+                const int g = f_r / m, k = f_r % m;
+                at3::cpx* B = F + ft * f_N + g * 4 * m + k;
                 f2 x0 = at3::ld2(B), x1 = at3::ld2(B + m), x2 = at3::ld2(B + 2 * m), x3 = at3::ld2(B + 3 * m);
-                at3::bfly4<false>(x0, x1, x2, x3, at3::ld2(tw + k * fstride), at3::ld2(tw + 2 * k * fstride), at3::ld2(tw + 3 * k * fstride));
+                at3::bfly4<false>(x0, x1, x2, x3, f_tw[st][0], f_tw[st][1], f_tw[st][2]);
                 at3::st2(B, x0);
                 at3::st2(B + m, x1);
                 at3::st2(B + 2 * m, x2);
@@ -398,19 +429,19 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
             wave_sync();
         }
     }
-    __syncthreads();
     if (p.debug == 6) return;
     // post-rotation (mdct.h:89-101), the high band's short-window gain and the mirrored bands (atrac1denc.cpp:92-97)
-    {
-        const int b = tid < 64 ? 0 : tid < 128 ? 1 : 2;
-        const int c = tid - (b == 0 ? 0 : b == 1 ? 64 : 128);
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const int b = round < 2 ? round : 2;
+        const int c = lane + (round == 3 ? 64 : 0);
         const bool sh = (mask >> b) & 1;
         const int n2 = sh ? 32 : (b == 2 ? 256 : 128);
         const int k = sh ? c >> 4 : 0;
         const int n = 2 * (sh ? (c & 15) : c);
         const at3::cpx v = s_f[(b == 0 ? 0 : b == 1 ? 64 : 128) + c];
-        const float* cs = s_cs + (sh ? 384 : b == 2 ? 0 : 256);
-        const float cc = cs[n], ss = cs[n + 1];
+        const f2 csv = sh ? cs_short : cs_long[round];
+        const float cc = csv.x, ss = csv.y;
         float o1 = -v.r * cc - v.i * ss;
         float o2 = -v.r * ss + v.i * cc;
         if (sh && b == 2) {
@@ -426,19 +457,18 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
             dst[n2 - 1 - n] = o2;
         }
     }
-    __syncthreads();
+    wave_sync();
 
     if (p.debug == 7) return;
+    // the spectrum leaves for HBM; the per-channel loudness (an ordered sum over its 512 lines) is k_at1_loud's
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        *reinterpret_cast<float4*>(p.specs + item * 512 + 4 * (lane + 64 * r)) = *reinterpret_cast<const float4*>(s_specs + 4 * (lane + 64 * r));
+    if (lane == 0) p.mask[item] = mask;
     {
-        // the spectrum leaves for HBM; the per-channel loudness (an ordered sum over its 512 lines) is k_at1_loud's
-        p.specs[item * 512 + tid] = s_specs[tid];
-        p.specs[item * 512 + tid + 256] = s_specs[tid + 256];
-    }
-    if (tid == 0) p.mask[item] = mask;
-    if (tid >= 64 && tid < 64 + kMaxBfus) {
         // TScaler<TAtrac1Data>::Scale / ScaleFrame (atrac/atrac_scale.cpp:141-188), one lane per BFU: the scale factor and
-        // the in-order energy sum; the divisions are spread over the whole workgroup below
-        const int bfu = tid - 64;
+        // the in-order energy sum; the divisions are spread over the whole wavefront below
+        const int bfu = lane < kMaxBfus ? lane : 0;
         const bool sh = (mask >> bfu_band(bfu)) & 1;
         const int src0 = sh ? bf_short : bf_long;
         const float* in = s_specs + src0;
@@ -457,26 +487,38 @@ __global__ __launch_bounds__(256) void k_at1_front(FrontParams p)
             }
         }
         if (max_abs > 1.0f) max_abs = 1.0f;
+        // smallest table entry >= max_abs (std::map::lower_bound in the reference): every lane takes part in the cross-lane
+        // look-ups, lanes without a BFU search for 0
         int lo = 0, hi = 63;
 #pragma unroll
         for (int it = 0; it < 6; ++it) {
             const int mid = (lo + hi) >> 1;
-            if (s_scale[mid] < max_abs) lo = mid + 1;
+            const float sm = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * mid, (int)__float_as_uint(my_scale)));
+            if (sm < max_abs) lo = mid + 1;
             else hi = mid;
         }
-        s_sf[bfu] = s_scale[lo];
-        s_srcoff[bfu] = src0 - bf_long;
-        p.sfi[item * 64 + bfu] = (uint8_t)lo;
-        p.energy[item * kMaxBfus + bfu] = e;
+        const float sfv = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * lo, (int)__float_as_uint(my_scale)));
+        if (lane < kMaxBfus) {
+            s_sf[bfu] = sfv;
+            s_srcoff[bfu] = src0 - bf_long;
+            p.sfi[item * 64 + bfu] = (uint8_t)lo;
+            p.energy[item * kMaxBfus + bfu] = e;
+        }
     }
-    __syncthreads();
-    {
-        float v0 = s_specs[s_srcoff[pos_bfu0] + tid] / s_sf[pos_bfu0];
-        float v1 = s_specs[s_srcoff[pos_bfu1] + tid + 256] / s_sf[pos_bfu1];
-        if (fabsf(v0) >= 1.0f) v0 = (v0 > 0) ? 0.99999f : -0.99999f;
-        if (fabsf(v1) >= 1.0f) v1 = (v1 > 0) ? 0.99999f : -0.99999f;
-        p.values[item * 512 + tid] = v0;
-        p.values[item * 512 + tid + 256] = v1;
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i0 = 4 * (lane + 64 * r);
+        const uint32_t pb4 = pos_bfu4[r];
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pb = (int)((pb4 >> (8 * q)) & 0xffu);
+            float x = s_specs[s_srcoff[pb] + i0 + q] / s_sf[pb];
+            if (fabsf(x) >= 1.0f) x = (x > 0) ? 0.99999f : -0.99999f;
+            v[q] = x;
+        }
+        *reinterpret_cast<float4*>(p.values + item * 512 + i0) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 

@@ -195,7 +195,7 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     fp.sfi = c->d_sfi;
     fp.mask = c->d_mask;
     fp.loud_ch = c->d_loud_ch;
-    hipLaunchKernelGGL(k_at1_front, dim3((unsigned)F, (unsigned)(S * C)), dim3(256), 0, st, fp);
+    hipLaunchKernelGGL(k_at1_front, dim3((unsigned)F, (unsigned)(S * C)), dim3(64), 0, st, fp);
     HIPCHK(c, hipGetLastError());
     LoudParams lp;
     lp.T = c->d_tables;

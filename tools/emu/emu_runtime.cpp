@@ -4,6 +4,8 @@
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 
+extern "C" char __start_emu_lds[] __attribute__((weak)), __stop_emu_lds[] __attribute__((weak));
+
 namespace {
 struct Fiber {
     ucontext_t ctx;
@@ -166,6 +168,7 @@ void emu_launch(const char* name, dim3 grid, dim3 block, const std::function<voi
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 blockIdx = dim3(bx, by, bz);
+                if (&__start_emu_lds[0] != nullptr && &__stop_emu_lds[0] > &__start_emu_lds[0]) memset(__start_emu_lds, 0xCD, (size_t)(__stop_emu_lds - __start_emu_lds));
                 g_live = nthr; g_bar_arrived = 0;
                 g_waves.assign((nthr + 63) / 64, Wave());
                 for (unsigned t = 0; t < nthr; ++t) {

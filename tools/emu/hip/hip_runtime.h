@@ -46,7 +46,9 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __global__
 #define __device__
 #define __host__
-#define __shared__ static
+// every __shared__ object lands in one section that the scheduler poisons before each workgroup starts: a kernel that
+// reads LDS it has not written sees 0xCD bytes here, not the zeros (or the previous workgroup's values) a plain static holds
+#define __shared__ static __attribute__((section("emu_lds")))
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __restrict__
