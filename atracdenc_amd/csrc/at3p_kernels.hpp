@@ -29,8 +29,11 @@ struct PqfParams {
 __global__ __launch_bounds__(256) void k_at3p_pqf(PqfParams p)
 {
     __shared__ __attribute__((aligned(16))) float s_x[kFrame + kOverlap];   // later: the frame's 16 x 128 output
-    __shared__ float s_yy[128][16];
-    __shared__ __attribute__((aligned(16))) at3::cpx s_f[1024];
+    // 128 steps x 16 matrixed values, then - same 8 KB - the 128 eight-point transforms (18 KB per workgroup: eight per CU,
+    // and the 4096 workgroups of the 64 x 32 batch are two whole rounds of the chip instead of 2.7)
+    __shared__ __attribute__((aligned(16))) float s_yy_f[128 * 16];
+    float (*const s_yy)[16] = reinterpret_cast<float (*)[16]>(s_yy_f);
+    at3::cpx* const s_f = reinterpret_cast<at3::cpx*>(s_yy_f);
     __shared__ float s_cs[16];
     __shared__ __attribute__((aligned(8))) at3::cpx s_tw[8];
 
@@ -76,14 +79,23 @@ __global__ __launch_bounds__(256) void k_at3p_pqf(PqfParams p)
 
     // atde_do_dct4_16 (lib/mdct/mdct.cpp:73-80) = TMIDCT<32> (lib/mdct/mdct.h:117-180) of the 16 values: pre-rotation into
     // the leaf order of an 8-point FFT, 128 transforms side by side
-    for (int q = tid; q < 1024; q += 256) {
-        const int step = q >> 3, pt = q & 7, n = 2 * pt;
-        const float r0 = s_yy[step][n], i0 = s_yy[step][15 - n];
-        const float c = s_cs[n], sn = s_cs[n + 1];
-        at3::cpx v;
-        v.r = (float)(-2.0 * (double)(i0 * sn + r0 * c));
-        v.i = (float)(-2.0 * (double)(i0 * c - r0 * sn));
-        s_f[8 * step + fft_leaf_pos<8>(pt)] = v;
+    {
+        at3::cpx v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = tid + 256 * r;
+            const int step = q >> 3, pt = q & 7, n = 2 * pt;
+            const float r0 = s_yy[step][n], i0 = s_yy[step][15 - n];
+            const float c = s_cs[n], sn = s_cs[n + 1];
+            v[r].r = (float)(-2.0 * (double)(i0 * sn + r0 * c));
+            v[r].i = (float)(-2.0 * (double)(i0 * c - r0 * sn));
+        }
+        __syncthreads();   // every matrixed value has been read: the transforms move in
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = tid + 256 * r;
+            s_f[8 * (q >> 3) + fft_leaf_pos<8>(q & 7)] = v[r];
+        }
     }
     __syncthreads();
     fft_lds<8, false>(s_f, 8, 128, s_tw, tid, 256);
@@ -127,8 +139,10 @@ __device__ __forceinline__ float at3p_second_half(float v, const float* w128, co
 
 __global__ __launch_bounds__(256) void k_at3p_mdct(MdctParams p)
 {
+    // the sixteen 256-sample work buffers; once the pre-rotation has read them the lower half holds the sixteen 64-point
+    // transforms and the upper half collects the spectrum (18 KB per workgroup: eight per CU, two whole rounds for 64 x 32)
     __shared__ __attribute__((aligned(16))) float s_tmp[16][256];
-    __shared__ __attribute__((aligned(16))) at3::cpx s_f[1024];
+    at3::cpx* const s_f = reinterpret_cast<at3::cpx*>(&s_tmp[0][0]);
     __shared__ float s_cs[128], s_w128[128], s_w64[64];
     __shared__ __attribute__((aligned(8))) at3::cpx s_tw[64];
 
@@ -163,26 +177,35 @@ __global__ __launch_bounds__(256) void k_at3p_mdct(MdctParams p)
     }
     __syncthreads();
     // TMDCT<256>::operator() (lib/mdct/mdct.h:51-104): pre-rotation into the 64-point FFT's leaf order, 16 transforms
-    for (int q = tid; q < 1024; q += 256) {
-        const int b = q >> 6, pt = q & 63, n = 2 * pt;
-        const float* in = s_tmp[b];
-        float r0, i0;
-        if (n < 64) {
-            r0 = in[191 - n] + in[192 + n];
-            i0 = in[64 + n] - in[63 - n];
-        } else {
-            r0 = in[191 - n] - in[n - 64];
-            i0 = in[64 + n] + in[319 - n];
+    {
+        at3::cpx v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = tid + 256 * r;
+            const int b = q >> 6, pt = q & 63, n = 2 * pt;
+            const float* in = s_tmp[b];
+            float r0, i0;
+            if (n < 64) {
+                r0 = in[191 - n] + in[192 + n];
+                i0 = in[64 + n] - in[63 - n];
+            } else {
+                r0 = in[191 - n] - in[n - 64];
+                i0 = in[64 + n] + in[319 - n];
+            }
+            const float c = s_cs[n], sn = s_cs[n + 1];
+            v[r].r = r0 * c + i0 * sn;
+            v[r].i = i0 * c - r0 * sn;
         }
-        const float c = s_cs[n], sn = s_cs[n + 1];
-        at3::cpx v;
-        v.r = r0 * c + i0 * sn;
-        v.i = i0 * c - r0 * sn;
-        s_f[64 * b + fft_leaf_pos<64>(pt)] = v;
+        __syncthreads();   // every work buffer has been read: the transforms move into the lower half
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = tid + 256 * r;
+            s_f[64 * (q >> 6) + fft_leaf_pos<64>(q & 63)] = v[r];
+        }
     }
     __syncthreads();
     fft_lds<64, false>(s_f, 64, 16, s_tw, tid, 256);
-    float* s_out = &s_tmp[0][0];
+    float* s_out = &s_tmp[8][0];
     for (int q = tid; q < 1024; q += 256) {
         const int b = q >> 6, pt = q & 63, n = 2 * pt;
         const at3::cpx v = s_f[q];
