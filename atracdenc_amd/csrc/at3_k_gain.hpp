@@ -20,7 +20,6 @@ struct GainParams {
     const float* sub;     // [S][2][4][(n_blocks+2)*256] raw L/R subbands, block b at (b+2)*256
     GainRec* rec;         // [S][n_blocks][2][3] by frame index
     cpx* bins;            // [items][kGainBins] rfft-512 bins 38 .. 256 of every item, k_gain_spec -> k_gain_analysis
-    float* micro;         // [items][256] RMS of the 8-sample micro-chunks of the upsampled band, k_gain_analysis -> k_gain_tail
     BandState* state;     // [S][2][4]
     Curve* curves;        // [S][n_blocks][2][4]
     int n_blocks;
@@ -549,11 +548,14 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
 
 
     // 4. AnalyzeGain over the upsampled samples [1024, 3072): 256 micro-chunks of 8 (4 per lane), 32 sub-frames of 64
-    // complex output j holds the real samples 2j, 2j+1; sample 1024 is complex slot 512 = padded slot 528. The RMS values
-    // leave for HBM; what is made of them (quartiles, plateau target) is a short serial affair of 32 lanes per item and
+    // complex output j holds the real samples 2j, 2j+1; sample 1024 is complex slot 512 = padded slot 528. The sub-frame RMS
+    // values and the quartiles leave for HBM; the plateau target made of them is a short serial affair of 32 lanes per item and
     // runs as k_gain_tail on the light stage's stream instead of holding this kernel's 17 KB of LDS for a third of its life.
     const float norm = 1.0f / 4096.0f;
-    float* micro = p.micro + item * 256;
+    // the 256 micro-chunk values stay on the chip: they go to the dead first quarter of the transform buffer, and while the first
+    // wavefront sums the sub-frames the second one sorts every sub-frame's eight values for the quartiles
+    // (transient_detector.cpp:113-133) - what used to travel to k_gain_tail as 1 KB per item is 256 bytes of results now
+    float* s_micro = reinterpret_cast<float*>(L.f);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = tid + 128 * q;
@@ -567,8 +569,9 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
             acc += sq.y;
         }
         acc /= 8;
-        micro[c] = sqrtf(acc);
+        s_micro[c] = sqrtf(acc);
     }
+    __syncthreads();
     if (tid < 32) {
         const cpx* src = L.f + 528 + 33 * lane;
         f2 x[32];
@@ -584,11 +587,25 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         }
         acc /= 64;
         rec->gain[lane] = sqrtf(acc);
+    } else if (wave == 1 && lane < 32) {
+        const float4 ma = *reinterpret_cast<const float4*>(s_micro + 8 * lane), mb = *reinterpret_cast<const float4*>(s_micro + 8 * lane + 4);
+        float m[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {   // insertion sort, ascending (static indices)
+#pragma unroll
+            for (int k = i; k > 0; --k) {
+                const float lo = fminf(m[k - 1], m[k]), hi = fmaxf(m[k - 1], m[k]);
+                m[k - 1] = lo;
+                m[k] = hi;
+            }
+        }
+        rec->lo[lane] = m[2];
+        rec->hi[lane] = m[6];
     }
 }
 
-// The rest of AnalyzeGain and CalcCurve's target for one item: quartiles of the 8 micro-chunk RMS values of every
-// sub-frame (transient_detector.cpp:113-133), the plateau target (:178-238, 284-297), the mean gain. 32 lanes per item,
+// CalcCurve's target for one item: the plateau target (transient_detector.cpp:178-238, 284-297), the mean gain (the quartiles
+// of the micro-chunk values are k_gain_analysis' since round 3: the 256 values no longer cross HBM). 32 lanes per item,
 // eight items per workgroup; items below the 5 % gate have no data and are skipped like k_gain_analysis skipped them.
 __global__ __launch_bounds__(256) void k_gain_tail(GainParams p, int n_items)
 {
@@ -608,33 +625,13 @@ __global__ __launch_bounds__(256) void k_gain_tail(GainParams p, int n_items)
     // fetched and dropped - two dependent global-memory latencies would cost this short kernel more)
     const float hfr = rec->hfr;
     const float g_j = rec->gain[j];
-    const float4 ma = *reinterpret_cast<const float4*>(p.micro + (size_t)item * 256 + j * 8);
-    const float4 mb = *reinterpret_cast<const float4*>(p.micro + (size_t)item * 256 + j * 8 + 4);
     const bool active = valid && !(hfr < 0.05f);
     if (__ballot(active) == 0ull) return;
     float* s_gain = s_g[grp];
     float* s_filt = s_f[grp];
     float* s_minv = s_m[grp];
-    float in_j = 0.0f;
-    float m[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (active) {
-        in_j = g_j;
-        m[0] = ma.x; m[1] = ma.y; m[2] = ma.z; m[3] = ma.w; m[4] = mb.x; m[5] = mb.y; m[6] = mb.z; m[7] = mb.w;
-    }
+    const float in_j = active ? g_j : 0.0f;
     s_gain[j] = in_j;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {   // insertion sort, ascending (static indices)
-#pragma unroll
-        for (int k = i; k > 0; --k) {
-            const float lo = fminf(m[k - 1], m[k]), hi = fmaxf(m[k - 1], m[k]);
-            m[k - 1] = lo;
-            m[k] = hi;
-        }
-    }
-    if (active) {
-        rec->lo[j] = m[2];
-        rec->hi[j] = m[6];
-    }
     wave_sync();
     // plateau target of CalcCurve (transient_detector.cpp:178-238, 284-297) with ballots
     float filt_j;

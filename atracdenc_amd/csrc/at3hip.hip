@@ -50,7 +50,6 @@ struct at3hip_ctx {
     hipStream_t mid_stream = nullptr;
     float* d_sub_b[2] = {nullptr, nullptr};      // subbands, by call parity (the heavy stage runs one call ahead)
     GainRec* d_rec_b[2] = {nullptr, nullptr};
-    float* d_micro_b[2] = {nullptr, nullptr};    // micro-chunk RMS values, k_gain_analysis (heavy) -> k_gain_tail (light)
     hipEvent_t ev_mid_done[2] = {};              // light stage finished with the parity's subbands and gain records
     bool mid_done_valid[2] = {false, false};
     // The back half of call N only consumes what the front half of call N produced (spectra, curves, energy scales),
@@ -361,8 +360,6 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
         c->d_sub_b[0] = c->d_sub;
         if ((rc = dev_alloc(c, &c->d_rec_b[1], S * B * 6)) != AT3HIP_OK) return bail(rc);
         if ((rc = dev_alloc(c, &c->d_sub_b[1], S * 8 * (B + 2) * 256)) != AT3HIP_OK) return bail(rc);
-        for (int q = 0; q < 2; ++q)
-            if ((rc = dev_alloc(c, &c->d_micro_b[q], S * B * 6 * 256)) != AT3HIP_OK) return bail(rc);
         if ((rc = dev_alloc(c, &c->d_bins, S * B * 6 * kGainBins)) != AT3HIP_OK) return bail(rc);
         for (int q = 0; q < 2; ++q)
             if ((rc = dev_alloc(c, &c->d_ges[q], S * B * 8)) != AT3HIP_OK) return bail(rc);
@@ -406,8 +403,6 @@ void at3hip_destroy(at3hip_ctx* c)
     if (c->back_stream) (void)hipStreamSynchronize(c->back_stream);
     if (c->d_rec_b[1]) (void)hipFree(c->d_rec_b[1]);
     if (c->d_sub_b[1]) (void)hipFree(c->d_sub_b[1]);
-    for (int q = 0; q < 2; ++q)
-        if (c->d_micro_b[q]) (void)hipFree(c->d_micro_b[q]);
     void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
                     c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
                     c->d_out,       c->d_quant,     c->d_stage,    c->d_sub_tail, c->d_bins};
@@ -661,7 +656,6 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.sub = d_sub;
             gp.rec = d_rec;
             gp.bins = c->d_bins;
-            gp.micro = c->d_micro_b[par];
             gp.state = c->d_state;
             gp.curves = d_curves;
             gp.n_blocks = n_blocks;
