@@ -974,6 +974,23 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
     if (prevTarget > 1e-6f) interRatio = fmaxf(prevTarget, target) / fmaxf(fminf(prevTarget, target), 1e-9f);
     const bool sticky = intraRatio <= 7.0f && interRatio <= 10.0f;
     const int raw = relation_to_idx(filt_j / target);
+    // Every sub-frame of both items at the unit level: the sticky chain below can only copy a left neighbour's level or keep
+    // the raw one, so every level stays 4, no transition exists and the items end as "no_curve" (the exit further down) -
+    // the rule on stationary material, taken here before the quartile ratios, the chain and the boundary scores are formed.
+    if (__ballot(active && j <= 30 && raw != 4) == 0ull) {
+        if (valid && j == 0) {
+            Curve out;
+            out.pad = 0;
+            out.n = 0;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                out.level[i] = 0;
+                out.loc[i] = 0;
+            }
+            *dst = out;
+        }
+        return;
+    }
     int minIdx = 0, maxIdx = 0;
     {
         float ratioLo = lo_j / target, ratioHi = hi_j / target;
