@@ -558,7 +558,11 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     float* s_micro = reinterpret_cast<float*>(L.f);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int c = tid + 128 * q;
+        // which chunk a work-item sums is free: chunk c starts 8 c + 2 (c / 8) dwords into the buffer, so the sixteen lanes an
+        // 8-byte LDS read serves together take chunks {0..3} + 8 {0..3} (+ 4 for the next sixteen) - sixteen different bank
+        // pairs - instead of sixteen neighbours, which share four (the reads were 4-way conflicts: a fifth of the kernel's LDS cycles)
+        const int n = tid + 128 * q;
+        const int c = (n & 3) | ((n & 0xc) << 1) | ((n & 0x10) >> 2) | (n & 0xe0);
         const cpx* src = L.f + 528 + 4 * c + (c >> 3);
         float acc = 0.0f;
 #pragma unroll
