@@ -570,11 +570,9 @@ __global__ __launch_bounds__(256) void k_mdct_sub(MdctSubParams p, const Tables*
     __shared__ float s_gi[32];
     static_assert(kRowScratch4 * 4 >= 256, "a row's 256 divisors share its exchange scratch");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid < 32) s_gi[tid] = T->gain_interp[tid < 31 ? tid : 30];
-    mdct_tab_build(s_tab, T, tid, 256);
-    __syncthreads();   // the only workgroup-level rendezvous: the shared tables
-    const int W = blockIdx.x * 4 + wave;
-    if (W >= p.n_waves) return;
+    // (a wavefront beyond the batch stays for the rendezvous below with the last run's indices and leaves after it)
+    const bool live = blockIdx.x * 4 + wave < p.n_waves;
+    const int W = live ? blockIdx.x * 4 + wave : p.n_waves - 1;
     const int n_out = p.n_blocks - p.f0;
     const int nchunks = p.frame_runs;   // runs per (stream, channel): the n_out frames are dealt out as evenly as possible
     const int chunk = W % nchunks;
@@ -604,6 +602,19 @@ __global__ __launch_bounds__(256) void k_mdct_sub(MdctSubParams p, const Tables*
     // The subbands of the next block are requested before the current one is transformed: a wavefront waits for HBM once.
     RowRaw raw_a, raw_b;
     rows_request(sb_own, sb_l, sb_r, JS, fa - 1, b, raw_a, raw_b);
+    // the frame's curve (16 bytes per row, lane 0 of the row) is requested one frame ahead like the subbands: fetched where it
+    // is used, every frame of the run waited a global-memory latency for it
+    auto curve_request = [&](int f) {
+        return *reinterpret_cast<const uint4*>((f < 0) ? &p.state[(size_t)s * 8 + ch * 4 + band].prev_curve
+                                                         : &p.curves[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + band]);
+    };
+    uint4 c4_next = {0u, 0u, 0u, 0u};
+    if (p.curves && L == 0) c4_next = curve_request(fa - 1);
+    // the run's first subbands and curve are on their way while the workgroup builds its tables
+    if (tid < 32) s_gi[tid] = T->gain_interp[tid < 31 ? tid : 30];
+    mdct_tab_build(s_tab, T, tid, 256);
+    __syncthreads();   // the only workgroup-level rendezvous: the shared tables
+    if (!live) return;
     for (int f = fa - 1; f < fb; ++f) {
         const bool emit = f >= fa;
         float X[4][4];
@@ -623,9 +634,8 @@ __global__ __launch_bounds__(256) void k_mdct_sub(MdctSubParams p, const Tables*
         if (p.curves) {
             // the frame's curve: 16 bytes per row, kept in LDS so that its point list can be walked with run-time indices
             if (L == 0) {
-                const uint4 c4 = *reinterpret_cast<const uint4*>((f < 0) ? &p.state[(size_t)s * 8 + ch * 4 + band].prev_curve
-                                                                         : &p.curves[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + band]);
-                *reinterpret_cast<uint4*>(&cv) = c4;
+                *reinterpret_cast<uint4*>(&cv) = c4_next;
+                if (f + 1 < fb) c4_next = curve_request(f + 1);
             }
             wave_sync();
             const bool has_curve = cv.n > 0;
