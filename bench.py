@@ -589,7 +589,7 @@ def main():
             try:
                 import glob
                 import re
-                prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isolated_rocprof_summary.txt")))[-1]
+                prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_isolated_rocprof_summary.txt")))[-1]
                 us = {}
                 for ln in open(prof):
                     m = re.match(r"^(k_qmf_sub8|k_mdct_sub<false>)\s+\d+\s+[\d.]+\s+([\d.]+)\s", ln)
