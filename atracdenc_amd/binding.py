@@ -13,7 +13,7 @@ AT3HIP_PCM_ON_DEVICE = 1
 AT3HIP_OUT_ON_DEVICE = 2
 AT3HIP_ASYNC = 4
 OPT_RUNS, OPT_FLATNESS_LITERAL, OPT_QUANT_TAP = 1, 2, 3
-TAP_SPECTRA, TAP_CURVES, TAP_ENERGY_SCALE, TAP_PSY, TAP_LOUDNESS, TAP_QUANT = 1, 2, 3, 4, 5, 6
+TAP_SPECTRA, TAP_CURVES, TAP_ENERGY_SCALE, TAP_PSY, TAP_LOUDNESS, TAP_QUANT, TAP_CLOCK = 1, 2, 3, 4, 5, 6, 7
 LP2 = 132300
 LP4 = 66150
 
@@ -61,8 +61,8 @@ class At1Timings(ctypes.Structure):
 
 def build_library(verbose=False):
     """Compile libat3hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-o", LIB_PATH, os.path.join(CSRC, "at3hip.hip"), os.path.join(CSRC, "at1hip.hip"), os.path.join(CSRC, "at3phip.hip"),
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fvisibility=hidden", "-fPIC", "-shared",
+           "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", LIB_PATH, os.path.join(CSRC, "at3hip.hip"), os.path.join(CSRC, "at1hip.hip"), os.path.join(CSRC, "at3phip.hip"),
            os.path.join(CSRC, "at3_tables.cpp")]
     if verbose:
         print(" ".join(cmd))
@@ -212,6 +212,12 @@ class At3Hip:
         out = np.zeros(shape, dtype=dtype)
         self._check(self.lib.at3hip_read_tap(self.ctx, int(kind), _vp(out), out.nbytes), "at3hip_read_tap")
         return out
+
+    def sclk_mhz(self):
+        """Shader clock observed under the last call's rate loop (AT3HIP_TAP_CLOCK: s_memtime cycles against the 100 MHz
+        s_memrealtime over the life of the allocation kernel's workgroup 0), or None before the first frames."""
+        c = self.read_tap(TAP_CLOCK, np.uint64, (2,))
+        return float(c[0]) / float(c[1]) * 100.0 if c[1] else None
 
     def sync(self):
         self._check(self.lib.at3hip_sync(self.ctx), "at3hip_sync")

@@ -692,6 +692,13 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     const int lane = threadIdx.x;
     const int n_out = p.n_blocks - p.f0;
     const size_t cf = blockIdx.x;
+    // AT3HIP_TAP_CLOCK: workgroup 0 reads the shader-cycle counter and the 100 MHz reference on entry and on exit
+    const bool clk_probe = p.clk != nullptr && blockIdx.x == 0;
+    unsigned long long clk_t0 = 0ull, clk_r0 = 0ull;
+    if (clk_probe) {
+        clk_t0 = __builtin_amdgcn_s_memtime();
+        clk_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     const int ch = (int)(cf & 1);
     const int fo = (int)((cf >> 1) % n_out);
     const int s = (int)((cf >> 1) / n_out);
@@ -1326,6 +1333,10 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             const uint8_t byte = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
             frame[dst0 + j] = byte;
         }
+    }
+    if (clk_probe && lane == 0) {
+        p.clk[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+        p.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
     }
 }
 

@@ -34,6 +34,8 @@ struct BackParams {
     struct QuantRec* quant;  // [S][n_out][2] the unit cache's final content, for the QUANT tap (zero for units never asked for); null unless AT3HIP_OPT_QUANT_TAP
     int flat_literal;        // AT3HIP_OPT_FLATNESS_LITERAL: every flatness measure by the literal per-line form (test aid; same results)
     int debug_stop;          // profiling aid (env AT3HIP_DEBUG_STOP, -DAT3HIP_DEBUG_KNOBS builds): stage exits of k_alloc_pack
+    unsigned long long* clk; // [2] AT3HIP_TAP_CLOCK: shader cycles (s_memtime) and 100 MHz reference ticks (s_memrealtime) that
+                             // workgroup 0 of k_alloc_pack lived - their ratio is the shader clock under the rate loop's load
 };
 
 struct QuantRec {            // per (stream, frame, channel)

@@ -78,6 +78,7 @@ struct at3hip_ctx {
     int runs_override = 0;   // AT3HIP_OPT_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
     int flat_literal = 0;    // AT3HIP_OPT_FLATNESS_LITERAL
     int n_cus = 256;
+    size_t lds_per_cu = 0;     // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor; the whole-round LDS padding below is tuned for 160 KB
     int wgs_per_cu = 3;        // resident workgroups per CU of the QMF kernel this context uses (k_qmf_sub8 or the fused one)
     int wgs_per_cu_mdct = 3;   // the same of k_mdct_sub
     int alloc_lds_pad = 0;     // dynamic LDS added to k_alloc_pack's launch: sets how many of its workgroups share a CU
@@ -100,6 +101,7 @@ struct at3hip_ctx {
     float* d_loud_state = nullptr;
     uint8_t* d_out = nullptr;
     QuantRec* d_quant = nullptr;     // allocated by AT3HIP_OPT_QUANT_TAP
+    unsigned long long* d_clk = nullptr;   // AT3HIP_TAP_CLOCK
     at3hip_timings tm = {};
     // grow-only device staging of the stage-level entry points (at3hip_mdct, at3hip_gain_energy_scale) for host buffers
     void* d_stage = nullptr;
@@ -215,6 +217,8 @@ struct LdsChoice {
 };
 size_t whole_rounds_pad(const at3hip_ctx* c, long long n_wgs, const LdsChoice* choice, int n_choices, bool ties_to_fewer)
 {
+    // the per-CU counts of the choices hold for a 160 KB LDS (gfx950): on any other geometry the launch is left alone
+    if (c->lds_per_cu != 160u * 1024u) return 0;
     const long long cus = c->n_cus > 0 ? c->n_cus : 256;
     if (n_wgs >= 32 * choice[0].per_cu * cus) return 0;
     double best_waste = 1e30;
@@ -373,9 +377,13 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_loud, S * B)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_loud_state, S)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_out, S * B * (size_t)c->frame_sz)) != AT3HIP_OK) return bail(rc);
+    if ((rc = dev_alloc(c, &c->d_clk, 2)) != AT3HIP_OK) return bail(rc);
+    if (hipMemsetAsync(c->d_clk, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(AT3HIP_EDEVICE);   // (reset_state below waits for the stream)
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
     hipDeviceProp_t prop;
-    c->n_cus = (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    const bool have_prop = hipGetDeviceProperties(&prop, c->device) == hipSuccess;
+    c->n_cus = (have_prop && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    c->lds_per_cu = have_prop ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 0;
     {
         int nb = 0;
         const bool gain = !c->cfg.no_gain_control;
@@ -405,7 +413,7 @@ void at3hip_destroy(at3hip_ctx* c)
     if (c->d_sub_b[1]) (void)hipFree(c->d_sub_b[1]);
     void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
                     c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
-                    c->d_out,       c->d_quant,     c->d_stage,    c->d_sub_tail, c->d_bins};
+                    c->d_out,       c->d_quant,     c->d_stage,    c->d_sub_tail, c->d_bins,     c->d_clk};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& row : c->ev)
@@ -732,6 +740,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
         bp.flat_literal = c->flat_literal;
         bp.debug_stop = c->dbg_stop;
         bp.quant = c->d_quant;
+        bp.clk = c->d_clk;
         hipLaunchKernelGGL(k_loud_sum, dim3((unsigned)((S * n_out * 2 + kLoudCf - 1) / kLoudCf)), dim3(256), 0, bk, bp, c->d_tables, S * n_out * 2);
         hipLaunchKernelGGL(k_psy, dim3((S * n_out * 2 + kPsyCf - 1) / kPsyCf), dim3(256), 0, bk, bp, c->d_tables, S * n_out * 2);
         HIPCHK(c, hipEventRecord(ev[6], bk));
@@ -794,6 +803,7 @@ int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
         case AT3HIP_TAP_PSY: src = c->d_psy; cap = S * B * 2 * sizeof(PsyRec); break;
         case AT3HIP_TAP_LOUDNESS: src = c->d_loud; cap = S * B * sizeof(float); break;
         case AT3HIP_TAP_QUANT: src = c->d_quant; cap = c->d_quant ? S * B * 2 * sizeof(QuantRec) : 0; break;
+        case AT3HIP_TAP_CLOCK: src = c->d_clk; cap = 2 * sizeof(unsigned long long); break;
         default: return fail(c, AT3HIP_EINVAL, "unknown tap");
     }
     if (!src || bytes > cap) return fail(c, AT3HIP_EINVAL, "tap not available or request too large");

@@ -314,7 +314,10 @@ public:
     int EncodePipelined(const float* pcm, int nBlocksTotal, int blocksPerCall, std::vector<uint8_t>& frames)
     {
         const size_t blockFloats = (size_t)1024 * Channels;
-        const int nfTotal = nBlocksTotal - 1;   // (fresh streams: the first block is the look-ahead)
+        // start of stream: the first block is the look-ahead (atrac3denc.cpp:715-718), so nBlocksTotal blocks give
+        // nBlocksTotal - 1 frames per stream - the node is reset here so that this holds whatever was encoded before
+        Reset();
+        const int nfTotal = nBlocksTotal - 1;
         frames.assign((size_t)NStreams * (nfTotal > 0 ? nfTotal : 0) * FrameSz, 0);
         std::vector<std::string> err(Parts.size());
         std::vector<long long> got(Parts.size(), 0);
@@ -334,6 +337,7 @@ public:
                             return nb;
                         },
                         [&](const uint8_t* fr, int nf) {
+                            if (written + nf > nfTotal) throw std::runtime_error("EncodePipelined: more frames than the output holds");
                             for (int s = 0; s < Count[i]; ++s)
                                 memcpy(frames.data() + ((size_t)(First[i] + s) * nfTotal + written) * FrameSz, fr + (size_t)s * nf * FrameSz,
                                        (size_t)nf * FrameSz);

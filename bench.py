@@ -283,11 +283,11 @@ def roofline_of(k1_avg_ms, frames_per_launch):
     return round(achieved, 2), round(achieved / HBM_PEAK_GBS, 5)
 
 
-def side_workload(name, S, F, bitrate, kind, steps, warmup):
+def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
     """One of SURVEY 8(d)'s other workloads on device 0, after the headline: whole-pipeline rate + K1 launch time."""
     out = {"workload": name}
     try:
-        job = DeviceJob(0, S, F, bitrate, False, kind, seed=11)
+        job = DeviceJob(0, S, F, bitrate, no_gain, kind, seed=11)
         job.warmup(warmup)
         dt = timed_region([job], steps, None)
         iso = job.isolated_k1()
@@ -299,6 +299,8 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup):
                     "frames_per_step": S * F, "frame_bytes": job.fsz, "input": kind,
                     "k1_avg_launch_ms": round(k1, 5), "k1_GBps": ach, "k1_frac": frac,
                     "k1_isolated_ms": round(iso, 5), "k1_isolated_GBps": ach_i, "k1_isolated_frac": frac_i,
+                    "k1_kernels": "k_qmf_mdct8 (fused QMF + MDCT, one launch)" if getattr(job, "k1_launches", 2) == 1 else "k_qmf_sub8 + k_mdct_sub (two launches)",
+                    "gain_control": not no_gain,
                     "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(stage.items())}})
         job.close()
         del job
@@ -509,8 +511,14 @@ def main():
             dt = timed_region(jobs, region_steps, dist)
             dt = at3dist.max_over_ranks(dt, dist, device="cpu")
             region_ms.append(dt / region_steps * 1e3)
-    steps_done = args.warmup + args.steps + (len(region_ms) - 1) * region_steps
+    # every step device 0's job has run since its LOOK_AHEAD call - warm-up, the one_gpu_same_workload regions of a
+    # one-process multi-GPU run, the timed regions - is what the replay has to repeat to land on the same batch parity
+    steps_done = j0.calls
     checksum = j0.checksum()
+    try:
+        sclk_mhz = j0.enc.sclk_mhz()
+    except Exception:   # noqa: BLE001 - diagnostic only
+        sclk_mhz = None
     k1_ms, stage_ms = j0.k1_stats(min(region_steps, 28), 0)      # the last region's launches
     iso_ms = j0.isolated_k1()                       # 3 synchronous steps after the timed regions
     parity = None
@@ -609,6 +617,7 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(med_ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_is": "median of the timed regions (SURVEY 8(d)); the contract's exactly --steps region alone is timing.value_contract_region",
             "x_realtime": round(value * 1024 / 44100.0, 1),
             "config": {"workload": f"ATRAC3 {cfgname} stereo, {S} streams x {F} frames = {S * F} frames per GPU per step "
                                    f"({'BASELINE configs[1]' if (S, F) == (64, 64) else 'per-GPU shard of BASELINE configs[2]' if (S, F) == (1024, 128) else 'custom'}), "
@@ -634,6 +643,9 @@ def main():
                                  "three streams and share the GPU with the neighbouring steps' gain analysis and rate loop - on purpose: "
                                  "that overlap is what shortens the step - so each launch takes longer than it does alone; `isolated` is "
                                  "the same launches with the GPU to themselves",
+                         "sclk_mhz_observed": None if sclk_mhz is None else round(sclk_mhz, 1),
+                         "sclk_note": "shader clock under the rate loop of the last timed step: s_memtime cycles / s_memrealtime (100 MHz) ticks over the "
+                                      "life of k_alloc_pack's workgroup 0 (AT3HIP_TAP_CLOCK)",
                          "valu_floor_ms": None if valu_floor_ms is None else round(valu_floor_ms, 5),
                          "valu_frac": None if valu_floor_ms is None else round(valu_floor_ms / iso_ms, 4),
                          "valu_floor_note": valu_note + "; valu_frac = valu_floor_ms / isolated.avg_launch_ms",
@@ -674,6 +686,8 @@ def main():
                     side_workload("configs[1] shape, 'tones' input (tonal extraction busy)", 64, 64, LP2, "tones", 30, 3),
                     side_workload("configs[3]: LP4 66 kbps joint stereo, configs[1] shape, 'noise'", 64, 64, LP4, "noise", 30, 3),
                     side_workload("shard_1024x128: per-GPU shard of configs[2] (1024 streams x 128 frames) on one GPU, 'noise'", 1024, 128, LP2, "noise", 10, 2),
+                    side_workload("configs[1] shape, 'noise', --nogaincontrol: the FUSED QMF + MDCT kernel k_qmf_mdct8 (north_star's kernel)", 64, 64, LP2, "noise", 30, 3, no_gain=True),
+                    side_workload("shard_1024x128, 'noise', --nogaincontrol: k_qmf_mdct8 at the per-GPU shard", 1024, 128, LP2, "noise", 10, 2, no_gain=True),
                 ]
                 line["host_pipeline"] = host_pipeline_workload(64, 64)
                 line["widened_rows"] = widened_rows(64)

@@ -17,6 +17,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: these declarations are its whole exported surface */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define AT1HIP_FRAME_SIZE 212   /* TAtrac1Data::SoundUnitSize, atrac/at1/atrac1.h:110 */
 #define AT1HIP_BLOCK 512        /* TAtrac1Data::NumSamples, atrac/at1/atrac1.h:121 */
@@ -76,6 +80,9 @@ int at1hip_read_tap(at1hip_ctx* ctx, int32_t kind, void* dst, size_t bytes);
 #define AT1HIP_TABLES_BYTES 6904
 int at1hip_host_tables(void* dst, size_t bytes);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: these declarations are its whole exported surface */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define AT3HIP_OK 0
 #define AT3HIP_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -155,6 +159,10 @@ int at3hip_sync(at3hip_ctx* ctx);
 #define AT3HIP_TAP_PSY 4
 #define AT3HIP_TAP_LOUDNESS 5
 #define AT3HIP_TAP_QUANT 6
+/* AT3HIP_TAP_CLOCK (diagnostic, 2 x uint64): shader cycles and 100 MHz reference ticks that workgroup 0 of the last call's
+ * allocation kernel lived; cycles / ticks x 100 = the shader clock in MHz under the rate loop's load (bench.py reports it
+ * as roofline.sclk_mhz_observed). */
+#define AT3HIP_TAP_CLOCK 7
 int at3hip_read_tap(at3hip_ctx* ctx, int32_t kind, void* dst, size_t bytes);
 
 /* Timings of the at3hip_encode call `ago` calls back (0 = the most recent one, at most 31); waits for queued work.
@@ -203,6 +211,9 @@ int at3hip_host_tables(void* dst, size_t bytes);
 /* Library/ABI version: (major << 16) | minor. */
 uint32_t at3hip_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

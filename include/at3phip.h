@@ -16,6 +16,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: these declarations are its whole exported surface */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define AT3PHIP_FRAME 2048            /* TAt3PEnc::NumSamples, samples per channel and frame */
 #define AT3PHIP_RESIDUAL_SCALE 16u    /* at3phip_mdct / at3phip_pqf_mdct: divide the subband samples by 32768 / 1.122018 first,
@@ -90,6 +94,9 @@ int at3phip_host_tables(void* dst, size_t bytes);
 #define AT3PHIP_WRITE_TABLES_BYTES 41384
 int at3phip_host_write_tables(void* dst, size_t bytes);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """Built with -fvisibility=hidden and csrc/exports.map: `nm -D` shows the three C ABIs of include/ and nothing else
+    (no kernel stubs, no table builders, no C++ symbols)."""
+    import subprocess
+    import atracdenc_amd
+    if not os.path.exists(atracdenc_amd.LIB_PATH):
+        atracdenc_amd.build_library()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", atracdenc_amd.LIB_PATH], text=True)
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    b = atracdenc_amd.binding
+    assert names == set(b.SYMBOLS) | set(b.AT1_SYMBOLS) | set(b.AT3P_SYMBOLS), sorted(names ^ (set(b.SYMBOLS) | set(b.AT1_SYMBOLS) | set(b.AT3P_SYMBOLS)))
+
+
 def test_no_cpu_fallback_when_library_missing(tmp_path):
     import atracdenc_amd
     with pytest.raises(atracdenc_amd.At3HipError):

@@ -376,7 +376,7 @@ def test_full_batch_config_properties(hip, oracle):
 
 
 @pytest.mark.parametrize("br", [LP2, LP4])
-def test_config3_shard_properties(hip, oracle, br):
+def test_configs2_shard_properties(hip, oracle, br):
     """The per-GPU shard of BASELINE configs[2]/[3] (1M frames on 8 GPUs): 1024 streams x 128 frames, LP2 and LP4.
     Long workgroup runs (32 frames), many grid rounds; checked through size-independent properties and spot streams."""
     S, nb = 1024, 129

@@ -99,8 +99,8 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
-struct hipDeviceProp_t { int multiProcessorCount; };
-static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 4; return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; size_t maxSharedMemoryPerMultiProcessor; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 4; p->maxSharedMemoryPerMultiProcessor = 160u * 1024u; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 
 // ---- wave-level (64 lanes) cross-lane primitives: implemented with a wave-wide rendezvous ----
@@ -120,6 +120,8 @@ void emu_wave_barrier();
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0ull; }
+static inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0ull; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 

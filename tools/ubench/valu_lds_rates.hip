@@ -1,5 +1,6 @@
 // Micro-benchmark (development aid, not part of the product): issue cost of the instructions the ATRAC3 kernels are
-// built from, in shader cycles per wave64 instruction per SIMD, at 1, 2 and 4 resident waves per SIMD.
+// built from, in shader cycles per wave64 instruction per SIMD, at 1, 2, 4, 6 and 8 resident waves per SIMD,
+// with the shader clock observed under each load (s_memtime cycles against the 100 MHz s_memrealtime).
 //   hipcc --offload-arch=gfx950 -O3 -o valu_lds_rates tools/ubench/valu_lds_rates.hip && ./valu_lds_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,9 +15,11 @@ constexpr int kUnroll = 16;
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, float seed)
+__global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, float seed, int iters)
 {
-    __shared__ __attribute__((aligned(16))) float s_buf[16384];
+    // 4 KB per workgroup: eight workgroups (eight waves per SIMD) fit a CU. (Round 2's version held 64 KB, so its "4 waves per
+    // SIMD" rows really ran as two rounds of two - the rates below 3 waves per SIMD are issue-limited per wave, not per SIMD.)
+    __shared__ __attribute__((aligned(16))) float s_buf[1024];
     const int tid = threadIdx.x;
     float a[16];
     f2 p[16];
@@ -26,7 +29,7 @@ __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, float 
         p[i].x = a[i];
         p[i].y = a[i] * 0.5f;
     }
-    for (int i = tid; i < 16384; i += 256) s_buf[i] = seed;
+    for (int i = tid; i < 1024; i += 256) s_buf[i] = seed;
     f4 acc4 = {0.f, 0.f, 0.f, 0.f};
     f2 acc2 = {0.f, 0.f};
     float acc1 = 0.f;
@@ -35,8 +38,9 @@ __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, float 
     w2.x = w;
     w2.y = w * 1.0001f;
     __syncthreads();
-    const long long t0 = clock64();
-    for (int it = 0; it < kIters; ++it) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    const long long r0 = (long long)__builtin_amdgcn_s_memrealtime();   // constant 100 MHz reference
+    for (int it = 0; it < iters; ++it) {
         if (KIND == 0) {
 #define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
             REP16(X)
@@ -138,37 +142,47 @@ __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, float 
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const long long t1 = clock64();
+    const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+    const long long r1 = (long long)__builtin_amdgcn_s_memrealtime();
     float s = acc4.x + acc2.x + acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += a[i] + p[i].x + p[i].y;
     out[blockIdx.x * 256 + tid] = s;
-    if ((tid & 63) == 0) cyc[blockIdx.x * 4 + (tid >> 6)] = t1 - t0;
+    if ((tid & 63) == 0) {
+        cyc[(blockIdx.x * 4 + (tid >> 6)) * 2] = t1 - t0;
+        cyc[(blockIdx.x * 4 + (tid >> 6)) * 2 + 1] = r1 - r0;
+    }
 }
 
 template <int KIND>
-void run(const char* name, int per_iter_instr, int wgs_per_cu, float* d_out, long long* d_cyc)
+void run(const char* name, int per_iter_instr, int wgs_per_cu, float* d_out, long long* d_cyc, int iters = kIters)
 {
     const int grid = 256 * wgs_per_cu;   // 4 waves per workgroup = one per SIMD
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), 0, 0, d_out, d_cyc, 1.0f);
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), 0, 0, d_out, d_cyc, 1.0f, iters);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), 0, 0, d_out, d_cyc, 1.0f);
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), 0, 0, d_out, d_cyc, 1.0f, iters);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<long long> c(grid * 4);
+    std::vector<long long> c(grid * 4 * 2);
     hipMemcpy(c.data(), d_cyc, c.size() * sizeof(long long), hipMemcpyDeviceToHost);
-    double avg = 0;
-    for (auto v : c) avg += (double)v;
-    avg /= c.size();
-    const double n = (double)kIters * per_iter_instr;
-    // clock64 = s_memtime at a fixed 100 MHz-class reference on some parts: report both the tick-based and the wall-based figure
-    printf("%-34s waves/SIMD=%d  ticks/instr(wave)=%7.3f  wall: %8.3f us  => %6.3f ns/instr/wave, %6.3f ns per instr-slot/SIMD\n", name,
-           wgs_per_cu, avg / n, ms * 1e3, ms * 1e6 / n, ms * 1e6 / n / wgs_per_cu);
+    double avg = 0, avg_rt = 0;
+    for (size_t i = 0; i < c.size(); i += 2) {
+        avg += (double)c[i];
+        avg_rt += (double)c[i + 1];
+    }
+    avg /= c.size() / 2;
+    avg_rt /= c.size() / 2;
+    const double n = (double)iters * per_iter_instr;
+    // s_memtime ticks = shader cycles, s_memrealtime = 100 MHz: their ratio is the shader clock UNDER THIS LOAD; cycles per
+    // wave-instruction per SIMD = the wave's cycles per instruction / the waves that share the SIMD
+    const double mhz = avg / avg_rt * 100.0;
+    printf("%-30s waves/SIMD=%d  sclk=%6.0f MHz  cyc/instr(wave)=%7.3f  cyc/instr/SIMD=%6.3f  wall %9.3f us => %6.3f ns per instr-slot/SIMD\n", name,
+           wgs_per_cu, mhz, avg / n, avg / n / wgs_per_cu, ms * 1e3, ms * 1e6 / n / wgs_per_cu);
 }
 
 int main()
@@ -176,8 +190,8 @@ int main()
     float* d_out;
     long long* d_cyc;
     hipMalloc(&d_out, 256 * 8 * 256 * sizeof(float));
-    hipMalloc(&d_cyc, 256 * 8 * 4 * sizeof(long long));
-    for (int w : {1, 2, 4}) {
+    hipMalloc(&d_cyc, 256 * 8 * 4 * 2 * sizeof(long long));
+    for (int w : {1, 2, 4, 6, 8}) {
         run<0>("v_mul_f32", 16, w, d_out, d_cyc);
         run<1>("v_add_f32", 16, w, d_out, d_cyc);
         run<2>("v_fma_f32", 16, w, d_out, d_cyc);
@@ -196,6 +210,13 @@ int main()
         run<14>("ds_bpermute_b32", 16, w, d_out, d_cyc);
         run<15>("pk_mul(sgpr)+pk_add pair", 32, w, d_out, d_cyc);
         run<16>("mul(sgpr)+add pair (plain)", 32, w, d_out, d_cyc);
+    }
+    // sustained load (tens of milliseconds per launch): the clock the part settles at under pure vector work
+    for (int w : {4, 8}) {
+        run<0>("SUSTAINED v_mul_f32", 16, w, d_out, d_cyc, kIters * 64);
+        run<3>("SUSTAINED v_pk_mul_f32", 16, w, d_out, d_cyc, kIters * 64);
+        run<15>("SUSTAINED pk_mul+pk_add pair", 32, w, d_out, d_cyc, kIters * 64);
+        run<10>("SUSTAINED ds_read_b64", 16, w, d_out, d_cyc, kIters * 16);
     }
     return 0;
 }
