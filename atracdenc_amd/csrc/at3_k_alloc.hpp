@@ -21,6 +21,26 @@
 
 namespace at3 {
 
+// Profiling builds (-DAT3HIP_DEBUG_KNOBS): every wavefront of k_alloc_pack stamps its phase boundaries with the shader-cycle
+// counter and adds the cycles it spent per phase to AT3HIP_TAP_CLOCK's slots 2.. (tools/alloc_phase_cycles.sh) - where a
+// wavefront's LIFE goes, measured on the real path (the stage exits of debug_stop leave the unit cache empty, so what follows
+// them is not the real bisection).
+#ifdef AT3HIP_DEBUG_KNOBS
+struct PhaseClock {
+    unsigned long long last;
+    uint32_t acc[12];
+};
+#define AT3_PH_END(pc, k)                                              \
+    do {                                                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+        (pc).acc[k] += (uint32_t)(t_ - (pc).last);                     \
+        (pc).last = t_;                                                \
+    } while (0)
+#else
+struct PhaseClock {};
+#define AT3_PH_END(pc, k) ((void)0)
+#endif
+
 constexpr int kTermLine0 = 96;   // BFUs 0..9 (lines 0..95) are quantised by small_units: no batch ever lists their lines
 constexpr int kChgWords = kEaLines / 32;   // 23: one bit per line from BFU 19 on (every such BFU covers whole words)
 struct AllocLds {
@@ -157,8 +177,9 @@ __device__ __forceinline__ uint32_t vlc_bits8(int wl, const VlcRow& row, const i
 
 // Quantise the units {(b, wl_b) : bit b of `need`}, wl_b = lane b's `bits` (QuantMantisas + CLC/VLC cost,
 // atrac3_bitstream.cpp:154-173, atrac_scale.cpp:40-130). Lane b < 32 passes BFU b's e1 in `my_e1`. Wave-uniform call.
-__device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, uint32_t need, int bits, float my_e1, int lane, float* qerr, int dbg = 0)
+__device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, uint32_t need, int bits, float my_e1, int lane, float* qerr, PhaseClock& pc, int dbg = 0)
 {
+    AT3_PH_END(pc, 4);
     // ---- (1) mantissa = lrint(value * MaxQuant[wl]) for the lines of the needed BFUs; energy-adaptive candidate codes ----
     // Four rounds of four lines per lane, line0 = 256 round + 4 lane: a wavefront's 16-byte LDS accesses are one contiguous
     // kilobyte (sixteen lines per lane, the first layout, put every fourth lane on the same banks).
@@ -197,6 +218,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
         }
     }
     wave_sync();
+    AT3_PH_END(pc, 5);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (dbg == 9) return;
 #endif
@@ -242,6 +264,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
         my_e2 = acc;
     }
     wave_sync();   // the terms' storage becomes the key list and the candidate records
+    AT3_PH_END(pc, 6);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (dbg == 10) return;
 #endif
@@ -255,6 +278,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
 #else
     const uint32_t ea_need = need & 0xfff80000u;
 #endif
+
     int my_nc = 0;   // lane 19 + ub: candidates of its unit
     if (ea_need) {
         uint32_t tie_units = 0;
@@ -370,6 +394,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             if (lane == bfu) my_nc = cnt_u;
             wave_sync();   // the key list is reused by the next unit
         }
+        AT3_PH_END(pc, 7);
         // equal keys among listed candidates: libstdc++'s std::sort order decides (rare). The order of equal elements
         // depends on the whole array the reference sorts, so the full |delta| < 0.25 list is rebuilt, sorted with the
         // restated algorithm and then filtered.
@@ -470,6 +495,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
         }
     }
     wave_sync();
+    AT3_PH_END(pc, 8);
     // ---- (4) VLC cost of the final mantissas; (5) cache entries ----
     // A unit's lines sit in 4, 8, 16 or 32 NEIGHBOURING lanes of one round (16-, 32-, 64-, 128-line BFUs from line 96 on, all
     // aligned to their own size), so its bit count is a sum over a quad, a half row, a row or two rows: DPP adds, no
@@ -519,6 +545,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
     }
     if (mine && qerr) qerr[(bits - 1) * 32 + lane] = my_e1 / my_e2;   // BFUs >= 10: nothing but the QUANT tap looks at their energy error
     wave_sync();
+    AT3_PH_END(pc, 9);
 }
 
 // The 70 units of BFUs 0..9 (8 or 16 lines each, no energy-adaptive pass below BFU 19), one lane per unit: ConsiderEnergyErr
@@ -699,6 +726,11 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         clk_t0 = __builtin_amdgcn_s_memtime();
         clk_r0 = __builtin_amdgcn_s_memrealtime();
     }
+    PhaseClock pc;
+#ifdef AT3HIP_DEBUG_KNOBS
+    pc.last = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < 12; ++k) pc.acc[k] = 0u;
+#endif
     const int ch = (int)(cf & 1);
     const int fo = (int)((cf >> 1) % n_out);
     const int s = (int)((cf >> 1) / n_out);
@@ -801,6 +833,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         }
     }
     __syncthreads();
+    AT3_PH_END(pc, 0);
     float my_e1 = 0.0f;   // lane b < 32: e1 of BFU b
     if (lane < 32) {
         const int start = bfu_start(lane), n = bfu_start(lane + 1) - start;
@@ -814,6 +847,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         my_e1 = acc;
     }
     __syncthreads();
+    AT3_PH_END(pc, 1);
     // units of the first ten BFUs at every wordlen: ConsiderEnergyErr (atrac3_bitstream.cpp:241-257) looks at their energy
     // errors whatever the allocation, and they are 96 lines in all
 #ifdef AT3HIP_DEBUG_KNOBS
@@ -821,6 +855,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #endif
     const LaneTab tab = lane_tab(lane);
     small_units(L, tab, lane, my_e1);
+    AT3_PH_END(pc, 2);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 2) return;
 #endif
@@ -932,6 +967,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     wave_sync();
     for (int k = lane; k < 7 * kChgWords; k += 64) L.chg[k] = 0u;   // (same bytes as the energy errors, dead from here on)
     wave_sync();
+    AT3_PH_END(pc, 3);
     // ---- rate loop: TConfigure / TAlloc under the bisection driver (uniform control flow) ----
     int num_bfu = p.bfu_idx_const ? p.bfu_idx_const : 32;
     if (target < 101) {
@@ -1011,7 +1047,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 } else
 #endif
                 if (need) {
-                    compute_units(L, tab, need, bits, my_e1, lane, qerr, p.debug_stop);
+                    compute_units(L, tab, need, bits, my_e1, lane, qerr, pc, p.debug_stop);
                     if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
                 }
             }
@@ -1134,6 +1170,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         if (!restart) break;
     }
     if (!bits_current) bits = (lane < num_bfu) ? alloc_bits(A, gate, tcount, gmap, final_lam) : 0;   // (mode is the last evaluation's)
+    AT3_PH_END(pc, 4);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 3) return;
 #endif
@@ -1338,6 +1375,13 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         p.clk[0] = __builtin_amdgcn_s_memtime() - clk_t0;
         p.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
     }
+#ifdef AT3HIP_DEBUG_KNOBS
+    AT3_PH_END(pc, 10);
+    if (p.clk != nullptr && lane == 0) {
+        for (int k = 0; k < 12; ++k) atomicAdd(&p.clk[2 + k], (unsigned long long)pc.acc[k]);
+        atomicAdd(&p.clk[14], 1ull);
+    }
+#endif
 }
 
 }  // namespace at3

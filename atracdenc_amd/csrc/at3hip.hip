@@ -377,8 +377,8 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_loud, S * B)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_loud_state, S)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_out, S * B * (size_t)c->frame_sz)) != AT3HIP_OK) return bail(rc);
-    if ((rc = dev_alloc(c, &c->d_clk, 2)) != AT3HIP_OK) return bail(rc);
-    if (hipMemsetAsync(c->d_clk, 0, 2 * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(AT3HIP_EDEVICE);   // (reset_state below waits for the stream)
+    if ((rc = dev_alloc(c, &c->d_clk, 16)) != AT3HIP_OK) return bail(rc);
+    if (hipMemsetAsync(c->d_clk, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(AT3HIP_EDEVICE);   // (reset_state below waits for the stream)
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
     hipDeviceProp_t prop;
     const bool have_prop = hipGetDeviceProperties(&prop, c->device) == hipSuccess;
@@ -803,7 +803,7 @@ int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
         case AT3HIP_TAP_PSY: src = c->d_psy; cap = S * B * 2 * sizeof(PsyRec); break;
         case AT3HIP_TAP_LOUDNESS: src = c->d_loud; cap = S * B * sizeof(float); break;
         case AT3HIP_TAP_QUANT: src = c->d_quant; cap = c->d_quant ? S * B * 2 * sizeof(QuantRec) : 0; break;
-        case AT3HIP_TAP_CLOCK: src = c->d_clk; cap = 2 * sizeof(unsigned long long); break;
+        case AT3HIP_TAP_CLOCK: src = c->d_clk; cap = 16 * sizeof(unsigned long long); break;   // (slots 2.. : per-phase cycles, profiling builds)
         default: return fail(c, AT3HIP_EINVAL, "unknown tap");
     }
     if (!src || bytes > cap) return fail(c, AT3HIP_EINVAL, "tap not available or request too large");

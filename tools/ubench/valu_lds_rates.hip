@@ -17,9 +17,11 @@ constexpr int kUnroll = 16;
 template <int KIND>
 __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, float seed, int iters)
 {
-    // 4 KB per workgroup: eight workgroups (eight waves per SIMD) fit a CU. (Round 2's version held 64 KB, so its "4 waves per
-    // SIMD" rows really ran as two rounds of two - the rates below 3 waves per SIMD are issue-limited per wave, not per SIMD.)
-    __shared__ __attribute__((aligned(16))) float s_buf[1024];
+    // Dynamic LDS sized by the host so that EXACTLY n workgroups fit a CU (160 KB / n each): the dispatcher has to give every
+    // CU its n - with a small footprint it stacks several workgroups on some CUs and leaves others empty, and the waves per
+    // SIMD are not what the row says. (Round 2's version held a fixed 64 KB, so its "4 waves per SIMD" rows really ran as two
+    // rounds of two.) Only the first 4 KB are touched.
+    extern __shared__ __attribute__((aligned(16))) float s_buf[];
     const int tid = threadIdx.x;
     float a[16];
     f2 p[16];
@@ -158,12 +160,17 @@ template <int KIND>
 void run(const char* name, int per_iter_instr, int wgs_per_cu, float* d_out, long long* d_cyc, int iters = kIters)
 {
     const int grid = 256 * wgs_per_cu;   // 4 waves per workgroup = one per SIMD
+    size_t lds = (size_t)(160 * 1024 / wgs_per_cu) & ~(size_t)1023;
+    if (lds * (wgs_per_cu + 1) <= 160 * 1024) lds += 1024;
+    if (lds > 160 * 1024) lds = 160 * 1024;
+    if (wgs_per_cu == 1) lds = 96 * 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rate<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), 0, 0, d_out, d_cyc, 1.0f, iters);
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), lds, 0, d_out, d_cyc, 1.0f, iters);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), 0, 0, d_out, d_cyc, 1.0f, iters);
+    hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(256), lds, 0, d_out, d_cyc, 1.0f, iters);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0;
@@ -191,7 +198,7 @@ int main()
     long long* d_cyc;
     hipMalloc(&d_out, 256 * 8 * 256 * sizeof(float));
     hipMalloc(&d_cyc, 256 * 8 * 4 * 2 * sizeof(long long));
-    for (int w : {1, 2, 4, 6, 8}) {
+    for (int w : {1, 2, 3, 4, 6, 8}) {
         run<0>("v_mul_f32", 16, w, d_out, d_cyc);
         run<1>("v_add_f32", 16, w, d_out, d_cyc);
         run<2>("v_fma_f32", 16, w, d_out, d_cyc);
