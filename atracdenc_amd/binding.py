@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 AT3HIP_PCM_ON_DEVICE = 1
 AT3HIP_OUT_ON_DEVICE = 2
 AT3HIP_ASYNC = 4
-OPT_RUNS, OPT_FLATNESS_LITERAL, OPT_QUANT_TAP = 1, 2, 3
+OPT_RUNS, OPT_FLATNESS_LITERAL, OPT_QUANT_TAP, OPT_GAIN_TWO_WAVES = 1, 2, 3, 4
 TAP_SPECTRA, TAP_CURVES, TAP_ENERGY_SCALE, TAP_PSY, TAP_LOUDNESS, TAP_QUANT, TAP_CLOCK = 1, 2, 3, 4, 5, 6, 7
 LP2 = 132300
 LP4 = 66150
@@ -316,6 +316,7 @@ AT3_TABLES_DTYPE = np.dtype([("qmf_win", "<f4", 48), ("scale", "<f4", 64), ("enc
                              ("loud_curve", "<f4", 1024), ("ath_bfu", "<f4", 32), ("tw128", "<f4", (128, 2)), ("tw256", "<f4", (256, 2)),
                              ("stw256", "<f4", (128, 2)), ("tw2048", "<f4", (2048, 2)), ("stw2048", "<f4", (1024, 2)),
                              ("log2f_tab", "<f8", (16, 2)), ("log2f_poly", "<f8", 4), ("gain_tw", "<f4", (27, 128, 2)),
+                             ("ga1_twb", "<f4", (2, 15, 16, 2)), ("ga1_twc", "<f4", (8, 3, 64, 2)),
                              ("spec16_win", "<f4", (16, 16, 2)), ("spec16_tw", "<f4", (15, 16, 2)), ("spec16_stw", "<f4", (9, 16, 2)), ("log_c", "<f8", 18),
                              ("log_tab", "<f8", (128, 2)), ("exp_c", "<f8", 8), ("exp_tab", "<u8", (128, 2))])
 

@@ -28,13 +28,13 @@ namespace at3 {
 #ifdef AT3HIP_DEBUG_KNOBS
 struct PhaseClock {
     unsigned long long last;
-    uint32_t acc[12];
+    unsigned long long* slots;   // this wavefront's row of 12 counters (256 rows, by workgroup index: no contention to speak of)
 };
-#define AT3_PH_END(pc, k)                                              \
-    do {                                                               \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
-        (pc).acc[k] += (uint32_t)(t_ - (pc).last);                     \
-        (pc).last = t_;                                                \
+#define AT3_PH_END(pc, k)                                                                    \
+    do {                                                                                     \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
+        if ((pc).slots && threadIdx.x == 0) atomicAdd((pc).slots + (k), t_ - (pc).last);     \
+        (pc).last = t_;                                                                      \
     } while (0)
 #else
 struct PhaseClock {};
@@ -282,6 +282,10 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
     int my_nc = 0;   // lane 19 + ub: candidates of its unit
     if (ea_need) {
         uint32_t tie_units = 0;
+        // per unit, formed once per batch by the lane that owns it: which way the pass moves its lines (3: equal energies, no
+        // pass) and MaxQuant of its wordlen
+        const uint32_t my_want = (my_e2 < my_e1) ? 1u : (my_e2 > my_e1) ? 2u : 3u;
+        const float my_mul = tab_f(tab.mq, bits);
         // BFUs 19..25 are 32 lines wide: two of them share a pass, one per half of the wavefront (same lists, same ranks,
         // half as many trips through the write / rendezvous / read-back sequence)
         for (uint32_t rem32 = (ea_need >> 19) & 0x7fu; rem32;) {
@@ -296,10 +300,8 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             const bool has = half == 0 || ubB >= 0;
             const int bfu = 19 + ((half && ubB >= 0) ? ubB : ubA);
             const int start = kEaLine0 + 32 * (bfu - 19), ustart = start - kEaLine0, line = start + l;   // == bfu_start(bfu) for BFUs 19..25
-            const float e1 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_e1)));
-            const float e2 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_e2)));
-            const uint32_t want = (e2 < e1) ? 1u : (e2 > e1) ? 2u : 3u;
-            const float mul = tab_f(tab.mq, __builtin_amdgcn_ds_bpermute(4 * bfu, bits));   // == max_quant(wordlen of the unit)
+            const uint32_t want = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)my_want);
+            const float mul = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_mul)));   // == max_quant(wordlen of the unit)
             const bool flag = has && ((L.code[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;
             const unsigned long long mask = __ballot(flag);
             const uint32_t hm = half ? (uint32_t)(mask >> 32) : (uint32_t)mask;
@@ -322,11 +324,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             if (flag) {
                 // eight keys per step: most units list eight candidates or fewer (5.5 on average on white noise)
                 const float4* t4 = reinterpret_cast<const float4*>(uk);
-                for (int q = 0; q < cnt; q += 8) {
-                    const float4 c0 = t4[(q >> 2)], c1 = t4[(q >> 2) + 1];
-                    rr += (c0.x < key) + (c0.y < key) + (c0.z < key) + (c0.w < key);
-                    rr += (c1.x < key) + (c1.y < key) + (c1.z < key) + (c1.w < key);
-                }
+                for (int q = 0; q < cnt; q += 8) rr = count_below8(t4[(q >> 2)], t4[(q >> 2) + 1], key, rr);
                 L.rec[ustart + rr] = (uint16_t)recv;
             }
             wave_sync();
@@ -340,9 +338,8 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
         for (uint32_t rem = (ea_need >> 19) & ~0x7fu; rem; rem &= rem - 1u) {
             const int ub = __builtin_ctz(rem), bfu = 19 + ub;
             const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start, ustart = start - kEaLine0;
-            const float e1 = readlane_f(my_e1, bfu), e2 = readlane_f(my_e2, bfu);
-            const uint32_t want = (e2 < e1) ? 1u : (e2 > e1) ? 2u : 3u;   // 3: equal energies, no pass
-            const float mul = max_quant(__builtin_amdgcn_readlane(bits, bfu));
+            const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)my_want, bfu);
+            const float mul = readlane_f(my_mul, bfu);
             bool flag[2];
             float key[2];
             uint32_t recv[2];
@@ -377,11 +374,8 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                     const float4* t4 = reinterpret_cast<const float4*>(L.uk);
                     int rr = 0;
                     for (int q = 0; q < cnt_u; q += 16) {
-                        const float4 c0 = t4[(q >> 2)], c1 = t4[(q >> 2) + 1], c2 = t4[(q >> 2) + 2], c3 = t4[(q >> 2) + 3];
-                        rr += (c0.x < key[r]) + (c0.y < key[r]) + (c0.z < key[r]) + (c0.w < key[r]);
-                        rr += (c1.x < key[r]) + (c1.y < key[r]) + (c1.z < key[r]) + (c1.w < key[r]);
-                        rr += (c2.x < key[r]) + (c2.y < key[r]) + (c2.z < key[r]) + (c2.w < key[r]);
-                        rr += (c3.x < key[r]) + (c3.y < key[r]) + (c3.z < key[r]) + (c3.w < key[r]);
+                        rr = count_below8(t4[(q >> 2)], t4[(q >> 2) + 1], key[r], rr);
+                        rr = count_below8(t4[(q >> 2) + 2], t4[(q >> 2) + 3], key[r], rr);
                     }
                     rank[r] = rr;
                     L.rec[ustart + rr] = (uint16_t)recv[r];
@@ -729,7 +723,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     PhaseClock pc;
 #ifdef AT3HIP_DEBUG_KNOBS
     pc.last = __builtin_amdgcn_s_memtime();
-    for (int k = 0; k < 12; ++k) pc.acc[k] = 0u;
+    pc.slots = p.clk ? p.clk + 16 + (blockIdx.x & 255u) * 12u : nullptr;
 #endif
     const int ch = (int)(cf & 1);
     const int fo = (int)((cf >> 1) % n_out);
@@ -1377,10 +1371,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     }
 #ifdef AT3HIP_DEBUG_KNOBS
     AT3_PH_END(pc, 10);
-    if (p.clk != nullptr && lane == 0) {
-        for (int k = 0; k < 12; ++k) atomicAdd(&p.clk[2 + k], (unsigned long long)pc.acc[k]);
-        atomicAdd(&p.clk[14], 1ull);
-    }
+    if (pc.slots && lane == 0) atomicAdd(pc.slots + 11, 1ull);   // wavefronts counted
 #endif
 }
 

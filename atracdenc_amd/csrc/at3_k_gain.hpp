@@ -27,6 +27,7 @@ struct GainParams {
     int js;
     int n_streams;
     int debug;   // profiling aid (env AT3HIP_DEBUG_GAIN): k_gain_curve returns early at stage N
+    unsigned long long* clk;   // profiling builds: 256 rows of 12 per-phase cycle counters of k_gain_analysis1 (tools/gain_phase_cycles.sh)
 };
 
 constexpr int kLowCutBin = 38;  // ceil(800 * 512 / 11025)
@@ -606,6 +607,309 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         rec->lo[lane] = m[2];
         rec->hi[lane] = m[6];
     }
+}
+
+#ifdef AT3HIP_DEBUG_KNOBS
+#define AT3_GPH_END(k)                                                                   \
+    do {                                                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+        if (ph_slots && threadIdx.x == 0) atomicAdd(ph_slots + (k), t_ - ph_last);       \
+        ph_last = t_;                                                                    \
+    } while (0)
+#else
+#define AT3_GPH_END(k) ((void)0)
+#endif
+
+// ---- the same second half as ONE wavefront per item (round 4) ---------------------------------------------------------
+// The 2048-point inverse core lives in the registers of the 64 lanes, 32 points per lane; what the passes exchange crosses
+// the wavefront three times:
+//   phase A  lane G forms the leaves of 32-block G from the item's bins (nine 8-byte loads, a row of lanes reads 512 contiguous
+//            bytes) and runs passes m = 2 and m = 8 on its two radix-16 units (parity 0 / 1) in registers;
+//   exchange 1 (LDS, row-local transposition, 9.5 KB): lane (row R, j) gets offsets 2 j and 2 j + 1 of the sixteen blocks of
+//            its row = the inputs of units (G2 = R, k = 2 j + u) of passes m = 32 and m = 128, one parity at a time;
+//   exchange 2 (no LDS: v_permlane32_swap / v_permlane16_swap, gfx950): the butterflies of pass m = 512 combine the same
+//            element of the four rows, so a 4 x 4 block transposition ACROSS the rows hands lane (R, j) elements i = 4 R .. 4 R + 3
+//            of every row;
+//   exchange 3 (LDS, 8.3 KB): the kept outputs (samples 1024 .. 3071) in sub-frame order for AnalyzeGain, whose ordered sums,
+//            micro-chunk values and quartiles are formed by the same wavefront.
+// No workgroup barrier, 9.5 KB of LDS per item: sixteen items per CU. Same butterflies on the same operands in the same order
+// as the two-wavefront version (kf_bfly4 / kf_bfly2, kiss_fft.c:21-90; kiss_fftri, tools/kiss_fftr.c:117-153).
+constexpr int kGa1RowStride = 18;                       // 8-byte slots per transposed position (16 + 2: conflict-free 16-byte reads)
+constexpr int kGa1RowSlots = 16 * kGa1RowStride + 16;   // per row of lanes: 2432 bytes (rows half a bank round apart)
+constexpr int kGa1SubStride = 33;                       // 8-byte slots per sub-frame of 32 complex outputs
+struct Gain1Lds {
+    union {
+        cpx x[4 * kGa1RowSlots];          // exchange 1
+        struct {
+            cpx out[32 * kGa1SubStride];  // exchange 3: outputs 512 .. 1535 of the core, sub-frame sf at 33 sf
+            float micro[256];             // micro-chunk RMS values, chunk c at c
+        };
+    };
+};
+static_assert(sizeof(Gain1Lds) <= 10240, "sixteen items per CU");
+
+struct PermPair {
+    int a, b;
+};
+// v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b; v_permlane16_swap: the odd rows (of 16 lanes) of a <-> the even rows of b
+__device__ __forceinline__ PermPair perm32_swap(int a, int b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return PermPair{(int)r[0], (int)r[1]};
+}
+__device__ __forceinline__ PermPair perm16_swap(int a, int b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    return PermPair{(int)r[0], (int)r[1]};
+}
+template <bool WIDE>
+__device__ __forceinline__ void swap_f2(f2& a, f2& b)
+{
+    const PermPair x = WIDE ? perm32_swap((int)__float_as_uint(a.x), (int)__float_as_uint(b.x)) : perm16_swap((int)__float_as_uint(a.x), (int)__float_as_uint(b.x));
+    const PermPair y = WIDE ? perm32_swap((int)__float_as_uint(a.y), (int)__float_as_uint(b.y)) : perm16_swap((int)__float_as_uint(a.y), (int)__float_as_uint(b.y));
+    a = mk2(__uint_as_float((uint32_t)x.a), __uint_as_float((uint32_t)y.a));
+    b = mk2(__uint_as_float((uint32_t)x.b), __uint_as_float((uint32_t)y.b));
+}
+
+__global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_gain_analysis1(GainParams p, const Tables* T)
+{
+    __shared__ __attribute__((aligned(16))) Gain1Lds L;
+    const int lane = threadIdx.x, R = lane >> 4, j = lane & 15;
+    const int nfr = p.n_blocks - p.f0;
+    int wg = blockIdx.x;
+    const size_t item = blockIdx.x;
+    const int band = wg % 3; wg /= 3;
+    const int ch = wg % 2; wg /= 2;
+    const int f = p.f0 + wg % nfr;
+    const int s = wg / nfr;
+    GainRec* rec = p.rec + (((size_t)s * p.n_blocks + f) * 2 + ch) * 3 + band;
+    // below 5 % high-band energy the reference drops the band before the upsampler output is looked at (atrac3denc.cpp:319-327)
+#ifdef AT3HIP_DEBUG_KNOBS
+    unsigned long long ph_last = __builtin_amdgcn_s_memtime();
+    unsigned long long* ph_slots = p.clk ? p.clk + (blockIdx.x & 255u) * 12u : nullptr;
+#endif
+    const float hfr = rec->hfr;
+    if (hfr < 0.05f) return;
+    const cpx* bins = p.bins + item * kGainBins;
+    const cpx* tw = T->tw2048;
+    AT3_GPH_END(0);
+
+    // Every table value a wavefront needs is requested one stage AHEAD of its use (a stage computes for a few thousand cycles,
+    // a fetch that is asked for where it is needed costs the wavefront about as much again: with four wavefronts per SIMD in the
+    // same stage nobody covers it). AT3_STAGE() keeps the compiler from sinking the requests back to their uses.
+#define AT3_STAGE() __builtin_amdgcn_sched_barrier(0)
+    // ---- phase A: leaves of 32-block G = lane. Slot 32 G + kappa + 2 i' is the leaf of input n + 1024 kappa,
+    // n = r0 + 64 (i' / 4) + 256 (i' % 4), r0 = the digit reversal of G; the radix-2 leaf butterfly of the pair (n, n + 1024) has one
+    // non-zero input at most: bin k = n in [38, 256] gives (a, a), input 2048 - k = n + 1024 (n in [768, 986]) gives (b, -b).
+    const int r0 = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
+    cpx ba[4], bb[4], sa[4], sb[4], b256 = {0.0f, 0.0f}, s256 = {0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ka = r0 + 64 * q, kb = 256 - r0 - 64 * q;
+        const int kac = ka >= kLowCutBin ? ka : kLowCutBin, kbc = kb >= kLowCutBin ? kb : kLowCutBin;   // (clamped: dropped below)
+        ba[q] = bins[kac - kLowCutBin];
+        sa[q] = T->stw2048[kac - 1];
+        bb[q] = bins[kbc - kLowCutBin];
+        sb[q] = T->stw2048[kbc - 1];
+    }
+    if (lane == 0) {
+        b256 = bins[256 - kLowCutBin];
+        s256 = T->stw2048[255];
+    }
+    const float hpf1 = T->hpf_w[1], hpf2 = T->hpf_w[2];
+    // the twiddles of passes m = 2 / 8 are the same in every lane (scalar registers): both parities' now
+    f2 a1[2], a3[2], w8[2][4][3];
+#pragma unroll
+    for (int kappa = 0; kappa < 2; ++kappa) {
+        a1[kappa] = ld2(tw + 256 * kappa);   // pass m = 2: fstride 256, k = kappa (tw[512 kappa] only ever meets a zero)
+        a3[kappa] = ld2(tw + 768 * kappa);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {     // pass m = 8: fstride 64, k = kappa + 2 jj
+            const int k = kappa + 2 * jj;
+            w8[kappa][jj][0] = ld2(tw + 64 * k);
+            w8[kappa][jj][1] = ld2(tw + 128 * k);
+            w8[kappa][jj][2] = ld2(tw + 192 * k);
+        }
+    }
+    // the fifteen twiddles of a unit of passes m = 32 / 128: one 128-byte run per slot (k = 2 j + kappa)
+    f2 twb[15];
+#pragma unroll
+    for (int sl = 0; sl < 15; ++sl) twb[sl] = ld2(&T->ga1_twb[0][sl][j]);
+    AT3_STAGE();
+    f2 la[4], lb[4], la256 = mk2(0.0f, 0.0f);   // a of bins r0 + 64 q4; b of bins 256 - r0 - 64 q4; a of bin 256 (lane 0)
+    {
+        auto leaf = [&](cpx fr, cpx stw, int k, bool want_b) -> f2 {
+            cpx fk;
+            const float scale = 8.0f;
+            if (k == 256) {
+                fk.r = fr.r * scale * 0.5f;
+                fk.i = 0.0f;
+            } else if (k >= kLowCutBin + 2) {
+                fk.r = fr.r * scale;
+                fk.i = fr.i * scale;
+            } else {
+                const float w = (k == kLowCutBin) ? hpf1 : hpf2;
+                fk.r = fr.r * scale * w;
+                fk.i = fr.i * scale * w;
+            }
+            const cpx fok = cmul(fk, stw);   // fnkc = conj(freq[2048 - k]) = (0, -0): fek = fk, tmp = fk
+            return want_b ? mk2(fk.r - fok.r, -(fk.i - fok.i)) : mk2(fk.r + fok.r, fk.i + fok.i);
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ka = r0 + 64 * q, kb = 256 - r0 - 64 * q;
+            la[q] = (ka >= kLowCutBin) ? leaf(ba[q], sa[q], ka, false) : mk2(0.0f, 0.0f);   // (ka <= 255 always)
+            lb[q] = (kb >= kLowCutBin) ? leaf(bb[q], sb[q], kb, true) : mk2(0.0f, 0.0f);    // (kb = 256 for r0 = 0, q = 0: bin 256's b)
+        }
+        if (lane == 0) la256 = leaf(b256, s256, 256, false);
+    }
+    AT3_GPH_END(1);
+    // the units' results after passes m = 32 / 128, element i of unit u at y[u][i]
+    f2 y[2][16];
+    f2 twc[2][4][3];   // pass m = 512: tw[(q + 1) kk] of butterfly kk = 2 j + u + 32 (4 R + t), 512 contiguous bytes per fetch
+#pragma unroll
+    for (int kappa = 0; kappa < 2; ++kappa) {
+        f2 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = mk2(0.0f, 0.0f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            x[4 * q] = la[q];                                                        // (a, a)
+            x[4 * q + 3] = kappa ? mk2(0.0f - lb[q].x, 0.0f - lb[q].y) : lb[q];      // (b, -b)
+        }
+        x[1] = la256;
+        // pass m = 2: the third input of every butterfly is a zero leaf, the second one too except for input 256
+        bfly4_inv_sparse<false>(x[0], x[1], x[2], x[3], a1[kappa], a3[kappa]);
+#pragma unroll
+        for (int g = 1; g < 4; ++g) bfly4_inv_sparse<true>(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3], a1[kappa], a3[kappa]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bfly4<true>(x[jj], x[jj + 4], x[jj + 8], x[jj + 12], w8[kappa][jj][0], w8[kappa][jj][1], w8[kappa][jj][2]);
+        AT3_GPH_END(2);
+        // exchange 1: x[i'] is slot 32 G + kappa + 2 i'; unit (G2 = R, k = 2 jk + kappa) of the next passes wants offset k of blocks 16 R + i
+        cpx* row = L.x + R * kGa1RowSlots;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st2(row + i * kGa1RowStride + j, x[i]);
+        wave_sync();
+        f2 b[16];
+        {
+            const float4* src = reinterpret_cast<const float4*>(row + j * kGa1RowStride);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float4 v = src[m];
+                b[2 * m] = mk2(v.x, v.y);
+                b[2 * m + 1] = mk2(v.z, v.w);
+            }
+        }
+        wave_sync();   // (the buffer takes the other parity next, then the outputs)
+        AT3_GPH_END(3);
+        // passes m = 32 (fstride 16, butterfly k) and m = 128 (fstride 4, butterflies k + 32 jj) of unit (R, k = 2 j + kappa)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bfly4<true>(b[4 * g], b[4 * g + 1], b[4 * g + 2], b[4 * g + 3], twb[0], twb[1], twb[2]);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bfly4<true>(b[jj], b[jj + 4], b[jj + 8], b[jj + 12], twb[3 + 3 * jj], twb[4 + 3 * jj], twb[5 + 3 * jj]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[kappa][i] = b[i];
+        AT3_STAGE();
+        // requested now, used a stage later: the other unit's twiddles, then the last pass'
+        if (kappa == 0) {
+#pragma unroll
+            for (int sl = 0; sl < 15; ++sl) twb[sl] = ld2(&T->ga1_twb[1][sl][j]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) twc[u][t][q] = ld2(&T->ga1_twc[4 * u + t][q][lane]);
+        }
+        AT3_STAGE();
+        AT3_GPH_END(4);
+    }
+    // ---- exchange 2: y[u][i] is slot 512 R + (2 j + u) + 32 i; butterfly kk = 2 j + u + 32 i of pass m = 512 wants it from every row.
+    // Rows R and R ^ 2 trade their halves i >= 8 / i < 8, then rows R and R ^ 1 the quarters: afterwards y[u][4 q + t] is
+    // element i = 4 R + t of row q.
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) swap_f2<true>(y[u][t], y[u][8 + t]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            swap_f2<false>(y[u][t], y[u][4 + t]);
+            swap_f2<false>(y[u][8 + t], y[u][12 + t]);
+        }
+    AT3_GPH_END(5);
+    // ---- pass m = 512 (fstride 1) and exchange 3: only the middle half of the upsampled frame is analysed (outputs kk + 512, kk + 1024)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int i = 4 * R + t;   // butterfly kk = 2 j + u + 32 i
+            bfly4<true>(y[u][t], y[u][4 + t], y[u][8 + t], y[u][12 + t], twc[u][t][0], twc[u][t][1], twc[u][t][2]);
+            st2(L.out + kGa1SubStride * i + 2 * j + u, y[u][4 + t]);          // slot 512 + kk: sub-frame i, position 2 j + u
+            st2(L.out + kGa1SubStride * (16 + i) + 2 * j + u, y[u][8 + t]);   // slot 1024 + kk: sub-frame 16 + i
+        }
+    wave_sync();
+    AT3_GPH_END(6);
+    // ---- AnalyzeGain over the upsampled samples [1024, 3072) (transient_detector.cpp:95-136): 256 micro-chunks of 8 samples (four
+    // per lane), 32 sub-frames of 64; complex output jj holds the real samples 2 jj, 2 jj + 1
+    const float norm = 1.0f / 4096.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // chunk c starts 4 c + c / 8 slots into the buffer; the sixteen lanes an 8-byte LDS read serves together take chunks
+        // {0..3} + 8 {0..3} (+ 4 for the next sixteen): sixteen different bank pairs
+        const int n = lane + 64 * q;
+        const int c = (n & 3) | ((n & 0xc) << 1) | ((n & 0x10) >> 2) | (n & 0xe0);
+        const cpx* src = L.out + 4 * c + (c >> 3);
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f2 v = ld2(src + i) * norm;
+            const f2 sq = v * v;
+            acc += sq.x;
+            acc += sq.y;
+        }
+        acc /= 8;
+        L.micro[c] = sqrtf(acc);
+    }
+    wave_sync();
+    AT3_GPH_END(7);
+    if (lane < 32) {
+        const cpx* src = L.out + kGa1SubStride * lane;
+        f2 x[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) x[i] = ld2(src + i);
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const f2 v = x[i] * norm;
+            const f2 sq = v * v;
+            acc += sq.x;
+            acc += sq.y;
+        }
+        acc /= 64;
+        rec->gain[lane] = sqrtf(acc);
+    } else {
+        const int sf = lane - 32;
+        const float4 ma = *reinterpret_cast<const float4*>(L.micro + 8 * sf), mb = *reinterpret_cast<const float4*>(L.micro + 8 * sf + 4);
+        float m[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {   // insertion sort, ascending (static indices)
+#pragma unroll
+            for (int k = i; k > 0; --k) {
+                const float lo = fminf(m[k - 1], m[k]), hi = fmaxf(m[k - 1], m[k]);
+                m[k - 1] = lo;
+                m[k] = hi;
+            }
+        }
+        rec->lo[sf] = m[2];
+        rec->hi[sf] = m[6];
+    }
+#ifdef AT3HIP_DEBUG_KNOBS
+    AT3_GPH_END(8);
+    if (ph_slots && lane == 0) atomicAdd(ph_slots + 11, 1ull);
+#endif
 }
 
 // CalcCurve's target for one item: the plateau target (transient_detector.cpp:178-238, 284-297), the mean gain (the quartiles

@@ -5,10 +5,13 @@
 
 namespace at3 {
 
-// CDNA issues a wave64 fp32 VALU instruction over four cycles; v_pk_mul_f32 / v_pk_add_f32 (VOP3P) carry TWO
-// independent IEEE fp32 operations per lane in the same four cycles. The reference arithmetic has no fused
-// multiply-add (-ffp-contract=off is part of the parity contract), so mul/add-bound code is issue bound and packing
-// doubles its rate without changing a single rounding. `f2` maps to an aligned VGPR pair; plain vector expressions
+// v_pk_mul_f32 / v_pk_add_f32 (VOP3P) carry TWO independent IEEE fp32 operations per lane. The reference arithmetic has
+// no fused multiply-add (-ffp-contract=off is part of the parity contract), so mul/add-bound code is issue bound; a packed
+// instruction does NOT issue at the rate of a plain one, though: measured (tools/ubench/valu_lds_rates, profiles/
+// r04_ubench_instruction_rates.txt, shader clock 2.1 - 2.4 GHz under load) a wavefront issues a plain fp32 instruction every
+// ~6 - 8 cycles and a packed one every ~8.5 - 14, so packing buys between nothing and 40 % per flop depending on how many
+// wavefronts share the SIMD - its surer gain is half the instruction count where the stream is latency bound. It never
+// changes a rounding. `f2` maps to an aligned VGPR pair; plain vector expressions
 // are selected as packed instructions by the compiler, the three complex forms whose lanes need DIFFERENT negate /
 // half-select modifiers are spelled out below.
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -42,6 +45,34 @@ __device__ __forceinline__ f2 pk_sub_ib(f2 a, f2 b)
 {
     f2 r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// r + the number of the eight values c0.x .. c1.w that are below `key`: a compare into a scalar pair and an add-with-carry
+// of zero per value, four compares ahead of their adds (a vector instruction may read a scalar pair two instructions after
+// the vector instruction that wrote it; spelled out here because the compiler, short of scalar registers in k_alloc_pack,
+// paired every compare with a select and a wait state)
+__device__ __forceinline__ int count_below8(float4 c0, float4 c1, float key, int r)
+{
+    unsigned long long m0, m1, m2, m3;
+    asm("v_cmp_lt_f32_e64 %1, %5, %13\n\t"
+        "v_cmp_lt_f32_e64 %2, %6, %13\n\t"
+        "v_cmp_lt_f32_e64 %3, %7, %13\n\t"
+        "v_cmp_lt_f32_e64 %4, %8, %13\n\t"
+        "v_addc_co_u32_e64 %0, %1, 0, %0, %1\n\t"
+        "v_addc_co_u32_e64 %0, %2, 0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, %3, 0, %0, %3\n\t"
+        "v_addc_co_u32_e64 %0, %4, 0, %0, %4\n\t"
+        "v_cmp_lt_f32_e64 %1, %9, %13\n\t"
+        "v_cmp_lt_f32_e64 %2, %10, %13\n\t"
+        "v_cmp_lt_f32_e64 %3, %11, %13\n\t"
+        "v_cmp_lt_f32_e64 %4, %12, %13\n\t"
+        "v_addc_co_u32_e64 %0, %1, 0, %0, %1\n\t"
+        "v_addc_co_u32_e64 %0, %2, 0, %0, %2\n\t"
+        "v_addc_co_u32_e64 %0, %3, 0, %0, %3\n\t"
+        "v_addc_co_u32_e64 %0, %4, 0, %0, %4"
+        : "+v"(r), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w), "v"(c1.x), "v"(c1.y), "v"(c1.z), "v"(c1.w), "v"(key));
     return r;
 }
 

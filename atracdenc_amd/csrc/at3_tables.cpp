@@ -121,6 +121,20 @@ AT3_RUNTIME_LIBM void build_tables(Tables* t)
             for (int q = 0; q < 3; ++q) t->gain_tw[15 + 3 * u + q][tid] = t->tw2048[(q + 1) * (tid + 128 * u)];
     }
 
+    for (int u = 0; u < 2; ++u)   // see at3_k_gain.hpp: k_gain_analysis1
+        for (int j = 0; j < 16; ++j) {
+            const int k = 2 * j + u;
+            for (int q = 0; q < 3; ++q) t->ga1_twb[u][q][j] = t->tw2048[16 * (q + 1) * k];
+            for (int jj = 0; jj < 4; ++jj)
+                for (int q = 0; q < 3; ++q) t->ga1_twb[u][3 + 3 * jj + q][j] = t->tw2048[4 * (q + 1) * (k + 32 * jj)];
+        }
+    for (int lane = 0; lane < 64; ++lane)
+        for (int u = 0; u < 2; ++u)
+            for (int tt = 0; tt < 4; ++tt) {
+                const int kk = 2 * (lane & 15) + u + 32 * (4 * (lane >> 4) + tt);
+                for (int q = 0; q < 3; ++q) t->ga1_twc[4 * u + tt][q][lane] = t->tw2048[(q + 1) * kk];
+            }
+
     {   // Planck taper, epsilon 0.15, N = 512
         const float eN = 0.15f * 512.0f;
         const float fN = 512.0f;

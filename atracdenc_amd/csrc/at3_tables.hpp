@@ -38,6 +38,12 @@ struct Tables {
     // irfft-4096 core, as [slot][t] so that a wavefront fetches each slot as one contiguous 512-byte run (picking them out
     // of tw2048 touched up to 32 cache lines per load). Slots: 0..2 pass m = 32, 3..14 pass m = 128, 15..26 pass m = 512.
     cpx gain_tw[27][128];
+    // k_gain_analysis1 (one wavefront per item), lane = 16 R + j:
+    //   ga1_twb[u][s][j]   the fifteen twiddles of unit k = 2 j + u of passes m = 32 / 128 (s as in gain_tw: 0..2 tw[16 (s + 1) k],
+    //                      3 + 3 jj + q: tw[4 (q + 1) (k + 32 jj)]); the four rows of lanes read the same 128 bytes
+    //   ga1_twc[4 u + t][q][lane]  pass m = 512: tw[(q + 1) kk] of butterfly kk = 2 j + u + 32 (4 R + t): 512 contiguous bytes per fetch
+    cpx ga1_twb[2][15][16];
+    cpx ga1_twc[8][3][64];
     // k_gain_spec: a 256-point transform lives in the 16 lanes of a DPP row, position L = lane & 15 (see at3_k_gain.hpp):
     //   spec16_win[t][L]  Planck window pair {w[2 i], w[2 i + 1]} of complex input i = L + 16 t
     //   spec16_tw[s][L]   s = 0..2: tw256[4 (s + 1) L] (pass m = 16, butterfly k = L);

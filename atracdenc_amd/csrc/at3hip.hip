@@ -77,6 +77,7 @@ struct at3hip_ctx {
     long long blocks_fed = 0;   // per stream
     int runs_override = 0;   // AT3HIP_OPT_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
     int flat_literal = 0;    // AT3HIP_OPT_FLATNESS_LITERAL
+    int gain_two_waves = 0;  // AT3HIP_OPT_GAIN_TWO_WAVES: the gain analysis' second half as the two-wavefront workgroups of rounds 2 - 3
     int n_cus = 256;
     size_t lds_per_cu = 0;     // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor; the whole-round LDS padding below is tuned for 160 KB
     int wgs_per_cu = 3;        // resident workgroups per CU of the QMF kernel this context uses (k_qmf_sub8 or the fused one)
@@ -377,8 +378,8 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_loud, S * B)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_loud_state, S)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_out, S * B * (size_t)c->frame_sz)) != AT3HIP_OK) return bail(rc);
-    if ((rc = dev_alloc(c, &c->d_clk, 16)) != AT3HIP_OK) return bail(rc);
-    if (hipMemsetAsync(c->d_clk, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(AT3HIP_EDEVICE);   // (reset_state below waits for the stream)
+    if ((rc = dev_alloc(c, &c->d_clk, 16 + 2 * 256 * 12)) != AT3HIP_OK) return bail(rc);
+    if (hipMemsetAsync(c->d_clk, 0, (16 + 2 * 256 * 12) * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(AT3HIP_EDEVICE);   // (reset_state below waits for the stream)
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
     hipDeviceProp_t prop;
     const bool have_prop = hipGetDeviceProperties(&prop, c->device) == hipSuccess;
@@ -512,6 +513,9 @@ int at3hip_set_option(at3hip_ctx* c, int32_t option, int32_t value)
             return AT3HIP_OK;
         case AT3HIP_OPT_FLATNESS_LITERAL:
             c->flat_literal = value != 0;
+            return AT3HIP_OK;
+        case AT3HIP_OPT_GAIN_TWO_WAVES:
+            c->gain_two_waves = value != 0;
             return AT3HIP_OK;
         case AT3HIP_OPT_QUANT_TAP: {
             at3host::DeviceGuard guard(c->device);
@@ -671,11 +675,13 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             gp.js = c->js;
             gp.n_streams = S;
             gp.debug = c->dbg_gain;
+            gp.clk = c->d_clk + 16 + 256 * 12;
             launch_qmf_sub();
             HIPCHK(c, hipEventRecord(ev[1], st));
             launch_state(st, 1);   // PCM history and subband tail: the next call's heavy stage needs nothing else from this one
             hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(64), spec_lds_pad(c, ((long long)S * n_out * 6 + 3) / 4), st, gp, c->d_tables, S * n_out * 6);
-            hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), analysis_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);
+            if (c->gain_two_waves) hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), analysis_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);
+            else hipLaunchKernelGGL(k_gain_analysis1, dim3(S * n_out * 6), dim3(64), 0, st, gp, c->d_tables);   // one wavefront per item
             HIPCHK(c, hipEventRecord(ev[2], st));
             HIPCHK(c, hipStreamWaitEvent(md, ev[2], 0));   // the light stage starts when this call's heavy stage is done
             hipLaunchKernelGGL(k_gain_tail, dim3((unsigned)((S * n_out * 6 + 7) / 8)), dim3(256), 0, md, gp, S * n_out * 6);
@@ -803,7 +809,7 @@ int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
         case AT3HIP_TAP_PSY: src = c->d_psy; cap = S * B * 2 * sizeof(PsyRec); break;
         case AT3HIP_TAP_LOUDNESS: src = c->d_loud; cap = S * B * sizeof(float); break;
         case AT3HIP_TAP_QUANT: src = c->d_quant; cap = c->d_quant ? S * B * 2 * sizeof(QuantRec) : 0; break;
-        case AT3HIP_TAP_CLOCK: src = c->d_clk; cap = 16 * sizeof(unsigned long long); break;   // (slots 2.. : per-phase cycles, profiling builds)
+        case AT3HIP_TAP_CLOCK: src = c->d_clk; cap = (16 + 2 * 256 * 12) * sizeof(unsigned long long); break;   // (from slot 16 on: 256 rows of per-phase cycles of k_alloc_pack, then of k_gain_analysis1; profiling builds)
         default: return fail(c, AT3HIP_EINVAL, "unknown tap");
     }
     if (!src || bytes > cap) return fail(c, AT3HIP_EINVAL, "tap not available or request too large");

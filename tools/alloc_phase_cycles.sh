@@ -17,11 +17,14 @@ sync = "--sync-steps" in args
 bench.DeviceJob.sync_steps = sync
 job = bench.DeviceJob(0, 64, 64, br, False, kind, seed=1)
 job.warmup(3)
-c0 = job.enc.read_tap(B.TAP_CLOCK, np.uint64, (16,)).astype(np.float64)
+def read():
+    c = job.enc.read_tap(B.TAP_CLOCK, np.uint64, (16 + 256 * 12,)).astype(np.float64)
+    return np.concatenate([c[:2], c[16:].reshape(256, 12).sum(axis=0)])
+c0 = read()
 job.run_steps(20)
-c1 = job.enc.read_tap(B.TAP_CLOCK, np.uint64, (16,)).astype(np.float64)
+c1 = read()
 d = c1 - c0
-waves = d[14]
+waves = d[13]
 names = ["loads+scale", "e1 sums", "small units", "config", "rate loop", "units: rounding", "units: e2 sums", "units: EA lists", "units: EA ties+seq",
          "units: VLC cost", "emission", "-"]
 tot = d[2:13].sum()

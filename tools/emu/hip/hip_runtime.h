@@ -115,13 +115,34 @@ int emu_readlane(int v, int lane);
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((int)(v), (lane))
 static inline __attribute__((always_inline)) float __shfl(float v, int lane, int = 64) { float r; int i; memcpy(&i, &v, 4); i = emu_readlane(i, lane); memcpy(&r, &i, 4); return r; }
 static inline __attribute__((always_inline)) float __shfl_xor(float v, int mask, int = 64) { return __shfl(v, (int)((threadIdx.x & 63u) ^ (unsigned)mask)); }
+// v_permlane32_swap / v_permlane16_swap (gfx950): returns {a', b'}
+typedef int emu_int2 __attribute__((ext_vector_type(2)));
+static inline __attribute__((always_inline)) emu_int2 __builtin_amdgcn_permlane32_swap(int a, int b, bool, bool)
+{
+    const int ln = (int)(threadIdx.x & 63u);
+    const int pa = emu_bpermute(4 * (ln ^ 32), a), pb = emu_bpermute(4 * (ln ^ 32), b);
+    emu_int2 r;
+    if (ln < 32) { r[0] = a; r[1] = pa; } else { r[0] = pb; r[1] = b; }
+    return r;
+}
+static inline __attribute__((always_inline)) emu_int2 __builtin_amdgcn_permlane16_swap(int a, int b, bool, bool)
+{
+    const int ln = (int)(threadIdx.x & 63u);
+    const int pa = emu_bpermute(4 * (ln ^ 16), a), pb = emu_bpermute(4 * (ln ^ 16), b);
+    emu_int2 r;
+    if ((ln & 16) == 0) { r[0] = a; r[1] = pa; } else { r[0] = pb; r[1] = b; }
+    return r;
+}
 void emu_wave_barrier();
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0ull; }
 static inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0ull; }
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned v) { const unsigned ln = threadIdx.x & 63u; return v + (unsigned)__builtin_popcount(mask & (ln >= 32 ? 0xffffffffu : ((1u << ln) - 1u))); }
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned v) { const unsigned ln = threadIdx.x & 63u; return v + (ln > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (ln - 32)) - 1u)) : 0u); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 
