@@ -77,7 +77,8 @@ struct at3hip_ctx {
     long long blocks_fed = 0;   // per stream
     int runs_override = 0;   // AT3HIP_OPT_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
     int flat_literal = 0;    // AT3HIP_OPT_FLATNESS_LITERAL
-    int gain_two_waves = 0;  // AT3HIP_OPT_GAIN_TWO_WAVES: the gain analysis' second half as the two-wavefront workgroups of rounds 2 - 3
+    int gain_two_waves = 0;  // AT3HIP_OPT_GAIN_TWO_WAVES: 0 / 1 = the two-wavefront workgroups of rounds 2 - 3 (default), 2 = one wavefront per item (k_gain_analysis1)
+    int gain_wgs_per_cu = 0; // AT3HIP_OPT_GAIN_WGS_PER_CU: k_gain_analysis1 workgroups per CU (dynamic LDS padding; 0 = chosen per launch)
     int n_cus = 256;
     size_t lds_per_cu = 0;     // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor; the whole-round LDS padding below is tuned for 160 KB
     int wgs_per_cu = 3;        // resident workgroups per CU of the QMF kernel this context uses (k_qmf_sub8 or the fused one)
@@ -238,6 +239,17 @@ size_t analysis_lds_pad(const at3hip_ctx* c, long long n_wgs)
 {
     static const LdsChoice kChoice[3] = {{9, 0}, {8, 3328}, {6, 8704}};
     return whole_rounds_pad(c, n_wgs, kChoice, 3, true);   // (equally whole rounds: the fewer, fatter slots measured better)
+}
+// The one-wavefront form (k_gain_analysis1, 9.5 KB per workgroup): sixteen per CU without padding.
+size_t analysis1_lds_pad(const at3hip_ctx* c, long long n_wgs)
+{
+    if (c->lds_per_cu != 160u * 1024u) return 0;
+    if (c->gain_wgs_per_cu > 0 && c->gain_wgs_per_cu < 16) {
+        const size_t each = ((160u * 1024u) / (size_t)c->gain_wgs_per_cu) & ~(size_t)255;
+        return each > 9728 ? each - 9728 : 0;
+    }
+    static const LdsChoice kChoice[3] = {{16, 0}, {12, 3584}, {8, 10240}};
+    return whole_rounds_pad(c, n_wgs, kChoice, 3, true);
 }
 // The same for k_gain_spec (9.5 KB per one-wavefront workgroup, sixteen per CU without padding): the 6144 workgroups of
 // 4096 frames are one and a half rounds of 256 x 16 and exactly two of 256 x 12 (+0.8 % on the step).
@@ -515,7 +527,11 @@ int at3hip_set_option(at3hip_ctx* c, int32_t option, int32_t value)
             c->flat_literal = value != 0;
             return AT3HIP_OK;
         case AT3HIP_OPT_GAIN_TWO_WAVES:
-            c->gain_two_waves = value != 0;
+            c->gain_two_waves = value;
+            return AT3HIP_OK;
+        case AT3HIP_OPT_GAIN_WGS_PER_CU:
+            if (value < 0 || value > 16) return fail(c, AT3HIP_EINVAL, "workgroups per CU must be 0 .. 16");
+            c->gain_wgs_per_cu = value;
             return AT3HIP_OK;
         case AT3HIP_OPT_QUANT_TAP: {
             at3host::DeviceGuard guard(c->device);
@@ -680,8 +696,10 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
             HIPCHK(c, hipEventRecord(ev[1], st));
             launch_state(st, 1);   // PCM history and subband tail: the next call's heavy stage needs nothing else from this one
             hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(64), spec_lds_pad(c, ((long long)S * n_out * 6 + 3) / 4), st, gp, c->d_tables, S * n_out * 6);
-            if (c->gain_two_waves) hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), analysis_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);
-            else hipLaunchKernelGGL(k_gain_analysis1, dim3(S * n_out * 6), dim3(64), 0, st, gp, c->d_tables);   // one wavefront per item
+            // default: the two-wavefront form. The one-wavefront form is 11 % faster alone (89 against 101 us at 4096 frames) and
+            // leaves the pipelined step 2 % slower at that size, equal at the 1024 x 128 shard (profiles/EXPERIMENTS.md)
+            if (c->gain_two_waves != 2) hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), analysis_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);
+            else hipLaunchKernelGGL(k_gain_analysis1, dim3(S * n_out * 6), dim3(64), analysis1_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);   // one wavefront per item
             HIPCHK(c, hipEventRecord(ev[2], st));
             HIPCHK(c, hipStreamWaitEvent(md, ev[2], 0));   // the light stage starts when this call's heavy stage is done
             hipLaunchKernelGGL(k_gain_tail, dim3((unsigned)((S * n_out * 6 + 7) / 8)), dim3(256), 0, md, gp, S * n_out * 6);

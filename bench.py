@@ -145,7 +145,10 @@ class DeviceJob:
             self.enc.set_option(B.OPT_RUNS, DeviceJob.runs)
         if DeviceJob.gain_two_waves:
             from atracdenc_amd import binding as B
-            self.enc.set_option(B.OPT_GAIN_TWO_WAVES, 1)
+            self.enc.set_option(B.OPT_GAIN_TWO_WAVES, DeviceJob.gain_two_waves)
+        if DeviceJob.gain_wgs:
+            from atracdenc_amd import binding as B
+            self.enc.set_option(B.OPT_GAIN_WGS_PER_CU, DeviceJob.gain_wgs)
         self.bitrate, self.no_gain = bitrate, no_gain
         self.fsz = self.enc.frame_size
         # synthetic PCM resident in HBM before timing: a priming look-ahead block + two alternating batches that are
@@ -172,6 +175,7 @@ class DeviceJob:
     sync_steps = False   # --sync-steps (profiling aid)
     runs = 0             # --runs (tuning aid: AT3HIP_OPT_RUNS)
     gain_two_waves = 0   # --gain-two-waves (A/B aid: AT3HIP_OPT_GAIN_TWO_WAVES)
+    gain_wgs = 0         # --gain-wgs (tuning aid: AT3HIP_OPT_GAIN_WGS_PER_CU)
 
     def replay(self, n_steps):
         """Start of stream again (at3hip_reset + the LOOK_AHEAD call), then n_steps steps exactly as the warm-up and the timed
@@ -436,8 +440,9 @@ def main():
     ap.add_argument("--region-ms", type=float, default=50.0)
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the frames after the timed regions")
     ap.add_argument("--runs", type=int, default=0, help="TUNING AID: AT3HIP_OPT_RUNS (runs per stream and channel of the QMF / MDCT kernels)")
-    ap.add_argument("--gain-two-waves", action="store_true", help="A/B AID: AT3HIP_OPT_GAIN_TWO_WAVES (the upsampler / AnalyzeGain kernel as the two-wavefront "
+    ap.add_argument("--gain-two-waves", type=int, default=0, help="A/B AID: AT3HIP_OPT_GAIN_TWO_WAVES (the upsampler / AnalyzeGain kernel as the two-wavefront "
                                                                   "workgroups of rounds 2 - 3; same results)")
+    ap.add_argument("--gain-wgs", type=int, default=0, help="TUNING AID: AT3HIP_OPT_GAIN_WGS_PER_CU")
     ap.add_argument("--sync-steps", action="store_true", help="PROFILING AID: run the timed steps synchronously (no overlap of "
                                                               "consecutive calls) so that rocprofv3 sees every kernel alone; "
                                                               "the line is marked and is not a valid throughput result")
@@ -450,6 +455,7 @@ def main():
     DeviceJob.sync_steps = args.sync_steps
     DeviceJob.runs = args.runs
     DeviceJob.gain_two_waves = int(args.gain_two_waves)
+    DeviceJob.gain_wgs = args.gain_wgs
     from atracdenc_amd import dist as at3dist
     rank, local_rank, world = at3dist.env_world()
     if world > 1 and args.gpus != world:

@@ -186,7 +186,9 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
 #define AT3HIP_OPT_RUNS 1
 #define AT3HIP_OPT_FLATNESS_LITERAL 2
 #define AT3HIP_OPT_QUANT_TAP 3
-#define AT3HIP_OPT_GAIN_TWO_WAVES 4   /* 1 = the upsampler / AnalyzeGain kernel as two-wavefront workgroups (the form of rounds 2 - 3; same results) */
+#define AT3HIP_OPT_GAIN_WGS_PER_CU 5  /* tuning aid: workgroups per CU of the one-wavefront upsampler kernel (LDS padding), 0 = chosen per launch */
+#define AT3HIP_OPT_GAIN_TWO_WAVES 4   /* which form of the upsampler / AnalyzeGain kernel runs (same results): 0 / 1 = two-wavefront
+                                        * workgroups (default), 2 = one wavefront per item (faster alone, not in the pipelined step) */
 int at3hip_set_option(at3hip_ctx* ctx, int32_t option, int32_t value);
 
 /* Host-buffer pipeline. The reference's caller hands host floats (TPCMEngine::ApplyProcess, pcmengin.h:152-192): with

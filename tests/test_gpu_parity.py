@@ -125,6 +125,30 @@ def test_stage_taps(hip, oracle, br):
                 assert np.array_equal(curves[i, f + 1, ch, b, 8:8 + n], tap["loc"][f, ch, b, :n].astype(np.uint8))
 
 
+@pytest.mark.parametrize("br", [LP2, LP4])
+def test_gain_analysis_forms_agree(hip, oracle, br):
+    """AT3HIP_OPT_GAIN_TWO_WAVES: the upsampler / AnalyzeGain kernel as two-wavefront workgroups (default) and as one wavefront
+    per item (k_gain_analysis1: leaves in registers, v_permlane swaps across the rows) - same curves, same frames, both
+    equal to the oracle's, on the signals that drive the gain-control path."""
+    from atracdenc_amd import binding as B
+    nb = 24
+    names = ["burst", "mix", "noise", "stress"]
+    sig = dict(SIGNALS, stress=lambda n: pcm_stress(n, seed=7))
+    pcm = np.stack([sig[n](nb) for n in names])
+    exp = oracle_frames(oracle, pcm, br)
+    got = {}
+    for form in (1, 2):
+        enc = hip.At3Hip(n_streams=len(names), max_blocks=nb, bitrate=br)
+        enc.set_option(B.OPT_GAIN_TWO_WAVES, form)
+        frames = np.concatenate([enc.encode(pcm[:, :7]), enc.encode(pcm[:, 7:])], axis=1)   # two calls: carried context
+        curves = enc.read_tap(B.TAP_CURVES, np.uint8, (len(names), nb - 7, 2, 4, 16))
+        enc.close()
+        assert np.array_equal(frames, exp), form
+        got[form] = curves
+    assert np.array_equal(got[1], got[2])
+    assert got[1][..., 0].any()          # the material does produce gain curves
+
+
 def _raw_spectra(hip, pcm, br=LP2):
     """Spectra BEFORE the tonal lines are removed: the same stream with NoTonalComponents (the spectra tap is untouched)."""
     from atracdenc_amd import binding as B

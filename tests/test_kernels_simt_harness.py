@@ -47,6 +47,12 @@ def test_atrac3_kernels(harness):
     _assert_clean(_run("run_emu.py", "--strict", "--nobuild"), 36)
 
 
+def test_atrac3_gain_analysis_one_wavefront_form(harness):
+    """AT3HIP_OPT_GAIN_TWO_WAVES = 2 (k_gain_analysis1, incl. the restated v_permlane32/16_swap, which tools/ubench/permlane_check
+    compares with the hardware): the signals with gain curves x LP2 / LP4 x three option sets."""
+    _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--gain-form=2", "burst", "stress"), 12)
+
+
 def test_atrac1_kernels(harness):
     _assert_clean(_run("run_emu_at1.py", "--nobuild"), 24 * 4)
 

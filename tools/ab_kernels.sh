@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box: isolated per-kernel durations (rocprofv3 --kernel-trace, bench.py --sync-steps) for each library
 # given on the command line, alternating, so that two builds are compared on the same box.
-# usage: tools/ab_kernels.sh libA.so libB.so [-- bench.py flags]
+# usage: tools/ab_kernels.sh libA.so libB.so [-- bench.py flags]      (SYNC= tools/ab_kernels.sh ... : pipelined steps instead)
 REPO=$(pwd)
 LIBS=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do LIBS+=("$1"); shift; done
@@ -11,7 +11,7 @@ cd /tmp
 for rep in 1 2; do
 for L in "${LIBS[@]}"; do
   rm -rf /tmp/abk
-  AT3HIP_LIB=$REPO/$L rocprofv3 --kernel-trace --stats -d /tmp/abk -o abk -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-workloads --sync-steps "$@" > /dev/null 2>&1
+  AT3HIP_LIB=$REPO/$L rocprofv3 --kernel-trace --stats -d /tmp/abk -o abk -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-side-workloads ${SYNC---sync-steps} "$@" > /dev/null 2>&1
   python3 - <<PY
 import glob, sqlite3
 out = []
