@@ -32,7 +32,7 @@ class Timings(ctypes.Structure):
                                                "alloc_ms")] + [("qmf_mdct_launches", ctypes.c_int32)]
 
 
-SYMBOLS = ["at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint_stereo", "at3hip_last_error",
+SYMBOLS = ["at3hip_encode_s16", "at3hip_create", "at3hip_destroy", "at3hip_frame_size", "at3hip_joint_stereo", "at3hip_last_error",
            "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
            "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago", "at3hip_read_tap",
            "at3hip_mdct_levels", "at3hip_gain_energy_scale", "at3hip_set_option", "at3hip_host_tables", "at3hip_host_alloc",
@@ -97,6 +97,7 @@ def load_library(path=None):
     lib.at3hip_last_error.argtypes = [vp]
     lib.at3hip_last_error.restype = ctypes.c_char_p
     lib.at3hip_encode.argtypes = [vp, vp, i32, vp, ctypes.POINTER(i32), ctypes.c_uint32]
+    lib.at3hip_encode_s16.argtypes = [vp, vp, i32, vp, ctypes.POINTER(i32), ctypes.c_uint32]
     lib.at3hip_reset.argtypes = [vp]
     lib.at3hip_mdct.argtypes = [vp, vp, vp, vp, vp, vp, i32, ctypes.c_uint32]
     lib.at3hip_mdct_levels.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, ctypes.c_uint32]
@@ -193,6 +194,25 @@ class At3Hip:
         return np.ascontiguousarray(out.reshape(-1)[: self.n_streams * n * self.frame_size].reshape(
             self.n_streams, n, self.frame_size))
 
+    def encode_s16(self, pcm):
+        """pcm int16 [n_streams, n_blocks, 1024, channels] (host) -> uint8 [n_streams, n_frames, frame_size] (at3hip_encode_s16)."""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        assert pcm.ndim == 4 and pcm.shape[0] == self.n_streams and pcm.shape[2:] == (1024, self.channels), pcm.shape
+        nb = pcm.shape[1]
+        out = np.zeros((self.n_streams, nb, self.frame_size), dtype=np.uint8)
+        nf = ctypes.c_int32()
+        self._check(self.lib.at3hip_encode_s16(self.ctx, _vp(pcm), nb, _vp(out), ctypes.byref(nf), 0), "at3hip_encode_s16")
+        n = nf.value
+        return np.ascontiguousarray(out.reshape(-1)[: self.n_streams * n * self.frame_size].reshape(self.n_streams, n, self.frame_size))
+
+    def encode_device_s16(self, pcm_ptr, n_blocks, out_ptr, asynchronous=False):
+        """Device-resident int16 PCM / out (raw pointers). Returns frames per stream."""
+        nf = ctypes.c_int32()
+        flags = AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE | (AT3HIP_ASYNC if asynchronous else 0)
+        self._check(self.lib.at3hip_encode_s16(self.ctx, ctypes.c_void_p(pcm_ptr), n_blocks, ctypes.c_void_p(out_ptr),
+                                               ctypes.byref(nf), flags), "at3hip_encode_s16")
+        return nf.value
+
     def encode_device(self, pcm_ptr, n_blocks, out_ptr, asynchronous=False):
         """Device-resident PCM/out (raw pointers, e.g. torch tensor .data_ptr()). Returns frames per stream.
         asynchronous=True only queues the work (AT3HIP_ASYNC): call sync() before the frames are read."""
@@ -241,7 +261,8 @@ class At3Hip:
         """Queues one call on host arrays (pinned ones overlap copies and kernels); returns frames per stream. `out` is valid
         after wait_frames(ago) / sync(), `pcm` may be refilled after wait_input(ago)."""
         nf = ctypes.c_int32()
-        self._check(self.lib.at3hip_encode(self.ctx, _vp(pcm), pcm.shape[1], _vp(out), ctypes.byref(nf), AT3HIP_ASYNC), "at3hip_encode")
+        fn = self.lib.at3hip_encode_s16 if pcm.dtype == np.int16 else self.lib.at3hip_encode
+        self._check(fn(self.ctx, _vp(pcm), pcm.shape[1], _vp(out), ctypes.byref(nf), AT3HIP_ASYNC), "at3hip_encode")
         return nf.value
 
     def wait_input(self, ago=0):

@@ -798,6 +798,26 @@ struct StateParams {
     int parts;              // 1 = PCM history and subband tail (known once the QMF has run), 2 = last curves, 3 = both
 };
 
+// 16-bit PCM (at3hip_encode_s16): x = s / 32768.0f, what libsndfile's sf_readf_float hands the reference for a 16-bit WAV
+// (pcm_io_sndfile.cpp:111-113 -> TPCMEngine -> the lambda). 2^-15 is a power of two: the product IS the quotient. Eight samples
+// (16 bytes in, 32 out) per work-item; n8 = samples / 8 (a block is 1024 samples per channel, so the count divides).
+__global__ __launch_bounds__(256) void k_s16_to_f32(const int16_t* __restrict__ in, float* __restrict__ out, size_t n8)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n8) {
+        const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[2 * k] = (float)(int16_t)(w[k] & 0xffffu) * 0x1p-15f;
+            f[2 * k + 1] = (float)(int16_t)(w[k] >> 16) * 0x1p-15f;
+        }
+        reinterpret_cast<float4*>(out)[2 * i] = make_float4(f[0], f[1], f[2], f[3]);
+        reinterpret_cast<float4*>(out)[2 * i + 1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+}
+
 // One-channel input: every sample becomes an (L, R) = (x, x) pair in the layout the stereo pipeline reads.
 __global__ __launch_bounds__(256) void k_mono_to_pairs(const float* __restrict__ mono, float* __restrict__ pairs, size_t n)
 {

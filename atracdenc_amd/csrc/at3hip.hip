@@ -63,6 +63,7 @@ struct at3hip_ctx {
     // H2D copy of call N+1 runs beside the kernels of call N (pinned host memory: at3hip_host_alloc).
     hipStream_t h2d_stream = nullptr;
     float* d_pcm_in_b[2] = {nullptr, nullptr};      // [S][max_blocks][1024][channels]
+    int16_t* d_s16_b[2] = {nullptr, nullptr};       // the same as 16-bit samples (at3hip_encode_s16 with host memory), by call parity
     hipEvent_t ev_h2d[2] = {};                      // the parity's PCM has arrived
     hipEvent_t ev_pcm_free[2] = {};                 // the parity's staging has been consumed (front half done with it)
     bool pcm_free_valid[2] = {false, false};
@@ -435,6 +436,7 @@ void at3hip_destroy(at3hip_ctx* c)
     if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
     for (int q = 0; q < 2; ++q) {
         if (c->d_pcm_in_b[q]) (void)hipFree(c->d_pcm_in_b[q]);
+        if (c->d_s16_b[q]) (void)hipFree(c->d_s16_b[q]);
         if (c->ev_h2d[q]) (void)hipEventDestroy(c->ev_h2d[q]);
         if (c->ev_pcm_free[q]) (void)hipEventDestroy(c->ev_pcm_free[q]);
     }
@@ -566,10 +568,30 @@ int at3hip_get_timings(const at3hip_ctx* c, at3hip_timings* out)
     return AT3HIP_OK;
 }
 
+namespace {
+int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, uint8_t* out_frames, int32_t* n_frames_out, uint32_t flags);
+}
+
 int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* out_frames, int32_t* n_frames_out,
                   uint32_t flags)
 {
-    if (!c || !pcm || n_blocks < 1 || n_blocks > c->cfg.max_blocks) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
+    return encode_impl(c, pcm, false, n_blocks, out_frames, n_frames_out, flags);
+}
+
+int at3hip_encode_s16(at3hip_ctx* c, const int16_t* pcm, int32_t n_blocks, uint8_t* out_frames, int32_t* n_frames_out,
+                      uint32_t flags)
+{
+    return encode_impl(c, pcm, true, n_blocks, out_frames, n_frames_out, flags);
+}
+
+}  // extern "C"
+
+namespace {
+
+int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, uint8_t* out_frames, int32_t* n_frames_out, uint32_t flags)
+{
+    const float* pcm = (const float*)pcm_any;   // (float samples unless s16)
+    if (!c || !pcm_any || n_blocks < 1 || n_blocks > c->cfg.max_blocks) return c ? fail(c, AT3HIP_EINVAL, "bad argument") : AT3HIP_EINVAL;
     at3host::DeviceGuard guard(c->device);
     HIPCHK(c, guard.error());
     const int S = c->cfg.n_streams;
@@ -583,18 +605,31 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     const float* d_pcm = pcm;
     const size_t n_in = (size_t)S * n_blocks * 1024 * c->cfg.channels;
     const float* d_staged = pcm;   // the call's PCM in device memory, [S][n_blocks][1024][channels]
+    const bool staged = s16 || !(flags & AT3HIP_PCM_ON_DEVICE);   // the call's float samples live in this parity's staging buffer
+    if (staged && !c->d_pcm_in_b[par]) {
+        const int rc = dev_alloc(c, &c->d_pcm_in_b[par], (size_t)S * c->cfg.max_blocks * 1024 * c->cfg.channels);
+        if (rc != AT3HIP_OK) return rc;
+    }
     if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
         // host memory: the copy runs on its own stream into this parity's staging buffer - beside the previous call's
-        // kernels when the memory is pinned - and the front half waits for its arrival
-        if (!c->d_pcm_in_b[par]) {
-            const int rc = dev_alloc(c, &c->d_pcm_in_b[par], (size_t)S * c->cfg.max_blocks * 1024 * c->cfg.channels);
+        // kernels when the memory is pinned - and the front half waits for its arrival. 16-bit samples cross the bus as they
+        // are (half the bytes: the host-fed rate is bound by them) and become floats on the device, on the same stream.
+        if (s16 && !c->d_s16_b[par]) {
+            const int rc = dev_alloc(c, &c->d_s16_b[par], (size_t)S * c->cfg.max_blocks * 1024 * c->cfg.channels);
             if (rc != AT3HIP_OK) return rc;
         }
         if (c->pcm_free_valid[par]) HIPCHK(c, hipStreamWaitEvent(c->h2d_stream, c->ev_pcm_free[par], 0));
-        HIPCHK(c, hipMemcpyAsync(c->d_pcm_in_b[par], pcm, n_in * sizeof(float), hipMemcpyHostToDevice, c->h2d_stream));
+        if (s16) HIPCHK(c, hipMemcpyAsync(c->d_s16_b[par], pcm_any, n_in * sizeof(int16_t), hipMemcpyHostToDevice, c->h2d_stream));
+        else HIPCHK(c, hipMemcpyAsync(c->d_pcm_in_b[par], pcm, n_in * sizeof(float), hipMemcpyHostToDevice, c->h2d_stream));
         HIPCHK(c, hipEventRecord(c->ev_h2d[par], c->h2d_stream));
         c->h2d_valid[par] = true;
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_h2d[par], 0));
+        // (the conversion runs on the front stream, not behind the copy: the copy stream carries nothing but copies, back to back)
+        if (s16) hipLaunchKernelGGL(k_s16_to_f32, dim3((unsigned)((n_in / 8 + 255) / 256)), dim3(256), 0, st, c->d_s16_b[par], c->d_pcm_in_b[par], n_in / 8);
+        d_staged = c->d_pcm_in_b[par];
+    } else if (s16) {
+        // 16-bit samples already in HBM: converted on the front stream (which also carries everything that reads the staging)
+        hipLaunchKernelGGL(k_s16_to_f32, dim3((unsigned)((n_in / 8 + 255) / 256)), dim3(256), 0, st, (const int16_t*)pcm_any, c->d_pcm_in_b[par], n_in / 8);
         d_staged = c->d_pcm_in_b[par];
     }
     d_pcm = d_staged;
@@ -780,7 +815,7 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     }
     HIPCHK(c, hipEventRecord(c->ev_front_done, st));
     c->front_done_valid = true;
-    if (!(flags & AT3HIP_PCM_ON_DEVICE)) {   // (the PCM is read by the first stage and by the carried-state update, both on `st`)
+    if (staged) {   // (the PCM is read by the first stage and by the carried-state update, both on `st`)
         HIPCHK(c, hipEventRecord(c->ev_pcm_free[par], st));
         c->pcm_free_valid[par] = true;
     }
@@ -796,6 +831,10 @@ int at3hip_encode(at3hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     }
     return AT3HIP_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int at3hip_sync(at3hip_ctx* c)
 {

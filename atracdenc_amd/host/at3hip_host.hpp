@@ -193,6 +193,15 @@ public:
         frames.resize((size_t)NStreams * nf * FrameSz);
         return nf;
     }
+    // the same with 16-bit samples (converted s / 32768.0f on the device: a 16-bit WAV as sf_readf_float reads it)
+    int EncodeS16(const int16_t* pcm, int nBlocks, std::vector<uint8_t>& frames)
+    {
+        frames.resize((size_t)NStreams * nBlocks * FrameSz);
+        int32_t nf = 0;
+        Check(at3hip_encode_s16(Ctx, pcm, nBlocks, frames.data(), &nf, 0), Ctx, "at3hip_encode_s16");
+        frames.resize((size_t)NStreams * nf * FrameSz);
+        return nf;
+    }
     void Reset() { Check(at3hip_reset(Ctx), Ctx, "at3hip_reset"); }
     at3hip_ctx* Handle() { return Ctx; }
 
@@ -200,11 +209,27 @@ public:
     // calls are asynchronous, so while the GPU encodes call k the host thread fills call k + 1's buffer (`fill`), the copy
     // engine moves it, and call k - 1's frames come back and are handed to `drain` - what TPCMEngine::ApplyProcess
     // (pcmengin.h:152-192) and ICompressedOutput::WriteFrame do around the reference's lambda, batched.
-    //   fill(float* dst, int maxBlocks) -> blocks written, [nStreams][blocks][1024][channels]; 0 ends the input
+    //   fill(TSample* dst, int maxBlocks) -> blocks written, [nStreams][blocks][1024][channels]; 0 ends the input
     //   drain(const uint8_t* frames, int nFrames): [nStreams][nFrames][FrameSize()], in call order
+    // TSample = float, or int16_t (EncodePipelinedS16): 16-bit samples cross the bus at half the bytes - the host-fed rate is
+    // bound by exactly those - and become floats on the device.
     // Returns the number of frames per stream.
     template <class TFill, class TDrain>
     long long EncodePipelined(int blocksPerCall, int channels, TFill fill, TDrain drain)
+    {
+        return EncodePipelinedT<float>(blocksPerCall, channels, fill, drain);
+    }
+    template <class TFill, class TDrain>
+    long long EncodePipelinedS16(int blocksPerCall, int channels, TFill fill, TDrain drain)
+    {
+        return EncodePipelinedT<int16_t>(blocksPerCall, channels, fill, drain);
+    }
+
+private:
+    static int EncodeAny(at3hip_ctx* c, const float* pcm, int32_t nb, uint8_t* out, int32_t* nf, uint32_t flags) { return at3hip_encode(c, pcm, nb, out, nf, flags); }
+    static int EncodeAny(at3hip_ctx* c, const int16_t* pcm, int32_t nb, uint8_t* out, int32_t* nf, uint32_t flags) { return at3hip_encode_s16(c, pcm, nb, out, nf, flags); }
+    template <class TSample, class TFill, class TDrain>
+    long long EncodePipelinedT(int blocksPerCall, int channels, TFill fill, TDrain drain)
     {
         struct TPinned {
             at3hip_ctx* Ctx;
@@ -213,8 +238,8 @@ public:
             ~TPinned() { at3hip_host_free(Ctx, P); }
         };
         const size_t inFloats = (size_t)NStreams * blocksPerCall * 1024 * channels, outBytes = (size_t)NStreams * blocksPerCall * FrameSz;
-        TPinned in0(Ctx, inFloats * sizeof(float)), in1(Ctx, inFloats * sizeof(float)), out0(Ctx, outBytes), out1(Ctx, outBytes);
-        float* in[2] = {(float*)in0.P, (float*)in1.P};
+        TPinned in0(Ctx, inFloats * sizeof(TSample)), in1(Ctx, inFloats * sizeof(TSample)), out0(Ctx, outBytes), out1(Ctx, outBytes);
+        TSample* in[2] = {(TSample*)in0.P, (TSample*)in1.P};
         uint8_t* out[2] = {(uint8_t*)out0.P, (uint8_t*)out1.P};
         int32_t nf[2] = {0, 0};
         long long total = 0;
@@ -226,7 +251,7 @@ public:
             const int nb = fill(in[q], blocksPerCall);
             if (nb <= 0) break;
             // frames of call - 2 (same output buffer) were drained after call - 1 was queued: out[q] is free
-            Check(at3hip_encode(Ctx, in[q], nb, out[q], &nf[q], AT3HIP_ASYNC), Ctx, "at3hip_encode");
+            Check(EncodeAny(Ctx, in[q], nb, out[q], &nf[q], AT3HIP_ASYNC), Ctx, "at3hip_encode");
             if (call >= 1) {   // while this call runs: the previous call's frames
                 Check(at3hip_wait_frames(Ctx, 1), Ctx, "at3hip_wait_frames");
                 if (nf[q ^ 1] > 0) drain(out[q ^ 1], (int)nf[q ^ 1]);
@@ -246,7 +271,6 @@ public:
         return total;
     }
 
-private:
     at3hip_ctx* Ctx = nullptr;
     int NStreams;
     int FrameSz = 0;

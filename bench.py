@@ -319,20 +319,21 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
     return out
 
 
-def host_pipeline_workload(S, F, steps=400, warmup=8):
+def host_pipeline_workload(S, F, steps=400, warmup=8, s16=False):
     """configs[1] fed from HOST memory the way the reference's caller hands it over (pcmengin.h:152-192), PCIe included: two
     page-locked PCM buffers and two frame buffers alternate, the calls are asynchronous, so the H2D copy of call k + 1, the
     kernels of call k and the D2H copy of call k - 1 overlap (at3hip_host_alloc / at3hip_wait_*). Never part of `value`."""
-    out = {"workload": f"configs[1] from host memory: {S} x {F} frames per call, pinned double-buffered staging, H2D + kernels + D2H overlapped"}
+    out = {"workload": f"configs[1] from host memory: {S} x {F} frames per call, pinned double-buffered staging, H2D + kernels + D2H overlapped"
+                       + (", 16-bit samples (at3hip_encode_s16: converted on the device)" if s16 else ", float32 samples")}
     try:
         import torch
         import atracdenc_amd
         enc = atracdenc_amd.At3Hip(n_streams=S, max_blocks=F + 1, bitrate=LP2, device_id=0)
-        ins = [enc.host_alloc((S, F, 1024, 2), np.float32) for _ in range(2)]
+        ins = [enc.host_alloc((S, F, 1024, 2), np.int16 if s16 else np.float32) for _ in range(2)]
         outs = [enc.host_alloc((S, F, enc.frame_size), np.uint8) for _ in range(2)]
         rng = np.random.RandomState(5)
         for a in ins:
-            a[...] = rng.randint(-8192, 8192, size=a.shape).astype(np.float32) / np.float32(32768.0)
+            a[...] = rng.randint(-8192, 8192, size=a.shape).astype(np.int16) if s16 else rng.randint(-8192, 8192, size=a.shape).astype(np.float32) / np.float32(32768.0)
         prime = synth_pcm(S, 1, 99)
         enc.encode(prime)                      # LOOK_AHEAD call
         for i in range(warmup):
@@ -703,6 +704,7 @@ def main():
                     side_workload("shard_1024x128, 'noise', --nogaincontrol: k_qmf_mdct8 at the per-GPU shard", 1024, 128, LP2, "noise", 10, 2, no_gain=True),
                 ]
                 line["host_pipeline"] = host_pipeline_workload(64, 64)
+                line["host_pipeline_s16"] = host_pipeline_workload(64, 64, s16=True)
                 line["widened_rows"] = widened_rows(64)
         print(json.dumps(line))
     for j in jobs:

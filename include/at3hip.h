@@ -97,6 +97,14 @@ const char* at3hip_last_error(const at3hip_ctx* ctx);
 int at3hip_encode(at3hip_ctx* ctx, const float* pcm, int32_t n_blocks, uint8_t* out_frames,
                   int32_t* n_frames_out, uint32_t flags);
 
+/* The same with 16-bit PCM: pcm [n_streams][n_blocks][1024][channels] int16, interleaved; every sample becomes
+ * s / 32768.0f on the device - what libsndfile's sf_readf_float hands the reference's TPCMEngine for a 16-bit WAV
+ * (pcm_io_sndfile.cpp:111-113, pcmengin.h:173-184) - so the frames equal at3hip_encode's on those floats byte for byte.
+ * Half the bytes per frame cross the bus: a host-fed context is bound by them ("Host buffers"). Same
+ * flags, same stream state (calls of both kinds may alternate on one context). */
+int at3hip_encode_s16(at3hip_ctx* ctx, const int16_t* pcm, int32_t n_blocks, uint8_t* out_frames, int32_t* n_frames_out,
+                      uint32_t flags);
+
 /* Back to start-of-stream state for every stream (a fresh TAtrac3Encoder). */
 int at3hip_reset(at3hip_ctx* ctx);
 

@@ -144,6 +144,46 @@ int main()
         EXPECT(nfp == nf && piped.size() == frames.size());
         EXPECT(memcmp(piped.data(), frames.data(), frames.size()) == 0);
         printf("TAtrac3EncoderNode::EncodePipelined (pinned staging, 5 calls of <= 2 blocks) compared\n");
+        // 16-bit samples: TAtrac3EncoderBatch::EncodeS16 and the 16-bit pipeline against the float path on s / 32768.0f
+        std::vector<int16_t> b16((size_t)S * n * 2048);
+        std::vector<float> bf((size_t)S * n * 2048);
+        for (size_t i = 0; i < b16.size(); ++i) {
+            b16[i] = (int16_t)lrintf(std::max(-32768.0f, std::min(32767.0f, batch[i] * 32768.0f)));
+            bf[i] = (float)b16[i] / 32768.0f;
+        }
+        TAtrac3EncoderBatch fb(st, S, n), sb(st, S, n), pb(st, S, n);
+        std::vector<uint8_t> ff, fs, fp;
+        const int nff = fb.Encode(bf.data(), n, ff), nfs = sb.EncodeS16(b16.data(), n, fs);
+        EXPECT(nff == nfs && ff == fs);
+        int fed = 0;
+        const long long tot = pb.EncodePipelinedS16(
+            2, 2,
+            [&](int16_t* dst, int maxBlocks) {
+                const int nbk = std::min(maxBlocks, n - fed);
+                for (int s = 0; s < S && nbk > 0; ++s) memcpy(dst + (size_t)s * nbk * 2048, b16.data() + ((size_t)s * n + fed) * 2048, (size_t)nbk * 2048 * sizeof(int16_t));
+                fed += nbk > 0 ? nbk : 0;
+                return nbk;
+            },
+            [&](const uint8_t* fr, int nfr) {
+                const size_t at = fp.size() / ((size_t)S * sb.FrameSize());   // frames per stream so far
+                fp.resize(fp.size() + (size_t)S * nfr * sb.FrameSize());
+                // (kept call-major here; compared call by call below)
+                memcpy(fp.data() + at * S * sb.FrameSize(), fr, (size_t)S * nfr * sb.FrameSize());
+            });
+        EXPECT(tot == nfs);
+        {   // the calls returned 1, 2, 2, 2, 1 frames per stream: stream-major inside each call
+            const int fsz = sb.FrameSize();
+            size_t off = 0;
+            int done = 0;
+            const int per_call[5] = {1, 2, 2, 2, 1};
+            for (int cidx = 0; cidx < 5; ++cidx) {
+                for (int s = 0; s < S; ++s)
+                    EXPECT(memcmp(fp.data() + off + (size_t)s * per_call[cidx] * fsz, fs.data() + ((size_t)s * nfs + done) * fsz, (size_t)per_call[cidx] * fsz) == 0);
+                off += (size_t)S * per_call[cidx] * fsz;
+                done += per_call[cidx];
+            }
+        }
+        printf("TAtrac3EncoderBatch::EncodeS16 / EncodePipelinedS16 compared with the float path\n");
     }
     // ---- TAt3PEncoder: 5 stereo frames of 2048 samples through a batch of 2; look-ahead call, silent first frame ----
     {

@@ -11,7 +11,7 @@ def test_library_exports_every_declared_symbol():
         atracdenc_amd.build_library()
     lib = atracdenc_amd.load_library()
     header = open(os.path.join(os.path.dirname(atracdenc_amd.__file__), "..", "include", "at3hip.h")).read()
-    declared = set(re.findall(r"\b(at3hip_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(at3hip_[a-z0-9_]+)\s*\(", header))
     assert declared == set(atracdenc_amd.binding.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name

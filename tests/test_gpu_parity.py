@@ -149,6 +149,49 @@ def test_gain_analysis_forms_agree(hip, oracle, br):
     assert got[1][..., 0].any()          # the material does produce gain curves
 
 
+@pytest.mark.parametrize("br", [LP2, LP4])
+@pytest.mark.parametrize("channels", [2, 1])
+def test_s16_entry_point(hip, oracle, br, channels):
+    """at3hip_encode_s16: 16-bit samples converted s / 32768.0f on the device (what sf_readf_float gives the reference for a
+    16-bit WAV) == at3hip_encode on those floats == the oracle, byte for byte; host and device pointers, calls of both kinds
+    alternating on one context (shared stream state), full-scale and -32768 samples included."""
+    import torch
+    nb = 12
+    rng = np.random.RandomState(21)
+    base = np.stack([np.round(np.clip(SIGNALS[n](nb), -1.0, 32767.0 / 32768.0) * 32768.0).astype(np.int16) for n in ("burst", "mix", "tones")])
+    wild = rng.randint(-32768, 32768, size=base[:1].shape).astype(np.int16)
+    wild[0, 0, :4] = [[-32768, 32767], [32767, -32768], [0, -1], [1, 0]]
+    s16 = np.concatenate([base, wild])[..., :channels].copy()
+    f32 = (s16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    S = s16.shape[0]
+    exp = np.stack([oracle.encode(f32[i], br)[0] for i in range(S)]) if channels == 2 else None   # (one-channel contexts: see test_mono_*)
+    a = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=br, channels=channels)
+    ref = a.encode(f32)
+    a.close()
+    if exp is not None:
+        assert np.array_equal(ref, exp)
+    b = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=br, channels=channels)
+    got = b.encode_s16(s16)                                  # host pointer
+    b.close()
+    assert np.array_equal(got, ref)
+    c = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=br, channels=channels)
+    d_s16 = torch.from_numpy(s16).cuda()
+    fsz = c.frame_size
+    outs = []
+    for lo, hi, kind in ((0, 3, "f32"), (3, 7, "s16dev"), (7, 8, "s16"), (8, 12, "s16dev")):   # alternating kinds, one stream state
+        if kind == "f32":
+            outs.append(c.encode(f32[:, lo:hi]))
+        elif kind == "s16":
+            outs.append(c.encode_s16(s16[:, lo:hi]))
+        else:
+            piece = d_s16[:, lo:hi].contiguous()
+            d_out = torch.zeros((S, hi - lo, fsz), dtype=torch.uint8, device="cuda")
+            n = c.encode_device_s16(piece.data_ptr(), hi - lo, d_out.data_ptr())
+            outs.append(d_out[:, :n].cpu().numpy())
+    c.close()
+    assert np.array_equal(np.concatenate(outs, axis=1), ref)
+
+
 def _raw_spectra(hip, pcm, br=LP2):
     """Spectra BEFORE the tonal lines are removed: the same stream with NoTonalComponents (the spectra tap is untouched)."""
     from atracdenc_amd import binding as B

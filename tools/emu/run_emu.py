@@ -40,7 +40,12 @@ if __name__ == "__main__":
                     from atracdenc_amd.binding import OPT_GAIN_TWO_WAVES
                     enc.set_option(OPT_GAIN_TWO_WAVES, gain_form)
                 # feed in two pieces to exercise the carried state
-                got = np.concatenate([enc.encode(pcm[:, :4]), enc.encode(pcm[:, 4:])], axis=1)
+                if "--s16" in sys.argv:   # at3hip_encode_s16: the same samples as 16-bit integers, converted on the "device"
+                    p16 = np.round(np.clip(pcm, -1.0, 32767.0 / 32768.0) * 32768.0).astype(np.int16)
+                    pcm = (p16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+                    got = np.concatenate([enc.encode_s16(p16[:, :4]), enc.encode(pcm[:, 4:5]), enc.encode_s16(p16[:, 5:])], axis=1)
+                else:
+                    got = np.concatenate([enc.encode(pcm[:, :4]), enc.encode(pcm[:, 4:])], axis=1)
                 enc.close()
                 exp = np.stack([o.encode(pcm[i], br, ng, nt)[0] for i in range(2)])
                 bad = (got != exp).any(axis=2)
