@@ -286,6 +286,18 @@ def timed_region(jobs, steps, dist):
     return elapsed
 
 
+def kernel_source_sha16():
+    """Hash of the kernel sources of this tree (the same function as tools/summarize_prof.py stamps its profiles with)."""
+    import hashlib
+    csrc = os.path.join(ROOT, "atracdenc_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hpp", ".hip", ".cpp", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def roofline_of(k1_avg_ms, frames_per_launch):
     achieved = ALGO_BYTES_PER_FRAME_K1 * frames_per_launch / (k1_avg_ms * 1e-3) / 1e9
     return round(achieved, 2), round(achieved / HBM_PEAK_GBS, 5)
@@ -558,8 +570,13 @@ def main():
         prof = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(prof) and (S, F) == (64, 64):
             try:
-                traffic = json.load(open(prof)).get("bytes_per_launch")
-                traffic_note = ("read from profiles/k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on "
+                tj = json.load(open(prof))
+                traffic = tj.get("bytes_per_launch")
+                if tj.get("kernel_source_sha16") != kernel_source_sha16():
+                    traffic_note = "STALE (profiles/k1_traffic.json was collected on other kernel sources than this tree's): "
+                else:
+                    traffic_note = ""
+                traffic_note += ("read from profiles/k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel on "
                                 "this workload, collected separately as the guide prescribes) - not measured in this run")
             except Exception:
                 traffic = None
@@ -570,13 +587,14 @@ def main():
         if os.path.exists(pt) and (S, F) == (64, 64) and not args.no_gain and fsz == 384:
             try:
                 pj = json.load(open(pt))
-                pipe_traffic = {"pipeline_bytes_per_frame": round(pj["pipeline_bytes_per_frame"], 1),
+                profile_stale = pj.get("kernel_source_sha16") != kernel_source_sha16()
+                pipe_traffic = {"profile_is_of_these_kernel_sources": not profile_stale, "pipeline_bytes_per_frame": round(pj["pipeline_bytes_per_frame"], 1),
                                 "algorithmic_bytes_per_frame": pj["algorithmic_bytes_per_frame"],
                                 "source": "profiles/pipeline_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE summed over the pipeline's "
                                           "kernels, separate passes, this workload - not measured in this run"}
                 # Issue floors. SQ_INSTS_VALU per kernel (profiles/pipeline_traffic.json) priced with the measured issue costs
-                # (tools/ubench, profiles/r02_ubench_instruction_rates.txt): 1.29 ns per plain wave-instruction and SIMD, 2.37 ns
-                # per packed fp32 one; the packed share of a kernel comes from the compiler's assembly (profiles/valu_mix.json)
+                # (tools/ubench, profiles/r04_ubench_instruction_rates.txt: resident wavefronts counted, shader clock 2.1 - 2.4 GHz under
+                # load): ~1.3 ns (2.5 - 3.2 cycles) per plain wave-instruction and SIMD, ~2.1 ns (4.3 - 4.6 cycles) per packed fp32 one; the packed share of a kernel comes from the compiler's assembly (profiles/valu_mix.json)
                 mix = {}
                 mp = os.path.join(ROOT, "profiles", "valu_mix.json")
                 if os.path.exists(mp):
@@ -584,13 +602,13 @@ def main():
                 n_simd = 1024
 
                 def floor_ms(counts):
-                    return sum(n * (mix.get(k, 0.0) * 2.37e-6 + (1.0 - mix.get(k, 0.0)) * 1.29e-6) for k, n in counts.items()) / n_simd
+                    return sum(n * (mix.get(k, 0.0) * 2.1e-6 + (1.0 - mix.get(k, 0.0)) * 1.3e-6) for k, n in counts.items()) / n_simd
 
                 k1_counts = pj.get("valu_wave_insts_per_launch", {})
                 if k1_counts:
                     valu_floor_ms = floor_ms(k1_counts)
                     valu_note = (f"{int(sum(k1_counts.values()))} vector wave-instructions per launch pair (SQ_INSTS_VALU, profiles/pipeline_traffic.json) / "
-                                 f"{n_simd} SIMDs, a plain fp32 instruction priced at its measured 1.29 ns of issue and a packed one at 2.37 ns "
+                                 f"{n_simd} SIMDs, a plain fp32 instruction priced at its measured 1.3 ns of issue (2.5 - 3.2 cycles at the observed 2.1 - 2.4 GHz) and a packed one at 2.1 ns "
                                  "(packed share per kernel from the compiler's assembly, profiles/valu_mix.json; the arithmetic contract "
                                  "forbids FMA, so the multiply-add pairs of the FIR are two packed instructions each)")
                 all_counts = pj.get("valu_wave_insts_per_launch_all", {})

@@ -1,9 +1,22 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 rocpd databases (kernel stats + PMC passes) into a short text summary for profiles/.
 usage: summarize_prof.py <dir with stats/ pmc_fetch/ pmc_write/ pmc_sq/>"""
-import glob, os, sqlite3, sys
+import glob, hashlib, os, sqlite3, sys
 
 root = sys.argv[1]
+
+
+def kernel_source_sha16():
+    """Hash of the kernel sources the profiled library was built from: bench.py compares it with the tree it runs in and marks
+    figures it derives from a profile of OTHER sources as stale."""
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "atracdenc_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hpp", ".hip", ".cpp", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
 
 def dbs(sub):
     return sorted(glob.glob(os.path.join(root, sub, "**", "*.db"), recursive=True))
@@ -63,6 +76,7 @@ if parts:
         "note": "bytes_per_launch = the kernels' sum: with gain control the subbands cross HBM between the two kernels (8 KB written + 8 KB "
                 "read per frame on top of the 16 KB of PCM in and spectra out) because the gain analysis needs them there anyway",
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/profile_gpu.sh)",
+        "kernel_source_sha16": kernel_source_sha16(),
     }
     json.dump(out, open(os.path.join(root, "k1_traffic.json"), "w"), indent=1)
     print("== k1 traffic ==", json.dumps(out))
@@ -84,7 +98,7 @@ if ours:
     rows = {k: {"FETCH_SIZE_KiB_raw": fetch[k], "WRITE_SIZE_KiB": write[k], "bytes_per_launch": (2.0 * fetch[k] + write[k]) * 1024.0} for k in sorted(ours)}
     mult = {k: (2 if k.startswith("k_state_update") else 1) for k in rows}
     total = sum(rows[k]["bytes_per_launch"] * mult[k] for k in rows)
-    out = {"workload": "64 streams x 64 frames (4096 frames per step), synchronous steps", "kernels": rows,
+    out = {"workload": "64 streams x 64 frames (4096 frames per step), synchronous steps", "kernels": rows, "kernel_source_sha16": kernel_source_sha16(),
            "bytes_per_step": total, "pipeline_bytes_per_frame": total / frames, "algorithmic_bytes_per_frame": 8192 + 384,
            "correction": "FETCH_SIZE x2 + WRITE_SIZE per kernel (MI355X_MICROARCH.md, HBM section), separate --pmc passes",
            "valu_wave_insts_per_launch": {k: v for k, v in valu.items() if k.startswith(("k_qmf", "k_mdct_sub"))},

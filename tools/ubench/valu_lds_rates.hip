@@ -151,8 +151,10 @@ __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, float 
     for (int i = 0; i < 16; ++i) s += a[i] + p[i].x + p[i].y;
     out[blockIdx.x * 256 + tid] = s;
     if ((tid & 63) == 0) {
-        cyc[(blockIdx.x * 4 + (tid >> 6)) * 2] = t1 - t0;
-        cyc[(blockIdx.x * 4 + (tid >> 6)) * 2 + 1] = r1 - r0;
+        cyc[(blockIdx.x * 4 + (tid >> 6)) * 4] = t1 - t0;
+        cyc[(blockIdx.x * 4 + (tid >> 6)) * 4 + 1] = r1 - r0;
+        cyc[(blockIdx.x * 4 + (tid >> 6)) * 4 + 2] = r0;   // when the wavefront's loop began and ended (100 MHz reference, one clock for the whole device)
+        cyc[(blockIdx.x * 4 + (tid >> 6)) * 4 + 3] = r1;
     }
 }
 
@@ -175,21 +177,30 @@ void run(const char* name, int per_iter_instr, int wgs_per_cu, float* d_out, lon
     hipDeviceSynchronize();
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    std::vector<long long> c(grid * 4 * 2);
+    std::vector<long long> c(grid * 4 * 4);
     hipMemcpy(c.data(), d_cyc, c.size() * sizeof(long long), hipMemcpyDeviceToHost);
     double avg = 0, avg_rt = 0;
-    for (size_t i = 0; i < c.size(); i += 2) {
+    long long first = c[2], last = c[3];
+    for (size_t i = 0; i < c.size(); i += 4) {
         avg += (double)c[i];
         avg_rt += (double)c[i + 1];
+        first = c[i + 2] < first ? c[i + 2] : first;
+        last = c[i + 3] > last ? c[i + 3] : last;
     }
-    avg /= c.size() / 2;
-    avg_rt /= c.size() / 2;
+    // how many wavefronts REALLY shared a SIMD on average: the wavefronts' loop times added up, over the span from the first
+    // loop's begin to the last one's end, per SIMD (the dispatcher does not always place what the grid asks for side by side)
+    const double resident = avg_rt * 0.0 + (avg_rt > 0 ? (avg_rt) : 0);   // (sum below)
+    (void)resident;
+    const double sum_rt = avg_rt;
+    avg /= c.size() / 4;
+    avg_rt /= c.size() / 4;
+    const double true_waves = sum_rt / ((double)(last - first) * 1024.0);
     const double n = (double)iters * per_iter_instr;
     // s_memtime ticks = shader cycles, s_memrealtime = 100 MHz: their ratio is the shader clock UNDER THIS LOAD; cycles per
     // wave-instruction per SIMD = the wave's cycles per instruction / the waves that share the SIMD
     const double mhz = avg / avg_rt * 100.0;
-    printf("%-30s waves/SIMD=%d  sclk=%6.0f MHz  cyc/instr(wave)=%7.3f  cyc/instr/SIMD=%6.3f  wall %9.3f us => %6.3f ns per instr-slot/SIMD\n", name,
-           wgs_per_cu, mhz, avg / n, avg / n / wgs_per_cu, ms * 1e3, ms * 1e6 / n / wgs_per_cu);
+    printf("%-30s waves/SIMD asked %d resident %4.2f  sclk=%5.0f MHz  cyc/instr(wave)=%7.3f  cyc/instr/SIMD=%6.3f (= %5.3f ns)  loops span %8.2f us, kernel %8.2f us\n", name,
+           wgs_per_cu, true_waves, mhz, avg / n, avg / n / true_waves, avg / n / true_waves / mhz * 1e3, (double)(last - first) / 100.0, ms * 1e3);
 }
 
 int main()
@@ -197,7 +208,7 @@ int main()
     float* d_out;
     long long* d_cyc;
     hipMalloc(&d_out, 256 * 8 * 256 * sizeof(float));
-    hipMalloc(&d_cyc, 256 * 8 * 4 * 2 * sizeof(long long));
+    hipMalloc(&d_cyc, 256 * 8 * 4 * 4 * sizeof(long long));
     for (int w : {1, 2, 3, 4, 6, 8}) {
         run<0>("v_mul_f32", 16, w, d_out, d_cyc);
         run<1>("v_add_f32", 16, w, d_out, d_cyc);
