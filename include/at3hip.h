@@ -190,6 +190,11 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
  *   AT3HIP_OPT_FLATNESS_LITERAL  1 = every spectral-flatness measure (CalcSpectralFlatnessPerBfu,
  *                                atrac_psy_common.cpp:158-199) by the literal per-line form; 0 (default) = the short form
  *                                with the literal one as fall-back where rounding could matter. Same values either way.
+ *                                SUPPORTED REFERENCE PLATFORM: both forms restate glibc 2.35's f64 log / exp (and log2f) in the
+ *                                variants its ifunc picks on an x86-64 host WITH FMA; glibc selects per CPU, so on a host without
+ *                                FMA the reference itself rounds differently in rare last-bit cases and "bit-identical" then means
+ *                                identical to the reference run on an FMA host (every box in play). tests/test_libm64.py and the
+ *                                gpu-marked pin check the host's libm against the restatement.
  *   AT3HIP_OPT_QUANT_TAP         1 = keep the AT3HIP_TAP_QUANT records (3.5 KB written per frame; off by default). */
 #define AT3HIP_OPT_RUNS 1
 #define AT3HIP_OPT_FLATNESS_LITERAL 2
