@@ -184,13 +184,25 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
     // Four rounds of four lines per lane, line0 = 256 round + 4 lane: a wavefront's 16-byte LDS accesses are one contiguous
     // kilobyte (sixteen lines per lane, the first layout, put every fourth lane on the same banks).
     int wl_h[4];
+    // the four rounds' cross-lane reads first, all in flight together (two dependent round trips for the call instead of two per
+    // round): the wordlen of every round's BFU, then MaxQuant and 1 / MaxQuant^2 of those wordlens
+    float mul_h[4], inv2_h[4];
+    {
+        int wl_r[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) wl_r[h] = __builtin_amdgcn_ds_bpermute(4 * (int)((tab.bfus >> (8 * h)) & 0xffu), bits);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            mul_h[h] = tab_f(tab.mq, wl_r[h]);
+            inv2_h[h] = tab_f(tab.inv, wl_r[h]);
+            wl_h[h] = ((need >> ((tab.bfus >> (8 * h)) & 0xffu)) & 1u) ? wl_r[h] : 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int line0 = 256 * h + 4 * lane;
-        const int b = (int)((tab.bfus >> (8 * h)) & 0xffu);
-        const int wl = __builtin_amdgcn_ds_bpermute(4 * b, bits);
-        wl_h[h] = ((need >> b) & 1u) ? wl : 0;
-        const float mul = tab_f(tab.mq, wl), inv2 = tab_f(tab.inv, wl);
+        const float mul = mul_h[h], inv2 = inv2_h[h];
         if (wl_h[h]) {
             const float4 va = *reinterpret_cast<const float4*>(L.val + line0);
             const float v[4] = {va.x, va.y, va.z, va.w};
@@ -302,6 +314,9 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             const int start = kEaLine0 + 32 * (bfu - 19), ustart = start - kEaLine0, line = start + l;   // == bfu_start(bfu) for BFUs 19..25
             const uint32_t want = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)my_want);
             const float mul = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_mul)));   // == max_quant(wordlen of the unit)
+            // (the line's value and mantissa are requested with its code, not behind the ballot: one LDS round trip less per pass)
+            const float val_l = L.val[line];
+            const int m0_l = (int)L.bm[line - kTermLine0];
             const bool flag = has && ((L.code[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;
             const unsigned long long mask = __ballot(flag);
             const uint32_t hm = half ? (uint32_t)(mask >> 32) : (uint32_t)mask;
@@ -311,10 +326,10 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             uint32_t recv = 0u;
             if (flag) {
                 const int slot = __popc(hm & ((1u << l) - 1u));
-                const float t = L.val[line] * mul;
+                const float t = val_l * mul;
                 key = fabsf(t - (truncf(t) + 0.5f));
                 uk[slot] = key;
-                const int m0 = (int)L.bm[line - kTermLine0];
+                const int m0 = m0_l;
                 const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
                 recv = (uint32_t)l | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12);
             }
@@ -351,14 +366,16 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                 recv[r] = 0u;
                 if (r == 1 && n <= 64) continue;   // (uniform) only the two 128-line units have a second round
                 const int j = 64 * r + lane, line = start + j;
+                const float val_l = L.val[line];
+                const int m0_l = (int)L.bm[line - kTermLine0];
                 flag[r] = j < n && ((L.code[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;
                 const unsigned long long mask = __ballot(flag[r]);
                 if (flag[r]) {
                     const int slot = cnt_u + __popcll(mask & ((1ull << lane) - 1ull));
-                    const float t = L.val[line] * mul;
+                    const float t = val_l * mul;
                     key[r] = fabsf(t - (truncf(t) + 0.5f));   // sort key |delta|
                     L.uk[slot] = key[r];
-                    const int m0 = (int)L.bm[line - kTermLine0];
+                    const int m0 = m0_l;
                     const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
                     recv[r] = (uint32_t)j | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12);
                 }
@@ -494,10 +511,14 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
     // A unit's lines sit in 4, 8, 16 or 32 NEIGHBOURING lanes of one round (16-, 32-, 64-, 128-line BFUs from line 96 on, all
     // aligned to their own size), so its bit count is a sum over a quad, a half row, a row or two rows: DPP adds, no
     // LDS traffic (the first version added every lane's count to a per-BFU LDS counter: up to 32 lanes on one address).
+    VlcRow row_h[4];   // (the four rounds' length rows requested together)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) row_h[h] = tab_row(tab, wl_h[h]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int wl = wl_h[h];
-        const VlcRow row = tab_row(tab, wl);
+        const VlcRow row = row_h[h];
         uint32_t vb = 0;
         if (wl) {
             const int line0 = 256 * h + 4 * lane;
@@ -807,17 +828,32 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 
     // ---- scaled values (TScaler::Scale, atrac_scale.cpp:141-172) and e1 = sum of value^2 per BFU, in line order ----
     const int my_sfi = rec->sfi[lane & 31];   // one load per lane (lanes 32..63 mirror 0..31)
+    // requested with the spectrum, wanted by CalcBitsAllocation's per-BFU constants after the small units: fetched where they are
+    // used, each was a global-memory round trip of its own on the wavefront's chain (the fences of the LDS phases keep the
+    // compiler from moving them up)
+    const int pre_band = (lane & 31) >= 30 ? 3 : (lane & 31) >= 26 ? 2 : (lane & 31) >= 18 ? 1 : 0;
+    const float pre_g = p.ges ? p.ges[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + pre_band] : 1.0f;
+    const float pre_energy = rec->energy[lane & 31];
+    const float pre_ath = T->ath_bfu[lane & 31];
     {
         const float* specs = p.specs + cf * 1024;
         const float my_scale = T->scale[lane];   // ScaleTable has 64 entries: looked up across lanes, not through memory
         float4 x4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) x4[k] = *reinterpret_cast<const float4*>(specs + 4 * (lane + 64 * k));
+        // (the four rounds' scale factors first: two cross-lane round trips in all, not two per round)
+        float sf4[4];
+        {
+            int sfi4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sfi4[k] = __builtin_amdgcn_ds_bpermute(4 * bfu_of_line(4 * (lane + 64 * k)), my_sfi);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sf4[k] = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * sfi4[k], (int)__float_as_uint(my_scale)));
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i0 = 4 * (lane + 64 * k);
-            const int sfi = __builtin_amdgcn_ds_bpermute(4 * bfu_of_line(i0), my_sfi);
-            const float sf = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * sfi, (int)__float_as_uint(my_scale)));
+            const float sf = sf4[k];
             const float4 x = x4[k];
             float v[4] = {x.x / sf, x.y / sf, x.z / sf, x.w / sf};
 #pragma unroll
@@ -830,13 +866,23 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     AT3_PH_END(pc, 0);
     float my_e1 = 0.0f;   // lane b < 32: e1 of BFU b
     if (lane < 32) {
+        // eight values per step, the next eight requested before this step's chain of additions runs (the chain of the 128-line
+        // BFUs is sixteen steps long: every step used to wait for its own LDS reads)
         const int start = bfu_start(lane), n = bfu_start(lane + 1) - start;
+        const float4* v4 = reinterpret_cast<const float4*>(L.val + start);
         float acc = 0.0f;
+        float4 a = v4[0], b = v4[1];
         for (int off = 0; off < n; off += 8) {
-            const float4 a = *reinterpret_cast<const float4*>(L.val + start + off), b = *reinterpret_cast<const float4*>(L.val + start + off + 4);
+            float4 na = a, nb = b;
+            if (off + 8 < n) {
+                na = v4[(off >> 2) + 2];
+                nb = v4[(off >> 2) + 3];
+            }
             const float term[8] = {a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w, b.x * b.x, b.y * b.y, b.z * b.z, b.w * b.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc += term[k];
+            a = na;
+            b = nb;
         }
         my_e1 = acc;
     }
@@ -922,13 +968,12 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         if (i >= 18) band = 1;
         if (i >= 26) band = 2;
         if (i >= 30) band = 3;
-        float g = 1.0f;
-        if (p.ges) g = p.ges[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + band];
+        float g = pre_g;   // (band == pre_band: the same BFU ranges)
         if (!(isfinite(g) && g > 0.0f)) g = 1.0f;
-        const float corrected = rec->energy[i] * g;
-        const float ath = T->ath_bfu[i] * loudness;
+        const float corrected = pre_energy * g;
+        const float ath = pre_ath * loudness;
         gate = corrected < ath;
-        const float csfi = fmaxf(0.0f, fminf(63.0f, (float)rec->sfi[i] + 1.5f * at3_log2f(T, g)));
+        const float csfi = fmaxf(0.0f, fminf(63.0f, (float)my_sfi + 1.5f * at3_log2f(T, g)));
         float x = 6.0f;
         if (i < 3) x = 2.8f;
         else if (i < 10) x = 2.6f;
