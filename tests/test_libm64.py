@@ -9,13 +9,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_check(tmp_path, n):
+def run_check(tmp_path, n, skip_ok=True):
     exe = str(tmp_path / "test_libm64")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", os.path.join(ROOT, "tests", "host", "test_libm64.cpp"),
                            "-o", exe, "-lm"])
     r = subprocess.run([exe, str(n)], capture_output=True, text=True)
     if r.returncode == 77:
-        pytest.skip(r.stdout.strip())
+        if skip_ok:
+            pytest.skip(r.stdout.strip())
+        pytest.fail("this host's libm does not run the variants at3_libm64.hpp restates (no FMA): frames are then bit-identical to the "
+                    "reference as an FMA host runs it, not to this host's - see README, 'Supported reference platform'. " + r.stdout.strip())
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 mismatches; exp:" in r.stdout and r.stdout.rstrip().endswith(" 0 mismatches"), r.stdout
     return r.stdout
@@ -41,4 +44,4 @@ def test_generated_data_is_current():
 @pytest.mark.gpu
 def test_restated_log_exp_equal_libm_on_the_gpu_box(tmp_path):
     """The same check on the host that builds the product's tables and runs the reference for cpu_baseline."""
-    run_check(tmp_path, 500000)
+    run_check(tmp_path, 500000, skip_ok=False)   # on the measurement box a mismatch of platforms must be loud, not a skip
