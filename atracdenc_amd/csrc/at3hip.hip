@@ -69,6 +69,11 @@ struct at3hip_ctx {
     bool pcm_free_valid[2] = {false, false};
     bool h2d_valid[2] = {false, false};
     hipEvent_t ev_back_done[2] = {};     // back half finished with the parity's cross buffers
+    // what the HOST waits for (at3hip_wait_input / at3hip_wait_frames), per call in a ring of four: the parity events above are
+    // re-recorded by the call after next, so a caller with three calls in flight would wait for the newest of them
+    static constexpr int kHostRing = 4;
+    hipEvent_t ev_host_in[kHostRing] = {}, ev_host_out[kHostRing] = {};
+    bool host_in_valid[kHostRing] = {}, host_out_valid[kHostRing] = {};
     bool back_done_valid[2] = {false, false};
     long long enc_calls = 0;             // at3hip_encode calls so far
     int last_slot = -1;                  // slot of the most recent call that produced frames
@@ -347,6 +352,10 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if (hipEventCreateWithFlags(&c->ev_front_done, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
     for (auto& e : c->ev_back_done)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    for (int q = 0; q < at3hip_ctx::kHostRing; ++q)
+        if (hipEventCreateWithFlags(&c->ev_host_in[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_host_out[q], hipEventDisableTiming) != hipSuccess)
+            return bail(AT3HIP_EDEVICE);
     for (auto& e : c->ev_mid_done)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
 
@@ -444,6 +453,10 @@ void at3hip_destroy(at3hip_ctx* c)
     if (c->ev_front_done) (void)hipEventDestroy(c->ev_front_done);
     for (auto& e : c->ev_back_done)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_host_in)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_host_out)
+        if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_mid_done)
         if (e) (void)hipEventDestroy(e);
     if (c->mid_stream) (void)hipStreamDestroy(c->mid_stream);
@@ -492,21 +505,21 @@ int at3hip_host_free(at3hip_ctx* c, void* p)
 
 int at3hip_wait_input(at3hip_ctx* c, int32_t ago)
 {
-    if (!c || ago < 0 || ago > 1 || ago >= c->enc_calls) return AT3HIP_EINVAL;
+    if (!c || ago < 0 || ago >= at3hip_ctx::kHostRing || ago >= c->enc_calls) return AT3HIP_EINVAL;
     at3host::DeviceGuard guard(c->device);
     HIPCHK(c, guard.error());
-    const int par = (int)((c->enc_calls - 1 - ago) & 1);
-    if (c->h2d_valid[par]) HIPCHK(c, hipEventSynchronize(c->ev_h2d[par]));
+    const int q = (int)((c->enc_calls - 1 - ago) % at3hip_ctx::kHostRing);
+    if (c->host_in_valid[q]) HIPCHK(c, hipEventSynchronize(c->ev_host_in[q]));
     return AT3HIP_OK;
 }
 
 int at3hip_wait_frames(at3hip_ctx* c, int32_t ago)
 {
-    if (!c || ago < 0 || ago > 1 || ago >= c->enc_calls) return AT3HIP_EINVAL;
+    if (!c || ago < 0 || ago >= at3hip_ctx::kHostRing || ago >= c->enc_calls) return AT3HIP_EINVAL;
     at3host::DeviceGuard guard(c->device);
     HIPCHK(c, guard.error());
-    const int par = (int)((c->enc_calls - 1 - ago) & 1);
-    if (c->back_done_valid[par]) HIPCHK(c, hipEventSynchronize(c->ev_back_done[par]));
+    const int q = (int)((c->enc_calls - 1 - ago) % at3hip_ctx::kHostRing);
+    if (c->host_out_valid[q]) HIPCHK(c, hipEventSynchronize(c->ev_host_out[q]));
     return AT3HIP_OK;
 }
 
@@ -605,6 +618,8 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
     const float* d_pcm = pcm;
     const size_t n_in = (size_t)S * n_blocks * 1024 * c->cfg.channels;
     const float* d_staged = pcm;   // the call's PCM in device memory, [S][n_blocks][1024][channels]
+    const int hq = (int)(c->enc_calls % at3hip_ctx::kHostRing);   // this call's slot in the host-visible event ring
+    bool host_in_recorded = false, host_out_recorded = false;
     const bool staged = s16 || !(flags & AT3HIP_PCM_ON_DEVICE);   // the call's float samples live in this parity's staging buffer
     if (staged && !c->d_pcm_in_b[par]) {
         const int rc = dev_alloc(c, &c->d_pcm_in_b[par], (size_t)S * c->cfg.max_blocks * 1024 * c->cfg.channels);
@@ -623,6 +638,8 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         else HIPCHK(c, hipMemcpyAsync(c->d_pcm_in_b[par], pcm, n_in * sizeof(float), hipMemcpyHostToDevice, c->h2d_stream));
         HIPCHK(c, hipEventRecord(c->ev_h2d[par], c->h2d_stream));
         c->h2d_valid[par] = true;
+        HIPCHK(c, hipEventRecord(c->ev_host_in[hq], c->h2d_stream));
+        host_in_recorded = true;
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_h2d[par], 0));
         // (the conversion runs on the front stream, not behind the copy: the copy stream carries nothing but copies, back to back)
         if (s16) hipLaunchKernelGGL(k_s16_to_f32, dim3((unsigned)((n_in / 8 + 255) / 256)), dim3(256), 0, st, c->d_s16_b[par], c->d_pcm_in_b[par], n_in / 8);
@@ -810,6 +827,8 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             HIPCHK(c, hipMemcpyAsync(out_frames, c->d_out, (size_t)S * n_out * c->frame_sz, hipMemcpyDeviceToHost, bk));
         HIPCHK(c, hipEventRecord(c->ev_back_done[par], bk));
         c->back_done_valid[par] = true;
+        HIPCHK(c, hipEventRecord(c->ev_host_out[hq], bk));
+        host_out_recorded = true;
         c->slot_has_frames[slot] = true;
         c->last_slot = slot;
     }
@@ -820,6 +839,8 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         c->pcm_free_valid[par] = true;
     }
     HIPCHK(c, hipGetLastError());
+    c->host_in_valid[hq] = host_in_recorded;     // (a call without a host copy / without frames has nothing to wait for)
+    c->host_out_valid[hq] = host_out_recorded;
     c->hist_cur ^= 1;
     c->blocks_fed += n_blocks;
     c->enc_calls++;

@@ -238,31 +238,38 @@ private:
             ~TPinned() { at3hip_host_free(Ctx, P); }
         };
         const size_t inFloats = (size_t)NStreams * blocksPerCall * 1024 * channels, outBytes = (size_t)NStreams * blocksPerCall * FrameSz;
-        TPinned in0(Ctx, inFloats * sizeof(TSample)), in1(Ctx, inFloats * sizeof(TSample)), out0(Ctx, outBytes), out1(Ctx, outBytes);
-        TSample* in[2] = {(TSample*)in0.P, (TSample*)in1.P};
-        uint8_t* out[2] = {(uint8_t*)out0.P, (uint8_t*)out1.P};
-        int32_t nf[2] = {0, 0};
+        // kDepth calls in flight: the device overlaps three stages of consecutive calls, so two calls leave it idle between them
+        // once the copies are as short as the kernels (16-bit samples); at3hip_wait_* reach three calls back
+        constexpr int kDepth = 3;
+        TPinned in0(Ctx, inFloats * sizeof(TSample)), in1(Ctx, inFloats * sizeof(TSample)), in2(Ctx, inFloats * sizeof(TSample));
+        TPinned out0(Ctx, outBytes), out1(Ctx, outBytes), out2(Ctx, outBytes);
+        TSample* in[kDepth] = {(TSample*)in0.P, (TSample*)in1.P, (TSample*)in2.P};
+        uint8_t* out[kDepth] = {(uint8_t*)out0.P, (uint8_t*)out1.P, (uint8_t*)out2.P};
+        int32_t nf[kDepth] = {0, 0, 0};
         long long total = 0;
-        int call = 0;
+        int call = 0, drained = 0;   // calls queued / calls whose frames were handed over
+        auto drain_next = [&] {
+            const int q = drained % kDepth;
+            if (nf[q] > 0) drain(out[q], (int)nf[q]);
+            total += nf[q];
+            ++drained;
+        };
         try {
         for (;; ++call) {
-            const int q = call & 1;
-            if (call >= 2) Check(at3hip_wait_input(Ctx, 1), Ctx, "at3hip_wait_input");   // call - 2 read in[q]: gone to the device by now?
+            const int q = call % kDepth;
+            if (call >= kDepth) Check(at3hip_wait_input(Ctx, kDepth - 1), Ctx, "at3hip_wait_input");   // call - kDepth read in[q]: gone to the device by now?
             const int nb = fill(in[q], blocksPerCall);
             if (nb <= 0) break;
-            // frames of call - 2 (same output buffer) were drained after call - 1 was queued: out[q] is free
+            // (out[q] is free: the frames of call - kDepth were drained below, after call - 1 was queued)
             Check(EncodeAny(Ctx, in[q], nb, out[q], &nf[q], AT3HIP_ASYNC), Ctx, "at3hip_encode");
-            if (call >= 1) {   // while this call runs: the previous call's frames
-                Check(at3hip_wait_frames(Ctx, 1), Ctx, "at3hip_wait_frames");
-                if (nf[q ^ 1] > 0) drain(out[q ^ 1], (int)nf[q ^ 1]);
-                total += nf[q ^ 1];
+            if (call >= kDepth - 1) {   // while the newer calls run: the oldest call's frames
+                Check(at3hip_wait_frames(Ctx, kDepth - 1), Ctx, "at3hip_wait_frames");
+                drain_next();
             }
         }
         if (call >= 1) {
             Check(at3hip_sync(Ctx), Ctx, "at3hip_sync");
-            const int q = (call - 1) & 1;
-            if (nf[q] > 0) drain(out[q], (int)nf[q]);
-            total += nf[q];
+            while (drained < call) drain_next();
         }
         } catch (...) {
             at3hip_sync(Ctx);   // the page-locked buffers are released on the way out: no copy may still be in flight

@@ -331,39 +331,40 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
     return out
 
 
-def host_pipeline_workload(S, F, steps=400, warmup=8, s16=False):
+def host_pipeline_workload(S, F, steps=400, warmup=24, s16=False):
     """configs[1] fed from HOST memory the way the reference's caller hands it over (pcmengin.h:152-192), PCIe included: two
     page-locked PCM buffers and two frame buffers alternate, the calls are asynchronous, so the H2D copy of call k + 1, the
     kernels of call k and the D2H copy of call k - 1 overlap (at3hip_host_alloc / at3hip_wait_*). Never part of `value`."""
-    out = {"workload": f"configs[1] from host memory: {S} x {F} frames per call, pinned double-buffered staging, H2D + kernels + D2H overlapped"
+    out = {"workload": f"configs[1] from host memory: {S} x {F} frames per call, pinned buffers, three calls in flight, H2D + kernels + D2H overlapped"
                        + (", 16-bit samples (at3hip_encode_s16: converted on the device)" if s16 else ", float32 samples")}
     try:
         import torch
         import atracdenc_amd
         enc = atracdenc_amd.At3Hip(n_streams=S, max_blocks=F + 1, bitrate=LP2, device_id=0)
-        ins = [enc.host_alloc((S, F, 1024, 2), np.int16 if s16 else np.float32) for _ in range(2)]
-        outs = [enc.host_alloc((S, F, enc.frame_size), np.uint8) for _ in range(2)]
+        D = 3   # calls in flight (at3hip_wait_* reach three calls back): buffers alternate D ways
+        ins = [enc.host_alloc((S, F, 1024, 2), np.int16 if s16 else np.float32) for _ in range(D)]
+        outs = [enc.host_alloc((S, F, enc.frame_size), np.uint8) for _ in range(D)]
         rng = np.random.RandomState(5)
         for a in ins:
             a[...] = rng.randint(-8192, 8192, size=a.shape).astype(np.int16) if s16 else rng.randint(-8192, 8192, size=a.shape).astype(np.float32) / np.float32(32768.0)
         prime = synth_pcm(S, 1, 99)
         enc.encode(prime)                      # LOOK_AHEAD call
         for i in range(warmup):
-            enc.encode_host_async(ins[i & 1], outs[i & 1])
+            enc.encode_host_async(ins[i % D], outs[i % D])
         enc.sync()
         t0 = time.perf_counter()
         for i in range(steps):
-            if i >= 2:
-                enc.wait_input(1)      # where the caller refills ins[i & 1]
-            enc.encode_host_async(ins[i & 1], outs[i & 1])
-            if i >= 1:
-                enc.wait_frames(1)     # where the caller consumes the previous call's frames: at most two calls in flight
+            if i >= D:
+                enc.wait_input(D - 1)      # where the caller refills ins[i % D]
+            enc.encode_host_async(ins[i % D], outs[i % D])
+            if i >= D - 1:
+                enc.wait_frames(D - 1)     # where the caller consumes the oldest call's frames: at most D calls in flight
         enc.sync()
         dt = (time.perf_counter() - t0) / steps
         # the same calls one at a time (copy, kernels, copy back, then the next): what the overlap buys
         t0 = time.perf_counter()
         for i in range(8):
-            enc.encode_host_async(ins[i & 1], outs[i & 1])
+            enc.encode_host_async(ins[i % D], outs[i % D])
             enc.sync()
         dt_serial = (time.perf_counter() - t0) / 8
         # the PCIe bound measured here: the same 32 MiB from page-locked memory, copies only

@@ -208,7 +208,8 @@ int at3hip_set_option(at3hip_ctx* ctx, int32_t option, int32_t value);
  * page-locked buffers from at3hip_host_alloc and AT3HIP_ASYNC calls that alternate between two input and two output
  * buffers, the H2D copy of call N+1 (on a copy stream of the ctx, into device staging double-buffered by call parity), the
  * kernels of call N and the D2H copy of call N-1's frames overlap. `ago` = 0 for the most recent at3hip_encode call, 1
- * for the one before it.
+ * for the one before it, up to 3: three calls in flight (three input and three output buffers) keep the device's own
+ * three-stage overlap of consecutive calls busy - with 16-bit samples the bus no longer hides a two-deep pipeline's bubbles.
  *   at3hip_wait_input   returns once that call's PCM has left the host buffer (it may be refilled)
  *   at3hip_wait_frames  returns once that call's frames are in out_frames (the completion point of ONE call; at3hip_sync
  *                       waits for all of them)

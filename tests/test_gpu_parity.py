@@ -738,33 +738,45 @@ def test_wild_scale_factor_spread(hip, oracle, ng):
 
 
 @pytest.mark.parametrize("br", [LP2, LP4])
-def test_host_buffer_pipeline(hip, oracle, br):
+@pytest.mark.parametrize("depth,s16", [(2, False), (3, False), (3, True), (4, True)])
+def test_host_buffer_pipeline(hip, oracle, br, depth, s16):
     """Host PCM through the copy stream and the parity-double-buffered device staging (include/at3hip.h, "Host-buffer
-    pipeline"): page-locked buffers from at3hip_host_alloc, asynchronous calls alternating between two input and two output
-    buffers that are REFILLED / read as soon as at3hip_wait_input / at3hip_wait_frames allow - any missing ordering between
-    the copy stream, the three compute streams and the host shows up as a wrong frame."""
+    pipeline"): page-locked buffers from at3hip_host_alloc, asynchronous calls alternating between `depth` input and `depth`
+    output buffers that are REFILLED / read as soon as at3hip_wait_input / at3hip_wait_frames allow (they reach three calls back)
+    - any missing ordering between the copy stream, the three compute streams and the host shows up as a wrong frame. Float and
+    16-bit samples."""
     nb, piece, S = 41, 5, 3
     pcm = np.stack([SIGNALS["mix"](nb, seed=31), SIGNALS["burst"](nb, phase=300), SIGNALS["noise"](nb, seed=32)])
+    if s16:
+        p16 = np.round(np.clip(pcm, -1.0, 32767.0 / 32768.0) * 32768.0).astype(np.int16)
+        pcm = (p16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    src = p16 if s16 else pcm
     enc = hip.At3Hip(n_streams=S, max_blocks=piece, bitrate=br)
-    ins = [enc.host_alloc((S, piece, 1024, 2), np.float32) for _ in range(2)]
-    outs = [enc.host_alloc((S, piece, enc.frame_size), np.uint8) for _ in range(2)]
+    ins = [enc.host_alloc((S, piece, 1024, 2), np.int16 if s16 else np.float32) for _ in range(depth)]
+    outs = [enc.host_alloc((S, piece, enc.frame_size), np.uint8) for _ in range(depth)]
     got, counts = [], []
     calls = [(pos, min(piece, nb - pos)) for pos in range(0, nb, piece)]
+
+    def take(k):   # the frames of call k out of its buffer
+        c = counts[k]
+        got.append(outs[k % depth].reshape(-1)[: S * c * enc.frame_size].reshape(S, c, enc.frame_size).copy())
+        outs[k % depth][...] = 0xEE
+
     for k, (pos, n) in enumerate(calls):
-        q = k & 1
-        if k >= 2:
-            enc.wait_input(1)                       # call k - 2 has left ins[q]
-        ins[q][:, :n] = pcm[:, pos:pos + n]
-        ins[q][:, n:] = np.nan                      # (never read)
+        q = k % depth
+        if k >= depth:
+            enc.wait_input(depth - 1)               # call k - depth has left ins[q]
+        ins[q][:, :n] = src[:, pos:pos + n]
+        ins[q][:, n:] = -1 if s16 else np.nan       # (never read)
         counts.append(enc.encode_host_async(ins[q][:, :n] if n == piece else np.ascontiguousarray(ins[q][:, :n]), outs[q]))
-        if k >= 1:
-            enc.wait_frames(1)                      # call k - 1's frames are in outs[q ^ 1]
-            c = counts[k - 1]
-            got.append(outs[q ^ 1].reshape(-1)[: S * c * enc.frame_size].reshape(S, c, enc.frame_size).copy())
-            outs[q ^ 1][...] = 0xEE
+        if k >= depth - 1:
+            enc.wait_frames(depth - 1)              # the oldest call in flight: its frames are in its buffer
+            take(k - (depth - 1))
     enc.sync()
-    c = counts[-1]
-    got.append(outs[(len(calls) - 1) & 1].reshape(-1)[: S * c * enc.frame_size].reshape(S, c, enc.frame_size).copy())
+    for k in range(max(0, len(calls) - (depth - 1)), len(calls)):
+        take(k)
+    with pytest.raises(hip.At3HipError):
+        enc.wait_frames(4)                          # (the ring is four calls deep)
     for a in ins + outs:
         enc.host_free(a)
     enc.close()
