@@ -1177,31 +1177,47 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             const int last_alloc = (p.bfu_idx_const || num_bfu <= 1) ? 1
                                    : __builtin_amdgcn_readlane(bits_current ? bits : alloc_bits(A, gate, tcount, gmap, lam), (num_bfu - 1) & 31);
             if (!p.bfu_idx_const && num_bfu > 1 && last_alloc == 0) {
-                // the dropped BFU leaves every recorded evaluation: its bits at that lambda, their cost, its place in the count
-                const int t = num_bfu - 1;
-                const int tc_t = __builtin_amdgcn_readlane(tcount, t);
-                if (tc_t > 0) {
-                    memo_n = 0;   // its tonal blocks leave the tonal side information too: nothing recorded stays valid
-                } else {
-                    const int b = alloc_bits(readlane_f(A, t), __builtin_amdgcn_readlane((int)gate, t) != 0, 0,
-                                             (uint32_t)__builtin_amdgcn_readlane((int)gmap, t), m_lam);
-                    if (lane < memo_n && b) {
-                        m_acc -= clc_bits(b, bfu_start(t + 1) - bfu_start(t)) | ((uint32_t)s_cost[(b - 1) * 32 + t] << 13);
-                        m_nz -= 1u;
+                for (;;) {
+                    // the dropped BFU leaves every recorded evaluation: its bits at that lambda, their cost, its place in the count
+                    const int t = num_bfu - 1;
+                    const int tc_t = __builtin_amdgcn_readlane(tcount, t);
+                    if (tc_t > 0) {
+                        memo_n = 0;   // its tonal blocks leave the tonal side information too: nothing recorded stays valid
+                    } else {
+                        const int b = alloc_bits(readlane_f(A, t), __builtin_amdgcn_readlane((int)gate, t) != 0, 0,
+                                                 (uint32_t)__builtin_amdgcn_readlane((int)gmap, t), m_lam);
+                        if (lane < memo_n && b) {
+                            m_acc -= clc_bits(b, bfu_start(t + 1) - bfu_start(t)) | ((uint32_t)s_cost[(b - 1) * 32 + t] << 13);
+                            m_nz -= 1u;
+                        }
                     }
-                }
-                num_bfu--;
-                restart = true;
-                resume = -1;
-                if (skip_ok && memo_n > 0 && path) {
-                    const uint32_t c1 = m_acc & 0x1fffu, v1 = (m_acc >> 13) & 0x3fffu;
-                    const uint32_t tot = (uint32_t)num_bfu * 3 + 6 * m_nz + (c1 <= v1 ? c1 : v1) + m_ton;
-                    const int nd = tot < (uint32_t)target ? 0 : tot > (uint32_t)target ? 1 : 2;
-                    const unsigned long long changed = __ballot(nd != m_dir) & path;
-                    resume = changed ? __builtin_ctzll(changed) : 63 - __builtin_clzll(path);
-                    path &= (2ull << resume) - 1ull;
-                } else {
-                    path = 0ull;
+                    num_bfu--;
+                    restart = true;
+                    resume = -1;
+                    bool unchanged = false;
+                    if (skip_ok && memo_n > 0 && path) {
+                        const uint32_t c1 = m_acc & 0x1fffu, v1 = (m_acc >> 13) & 0x3fffu;
+                        const uint32_t tot = (uint32_t)num_bfu * 3 + 6 * m_nz + (c1 <= v1 ? c1 : v1) + m_ton;
+                        const int nd = tot < (uint32_t)target ? 0 : tot > (uint32_t)target ? 1 : 2;
+                        const unsigned long long changed = __ballot(nd != m_dir) & path;
+                        unchanged = changed == 0ull;
+                        resume = changed ? __builtin_ctzll(changed) : 63 - __builtin_clzll(path);
+                        path &= (2ull << resume) - 1ull;
+                    } else {
+                        path = 0ull;
+                    }
+                    // No recorded comparison goes another way with one BFU less: the repeat would walk the same records, leave the
+                    // last of them the same way, run out of interval at the same lambda and stop there (that evaluation's total is not
+                    // compared) - with this allocation. So the only thing it would find out is whether the NEW last BFU has bits at
+                    // that lambda: looked at here, without the two trips through the loop (on LP4 a channel-frame of white noise
+                    // sheds eleven BFUs one after the other this way).
+                    if (!unchanged || num_bfu <= 1) break;
+                    const int la = __builtin_amdgcn_readlane(alloc_bits(A, gate, tcount, gmap, lam), (num_bfu - 1) & 31);
+                    if (la != 0) {
+                        restart = false;        // the bisection is over: lam, mode and the records stand
+                        bits_current = false;   // (the allocation is formed again for num_bfu BFUs below)
+                        break;
+                    }
                 }
             }
             break;
