@@ -1372,35 +1372,38 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
         }
     }
     wave_sync();
-    if (j == 0 && nt > 0) {
-        int* tloc = s_tloc[grp];
-        int* tlev = s_tlev[grp];
-        int* tdelta = s_tdelta[grp];
-        for (int a = 0, b = nt - 1; a < b; ++a, --b) {   // descending loc -> ascending
-            const int x0 = tloc[a]; tloc[a] = tloc[b]; tloc[b] = x0;
-            const int x1 = tdelta[a]; tdelta[a] = tdelta[b]; tdelta[b] = x1;
-            const int x2 = tlev[a]; tlev[a] = tlev[b]; tlev[b] = x2;
+    // The transitions sit in s_t*[grp][0 .. nt) in DESCENDING location order. The reference reverses them, and when there are more
+    // than six keeps the six largest |delta| (ties: the rightmost location) and puts those back in ascending location order
+    // (transient_detector.cpp:446-475; locations are distinct, so (delta desc, loc desc) is a strict order and the stable sort has
+    // nothing to decide). Lane i of the group takes transition i: its place in that order is the number of transitions ahead of it,
+    // its place in the result the number of kept transitions with a smaller location = kept lanes above it. (The first version
+    // was one lane swapping and insertion-sorting through LDS: quadratic in nt with an LDS round trip per step - on material
+    // whose levels flicker, 22 of the kernel's 56 us.)
+    {
+        const bool has_t = j < nt;
+        int my_loc = 0, my_lev = 0, my_delta = 0;
+        if (has_t) {
+            my_loc = s_tloc[grp][j];
+            my_lev = s_tlev[grp][j];
+            my_delta = s_tdelta[grp][j];
         }
-        if (nt > 6) {   // keep the 6 largest |delta| (ties: rightmost), stable; then back to loc order (:462-475)
-            for (int i = 1; i < nt; ++i) {
-                const int l0 = tloc[i], d0 = tdelta[i], v0 = tlev[i];
-                int k = i - 1;
-                while (k >= 0 && ((d0 != tdelta[k]) ? (d0 > tdelta[k]) : (l0 > tloc[k]))) {
-                    tloc[k + 1] = tloc[k]; tdelta[k + 1] = tdelta[k]; tlev[k + 1] = tlev[k];
-                    --k;
-                }
-                tloc[k + 1] = l0; tdelta[k + 1] = d0; tlev[k + 1] = v0;
-            }
-            for (int i = 1; i < 6; ++i) {
-                const int l0 = tloc[i], d0 = tdelta[i], v0 = tlev[i];
-                int k = i - 1;
-                while (k >= 0 && l0 < tloc[k]) {
-                    tloc[k + 1] = tloc[k]; tdelta[k + 1] = tdelta[k]; tlev[k + 1] = tlev[k];
-                    --k;
-                }
-                tloc[k + 1] = l0; tdelta[k + 1] = d0; tlev[k + 1] = v0;
+        int ahead = 0;
+        if (nt > 6) {
+#pragma unroll 4
+            for (int k = 0; k < nt; ++k) {
+                const int dk = s_tdelta[grp][k], lk = s_tloc[grp][k];   // (the same address in every lane of the group: a broadcast)
+                ahead += (dk > my_delta || (dk == my_delta && lk > my_loc)) ? 1 : 0;
             }
         }
+        const bool keep_t = has_t && ahead < 6;
+        const uint32_t kept = (uint32_t)(__ballot(keep_t) >> (32 * half));
+        const int pos = j < 31 ? __popc(kept >> (j + 1)) : 0;
+        wave_sync();   // every lane has read its transition: the lists are rewritten in place
+        if (keep_t) {
+            s_tlev[grp][pos] = my_lev;
+            s_tloc[grp][pos] = my_loc;
+        }
+        nt = __popc(kept);
     }
     wave_sync();
     if (nt > 6) nt = 6;
