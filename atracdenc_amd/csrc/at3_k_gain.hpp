@@ -1096,31 +1096,41 @@ struct CurvePts {   // register-resident curve (redundant in every lane of the i
 };
 
 // CalcCurveEarlyMismatchScore (atrac3denc.cpp:228-297); in_j / in_next are this lane's gain[j], gain[j+1].
-__device__ __forceinline__ float early_mismatch_score_grp(const Log2fTab* L2, const float* gain_interp, float in_j, float in_next, float target,
-                                                          const CurvePts& cp, float* s_tmp, uint8_t* s_pts, int j, int half)
+
+// CalcCurveEarlyMismatchScore (atrac3denc.cpp:259-297) for TWO curves of one item at once (the curve before and after the point-0
+// logic: the reference calls it twice):
+// the two evaluations share every LDS rendezvous and their chains interleave - the kernel's slowest wavefronts are the ones that
+// score, and a wavefront that waits on one dependent chain at a time is what sets the kernel's duration. A's lists live in
+// s_tmpA (128 floats) / s_ptsA, B's in aB (32 floats) + sqB / ltB (32 floats each) / s_ptsB; the weights list is A's.
+__device__ __forceinline__ void early_mismatch_score_pair(const Log2fTab* L2, const float* gain_interp, float in_j, float in_next, float target,
+                                                          const CurvePts& cpA, const CurvePts& cpB, float* s_tmpA, uint8_t* s_ptsA,
+                                                          float* aB, float* sqB, float* ltB, uint8_t* s_ptsB, int j, float& scoreA, float& scoreB)
 {
-    // BuildSampleDivisors restricted to sub-frame j (samples 8j .. 8j+7): level boundaries and ramps are aligned to
-    // these cells, so the eight divisors are all 1, all one level, or one running-product ramp (same values as
-    // curve_divisor sample by sample). The points are walked from LDS: indexing a register-resident list with a
-    // run-time index costs a select chain per access, which made this the longest path of the kernel.
     if (j < 7) {
-        int lv = 0, lc = 0;
+        int lvA = 0, lcA = 0, lvB = 0, lcB = 0;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            lv = (j == i) ? cp.level[i] : lv;
-            lc = (j == i) ? cp.loc[i] : lc;
+            lvA = (j == i) ? cpA.level[i] : lvA;
+            lcA = (j == i) ? cpA.loc[i] : lcA;
+            lvB = (j == i) ? cpB.level[i] : lvB;
+            lcB = (j == i) ? cpB.loc[i] : lcB;
         }
-        s_pts[j] = (uint8_t)lv;
-        s_pts[8 + j] = (uint8_t)lc;
+        s_ptsA[j] = (uint8_t)lvA;
+        s_ptsA[8 + j] = (uint8_t)lcA;
+        s_ptsB[j] = (uint8_t)lvB;
+        s_ptsB[8 + j] = (uint8_t)lcB;
     }
     wave_sync();
-    float dsum = 0.0f;
-    {
+    // BuildSampleDivisors restricted to sub-frame j (samples 8j .. 8j+7): level boundaries and ramps are aligned to these cells, so
+    // the eight divisors are all 1, all one level, or one running-product ramp (same values as curve_divisor sample by sample). The
+    // points are walked from LDS: indexing a register-resident list with a run-time index costs a select chain per access.
+    auto cell_div = [&](const uint8_t* s_pts, int n) -> float {
+        float dsum = 0.0f;
         const int cell = 8 * j;
         int kind = 0;
         float lvl = 1.0f, inc = 1.0f;
         int pos = 0;
-        for (int q = 0; q < cp.n; ++q) {
+        for (int q = 0; q < n; ++q) {
             const int lastPos = (int)s_pts[8 + q] << 3;
             if (cell >= pos && cell < lastPos) {
                 kind = 1;
@@ -1132,7 +1142,7 @@ __device__ __forceinline__ float early_mismatch_score_grp(const Log2fTab* L2, co
                 if (cell >= pos && cell < lastPos + 8) {
                     kind = 2;
                     lvl = gain_level_of(s_pts[q]);
-                    inc = gain_interp[((q + 1) < cp.n ? (int)s_pts[q + 1] : 4) - (int)s_pts[q] + 15];
+                    inc = gain_interp[((q + 1) < n ? (int)s_pts[q + 1] : 4) - (int)s_pts[q] + 15];
                     break;
                 }
                 pos = lastPos + 8;
@@ -1144,76 +1154,96 @@ __device__ __forceinline__ float early_mismatch_score_grp(const Log2fTab* L2, co
             dsum += d;
             if (kind == 2) d *= inc;
         }
-    }
-    wave_sync();   // s_pts is rewritten by the next call
-    const float div = dsum / 8.0f;
-    int maxLoc = 0;
+        return dsum / 8.0f;
+    };
+    const float divA = cell_div(s_ptsA, cpA.n), divB = cell_div(s_ptsB, cpB.n);
+    wave_sync();   // the point lists are rewritten by the next call
+    int maxLocA = 0, maxLocB = 0;
 #pragma unroll
-    for (int i = 0; i < 7; ++i)
-        if (i < cp.n && cp.loc[i] > maxLoc) maxLoc = cp.loc[i];
-    int evalSf = maxLoc + 3 > 3 ? maxLoc + 3 : 3;
-    if (evalSf > 32) evalSf = 32;
+    for (int i = 0; i < 7; ++i) {
+        if (i < cpA.n && cpA.loc[i] > maxLocA) maxLocA = cpA.loc[i];
+        if (i < cpB.n && cpB.loc[i] > maxLocB) maxLocB = cpB.loc[i];
+    }
+    int evalA = maxLocA + 3 > 3 ? maxLocA + 3 : 3, evalB = maxLocB + 3 > 3 ? maxLocB + 3 : 3;
+    if (evalA > 32) evalA = 32;
+    if (evalB > 32) evalB = 32;
     const float eps = 1e-9f;
-    const float mod = in_j / fmaxf(div, eps);
-    const float e = at3_log2f(L2, fmaxf(mod, eps) / fmaxf(target, eps));
-    const float sq = e * e;
-    const float a = at3_log2f(L2, fmaxf(div, eps));
-    s_tmp[j] = a;
+    const float modA = in_j / fmaxf(divA, eps), modB = in_j / fmaxf(divB, eps);
+    const float eA = at3_log2f(L2, fmaxf(modA, eps) / fmaxf(target, eps)), eB = at3_log2f(L2, fmaxf(modB, eps) / fmaxf(target, eps));
+    const float sqA = eA * eA, sqvB = eB * eB;
+    const float aA = at3_log2f(L2, fmaxf(divA, eps)), avB = at3_log2f(L2, fmaxf(divB, eps));
+    s_tmpA[j] = aA;
+    aB[j] = avB;
     wave_sync();
-    const float a_next = s_tmp[j < 31 ? j + 1 : 31];
+    const float aA_next = s_tmpA[j < 31 ? j + 1 : 31], aB_next = aB[j < 31 ? j + 1 : 31];
     wave_sync();
-    const float d = a_next - a;
+    const float dA = aA_next - aA, dB = aB_next - avB;
     const float w = 0.5f * (in_j + in_next);
-    const float lterm = d * d * w;
-    // three ordered 32-term sums: the terms go through LDS and every lane adds them up in order (wide broadcast reads)
-    float* st = s_tmp + 32;   // [3][32] behind the first 32 floats of the item's scratch
-    st[j] = sq;
-    st[32 + j] = lterm;
+    const float ltermA = dA * dA * w, ltermB = dB * dB * w;
+    float* st = s_tmpA + 32;   // A: [3][32] behind the first 32 floats of the item's scratch
+    st[j] = sqA;
+    st[32 + j] = ltermA;
     st[64 + j] = w;
+    sqB[j] = sqvB;
+    ltB[j] = ltermB;
     wave_sync();
-    float fit = 0.0f, leak = 0.0f, wsum = 0.0f;
+    float fitA = 0.0f, leakA = 0.0f, wsumA = 0.0f, fitB = 0.0f, leakB = 0.0f, wsumB = 0.0f;
     {
         const float4* a4 = reinterpret_cast<const float4*>(st);
-        float4 va[8], vl[8], vw[8];
+        const float4* s4 = reinterpret_cast<const float4*>(sqB);
+        const float4* l4 = reinterpret_cast<const float4*>(ltB);
+        float4 va[8], vl[8], vw[8], vb[8], vm[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             va[q] = a4[q];
             vl[q] = a4[8 + q];
             vw[q] = a4[16 + q];
+            vb[q] = s4[q];
+            vm[q] = l4[q];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float v[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
             const float lt[4] = {vl[q].x, vl[q].y, vl[q].z, vl[q].w};
             const float ww[4] = {vw[q].x, vw[q].y, vw[q].z, vw[q].w};
+            const float vB[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
+            const float lB[4] = {vm[q].x, vm[q].y, vm[q].z, vm[q].w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int sf = 4 * q + t;
-                if (sf < evalSf) fit += v[t];
-                if (sf + 1 < evalSf) {
-                    leak += lt[t];
-                    wsum += ww[t];
+                if (sf < evalA) fitA += v[t];
+                if (sf + 1 < evalA) {
+                    leakA += lt[t];
+                    wsumA += ww[t];
+                }
+                if (sf < evalB) fitB += vB[t];
+                if (sf + 1 < evalB) {
+                    leakB += lB[t];
+                    wsumB += ww[t];
                 }
             }
         }
     }
-    wave_sync();   // the scratch is rewritten by the next call
-    fit /= (float)evalSf;
-    if (wsum > eps) leak /= wsum;
-    const float score = fit + 0.25f * leak;
-    return (target <= 1e-9f) ? 0.0f : score;
+    wave_sync();   // the scratch is rewritten by the next user
+    fitA /= (float)evalA;
+    fitB /= (float)evalB;
+    if (wsumA > eps) leakA /= wsumA;
+    if (wsumB > eps) leakB /= wsumB;
+    scoreA = (target <= 1e-9f) ? 0.0f : fitA + 0.25f * leakA;
+    scoreB = (target <= 1e-9f) ? 0.0f : fitB + 0.25f * leakB;
 }
 
 // 256 threads = 8 items per workgroup.
 __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* T, int n_streams)
 {
     __shared__ float s_in[8][32];
-    __shared__ float s_filt[8][32];
+    __shared__ __attribute__((aligned(16))) float s_filt[8][32];   // (after the boundary scores: the paired evaluation's second a-list)
     __shared__ __attribute__((aligned(16))) float s_tmp[8][128];   // per item: 32 floats + three 32-term lists of the early-mismatch score
-    __shared__ int s_tloc[8][32];
-    __shared__ int s_tdelta[8][32];
+    __shared__ __attribute__((aligned(16))) int s_tloc[8][32];     // (after the curve points are formed: the paired evaluation's
+    __shared__ __attribute__((aligned(16))) int s_tdelta[8][32];   //  second term lists)
     __shared__ int s_tlev[8][32];
     __shared__ uint8_t s_pts[8][16];  // per item: levels [0..6], locations [8..14] of the curve being scored
+    __shared__ uint8_t s_pts2[8][16]; // the same for the second curve of the paired evaluation
     __shared__ Log2fTab s_l2[4];      // per wavefront: the log2f tables and GainInterpolation, so that the rare long
     __shared__ float s_gi4[4][32];    // path (a few items with curves set the kernel's duration) has no dependent global loads
     const int tid = threadIdx.x;
@@ -1486,10 +1516,10 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
         }
     }
     if (p.debug == 3) return;
-    // both scores are evaluated unconditionally (wave-uniform control flow); used only when `changed`
-    const float scoreBefore = early_mismatch_score_grp(L2, gi, in_j, in_next, target, before, s_tmp[grp], s_pts[grp], j, half);
-    if (p.debug == 4) { if (scoreBefore == 12345.0f) *dst = Curve(); return; }
-    const float scoreAfter = early_mismatch_score_grp(L2, gi, in_j, in_next, target, pts, s_tmp[grp], s_pts[grp], j, half);
+    // both scores are evaluated unconditionally (wave-uniform control flow) and TOGETHER; used only when `changed`
+    float scoreBefore, scoreAfter;
+    early_mismatch_score_pair(L2, gi, in_j, in_next, target, before, pts, s_tmp[grp], s_pts[grp], s_filt[grp], reinterpret_cast<float*>(s_tloc[grp]),
+                              reinterpret_cast<float*>(s_tdelta[grp]), s_pts2[grp], j, scoreBefore, scoreAfter);
     if (p.debug == 5) { if (scoreBefore + scoreAfter == 12345.0f) *dst = Curve(); return; }
     if (changed) {
         bool keepByBoundary = false;
