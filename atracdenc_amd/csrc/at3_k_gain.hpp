@@ -1192,22 +1192,16 @@ __device__ __forceinline__ void early_mismatch_score_pair(const Log2fTab* L2, co
         const float4* a4 = reinterpret_cast<const float4*>(st);
         const float4* s4 = reinterpret_cast<const float4*>(sqB);
         const float4* l4 = reinterpret_cast<const float4*>(ltB);
-        float4 va[8], vl[8], vw[8], vb[8], vm[8];
+        // (sixteen terms of each of the five lists per step, the next step's requested ahead by the compiler's schedule: holding all
+        // forty 16-byte words at once cost the kernel a wavefront per SIMD)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            va[q] = a4[q];
-            vl[q] = a4[8 + q];
-            vw[q] = a4[16 + q];
-            vb[q] = s4[q];
-            vm[q] = l4[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float v[4] = {va[q].x, va[q].y, va[q].z, va[q].w};
-            const float lt[4] = {vl[q].x, vl[q].y, vl[q].z, vl[q].w};
-            const float ww[4] = {vw[q].x, vw[q].y, vw[q].z, vw[q].w};
-            const float vB[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
-            const float lB[4] = {vm[q].x, vm[q].y, vm[q].z, vm[q].w};
+            const float4 va = a4[q], vl = a4[8 + q], vw = a4[16 + q], vb = s4[q], vm = l4[q];
+            const float v[4] = {va.x, va.y, va.z, va.w};
+            const float lt[4] = {vl.x, vl.y, vl.z, vl.w};
+            const float ww[4] = {vw.x, vw.y, vw.z, vw.w};
+            const float vB[4] = {vb.x, vb.y, vb.z, vb.w};
+            const float lB[4] = {vm.x, vm.y, vm.z, vm.w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int sf = 4 * q + t;
