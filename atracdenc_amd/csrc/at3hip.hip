@@ -90,6 +90,7 @@ struct at3hip_ctx {
     int wgs_per_cu = 3;        // resident workgroups per CU of the QMF kernel this context uses (k_qmf_sub8 or the fused one)
     int wgs_per_cu_mdct = 3;   // the same of k_mdct_sub
     int alloc_lds_pad = 0;     // dynamic LDS added to k_alloc_pack's launch: sets how many of its workgroups share a CU
+    int dbg_pad[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // AT3HIP_DEBUG_KNOBS builds: dynamic LDS added to other launches (AT3HIP_PAD_*), co-residency experiments
     int dbg_front = 0, dbg_gain = 0, dbg_stop = 0;   // AT3HIP_DEBUG_* (profiling aids), honoured by -DAT3HIP_DEBUG_KNOBS builds only
 
     Tables* d_tables = nullptr;
@@ -243,7 +244,15 @@ size_t whole_rounds_pad(const at3hip_ctx* c, long long n_wgs, const LdsChoice* c
 }
 size_t analysis_lds_pad(const at3hip_ctx* c, long long n_wgs)
 {
-    static const LdsChoice kChoice[3] = {{9, 0}, {8, 3328}, {6, 8704}};
+    if (c->lds_per_cu == 160u * 1024u && c->gain_wgs_per_cu > 0 && c->gain_wgs_per_cu < 9) {   // AT3HIP_OPT_GAIN_WGS_PER_CU (tuning aid)
+        const size_t each = ((160u * 1024u) / (size_t)c->gain_wgs_per_cu) & ~(size_t)255;
+        return each > sizeof(GainLds) + 256 ? each - sizeof(GainLds) - 256 : 0;
+    }
+    if (c->lds_per_cu == 160u * 1024u && c->gain_wgs_per_cu >= 256) return (size_t)c->gain_wgs_per_cu;   // (values from 256: the pad itself)
+    if (c->gain_wgs_per_cu >= 9) return 0;
+    // (six per CU at 26 KB each leave 4 KB of the CU's LDS: with the 8704-byte pad of round 3 they left exactly the 10 KB of one
+    // k_alloc_pack wavefront, and the step was 0.8 % slower for every CU carrying that lodger - tools/ab_step.sh, --gain-wgs)
+    static const LdsChoice kChoice[3] = {{9, 0}, {8, 3328}, {6, 9728}};
     return whole_rounds_pad(c, n_wgs, kChoice, 3, true);   // (equally whole rounds: the fewer, fatter slots measured better)
 }
 // The one-wavefront form (k_gain_analysis1, 9.5 KB per workgroup): sixteen per CU without padding.
@@ -321,6 +330,11 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if (guard.error() != hipSuccess) return bail(AT3HIP_EDEVICE);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (const char* e = getenv("AT3HIP_DEBUG_FRONT")) c->dbg_front = atoi(e);
+    {
+        static const char* const kPadEnv[8] = {"AT3HIP_PAD_QMF", "AT3HIP_PAD_MDCT", "AT3HIP_PAD_CURVE", "AT3HIP_PAD_GES", "AT3HIP_PAD_TAIL", "AT3HIP_PAD_LOUD", "AT3HIP_PAD_PSY", "AT3HIP_PAD_SCAN"};
+        for (int i = 0; i < 8; ++i)
+            if (const char* e = getenv(kPadEnv[i])) c->dbg_pad[i] = atoi(e);
+    }
     if (const char* e = getenv("AT3HIP_DEBUG_GAIN")) c->dbg_gain = atoi(e);
     if (const char* e = getenv("AT3HIP_DEBUG_STOP")) c->dbg_stop = atoi(e);
     if (const char* e = getenv("AT3HIP_ALLOC_PAD")) c->alloc_lds_pad = atoi(e);
@@ -545,7 +559,7 @@ int at3hip_set_option(at3hip_ctx* c, int32_t option, int32_t value)
             c->gain_two_waves = value;
             return AT3HIP_OK;
         case AT3HIP_OPT_GAIN_WGS_PER_CU:
-            if (value < 0 || value > 16) return fail(c, AT3HIP_EINVAL, "workgroups per CU must be 0 .. 16");
+            if (value < 0 || (value > 16 && value < 256) || value > 64 * 1024) return fail(c, AT3HIP_EINVAL, "workgroups per CU must be 0 .. 16 (or a pad of 256 .. 65536 bytes)");
             c->gain_wgs_per_cu = value;
             return AT3HIP_OK;
         case AT3HIP_OPT_QUANT_TAP: {
@@ -707,7 +721,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         fp.js = c->js;
         fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35);
         const int n_waves = S * 2 * fp.sub_runs;
-        hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
+        hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), (size_t)c->dbg_pad[0], st, fp, c->d_tables, n_waves);
     }
     if (n_out > 0) {
         FrontParams fp;
@@ -729,7 +743,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         auto launch_qmf_sub = [&] {
             fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35);
             const int n_waves = S * 2 * fp.sub_runs;   // one wavefront per (stream, channel, run)
-            hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
+            hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), (size_t)c->dbg_pad[0], st, fp, c->d_tables, n_waves);
         };
         if (gain) {
             GainParams gp;
@@ -754,10 +768,10 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             else hipLaunchKernelGGL(k_gain_analysis1, dim3(S * n_out * 6), dim3(64), analysis1_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);   // one wavefront per item
             HIPCHK(c, hipEventRecord(ev[2], st));
             HIPCHK(c, hipStreamWaitEvent(md, ev[2], 0));   // the light stage starts when this call's heavy stage is done
-            hipLaunchKernelGGL(k_gain_tail, dim3((unsigned)((S * n_out * 6 + 7) / 8)), dim3(256), 0, md, gp, S * n_out * 6);
-            hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), 0, md, gp, S);
-            hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), 0, md, gp, c->d_tables, S);
-            hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), 0, md, fp, c->d_tables, S * n_out);
+            hipLaunchKernelGGL(k_gain_tail, dim3((unsigned)((S * n_out * 6 + 7) / 8)), dim3(256), (size_t)c->dbg_pad[4], md, gp, S * n_out * 6);
+            hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), (size_t)c->dbg_pad[7], md, gp, S);
+            hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), (size_t)c->dbg_pad[2], md, gp, c->d_tables, S);
+            hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), (size_t)c->dbg_pad[3], md, fp, c->d_tables, S * n_out);
         } else {
             if (split) launch_qmf_sub();   // joint stereo without gain control: the QMF kernel, timed as qmf_ms
             HIPCHK(c, hipEventRecord(ev[1], st));
@@ -777,7 +791,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             mp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu_mdct, 0.3);
             mp.n_waves = S * 2 * mp.frame_runs;
             if (c->js) hipLaunchKernelGGL(k_mdct_sub<true>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, md, mp, c->d_tables);
-            else hipLaunchKernelGGL(k_mdct_sub<false>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, md, mp, c->d_tables);
+            else hipLaunchKernelGGL(k_mdct_sub<false>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), (size_t)c->dbg_pad[1], md, mp, c->d_tables);
         } else {
             const int n_waves = S * 2 * fp.frame_runs;
             hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
@@ -817,8 +831,8 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         bp.debug_stop = c->dbg_stop;
         bp.quant = c->d_quant;
         bp.clk = c->d_clk;
-        hipLaunchKernelGGL(k_loud_sum, dim3((unsigned)((S * n_out * 2 + kLoudCf - 1) / kLoudCf)), dim3(256), 0, bk, bp, c->d_tables, S * n_out * 2);
-        hipLaunchKernelGGL(k_psy, dim3((S * n_out * 2 + kPsyCf - 1) / kPsyCf), dim3(256), 0, bk, bp, c->d_tables, S * n_out * 2);
+        hipLaunchKernelGGL(k_loud_sum, dim3((unsigned)((S * n_out * 2 + kLoudCf - 1) / kLoudCf)), dim3(256), (size_t)c->dbg_pad[5], bk, bp, c->d_tables, S * n_out * 2);
+        hipLaunchKernelGGL(k_psy, dim3((S * n_out * 2 + kPsyCf - 1) / kPsyCf), dim3(256), (size_t)c->dbg_pad[6], bk, bp, c->d_tables, S * n_out * 2);
         HIPCHK(c, hipEventRecord(ev[6], bk));
         hipLaunchKernelGGL(k_loudness, dim3(S), dim3(64), 0, bk, bp);
         hipLaunchKernelGGL(k_alloc_pack, dim3(S * n_out * 2), dim3(64), (size_t)c->alloc_lds_pad, bk, bp, c->d_tables);
