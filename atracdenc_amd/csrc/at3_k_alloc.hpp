@@ -29,11 +29,13 @@ namespace at3 {
 struct PhaseClock {
     unsigned long long last;
     unsigned long long* slots;   // this wavefront's row of 12 counters (256 rows, by workgroup index: no contention to speak of)
+    unsigned long long* item;    // the first 16384 workgroups also keep their own 12 (tools/alloc_item_times.sh)
 };
 #define AT3_PH_END(pc, k)                                                                    \
     do {                                                                                     \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
         if ((pc).slots && threadIdx.x == 0) atomicAdd((pc).slots + (k), t_ - (pc).last);     \
+        if ((pc).item && threadIdx.x == 0) (pc).item[k] += t_ - (pc).last;                   \
         (pc).last = t_;                                                                      \
     } while (0)
 #else
@@ -745,6 +747,10 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #ifdef AT3HIP_DEBUG_KNOBS
     pc.last = __builtin_amdgcn_s_memtime();
     pc.slots = p.clk ? p.clk + 16 + (blockIdx.x & 255u) * 12u : nullptr;
+    const unsigned long long item_r0 = __builtin_amdgcn_s_memrealtime();   // per-item life (100 MHz): tools/alloc_item_times.sh
+    pc.item = (p.clk && blockIdx.x < 16384u) ? p.clk + 16 + 2 * 256 * 12 + 2 * 16384 + 12 * blockIdx.x : nullptr;
+    if (pc.item && lane == 0)
+        for (int k = 0; k < 12; ++k) pc.item[k] = 0ull;
 #endif
     const int ch = (int)(cf & 1);
     const int fo = (int)((cf >> 1) % n_out);
@@ -1433,6 +1439,11 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #ifdef AT3HIP_DEBUG_KNOBS
     AT3_PH_END(pc, 10);
     if (pc.slots && lane == 0) atomicAdd(pc.slots + 11, 1ull);   // wavefronts counted
+    if (p.clk && lane == 0 && blockIdx.x < 16384u) {
+        unsigned long long* it = p.clk + 16 + 2 * 256 * 12 + 2 * blockIdx.x;
+        it[0] = item_r0;
+        it[1] = __builtin_amdgcn_s_memrealtime();
+    }
 #endif
 }
 

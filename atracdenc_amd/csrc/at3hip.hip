@@ -35,6 +35,9 @@ struct DevBuf {
 
 }  // namespace
 
+// AT3HIP_TAP_CLOCK: 16 header words, 2 x 256 rows of 12 per-phase cycle sums (k_alloc_pack, k_gain_analysis1), then, in profiling
+// builds, the entry and exit times (100 MHz) of k_alloc_pack's first 16384 workgroups
+constexpr size_t kClkWords = 16 + 2 * 256 * 12 + 2 * 16384 + 12 * 16384;   // (... and their own per-phase cycles)
 struct at3hip_ctx {
     at3hip_config cfg;
     int frame_sz = 0;
@@ -110,7 +113,7 @@ struct at3hip_ctx {
     float* d_loud_state = nullptr;
     uint8_t* d_out = nullptr;
     QuantRec* d_quant = nullptr;     // allocated by AT3HIP_OPT_QUANT_TAP
-    unsigned long long* d_clk = nullptr;   // AT3HIP_TAP_CLOCK
+    unsigned long long* d_clk = nullptr;   // AT3HIP_TAP_CLOCK (kClkWords)
     at3hip_timings tm = {};
     // grow-only device staging of the stage-level entry points (at3hip_mdct, at3hip_gain_energy_scale) for host buffers
     void* d_stage = nullptr;
@@ -414,8 +417,8 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_loud, S * B)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_loud_state, S)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_out, S * B * (size_t)c->frame_sz)) != AT3HIP_OK) return bail(rc);
-    if ((rc = dev_alloc(c, &c->d_clk, 16 + 2 * 256 * 12)) != AT3HIP_OK) return bail(rc);
-    if (hipMemsetAsync(c->d_clk, 0, (16 + 2 * 256 * 12) * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(AT3HIP_EDEVICE);   // (reset_state below waits for the stream)
+    if ((rc = dev_alloc(c, &c->d_clk, kClkWords)) != AT3HIP_OK) return bail(rc);
+    if (hipMemsetAsync(c->d_clk, 0, (kClkWords) * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(AT3HIP_EDEVICE);   // (reset_state below waits for the stream)
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
     hipDeviceProp_t prop;
     const bool have_prop = hipGetDeviceProperties(&prop, c->device) == hipSuccess;
@@ -901,7 +904,7 @@ int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
         case AT3HIP_TAP_PSY: src = c->d_psy; cap = S * B * 2 * sizeof(PsyRec); break;
         case AT3HIP_TAP_LOUDNESS: src = c->d_loud; cap = S * B * sizeof(float); break;
         case AT3HIP_TAP_QUANT: src = c->d_quant; cap = c->d_quant ? S * B * 2 * sizeof(QuantRec) : 0; break;
-        case AT3HIP_TAP_CLOCK: src = c->d_clk; cap = (16 + 2 * 256 * 12) * sizeof(unsigned long long); break;   // (from slot 16 on: 256 rows of per-phase cycles of k_alloc_pack, then of k_gain_analysis1; profiling builds)
+        case AT3HIP_TAP_CLOCK: src = c->d_clk; cap = (kClkWords) * sizeof(unsigned long long); break;   // (from slot 16 on: 256 rows of per-phase cycles of k_alloc_pack, then of k_gain_analysis1; profiling builds)
         default: return fail(c, AT3HIP_EINVAL, "unknown tap");
     }
     if (!src || bytes > cap) return fail(c, AT3HIP_EINVAL, "tap not available or request too large");
