@@ -13,7 +13,7 @@ AT3HIP_PCM_ON_DEVICE = 1
 AT3HIP_OUT_ON_DEVICE = 2
 AT3HIP_ASYNC = 4
 OPT_RUNS, OPT_FLATNESS_LITERAL, OPT_QUANT_TAP, OPT_GAIN_TWO_WAVES, OPT_GAIN_WGS_PER_CU = 1, 2, 3, 4, 5
-TAP_SPECTRA, TAP_CURVES, TAP_ENERGY_SCALE, TAP_PSY, TAP_LOUDNESS, TAP_QUANT, TAP_CLOCK = 1, 2, 3, 4, 5, 6, 7
+TAP_SPECTRA, TAP_CURVES, TAP_ENERGY_SCALE, TAP_PSY, TAP_LOUDNESS, TAP_QUANT, TAP_CLOCK, TAP_GAIN_ANALYSIS = 1, 2, 3, 4, 5, 6, 7, 8
 LP2 = 132300
 LP4 = 66150
 

@@ -27,6 +27,7 @@ struct GainParams {
     int js;
     int n_streams;
     int debug;   // profiling aid (env AT3HIP_DEBUG_GAIN): k_gain_curve returns early at stage N
+    int literal; // AT3HIP_OPT_FLATNESS_LITERAL: k_gain_spec's energy sums as the reference's two 257-term chains for every item
     unsigned long long* clk;   // profiling builds: 256 rows of 12 per-phase cycle counters of k_gain_analysis1 (tools/gain_phase_cycles.sh)
 };
 
@@ -231,6 +232,22 @@ __device__ __forceinline__ void irfft_pass_512(cpx* F, const Tw512<NT>& t, int t
 //                    items whose ratio reaches 5 % (atrac3denc.cpp:319-327), two wavefronts per item.
 // (One kernel did both at first: its cheap first half then ran at the 8-items-per-CU occupancy of the LDS-hungry second
 // half, with its sequential chains on two lanes of 128.)
+// Inclusive scan of an f64 over the 16-lane row (row_shr with zero fill: lane 15 ends up with the row's sum)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_zero_fill(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)AT3_DPP((uint32_t)b, CTRL, true), hi = (uint32_t)AT3_DPP((uint32_t)(b >> 32), CTRL, true);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double row_scan_add_f64(double v)
+{
+    v += dpp_f64_zero_fill<0x111>(v);   // row_shr:1
+    v += dpp_f64_zero_fill<0x112>(v);   // row_shr:2
+    v += dpp_f64_zero_fill<0x114>(v);   // row_shr:4
+    v += dpp_f64_zero_fill<0x118>(v);   // row_shr:8
+    return v;
+}
 constexpr int kGainBins = 220;   // bins 38 .. 256 (219), padded to an even count
 
 // ---- rfft-512 of one item in a 16-lane row --------------------------------------------------------------------------
@@ -392,10 +409,64 @@ __global__ __launch_bounds__(64) void k_gain_spec(GainParams p, const Tables* T,
     if (p.debug == 23) return;
 #endif
     // highFreqRatio (transient_spectral_upsampler.cpp:99-118): two ordered f64 sums over the 257 bin energies, the second
-    // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on). The energies are parked (as f64)
-    // in the item's storage; lanes 0..7 of the wavefront add them up - item lane / 2: even lanes e[0..256], odd lanes the
-    // two weighted terms followed by e[40..256] (the skipped terms of the reference are exact zeros and the padding read
-    // past bin 256 is zero).
+    // one weighted with the squared high-pass response (0 below bin 38, 1 from bin 40 on), and the f32 of their quotient.
+    //
+    // SHORT FORM. The reference adds each sum up as one chain of 257 dependent f64 additions; eight lanes of the wavefront doing
+    // that were a fifth of this kernel's life. The terms are non-negative, so ANY order of adding n <= 257 of them lands within
+    // gamma = 256 * 2^-53 (relative) of their exact sum; the quotient of two such sums is then within 4 gamma + 2 * 2^-53 =
+    // 1.15e-13 of the chain's quotient. Every lane adds its 17 energies, a 16-lane row scan adds the lanes, and the f32 of the
+    // quotient is taken as it stands whenever the quotient is further than 4e-13 (relative) from both rounding boundaries of that
+    // f32 - the chain's quotient then rounds to the same f32, bit for bit. Otherwise (about one item in 10^5), for quotients
+    // below the normal f32 range, and under AT3HIP_OPT_FLATNESS_LITERAL, the wavefront walks the chains.
+    bool fast_done = false;
+    {
+        const double h1 = (double)T->hpf_w[1], h2 = (double)T->hpf_w[2];
+        double et = 0.0, ef = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = L + 16 * jj;   // <= 127; its partner 256 - k >= 129 passes the filter unweighted
+            const double ea = (double)fa[jj].x * fa[jj].x + (double)fa[jj].y * fa[jj].y;
+            const double eb = (double)fb[jj].x * fb[jj].x + (double)fb[jj].y * fb[jj].y;
+            et += ea;
+            et += eb;
+            const double wa = (k < kLowCutBin) ? 0.0 : (k == kLowCutBin) ? ea * h1 * h1 : (k == kLowCutBin + 1) ? ea * h2 * h2 : ea;
+            ef += wa;
+            ef += eb;
+        }
+        if (L == 0) {
+            const double e128 = (double)f128.x * f128.x + (double)f128.y * f128.y;
+            et += e128;
+            ef += e128;
+        }
+        et = row_scan_add_f64(et);
+        ef = row_scan_add_f64(ef);   // lane 15 of the row: the item's two sums
+        bool need = false;
+        float hfr = 0.0f;
+        if (L == 15) {
+            if (et > 0.0 && ef > 0.0) {
+                const double r = ef / et;
+                hfr = (float)r;
+                if (!(hfr >= 1e-30f)) {
+                    need = true;
+                } else {
+                    const uint32_t hb = __float_as_uint(hfr);
+                    const double below = ((double)__uint_as_float(hb - 1u) + (double)hfr) * 0.5, above = ((double)hfr + (double)__uint_as_float(hb + 1u)) * 0.5;
+                    const double margin = r * 4e-13;
+                    need = !(r - below > margin && above - r > margin);
+                }
+            }   // (no energy at all, or none behind the filter: every term of that chain is an exact zero too)
+        }
+        if (p.literal || __ballot(need && valid) != 0ull) {
+            fast_done = false;
+        } else {
+            if (valid && L == 15) rec->hfr = hfr;
+            fast_done = true;
+        }
+    }
+    if (fast_done) return;
+    // The chains. The energies are parked (as f64) in the item's storage; lanes 0..7 of the wavefront add them up - item
+    // lane / 2: even lanes e[0..256], odd lanes the two weighted terms followed by e[40..256] (the skipped terms of the
+    // reference are exact zeros and the padding read past bin 256 is zero).
     {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {

@@ -760,6 +760,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             gp.js = c->js;
             gp.n_streams = S;
             gp.debug = c->dbg_gain;
+            gp.literal = c->flat_literal;
             gp.clk = c->d_clk + 16 + 256 * 12;
             launch_qmf_sub();
             HIPCHK(c, hipEventRecord(ev[1], st));
@@ -904,6 +905,7 @@ int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
         case AT3HIP_TAP_PSY: src = c->d_psy; cap = S * B * 2 * sizeof(PsyRec); break;
         case AT3HIP_TAP_LOUDNESS: src = c->d_loud; cap = S * B * sizeof(float); break;
         case AT3HIP_TAP_QUANT: src = c->d_quant; cap = c->d_quant ? S * B * 2 * sizeof(QuantRec) : 0; break;
+        case AT3HIP_TAP_GAIN_ANALYSIS: src = c->d_rec_b[par]; cap = c->d_rec_b[par] ? S * B * 6 * sizeof(GainRec) : 0; break;
         case AT3HIP_TAP_CLOCK: src = c->d_clk; cap = (kClkWords) * sizeof(unsigned long long); break;   // (from slot 16 on: 256 rows of per-phase cycles of k_alloc_pack, then of k_gain_analysis1; profiling builds)
         default: return fail(c, AT3HIP_EINVAL, "unknown tap");
     }

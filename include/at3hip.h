@@ -171,6 +171,11 @@ int at3hip_sync(at3hip_ctx* ctx);
  * allocation kernel lived; cycles / ticks x 100 = the shader clock in MHz under the rate loop's load (bench.py reports it
  * as roofline.sclk_mhz_observed). */
 #define AT3HIP_TAP_CLOCK 7
+/* AT3HIP_TAP_GAIN_ANALYSIS (diagnostic, gain control on): 416-byte records [n_streams][n_blocks of the last call][2][3] of (block,
+ * channel, band < 3); the blocks that produced no frame (block 0 of a stream's first call) hold nothing. float highFreqRatio
+ * (transient_spectral_upsampler.cpp:99-118), target, mean gain, three context floats, 2 padding floats, float gain[32] (AnalyzeGain's
+ * sub-frame RMS), lo[32], hi[32] (quartiles). Records of items below the 5 % gate hold the ratio only. */
+#define AT3HIP_TAP_GAIN_ANALYSIS 8
 int at3hip_read_tap(at3hip_ctx* ctx, int32_t kind, void* dst, size_t bytes);
 
 /* Timings of the at3hip_encode call `ago` calls back (0 = the most recent one, at most 31); waits for queued work.
@@ -190,6 +195,10 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
  *   AT3HIP_OPT_FLATNESS_LITERAL  1 = every spectral-flatness measure (CalcSpectralFlatnessPerBfu,
  *                                atrac_psy_common.cpp:158-199) by the literal per-line form; 0 (default) = the short form
  *                                with the literal one as fall-back where rounding could matter. Same values either way.
+ *                                The same switch governs the other guarded short form of the path: highFreqRatio
+ *                                (transient_spectral_upsampler.cpp:99-118), whose two 257-term f64 energy sums are added in
+ *                                lane order and whose f32 is kept only when an error bound (4e-13 against a provable
+ *                                1.15e-13) says the reference's chains round to the same f32; 1 = the chains for every item.
  *                                SUPPORTED REFERENCE PLATFORM: both forms restate glibc 2.35's f64 log / exp (and log2f) in the
  *                                variants its ifunc picks on an x86-64 host WITH FMA; glibc selects per CPU, so on a host without
  *                                FMA the reference itself rounds differently in rare last-bit cases and "bit-identical" then means
@@ -199,7 +208,7 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
 #define AT3HIP_OPT_RUNS 1
 #define AT3HIP_OPT_FLATNESS_LITERAL 2
 #define AT3HIP_OPT_QUANT_TAP 3
-#define AT3HIP_OPT_GAIN_WGS_PER_CU 5  /* tuning aid: workgroups per CU of the one-wavefront upsampler kernel (LDS padding), 0 = chosen per launch */
+#define AT3HIP_OPT_GAIN_WGS_PER_CU 5  /* tuning aid: workgroups per CU of the upsampler kernel (1 .. 16: by LDS padding; from 256: the pad in bytes), 0 = chosen per launch */
 #define AT3HIP_OPT_GAIN_TWO_WAVES 4   /* which form of the upsampler / AnalyzeGain kernel runs (same results): 0 / 1 = two-wavefront
                                         * workgroups (default), 2 = one wavefront per item (faster alone, not in the pipelined step) */
 int at3hip_set_option(at3hip_ctx* ctx, int32_t option, int32_t value);

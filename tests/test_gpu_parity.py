@@ -259,6 +259,31 @@ def test_flatness_threshold_adversarial(hip, oracle, literal):
         assert np.array_equal(got[i], frames), i
 
 
+def test_high_freq_ratio_short_form(hip, oracle):
+    """highFreqRatio (transient_spectral_upsampler.cpp:99-118) gates the gain analysis (`< 0.05`, `< 0.3`). k_gain_spec adds the
+    two f64 energy sums in lane order and keeps the f32 of the quotient only when an error bound says the reference's 257-term
+    chains round to the same f32; AT3HIP_OPT_FLATNESS_LITERAL walks the chains for every item. The ratios of both forms are
+    equal bit for bit over every item of a mixed batch, and the frames equal the oracle's in both forms."""
+    from atracdenc_amd import binding as B
+    nb = 10
+    names = sorted(SIGNALS)
+    pcm = np.stack([SIGNALS[n](nb) for n in names] + [pcm_stress(nb, seed=s) for s in range(3, 27)])
+    S = pcm.shape[0]
+    want = oracle_frames(oracle, pcm, LP2, 0, 0)
+    ratios = []
+    for literal in (0, 1):
+        enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2)
+        enc.set_option(B.OPT_FLATNESS_LITERAL, literal)
+        got = enc.encode(pcm)
+        rec = enc.read_tap(B.TAP_GAIN_ANALYSIS, np.uint32, (S, nb, 2, 3, 104))
+        enc.close()
+        assert np.array_equal(got, want), literal
+        ratios.append(rec[:, 1:, :, :, 0].copy())
+    assert np.array_equal(ratios[0], ratios[1])
+    r = ratios[0].view(np.float32)
+    assert (r >= 0.05).sum() > r.size // 4 and (r < 0.05).sum() > 0    # both sides of the gate occur
+
+
 def test_fuzz_slice(hip, oracle):
     """A slice of tools/fuzz_gpu.py (twelve families of random material from 1-LSB dither to clipped full scale):
     the long campaign (2.9 M frames, all option sets) is run by hand on the GPU box, this keeps the generator honest."""

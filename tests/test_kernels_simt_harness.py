@@ -53,6 +53,11 @@ def test_atrac3_gain_analysis_one_wavefront_form(harness):
     _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--gain-form=2", "burst", "stress"), 12)
 
 
+def test_atrac3_literal_forms(harness):
+    """AT3HIP_OPT_FLATNESS_LITERAL: the flatness measure per line and k_gain_spec's energy sums as the reference's chains."""
+    _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--literal", "mix", "stress"), 12)
+
+
 def test_atrac3_s16_entry_point(harness):
     """at3hip_encode_s16 (k_s16_to_f32 + the unchanged pipeline), calls of both kinds alternating on one context."""
     _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--s16", "mix"), 6)

@@ -39,6 +39,9 @@ if __name__ == "__main__":
                 if gain_form:
                     from atracdenc_amd.binding import OPT_GAIN_TWO_WAVES
                     enc.set_option(OPT_GAIN_TWO_WAVES, gain_form)
+                if "--literal" in sys.argv:   # AT3HIP_OPT_FLATNESS_LITERAL: the guarded short forms (flatness, highFreqRatio) take their literal paths
+                    from atracdenc_amd.binding import OPT_FLATNESS_LITERAL
+                    enc.set_option(OPT_FLATNESS_LITERAL, 1)
                 # feed in two pieces to exercise the carried state
                 if "--s16" in sys.argv:   # at3hip_encode_s16: the same samples as 16-bit integers, converted on the "device"
                     p16 = np.round(np.clip(pcm, -1.0, 32767.0 / 32768.0) * 32768.0).astype(np.int16)
