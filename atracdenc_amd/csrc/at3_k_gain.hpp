@@ -635,12 +635,13 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         // pairs - instead of sixteen neighbours, which share four (the reads were 4-way conflicts: a fifth of the kernel's LDS cycles)
         const int n = tid + 128 * q;
         const int c = (n & 3) | ((n & 0xc) << 1) | ((n & 0x10) >> 2) | (n & 0xe0);
-        const cpx* src = L.f + 528 + 4 * c + (c >> 3);
+        cpx* src = L.f + 528 + 4 * c + (c >> 3);
         float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f2 v = ld2(src + i) * norm;
             const f2 sq = v * v;
+            st2(src + i, sq);   // the sub-frame sums below add the same squares: formed here by 128 work-items, not there by 32
             acc += sq.x;
             acc += sq.y;
         }
@@ -656,10 +657,8 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
         float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            const f2 v = x[i] * norm;
-            const f2 sq = v * v;
-            acc += sq.x;
-            acc += sq.y;
+            acc += x[i].x;
+            acc += x[i].y;
         }
         acc /= 64;
         rec->gain[lane] = sqrtf(acc);
