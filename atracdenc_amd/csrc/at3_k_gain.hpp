@@ -520,10 +520,12 @@ struct GainLds {
     cpx f[2048 + 64];   // the irfft-4096 core / upsampled samples, padded (irfft_pad)
 };
 
-__global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Tables* T)
+__global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Tables* __restrict__ T)
 {
     __shared__ __attribute__((aligned(16))) GainLds s_item[1];
-    const int tid = threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (readfirstlane: the wavefront index as a scalar - the two halves of pass m = 2 / 8 then branch on the scalar unit and fetch
+    // their wavefront-wide twiddles through it instead of as 13 vector loads behind the first barrier)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     GainLds& L = s_item[0];
     const int nfr = p.n_blocks - p.f0;
     const bool valid = true;
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     const cpx stw_in0 = T->stw2048[k0 - 1];
     const cpx stw_in1 = T->stw2048[k1 - 1 < 1024 ? k1 - 1 : 1023];
     const float hpf1 = T->hpf_w[1], hpf2 = T->hpf_w[2];
+    __builtin_amdgcn_sched_barrier(0);   // what the leaves need is REQUESTED FIRST (loads return in issue order; see the leaves below)
     const Tw32_128 tw_b = irfft_tw_32_128(T->gain_tw, tid);
     const Tw512<128> tw_c = irfft_tw_512<128>(T->gain_tw, tid);
 #ifdef AT3HIP_DEBUG_KNOBS
@@ -561,30 +564,33 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
     // 3. kiss_fftri input. Only bins 38..256 survive the high-pass, so tmpbuf is non-zero at k in [38,256] and
     //    [1792,2010]; each of those meets an exact zero in its radix-2 leaf butterfly (x +- 0*w), whose two outputs
     //    are therefore stored directly.
+    // (Loads return in issue order. The leaf values are formed for both bins unconditionally - k0 <= 165 always, only the second
+    // bin's stores depend on k1 <= 256: with the arithmetic inside an `if` the compiler sank the two input twiddles' requests
+    // into it, BEHIND the 27 twiddle requests above, and the leaves then waited for every one of those.)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int k = q ? k1 : k0;
+        const cpx fr = q ? bin1 : bin0;
+        cpx fk;
+        const float scale = 8.0f;
+        if (k == 256) {
+            fk.r = fr.r * scale * 0.5f;
+            fk.i = 0.0f;
+        } else if (k >= kLowCutBin + 2) {
+            fk.r = fr.r * scale;
+            fk.i = fr.i * scale;
+        } else {
+            const float w = (k == kLowCutBin) ? hpf1 : hpf2;
+            fk.r = fr.r * scale * w;
+            fk.i = fr.i * scale * w;
+        }
+        // fnkc = conj(freq[2048 - k]) = (0, -0): fek = fk, tmp = fk
+        const cpx fok = cmul(fk, q ? stw_in1 : stw_in0);
+        cpx a, b, nb;
+        a.r = fk.r + fok.r; a.i = fk.i + fok.i;
+        b.r = fk.r - fok.r; b.i = -(fk.i - fok.i);
+        nb.r = 0.0f - b.r; nb.i = 0.0f - b.i;
         if (k <= 256) {
-            const cpx fr = q ? bin1 : bin0;
-            cpx fk;
-            const float scale = 8.0f;
-            if (k == 256) {
-                fk.r = fr.r * scale * 0.5f;
-                fk.i = 0.0f;
-            } else if (k >= kLowCutBin + 2) {
-                fk.r = fr.r * scale;
-                fk.i = fr.i * scale;
-            } else {
-                const float w = (k == kLowCutBin) ? hpf1 : hpf2;
-                fk.r = fr.r * scale * w;
-                fk.i = fr.i * scale * w;
-            }
-            // fnkc = conj(freq[2048 - k]) = (0, -0): fek = fk, tmp = fk
-            const cpx fok = cmul(fk, q ? stw_in1 : stw_in0);
-            cpx a, b, nb;
-            a.r = fk.r + fok.r; a.i = fk.i + fok.i;
-            b.r = fk.r - fok.r; b.i = -(fk.i - fok.i);
-            nb.r = 0.0f - b.r; nb.i = 0.0f - b.i;
             const int pa = fft_leaf_pos<2048>(k);          // even slot: partner input k + 1024 is zero
             L.f[irfft_pad(pa)] = a;
             L.f[irfft_pad(pa) + 1] = a;
