@@ -760,7 +760,30 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     const PsyRec* rec = recs + ch;
     const Curve* curves = p.curves + ((size_t)s * p.n_blocks + f) * 8;
     const int half = p.frame_sz >> 1;
+    // Everything the wavefront wants from global memory before the rate loop is requested HERE, in one batch, and nothing below
+    // waits for more than its own value (loads return in issue order). Requested where they were used, the tonal count, the
+    // curves' point counts, the channel loudnesses (joint stereo) and the spectrum were four round trips one after the other
+    // at the head of every wavefront's life; a load inside an `if` with a default value costs a wait where the two paths join.
     const int n_tonal = rec->n_tonal;
+    const uint32_t curve_w0 = *reinterpret_cast<const uint32_t*>(curves + (lane & 7));
+    const float loud_m = recs[0].loud_ch, loud_s = recs[1].loud_ch;
+    const float loud_raw = p.loud[(size_t)s * n_out + fo];
+    const int my_sfi = rec->sfi[lane & 31];   // one load per lane (lanes 32..63 mirror 0..31)
+    // wanted by CalcBitsAllocation's per-BFU constants after the small units
+    const int pre_band = (lane & 31) >= 30 ? 3 : (lane & 31) >= 26 ? 2 : (lane & 31) >= 18 ? 1 : 0;
+    const float* ges_src = p.ges ? p.ges + ((size_t)s * p.n_blocks + f) * 8 + ch * 4 + pre_band : &T->scale[63];   // (ScaleTable[63] = 2^0)
+    const float pre_g = *ges_src;
+    const float pre_energy = rec->energy[lane & 31];
+    const float pre_ath = T->ath_bfu[lane & 31];
+    const float my_scale = T->scale[lane];   // ScaleTable has 64 entries: looked up across lanes, not through memory
+    const int pre_fixed = (int)c_fixed_alloc[lane & 31];
+    float4 x4[4];
+    {
+        const float* specs = p.specs + cf * 1024;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x4[k] = *reinterpret_cast<const float4*>(specs + 4 * (lane + 64 * k));
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     for (int i = lane; i < 7 * 32; i += 64) s_cost[i] = 0u;
     float* qerr = p.quant ? &p.quant[cf].err[0][0] : nullptr;
@@ -771,8 +794,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     // lanes 0..7 hold the frame's eight gain curves (16 bytes each) from here to the emission
     // (only the point counts are needed before the emission: the curves themselves are fetched again there rather than
     // held in four registers across the whole rate loop)
-    int curve_n = 0;
-    if (lane < 8) curve_n = (int)(*reinterpret_cast<const uint32_t*>(curves + lane) & 0xffu);
+    const int curve_n = lane < 8 ? (int)(curve_w0 & 0xffu) : 0;
     int hdr[2];
     for (int c2 = 0; c2 < 2; ++c2) {
         int bits = (p.js && c2 == 1) ? 14 : 6;
@@ -790,7 +812,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         const int b0 = -6 - hdr[0], b1 = -6 - hdr[1];
         const int totalUsed = 0 - b0 - b1;
         const int maxShift = (int)((uint32_t)p.frame_sz / 2 - (1 + ((uint32_t)totalUsed - 1) / 8));
-        const float m = recs[0].loud_ch, sd = recs[1].loud_ch;
+        const float m = loud_m, sd = loud_s;
         const float total = sd + m;
         float ratio = 0.0f;
         if (total > 0) ratio = (float)((double)(m / total) - 0.5);
@@ -803,7 +825,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     int target = -6 - hdr[ch] + 8 * nbytes;
     if (target < 1) target = 1;
     target &= 0xffff;
-    const float loudness = p.loud[(size_t)s * n_out + fo] / 0.006f;
+    const float loudness = loud_raw / 0.006f;
 
     if (p.mono_js && ch == 1) {
         for (int i = lane; i < kBitWords; i += 64) s_words[i] = 0;
@@ -833,20 +855,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 
 
     // ---- scaled values (TScaler::Scale, atrac_scale.cpp:141-172) and e1 = sum of value^2 per BFU, in line order ----
-    const int my_sfi = rec->sfi[lane & 31];   // one load per lane (lanes 32..63 mirror 0..31)
-    // requested with the spectrum, wanted by CalcBitsAllocation's per-BFU constants after the small units: fetched where they are
-    // used, each was a global-memory round trip of its own on the wavefront's chain (the fences of the LDS phases keep the
-    // compiler from moving them up)
-    const int pre_band = (lane & 31) >= 30 ? 3 : (lane & 31) >= 26 ? 2 : (lane & 31) >= 18 ? 1 : 0;
-    const float pre_g = p.ges ? p.ges[((size_t)s * p.n_blocks + f) * 8 + ch * 4 + pre_band] : 1.0f;
-    const float pre_energy = rec->energy[lane & 31];
-    const float pre_ath = T->ath_bfu[lane & 31];
     {
-        const float* specs = p.specs + cf * 1024;
-        const float my_scale = T->scale[lane];   // ScaleTable has 64 entries: looked up across lanes, not through memory
-        float4 x4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) x4[k] = *reinterpret_cast<const float4*>(specs + 4 * (lane + 64 * k));
         // (the four rounds' scale factors first: two cross-lane round trips in all, not two per round)
         float sf4[4];
         {
@@ -986,7 +995,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         else if (i < 15) x = 3.3f;
         else if (i <= 20) x = 3.6f;
         else if (i <= 28) x = 4.2f;
-        A = spread * (csfi / x) + (1.0f - spread) * (float)c_fixed_alloc[i];
+        A = spread * (csfi / x) + (1.0f - spread) * (float)pre_fixed;
         // (tonal blocks per BFU: counted below from the per-lane copies of the blocks' BFU indices)
     }
     // ConsiderEnergyErr as a per-BFU map wl -> wl' (first 10 BFUs, atrac3_bitstream.cpp:241-257, :638-641): BFUs are
@@ -1244,8 +1253,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     }
     // requested now, wanted after the mantissas below have been formed: the frame's curves (lanes 0..7, for the header) and
     // the code tables (their LDS storage was the key lists' until here)
-    uint4 cw = {0u, 0u, 0u, 0u};
-    if (lane < 8) cw = *reinterpret_cast<const uint4*>(curves + lane);
+    const uint4 cw = *reinterpret_cast<const uint4*>(curves + (lane & 7));   // (every lane asks: a load inside `if (lane < 8)` is waited for where the paths join)
     const uint32_t huff_a = c_huff[lane], huff_b = c_huff[64 + lane], huff_c = lane < 2 ? c_huff[128 + lane] : 0u;
     if (lane < 32) s_alloc[lane] = (uint8_t)bits;
     for (int k = lane; k < kBitWords; k += 64) s_words[k] = 0;   // the key lists are dead: their storage becomes the bit buffer
