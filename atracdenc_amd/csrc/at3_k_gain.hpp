@@ -292,9 +292,12 @@ __global__ __launch_bounds__(64) void k_gain_spec(GainParams p, const Tables* T,
     cpx* bins = p.bins + (size_t)item * kGainBins;
 
     // 1. window and pack: complex input i = L + 16 t is samples (2 i, 2 i + 1); a[4 q3 + q4] = input t = q3 + 4 q4
+    // Table values are requested a stage AHEAD of their use, in batches (a request made where the value is wanted costs the
+    // wavefront an L2 round trip right there - three of them in a ten-microsecond life, with three wavefronts per SIMD to cover):
+    // the window with the samples, the lane's fifteen twiddles while passes m = 1 and 4 run.
     f2 a[16];
     {
-        f2 raw[16], rb[16];
+        f2 raw[16], rb[16], win[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int i = L + 16 * t;
@@ -302,13 +305,19 @@ __global__ __launch_bounds__(64) void k_gain_spec(GainParams p, const Tables* T,
             if (p.js) rb[t] = *reinterpret_cast<const f2*>(sb1 + 2 * i);
         }
 #pragma unroll
+        for (int t = 0; t < 16; ++t) win[t] = ld2(&T->spec16_win[t][L]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
         for (int t = 0; t < 16; ++t) {
             f2 v = raw[t];
             if (p.js) v = (ch == 0) ? (v + rb[t]) * mk2(0.5f, 0.5f) : (v - rb[t]) * mk2(0.5f, 0.5f);
-            const f2 w = ld2(&T->spec16_win[t][L]);
-            a[4 * (t & 3) + (t >> 2)] = v * w;
+            a[4 * (t & 3) + (t >> 2)] = v * win[t];
         }
     }
+    f2 tw_l[15];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) tw_l[q] = ld2(&T->spec16_tw[q][L]);
+    __builtin_amdgcn_sched_barrier(0);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug == 21) return;
 #endif
@@ -338,13 +347,11 @@ __global__ __launch_bounds__(64) void k_gain_spec(GainParams p, const Tables* T,
     }
     // passes m = 16 (butterfly k = L over q2, for every q1) and m = 64 (butterfly k = L + 16 j over q1)
     {
-        const f2 u1 = ld2(&T->spec16_tw[0][L]), u2 = ld2(&T->spec16_tw[1][L]), u3 = ld2(&T->spec16_tw[2][L]);
+        const f2 u1 = tw_l[0], u2 = tw_l[1], u3 = tw_l[2];
 #pragma unroll
         for (int q1 = 0; q1 < 4; ++q1) bfly4<false>(b[q1], b[q1 + 4], b[q1 + 8], b[q1 + 12], u1, u2, u3);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            bfly4<false>(b[4 * j], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3], ld2(&T->spec16_tw[3 + 3 * j][L]), ld2(&T->spec16_tw[4 + 3 * j][L]),
-                         ld2(&T->spec16_tw[5 + 3 * j][L]));
+        for (int j = 0; j < 4; ++j) bfly4<false>(b[4 * j], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3], tw_l[3 + 3 * j], tw_l[4 + 3 * j], tw_l[5 + 3 * j]);
     }
     // now b[q + 4 j] = F[L + 16 (j + 4 q)]: F[L + 16 jj] = b[(jj >> 2) + 4 (jj & 3)]
 #ifdef AT3HIP_DEBUG_KNOBS
