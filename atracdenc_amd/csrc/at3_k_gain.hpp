@@ -548,19 +548,24 @@ __global__ __launch_bounds__(128) void k_gain_analysis(GainParams p, const Table
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug == 11) return;   // launch cost alone
 #endif
+    // Loads return in issue order. The item's gate goes first and the bins and input twiddles right behind it, in the same round
+    // trip: a workgroup that passes the gate (they all do on busy material) has its leaves' inputs arriving while it tests the
+    // ratio, one that fails leaves after the one latency it always paid. The 27 twiddles of the later passes are requested after
+    // the gate and BEHIND what the leaves need (sched_barrier: see the leaves below), out of L2, with a whole stage to arrive in.
     const float hfr = rec->hfr;
-    if (hfr < 0.05f) return;
     const cpx* bins = p.bins + item * kGainBins;
-    // this work-item's bins (k = 38 + tid and 166 + tid), tables and twiddles: one global-memory latency for all of them
     const int k0 = kLowCutBin + tid, k1 = kLowCutBin + 128 + tid;
     const cpx bin0 = bins[tid];
-    const cpx bin1 = (k1 <= 256) ? bins[128 + tid] : bin0;
+    const cpx bin1 = bins[k1 <= 256 ? 128 + tid : tid];
     const cpx stw_in0 = T->stw2048[k0 - 1];
     const cpx stw_in1 = T->stw2048[k1 - 1 < 1024 ? k1 - 1 : 1023];
     const float hpf1 = T->hpf_w[1], hpf2 = T->hpf_w[2];
-    __builtin_amdgcn_sched_barrier(0);   // what the leaves need is REQUESTED FIRST (loads return in issue order; see the leaves below)
+    __builtin_amdgcn_sched_barrier(0);
+    if (hfr < 0.05f) return;
+    __builtin_amdgcn_sched_barrier(0);   // (requests the compiler sinks below the gate still stay in front of the twiddles')
     const Tw32_128 tw_b = irfft_tw_32_128(T->gain_tw, tid);
     const Tw512<128> tw_c = irfft_tw_512<128>(T->gain_tw, tid);
+    __builtin_amdgcn_sched_barrier(0);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug == 12) {   // launch + the fetches
         float sink = bin0.r + bin1.i + stw_in0.r + stw_in1.i + hpf1 + hpf2 + tw_b.a[0].x + tw_b.w[3][2].y + tw_c.w[0][0].x + tw_c.w[3][2].y;
