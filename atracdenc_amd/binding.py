@@ -338,7 +338,7 @@ AT3_TABLES_DTYPE = np.dtype([("qmf_win", "<f4", 48), ("scale", "<f4", 64), ("enc
                              ("stw256", "<f4", (128, 2)), ("tw2048", "<f4", (2048, 2)), ("stw2048", "<f4", (1024, 2)),
                              ("log2f_tab", "<f8", (16, 2)), ("log2f_poly", "<f8", 4), ("gain_tw", "<f4", (27, 128, 2)),
                              ("ga1_twb", "<f4", (2, 15, 16, 2)), ("ga1_twc", "<f4", (8, 3, 64, 2)),
-                             ("spec16_win", "<f4", (16, 16, 2)), ("spec16_tw", "<f4", (15, 16, 2)), ("spec16_stw", "<f4", (9, 16, 2)), ("log_c", "<f8", 18),
+                             ("mdct_tab", "<f4", (18, 16, 4)), ("spec16_win", "<f4", (16, 16, 2)), ("spec16_tw", "<f4", (15, 16, 2)), ("spec16_stw", "<f4", (9, 16, 2)), ("log_c", "<f8", 18),
                              ("log_tab", "<f8", (128, 2)), ("exp_c", "<f8", 8), ("exp_tab", "<u8", (128, 2))])
 
 

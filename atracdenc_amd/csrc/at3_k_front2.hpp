@@ -305,33 +305,25 @@ struct MdctTab {
     float4 e[18][16];
 };
 
-// Built by all threads of the workgroup; the caller synchronises before the first use.
-__device__ __forceinline__ void mdct_tab_build(MdctTab& tab, const Tables* T, int tid, int nthr)
+// Copied from Tables::mdct_tab by the 256 work-items of the workgroup (one 16-byte load each, 32 of them a second one); the
+// caller synchronises before the first use. Request and store are two calls so that a kernel can put its first HBM requests
+// between them: loads return in issue order, and the table - out of L2, asked for first - is then in LDS long before they land.
+struct MdctTabRegs {
+    float4 a, b;
+};
+__device__ __forceinline__ MdctTabRegs mdct_tab_request(const Tables* T, int tid)
 {
-    for (int idx = tid; idx < 18 * 16; idx += nthr) {
-        const int en = idx >> 4, L = idx & 15;
-        const int q1 = L >> 2, q2 = L & 3, b = q1 + 4 * q2;
-        float4 v;
-        if (en < 4) {
-            const int e = 2 * b + 32 * en;
-            v = make_float4(T->enc_win[e], T->enc_win[128 + e], T->enc_win[127 - e], T->enc_win[255 - e]);
-        } else if (en < 8) {
-            const int n = 2 * (b + 16 * (en - 4));
-            v = make_float4(T->mdct_sincos[n], T->mdct_sincos[n + 1], T->mdct_sincos[n + 128], T->mdct_sincos[n + 129]);
-        } else if (en < 12) {
-            const int n = 2 * (8 * q1 + 2 * q2 + 32 * (en - 8));
-            v = make_float4(T->mdct_sincos[n], T->mdct_sincos[n + 1], T->mdct_sincos[n + 2], T->mdct_sincos[n + 3]);
-        } else if (en < 15) {
-            const int j = en - 11, k = 2 * q2;
-            const cpx a = T->tw128[4 * j * k], c = T->tw128[4 * j * (k + 1)];
-            v = make_float4(a.r, a.i, c.r, c.i);
-        } else {
-            const int j = en - 14, k = 8 * q1 + 2 * q2;
-            const cpx a = T->tw128[j * k], c = T->tw128[j * (k + 1)];
-            v = make_float4(a.r, a.i, c.r, c.i);
-        }
-        tab.e[en][L] = v;
-    }
+    const float4* flat = reinterpret_cast<const float4*>(&T->mdct_tab[0][0][0]);
+    MdctTabRegs r;
+    r.a = flat[tid];
+    r.b = flat[256 + (tid & 31)];
+    return r;
+}
+__device__ __forceinline__ void mdct_tab_store(MdctTab& tab, const MdctTabRegs& r, int tid)
+{
+    float4* flat = &tab.e[0][0];
+    flat[tid] = r.a;
+    if (tid < 32) flat[256 + tid] = r.b;
 }
 
 // The lane's sixteen samples from its row's 256. The lane reads the even-index pairs (x[i], x[i+1]) at i = e and
@@ -600,6 +592,9 @@ __global__ __launch_bounds__(256) void k_mdct_sub(MdctSubParams p, const Tables*
     float* spec_base = p.specs + ((size_t)s * n_out * 2 + ch) * 1024 + band * 256;
     // block f - 1 is frame f's new half; block fa - 2 primes the overlap of the run (modulated by frame fa - 1's curve).
     // The subbands of the next block are requested before the current one is transformed: a wavefront waits for HBM once.
+    const MdctTabRegs tab_regs = mdct_tab_request(T, tid);
+    const float gi_v = T->gain_interp[(tid & 31) < 31 ? (tid & 31) : 30];
+    __builtin_amdgcn_sched_barrier(0);   // (the workgroup's tables are asked for FIRST: see mdct_tab_request)
     RowRaw raw_a, raw_b;
     rows_request(sb_own, sb_l, sb_r, JS, fa - 1, b, raw_a, raw_b);
     // the frame's curve (16 bytes per row, lane 0 of the row) is requested one frame ahead like the subbands: fetched where it
@@ -610,9 +605,10 @@ __global__ __launch_bounds__(256) void k_mdct_sub(MdctSubParams p, const Tables*
     };
     uint4 c4_next = {0u, 0u, 0u, 0u};
     if (p.curves && L == 0) c4_next = curve_request(fa - 1);
-    // the run's first subbands and curve are on their way while the workgroup builds its tables
-    if (tid < 32) s_gi[tid] = T->gain_interp[tid < 31 ? tid : 30];
-    mdct_tab_build(s_tab, T, tid, 256);
+    __builtin_amdgcn_sched_barrier(0);
+    // the run's first subbands and curve are on their way while the workgroup stores its tables
+    if (tid < 32) s_gi[tid] = gi_v;
+    mdct_tab_store(s_tab, tab_regs, tid);
     __syncthreads();   // the only workgroup-level rendezvous: the shared tables
     if (!live) return;
     for (int f = fa - 1; f < fb; ++f) {
@@ -681,10 +677,14 @@ __global__ __launch_bounds__(256) void k_qmf_mdct8(FrontParams p, const Tables* 
     static_assert(sizeof(float) * kPcmRing8 >= sizeof(float) * 4 * 264, "the block's subbands reuse the PCM ring");
     static_assert(sizeof(float) * 2 * kS1Ring8 >= sizeof(float4) * 4 * kRowScratch4, "the exchange scratch reuses the stage-1 rings");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    mdct_tab_build(s_tab, T, tid, 256);
-    __syncthreads();   // the only workgroup-level rendezvous: the shared table
-    const int W = blockIdx.x * 4 + wave;
-    if (W >= n_waves) return;
+    // The shared table is asked for first and stored behind the run's prologue - the wavefront's first PCM requests do not queue up
+    // behind a workgroup rendezvous. (A wavefront past the end of the launch runs the last run's prologue, which writes nothing but
+    // its own LDS, and leaves after the rendezvous.)
+    const MdctTabRegs tab_regs = mdct_tab_request(T, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    const int W0 = blockIdx.x * 4 + wave;
+    const bool live = W0 < n_waves;
+    const int W = live ? W0 : n_waves - 1;
     QmfLdsW& S = s_q[wave];
     const int n_out = p.n_blocks - p.f0;
     const int nchunks = p.frame_runs;   // runs per (stream, channel): the n_out frames are dealt out as evenly as possible
@@ -714,6 +714,9 @@ __global__ __launch_bounds__(256) void k_qmf_mdct8(FrontParams p, const Tables* 
     float4* scratch = reinterpret_cast<float4*>(S.s1) + band * kRowScratch4;   // after stage 2
     const int b0 = fa - 2, b_last = fb - 2;
     qmf_prologue<false>(S, q, S.s1 + kPrologueTmp, Wp, b0, b_last, lane);
+    mdct_tab_store(s_tab, tab_regs, tid);
+    __syncthreads();   // the only workgroup-level rendezvous: the shared table
+    if (!live) return;
     float* spec_base = p.specs + ((size_t)s * n_out * 2 + ch) * 1024 + band * 256;
     const int which = lane >> 5, g = lane & 31;
     for (int blk = b0; blk <= b_last; ++blk) {

@@ -135,6 +135,28 @@ AT3_RUNTIME_LIBM void build_tables(Tables* t)
                 for (int q = 0; q < 3; ++q) t->ga1_twc[4 * u + tt][q][lane] = t->tw2048[(q + 1) * kk];
             }
 
+    for (int en = 0; en < 18; ++en)   // see MdctTab (at3_k_front2.hpp); needs enc_win, mdct_sincos and tw128 from above
+        for (int L = 0; L < 16; ++L) {
+            const int q1 = L >> 2, q2 = L & 3, b = q1 + 4 * q2;
+            float* v = t->mdct_tab[en][L];
+            if (en < 4) {
+                const int e = 2 * b + 32 * en;
+                v[0] = t->enc_win[e]; v[1] = t->enc_win[128 + e]; v[2] = t->enc_win[127 - e]; v[3] = t->enc_win[255 - e];
+            } else if (en < 8) {
+                const int n = 2 * (b + 16 * (en - 4));
+                v[0] = t->mdct_sincos[n]; v[1] = t->mdct_sincos[n + 1]; v[2] = t->mdct_sincos[n + 128]; v[3] = t->mdct_sincos[n + 129];
+            } else if (en < 12) {
+                const int n = 2 * (8 * q1 + 2 * q2 + 32 * (en - 8));
+                v[0] = t->mdct_sincos[n]; v[1] = t->mdct_sincos[n + 1]; v[2] = t->mdct_sincos[n + 2]; v[3] = t->mdct_sincos[n + 3];
+            } else if (en < 15) {
+                const int j = en - 11, k = 2 * q2;
+                v[0] = t->tw128[4 * j * k].r; v[1] = t->tw128[4 * j * k].i; v[2] = t->tw128[4 * j * (k + 1)].r; v[3] = t->tw128[4 * j * (k + 1)].i;
+            } else {
+                const int j = en - 14, k = 8 * q1 + 2 * q2;
+                v[0] = t->tw128[j * k].r; v[1] = t->tw128[j * k].i; v[2] = t->tw128[j * (k + 1)].r; v[3] = t->tw128[j * (k + 1)].i;
+            }
+        }
+
     {   // Planck taper, epsilon 0.15, N = 512
         const float eN = 0.15f * 512.0f;
         const float fN = 512.0f;

@@ -49,6 +49,9 @@ struct Tables {
     //   spec16_tw[s][L]   s = 0..2: tw256[4 (s + 1) L] (pass m = 16, butterfly k = L);
     //                     s = 3 + 3 j + q - 1: tw256[q (L + 16 j)], j = 0..3, q = 1..3 (pass m = 64, butterfly k = L + 16 j)
     //   spec16_stw[jj][L] super twiddle stw256[k - 1] of bin k = L + 16 jj, jj = 0..7 (k = 0: unused); [8][0] = stw256[127] (bin 128)
+    // k_mdct_sub / k_qmf_mdct8: the row transform's per-lane constants, entry e of row position L at [e][L] (see MdctTab in
+    // at3_k_front2.hpp for what the 18 entries are) - copied into LDS by every workgroup, one 16-byte load per work-item
+    float mdct_tab[18][16][4];
     cpx spec16_win[16][16];
     cpx spec16_tw[15][16];
     cpx spec16_stw[9][16];
