@@ -229,8 +229,8 @@ __device__ __forceinline__ void qmf_prologue(QmfLdsW& S, QmfRunW& q, float* tmp,
 
 // ---- subband analysis only (feeds the gain-control kernels and the MDCT-from-subbands kernel) ----------------------
 // Raw L/R subbands of blocks 0 .. n_blocks-1 to HBM; blocks -2 and -1 (look-back of the gain analysis, overlap of the
-// first frame) are the previous call's last two, carried in `sub_tail` and copied in front by the run that starts at
-// block 0. One wavefront = (stream, channel, one of `sub_runs` runs of blocks); a workgroup is four independent wavefronts.
+// first frame) are the previous call's last two, carried in `sub_tail` and copied in front by the (stream, channel)'s runs
+// between them. One wavefront = (stream, channel, one of `sub_runs` runs of blocks); a workgroup is four independent wavefronts.
 __global__ __launch_bounds__(256) void k_qmf_sub8(FrontParams p, const Tables* T, int n_waves)
 {
     __shared__ __attribute__((aligned(16))) QmfLdsW s_q[4];
@@ -246,14 +246,6 @@ __global__ __launch_bounds__(256) void k_qmf_sub8(FrontParams p, const Tables* T
     const int ba = (chunk * p.n_blocks) / nchunks;
     const int bb = ((chunk + 1) * p.n_blocks) / nchunks;
     const size_t sublen = (size_t)nb2 * 256;
-    if (chunk == 0) {   // 4 bands x 512 carried floats = 512 sixteen-byte words
-        const float4* src = reinterpret_cast<const float4*>(p.sub_tail + ((size_t)s * 8 + ch * 4) * 512);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = lane + 64 * k, band = i >> 7;
-            reinterpret_cast<float4*>(p.sub + ((size_t)s * 8 + ch * 4 + band) * sublen)[i & 127] = src[i];
-        }
-    }
     f2 Wp[24];
     load_taps(T, Wp);
     QmfRunW q;
@@ -282,6 +274,17 @@ __global__ __launch_bounds__(256) void k_qmf_sub8(FrontParams p, const Tables* T
         o1[0] = make_float4(up[0], up[1], up[2], up[3]);
         o1[1] = make_float4(up[4], up[5], up[6], up[7]);
         wave_sync();
+    }
+    // The carried blocks -2 and -1 of this (stream, channel) - 4 bands x 512 floats = 512 sixteen-byte words - move in front of
+    // the call's subbands: nobody in this kernel reads them, so the runs SHARE the copy (word chunk * 64 + lane, + 64 runs, ...)
+    // and make it their last act. The run of block 0 used to do all of it first, as eight load-store pairs that may alias for all
+    // the compiler knows: eight global round trips one after the other before that wavefront began its real work.
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.sub_tail + ((size_t)s * 8 + ch * 4) * 512);
+        for (int i = chunk * 64 + lane; i < 512; i += 64 * nchunks) {
+            const int band = i >> 7;
+            reinterpret_cast<float4*>(p.sub + ((size_t)s * 8 + ch * 4 + band) * sublen)[i & 127] = src[i];
+        }
     }
 }
 
