@@ -203,9 +203,12 @@ __device__ __forceinline__ void qmf_prologue(QmfLdsW& S, QmfRunW& q, float* tmp,
 {
     // stage-1 outputs m = -48 .. -1 need samples -142 .. -1 (output m reads samples 2m - 46 .. 2m + 1)
     tile_fetch(q, b0, lane);
-    float h[3];
+    float h[3];   // (every lane asks, at a clamped index: a load under a lane condition is issued late and waited for where the paths join)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) h[k] = (lane + 64 * k < 144) ? pcm_at(q, b0 * 1024 - 144 + lane + 64 * k) * 0.25f : 0.0f;
+    for (int k = 0; k < 3; ++k) h[k] = pcm_at(q, b0 * 1024 - 144 + (lane + 64 * k < 144 ? lane + 64 * k : 143));
+    __builtin_amdgcn_sched_barrier(0);   // (all three requested before the first is waited for)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) h[k] *= 0.25f;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
         if (lane + 64 * k < 144) tmp[lane + 64 * k] = h[k];
