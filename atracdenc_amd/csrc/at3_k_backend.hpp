@@ -144,17 +144,21 @@ __global__ __launch_bounds__(256) void k_loud_sum(BackParams p, const Tables* T,
     __shared__ __attribute__((aligned(16))) float s_curve[1024];   // LoudnessCurve: a global load per chunk would stall the producers
     __shared__ __attribute__((aligned(16))) float s_ges[kLoudCf * 4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    *reinterpret_cast<float4*>(s_curve + 4 * tid) = *reinterpret_cast<const float4*>(T->loud_curve + 4 * tid);
+    // (the curve, the band scales and the first two chunks of spectra are ONE round trip: every work-item asks for its curve words and,
+    // at a clamped index, for a channel-frame's scales before anything is stored - written as load-store pairs under conditions they
+    // were three round trips one after the other at the head of the workgroup's life)
+    const float4 curve_v = *reinterpret_cast<const float4*>(T->loud_curve + 4 * tid);
     const int c0 = blockIdx.x * kLoudCf;
     const int n_out = p.n_blocks - p.f0;
-    if (tid < kLoudCf) {   // the channel-frames' four band scales
-        const int c = c0 + tid;
-        float4 gv = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        if (p.ges && c < n_cf) {
-            const int ch = c & 1, fo = (c >> 1) % n_out, s = (c >> 1) / n_out;
-            gv = *reinterpret_cast<const float4*>(p.ges + ((size_t)s * p.n_blocks + fo + p.f0) * 8 + ch * 4);
-        }
-        *reinterpret_cast<float4*>(s_ges + 4 * tid) = gv;
+    float4 ges_v;
+    bool ges_ok;
+    {
+        const int cq = c0 + (tid < kLoudCf ? tid : 0);
+        const int c = cq < n_cf ? cq : n_cf - 1;
+        const int ch = c & 1, fo = (c >> 1) % n_out, s = (c >> 1) / n_out;
+        const float* src = p.ges ? p.ges + ((size_t)s * p.n_blocks + fo + p.f0) * 8 + ch * 4 : T->loud_curve;
+        ges_v = *reinterpret_cast<const float4*>(src);
+        ges_ok = p.ges && cq < n_cf;
     }
     // producer role: thread u = tid - 64 of 192 forms the terms of the 16-byte words w = u + 192 i of a chunk (word w =
     // lines 4 (w % words per row) .. + 3 of channel-frame w / words per row). The spectra of chunk k + 2 are requested while
@@ -166,6 +170,8 @@ __global__ __launch_bounds__(256) void k_loud_sum(BackParams p, const Tables* T,
         loud_request(p.specs, c0, n_cf, u, 0, xa);
         loud_request(p.specs, c0, n_cf, u, 1, xb);
     }
+    *reinterpret_cast<float4*>(s_curve + 4 * tid) = curve_v;
+    if (tid < kLoudCf) *reinterpret_cast<float4*>(s_ges + 4 * tid) = ges_ok ? ges_v : make_float4(1.0f, 1.0f, 1.0f, 1.0f);   // the channel-frames' four band scales
     __syncthreads();   // the curve is in LDS
     if (wave > 0) {
         loud_produce(s_t[0], s_curve, s_ges, u, 0, xa);
@@ -258,12 +264,15 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
     float* specs0 = p.specs + (size_t)c0 * 1024;
     PsyRec* rec0 = p.psy + c0;
 
+    // (every work-item asks for everything at once, at clamped indices: a load under a condition with a default value is waited for
+    // where the paths join, and the ScaleTable request behind it was a second round trip before the first rendezvous)
+    const float scale_v = T->scale[tid & 63];
     {
         float4 x4[kPsyCf];
 #pragma unroll
-        for (int k = 0; k < kPsyCf; ++k) x4[k] = (k < ncf) ? *reinterpret_cast<const float4*>(specs0 + (size_t)k * 1024 + 4 * tid) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < kPsyCf; ++k) x4[k] = *reinterpret_cast<const float4*>(specs0 + (size_t)(k < ncf ? k : 0) * 1024 + 4 * tid);
 #pragma unroll
-        for (int k = 0; k < kPsyCf; ++k) *reinterpret_cast<float4*>(s_spec[k] + 4 * tid) = x4[k];
+        for (int k = 0; k < kPsyCf; ++k) *reinterpret_cast<float4*>(s_spec[k] + 4 * tid) = (k < ncf) ? x4[k] : float4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     if (tid < 32 * kPsyCf) {
         (&s_run_len[0][0])[tid] = 0;
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
         if (k < ncf && (p.no_tonal || b < 8 || b > 28)) rec0[k].flat[b] = 0.0f;
     }
     if (tid < kPsyCf) s_any[tid] = 0;
-    if (tid >= 128 && tid < 192) s_scale[tid - 128] = T->scale[tid - 128];
+    if (tid >= 128 && tid < 192) s_scale[tid - 128] = scale_v;
     __syncthreads();
 
     int fk, fb;

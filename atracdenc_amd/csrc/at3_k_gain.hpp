@@ -1021,6 +1021,7 @@ __global__ __launch_bounds__(256) void k_gain_tail(GainParams p, int n_items)
     // fetched and dropped - two dependent global-memory latencies would cost this short kernel more)
     const float hfr = rec->hfr;
     const float g_j = rec->gain[j];
+    asm volatile("" ::"v"(g_j));   // (keeps the second request in front of the gate: the compiler sinks it behind the branch otherwise)
     const bool active = valid && !(hfr < 0.05f);
     if (__ballot(active) == 0ull) return;
     float* s_gain = s_g[grp];
@@ -1546,8 +1547,10 @@ __global__ __launch_bounds__(256) void k_gain_curve(GainParams p, const Tables* 
     // ---- CreateSubbandInfo tail (atrac3denc.cpp:410-577), band < 3 ----
     {   // (the tables are staged only by the few wavefronts that get here)
         const int wv = tid >> 6, ln = tid & 63;
-        if (ln < 36) reinterpret_cast<double*>(&s_l2[wv])[ln] = (&T->log2f_tab[0][0])[ln];
-        if (ln < 32) s_gi4[wv][ln] = T->gain_interp[ln < 31 ? ln : 30];
+        const double l2v = (&T->log2f_tab[0][0])[ln < 36 ? ln : 35];   // (both asked for by every lane before either is stored: one round trip)
+        const float giv = T->gain_interp[(ln & 31) < 31 ? (ln & 31) : 30];
+        if (ln < 36) reinterpret_cast<double*>(&s_l2[wv])[ln] = l2v;
+        if (ln < 32) s_gi4[wv][ln] = giv;
         wave_sync();
     }
     if (maxGain < 1e-4f) pts.n = 0;
