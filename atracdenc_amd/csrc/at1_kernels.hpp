@@ -202,6 +202,12 @@ __global__ __launch_bounds__(64) void k_at1_front(FrontParams p)
     const int lane = threadIdx.x;
     const size_t item = ((size_t)s * p.n_frames + f) * nch + ch;
 
+    // (asked for by every lane at clamped indices, AHEAD of the PCM window - loads return in issue order - and stored below: as
+    // load-store pairs under lane conditions behind the window each was a round trip of its own)
+    const float my_scale = T->scale[lane];   // ScaleTable has 64 entries: looked up across the lanes
+    const float sine_v = T->sine[lane & 31];
+    const double logf_v = (&T->logf_tab[0][0])[lane < 36 ? lane : 35];   // 16 x 2 table entries, ln 2, three coefficients
+    __builtin_amdgcn_sched_barrier(0);
     {
         float v[13];
 #pragma unroll
@@ -216,11 +222,8 @@ __global__ __launch_bounds__(64) void k_at1_front(FrontParams p)
         for (int r = 0; r < 13; ++r)
             if (lane + 64 * r < 800) s_pcm[qmf_pad(lane + 64 * r)] = v[r];
     }
-    const float my_scale = T->scale[lane];   // ScaleTable has 64 entries: looked up across the lanes
     // everything the later phases read from tables at indices that are known now is requested now, behind the PCM window:
     // a global load issued where its value is needed costs a wavefront a microsecond of its 24
-    if (lane < 32) s_sine[lane] = T->sine[lane];
-    if (lane < 36) (&s_logf.tab[0][0])[lane] = (&T->logf_tab[0][0])[lane];   // 16 x 2 table entries, ln 2, three coefficients
     // rotation factors of the lane's point in the four pre- / post-rotation rounds, long window (index 2 c), and of its
     // point in a short block (index 2 (c & 15), the same in every round); sc512 | sc256 | sc64 are contiguous
     f2 cs_long[4];
@@ -229,6 +232,8 @@ __global__ __launch_bounds__(64) void k_at1_front(FrontParams p)
         cs_long[round] = *reinterpret_cast<const f2*>(&T->sc512[0] + (round < 2 ? 256 : 0) + 2 * (lane + (round == 3 ? 64 : 0)));
     const f2 cs_short = *reinterpret_cast<const f2*>(&T->sc512[0] + 384 + 2 * (lane & 15));
     const uint32_t pos_bfu4[2] = {*reinterpret_cast<const uint32_t*>(c_bfu_of_pos + 4 * lane), *reinterpret_cast<const uint32_t*>(c_bfu_of_pos + 4 * (lane + 64))};
+    if (lane < 32) s_sine[lane] = sine_v;
+    if (lane < 36) (&s_logf.tab[0][0])[lane] = logf_v;
     int bf_long = 0, bf_short = 0, bf_len = 0;
     if (lane < kMaxBfus) {
         bf_long = c_start_long[lane];
@@ -721,26 +726,35 @@ __global__ __launch_bounds__(256) void k_at1_alloc_pack(PackParams p)
     uint32_t* W = s_words[wave];
     if (lane < 56) W[lane] = 0;
 
-    const int mask = p.mask[item];
+    // Everything the wavefront reads from global memory is requested here, in one batch, at clamped indices and without conditions
+    // (both fixed-allocation rows: which one counts depends on the window mask that is still on its way); written where they are
+    // used the mask, the loudness and the table rows were three round trips one after the other.
     const bool in_tab = lane < kMaxBfus;
     const int bl = in_tab ? lane : 0;
-    const int band = bfu_band(bl);
-    const bool sh = (mask >> band) & 1;
-    const int sfi = in_tab ? p.sfi[(size_t)item * 64 + lane] : 0;
+    const int mask = p.mask[item];
+    const int sfi_raw = p.sfi[(size_t)item * 64 + lane];
     const float energy = p.energy[(size_t)item * kMaxBfus + bl];
-    const int spb = in_tab ? c_spb[bl] : 0;
-    const float loudness = p.loud_track[item / p.nch] / 0.006f;
-    const float fix = sh ? T->fix_short[bl] : T->fix_long[bl];
-    const bool gate = !sh && energy < T->ath_bfu[bl] * loudness;
-    const float spread = 0.4f;
-    const float base = spread * ((float)sfi / 3.2f) + (1.0f - spread) * fix;
-
+    const float loud_raw = p.loud_track[item / p.nch];
+    const float fix_s = T->fix_short[bl], fix_l = T->fix_long[bl];
+    const float ath_v = T->ath_bfu[bl];
+    const int spb_raw = c_spb[bl];
     // the lane's share of the mantissa sources for the packing step at the end: eight consecutive positions of the
     // BFU-ordered value array, their owning BFUs, and (lane = BFU) where each BFU's run starts. Fetched now, used last.
     const uint2 pos_bfu = *reinterpret_cast<const uint2*>(c_bfu_of_pos + 8 * lane);
     const float4 val_a = *reinterpret_cast<const float4*>(p.values + (size_t)item * 512 + 8 * lane);
     const float4 val_b = *reinterpret_cast<const float4*>(p.values + (size_t)item * 512 + 8 * lane + 4);
-    const int run_start = in_tab ? c_start_long[lane] : 512;
+    const int run_raw = c_start_long[bl];
+    __builtin_amdgcn_sched_barrier(0);
+    const int band = bfu_band(bl);
+    const bool sh = (mask >> band) & 1;
+    const int sfi = in_tab ? sfi_raw : 0;
+    const int spb = in_tab ? spb_raw : 0;
+    const float loudness = loud_raw / 0.006f;
+    const float fix = sh ? fix_s : fix_l;
+    const bool gate = !sh && energy < ath_v * loudness;
+    const float spread = 0.4f;
+    const float base = spread * ((float)sfi / 3.2f) + (1.0f - spread) * fix;
+    const int run_start = in_tab ? run_raw : 512;
 
     const int sum_low = wave_sum_i32(lane < 20 ? sfi : 0, lane);
     int bfu_idx = p.bfu_idx_const ? p.bfu_idx_const - 1 : 7;

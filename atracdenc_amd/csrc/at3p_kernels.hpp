@@ -51,16 +51,28 @@ __global__ __launch_bounds__(256) void k_at3p_pqf(PqfParams p)
         fa[j] = T->fir[ra * 12 + j];
         fb[j] = T->fir[rb * 12 + j];
     }
-    for (int j = tid; j < kFrame + kOverlap; j += 256) {
-        const int t = j - kOverlap;   // sample index inside the frame
-        float v;
-        if (t >= 0) v = p.pcm[(((size_t)s * p.n_frames + f) * kFrame + t) * nch + ch];
-        else if (f > 0) v = p.pcm[(((size_t)s * p.n_frames + f - 1) * kFrame + kFrame + t) * nch + ch];
-        else v = p.hist[((size_t)s * nch + ch) * kOverlap + j];
-        s_x[j] = v;
+    // The frame's window of samples: every request first (ten per work-item, one source pointer each, clamped past the end), then
+    // the stores. As a loop of load-store pairs the compiler kept it a loop: ten global round trips one after the other.
+    {
+        constexpr int kTot = kFrame + kOverlap, kIt = (kTot + 255) / 256;
+        const float cs_v = T->sc32[tid & 15];
+        const at3::cpx tw_v = T->tw8[tid & 7];
+        float v[kIt];
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int j0 = tid + 256 * i, j = j0 < kTot ? j0 : kTot - 1;
+            const int t = j - kOverlap;   // sample index inside the frame
+            const float* src = (t >= 0) ? &p.pcm[(((size_t)s * p.n_frames + f) * kFrame + t) * nch + ch]
+                             : (f > 0)  ? &p.pcm[(((size_t)s * p.n_frames + f - 1) * kFrame + kFrame + t) * nch + ch]
+                                        : &p.hist[((size_t)s * nch + ch) * kOverlap + j];
+            v[i] = *src;
+        }
+#pragma unroll
+        for (int i = 0; i < kIt; ++i)
+            if (tid + 256 * i < kTot) s_x[tid + 256 * i] = v[i];
+        if (tid < 16) s_cs[tid] = cs_v;
+        else if (tid < 24) s_tw[tid - 16] = tw_v;
     }
-    if (tid < 16) s_cs[tid] = T->sc32[tid];
-    else if (tid < 24) s_tw[tid - 16] = T->tw8[tid - 16];
     __syncthreads();
 
     // vectoring (:62-70): float products, double running sums over the 12 taps, two rows per value
@@ -161,18 +173,29 @@ __global__ __launch_bounds__(256) void k_at3p_mdct(MdctParams p)
     } else {
         s_tw[tid - 192] = T->tw64[tid - 192];
     }
-    auto fetch = [&](const float* q) {
-        float v = *q;
+    // the sixteen subband samples of the work-item: all requested before the tables' rendezvous (one source pointer each), windowed
+    // behind it - as a loop of load, window, store the compiler kept it a loop of sixteen global round trips
+    float raw[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = tid + 256 * i, b = j >> 8, o = j & 255;
+        const float* src = (o >= 128) ? p.bands + item * kFrame + 128 * b + (o - 128)
+                         : (f > 0)    ? p.bands + (item - nch) * kFrame + 128 * b + o
+                                      : p.hist + (((size_t)s * nch + ch) * 16 + b) * 128 + o;
+        raw[i] = *src;
+    }
+    auto scaled = [&](float v) {
         if (p.residual_scale) v = (float)((double)v / (32768.0 / 1.122018));
         return v;
     };
     __syncthreads();
-    for (int j = tid; j < 4096; j += 256) {
-        const int b = j >> 8, o = j & 255;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = tid + 256 * i, b = j >> 8, o = j & 255;
         float v;
-        if (o >= 128) v = at3p_second_half(fetch(p.bands + item * kFrame + 128 * b + (o - 128)), s_w128, s_w64, (cur_flags >> b) & 1, o - 128);
-        else if (f > 0) v = at3p_first_half(fetch(p.bands + (item - nch) * kFrame + 128 * b + o), s_w128, s_w64, (prev_flags >> b) & 1, o);
-        else v = p.hist[(((size_t)s * nch + ch) * 16 + b) * 128 + o];
+        if (o >= 128) v = at3p_second_half(scaled(raw[i]), s_w128, s_w64, (cur_flags >> b) & 1, o - 128);
+        else if (f > 0) v = at3p_first_half(scaled(raw[i]), s_w128, s_w64, (prev_flags >> b) & 1, o);
+        else v = raw[i];
         s_tmp[b][o] = v;
     }
     __syncthreads();

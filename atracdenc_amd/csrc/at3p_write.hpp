@@ -286,18 +286,33 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     s_out[256 + tid] = 0u;
     (&s_qbits[0][0][0])[tid] = 0u;
     (&s_qbits[0][0][0])[256 + tid] = 0u;
-    if (tid < 64) {
-        (&s_max[0][0])[tid] = 0u;
-        s_scale[tid] = W->scale[tid];
-    }
-    if (tid >= 64 && tid < 120) s_info[tid - 64] = W->info56[tid - 64];
-    for (int k = tid; k < (kLenEntries + 7) / 8; k += 256) s_len4[k] = W->len4[k];
+    // Every request of the prologue first - the chunk's sixteen lines, the thread's table words at clamped indices, the word
+    // length's multiplier for the quantiser further down - and the stores behind them: as load-store pairs under thread conditions
+    // and a copy loop they were five global round trips one after the other.
+    constexpr int kLenWords = (kLenEntries + 7) / 8, kLenIt = (kLenWords + 255) / 256;
     float x[16];
+    const float mul_wl = W->inv_mant[wl];
     {
         const float4* src = reinterpret_cast<const float4*>(p.specs + (item * nch + (active ? ch : 0)) * 2048 + 16 * c);
+        float4 xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[k] = src[k];
+        const float scale_v = W->scale[tid & 63];
+        const uint32_t info_v = W->info56[(tid >= 64 && tid < 120) ? tid - 64 : 0];
+        uint32_t len_v[kLenIt];
+#pragma unroll
+        for (int i = 0; i < kLenIt; ++i) len_v[i] = W->len4[tid + 256 * i < kLenWords ? tid + 256 * i : kLenWords - 1];
+        if (tid < 64) {
+            (&s_max[0][0])[tid] = 0u;
+            s_scale[tid] = scale_v;
+        }
+        if (tid >= 64 && tid < 120) s_info[tid - 64] = info_v;
+#pragma unroll
+        for (int i = 0; i < kLenIt; ++i)
+            if (tid + 256 * i < kLenWords) s_len4[tid + 256 * i] = len_v[i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float4 v = active ? src[k] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            const float4 v = active ? xv[k] : float4{0.0f, 0.0f, 0.0f, 0.0f};
             x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
         }
     }
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(256) void k_at3p_write(WriteParams p)
     for (int k = 0; k < 16; ++k) qv[k] = 0;
     if (active) {
         const float sf = s_scale[s_sfi[ch][qu]];
-        const float mul = W->inv_mant[wl];
+        const float mul = mul_wl;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             float v = x[k] / sf;
