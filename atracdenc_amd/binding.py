@@ -12,7 +12,10 @@ CSRC = os.path.join(HERE, "csrc")
 AT3HIP_PCM_ON_DEVICE = 1
 AT3HIP_OUT_ON_DEVICE = 2
 AT3HIP_ASYNC = 4
-OPT_RUNS, OPT_FLATNESS_LITERAL, OPT_QUANT_TAP, OPT_GAIN_TWO_WAVES, OPT_GAIN_WGS_PER_CU = 1, 2, 3, 4, 5
+OPT_RUNS, OPT_LITERAL_FORMS, OPT_QUANT_TAP, OPT_GAIN_FORM, OPT_GAIN_WGS_PER_CU = 1, 2, 3, 4, 5
+OPT_FLATNESS_LITERAL = OPT_LITERAL_FORMS           # (former name, same number)
+GAIN_FORM_TWO_WAVES, GAIN_FORM_ONE_WAVE = 0, 1
+AT3HIP_VERSION = (1 << 16) | 3                     # include/at3hip.h this stub mirrors: load_library refuses an older library
 TAP_SPECTRA, TAP_CURVES, TAP_ENERGY_SCALE, TAP_PSY, TAP_LOUDNESS, TAP_QUANT, TAP_CLOCK, TAP_GAIN_ANALYSIS = 1, 2, 3, 4, 5, 6, 7, 8
 LP2 = 132300
 LP4 = 66150
@@ -27,6 +30,10 @@ class Config(ctypes.Structure):
                                                "n_streams", "max_blocks", "device_id")]
 
 
+class Counters(ctypes.Structure):
+    _fields_ = [("scale_overflow", ctypes.c_uint64), ("clipped_values", ctypes.c_uint64)]
+
+
 class Timings(ctypes.Structure):
     _fields_ = [(n, ctypes.c_float) for n in ("total_ms", "qmf_ms", "gain_ms", "curve_ms", "qmf_mdct_ms", "psy_ms",
                                                "alloc_ms")] + [("qmf_mdct_launches", ctypes.c_int32)]
@@ -36,7 +43,7 @@ SYMBOLS = ["at3hip_encode_s16", "at3hip_create", "at3hip_destroy", "at3hip_frame
            "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
            "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago", "at3hip_read_tap",
            "at3hip_mdct_levels", "at3hip_gain_energy_scale", "at3hip_set_option", "at3hip_host_tables", "at3hip_host_alloc",
-           "at3hip_host_free", "at3hip_wait_input", "at3hip_wait_frames"]
+           "at3hip_host_free", "at3hip_wait_input", "at3hip_wait_frames", "at3hip_get_counters"]
 # include/at1hip.h
 AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_encode", "at1hip_reset", "at1hip_get_timings",
                "at1hip_read_tap", "at1hip_host_tables"]
@@ -88,6 +95,11 @@ def load_library(path=None):
                           "there is no CPU fallback")
     lib = ctypes.CDLL(path)
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    lib.at3hip_version.restype = ctypes.c_uint32
+    have = lib.at3hip_version()
+    # same major number, and every entry point / option / wait depth this stub relies on (at3hip.h lists them per minor number)
+    if have >> 16 != AT3HIP_VERSION >> 16 or have < AT3HIP_VERSION:
+        raise At3HipError(f"{path} implements at3hip ABI {have >> 16}.{have & 0xffff}, this binding needs {AT3HIP_VERSION >> 16}.{AT3HIP_VERSION & 0xffff}: rebuild it")
     lib.at3hip_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
     lib.at3hip_create.restype = ctypes.c_int
     lib.at3hip_destroy.argtypes = [vp]
@@ -114,6 +126,7 @@ def load_library(path=None):
     lib.at3hip_wait_frames.argtypes = [vp, i32]
     lib.at3hip_read_tap.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.at3hip_get_timings_ago.argtypes = [vp, i32, ctypes.POINTER(Timings)]
+    lib.at3hip_get_counters.argtypes = [vp, ctypes.POINTER(Counters), i32]
     lib.at3hip_version.restype = ctypes.c_uint32
     lib.at1hip_create.argtypes = [ctypes.POINTER(At1Config), ctypes.POINTER(vp)]
     lib.at1hip_destroy.argtypes = [vp]
@@ -241,6 +254,12 @@ class At3Hip:
 
     def sync(self):
         self._check(self.lib.at3hip_sync(self.ctx), "at3hip_sync")
+
+    def counters(self, reset=False):
+        """at3hip_get_counters: what TScaler::Scale would have printed since create / reset - {"scale_overflow", "clipped_values"}."""
+        c = Counters()
+        self._check(self.lib.at3hip_get_counters(self.ctx, ctypes.byref(c), int(bool(reset))), "at3hip_get_counters")
+        return {"scale_overflow": int(c.scale_overflow), "clipped_values": int(c.clipped_values)}
 
     def host_alloc(self, shape, dtype):
         """Page-locked host array (at3hip_host_alloc); free it with host_free(array) before close()."""

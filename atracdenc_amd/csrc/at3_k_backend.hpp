@@ -32,8 +32,11 @@ struct BackParams {
     int bfu_idx_const;
     int mono_js;             // one input channel in a joint-stereo container: empty second sound unit (atrac3denc.cpp:843-849)
     struct QuantRec* quant;  // [S][n_out][2] the unit cache's final content, for the QUANT tap (zero for units never asked for); null unless AT3HIP_OPT_QUANT_TAP
-    int flat_literal;        // AT3HIP_OPT_FLATNESS_LITERAL: every flatness measure by the literal per-line form (test aid; same results)
+    int flat_literal;        // AT3HIP_OPT_LITERAL_FORMS: every flatness measure by the literal per-line form (test aid; same results)
     int debug_stop;          // profiling aid (env AT3HIP_DEBUG_STOP, -DAT3HIP_DEBUG_KNOBS builds): stage exits of k_alloc_pack
+    unsigned long long* counters;   // [2] at3hip_get_counters: blocks TScaler::Scale would report as "Scale error", values it would report as
+                                    // "clipping" (atrac_scale.cpp:150-153, 163-167); added to by k_psy, null = not counted
+    int one_channel;         // one input channel (the pipeline runs on (x, x) pairs): only channel 0 is what the reference scales
     unsigned long long* clk; // [2] AT3HIP_TAP_CLOCK: shader cycles (s_memtime) and 100 MHz reference ticks (s_memrealtime) that
                              // workgroup 0 of k_alloc_pack lived - their ratio is the shader clock under the rate loop's load
 };
@@ -414,6 +417,17 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
                     for (int j = len; j < 7; ++j) tb->values[j] = 0.0f;
                     tb->sfi = (uint8_t)scale_block(s_scale, s_tv_val[k0] + startPos, len, tb->values, nullptr);
                 }
+                // TScaler::Scale's diagnostics for this component (atrac_scale.cpp:150-153, 163-167): a block whose largest magnitude
+                // exceeds MAX_SCALE = 1.0 is scaled by ScaleTable[63] = 1.0, so its clipped values are those above 1.0. (The reference
+                // scales every component it maps, also those beyond the 24 a sound unit keeps.)
+                if (p.counters && !(p.one_channel && ((c0 + k0) & 1))) {
+                    int over = 0;
+                    for (int j = 0; j < len; ++j) over += fabsf(s_tv_val[k0][startPos + j]) > 1.0f;
+                    if (over) {
+                        atomicAdd(p.counters, 1ull);
+                        atomicAdd(p.counters + 1, (unsigned long long)over);
+                    }
+                }
                 ++nb;
             }
         }
@@ -432,6 +446,9 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
             const float4 v = *reinterpret_cast<const float4*>(s_spec[k] + 4 * tid);
             const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
             atomicMax(&s_maxbits[k][b], __float_as_uint(m));
+            // "clipping, scaled value": a value above MAX_SCALE = 1.0 sits in a block scaled by ScaleTable[63] = 1.0 (below)
+            if (m > 1.0f && p.counters && k < ncf && !(p.one_channel && ((c0 + k) & 1)))
+                atomicAdd(p.counters + 1, (unsigned long long)((fabsf(v.x) > 1.0f) + (fabsf(v.y) > 1.0f) + (fabsf(v.z) > 1.0f) + (fabsf(v.w) > 1.0f)));
         }
     }
     __syncthreads();
@@ -439,7 +456,10 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
     if (psy_scale_job(wave, lane, sk, sb) && sk < ncf) {
         const int start = bfu_start(sb), len = bfu_start(sb + 1) - start;
         float maxAbs = __uint_as_float(s_maxbits[sk][sb]);
-        if (maxAbs > 1.0f) maxAbs = 1.0f;
+        if (maxAbs > 1.0f) {   // "Scale error: absSpec > MAX_SCALE" (atrac_scale.cpp:150-153)
+            if (p.counters && !(p.one_channel && ((c0 + sk) & 1))) atomicAdd(p.counters, 1ull);
+            maxAbs = 1.0f;
+        }
         const int sfi = scale_index(s_scale, maxAbs);
         const float4* x4 = reinterpret_cast<const float4*>(s_spec[sk] + start);
         float e = 0.0f;

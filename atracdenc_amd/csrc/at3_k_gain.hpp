@@ -27,7 +27,7 @@ struct GainParams {
     int js;
     int n_streams;
     int debug;   // profiling aid (env AT3HIP_DEBUG_GAIN): k_gain_curve returns early at stage N
-    int literal; // AT3HIP_OPT_FLATNESS_LITERAL: k_gain_spec's energy sums as the reference's two 257-term chains for every item
+    int literal; // AT3HIP_OPT_LITERAL_FORMS: k_gain_spec's energy sums as the reference's two 257-term chains for every item
     unsigned long long* clk;   // profiling builds: 256 rows of 12 per-phase cycle counters of k_gain_analysis1 (tools/gain_phase_cycles.sh)
 };
 
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64) void k_gain_spec(GainParams p, const Tables* T,
     // 1.15e-13 of the chain's quotient. Every lane adds its 17 energies, a 16-lane row scan adds the lanes, and the f32 of the
     // quotient is taken as it stands whenever the quotient is further than 4e-13 (relative) from both rounding boundaries of that
     // f32 - the chain's quotient then rounds to the same f32, bit for bit. Otherwise (about one item in 10^5), for quotients
-    // below the normal f32 range, and under AT3HIP_OPT_FLATNESS_LITERAL, the wavefront walks the chains.
+    // below the normal f32 range, and under AT3HIP_OPT_LITERAL_FORMS, the wavefront walks the chains.
     bool fast_done = false;
     {
         const double h1 = (double)T->hpf_w[1], h2 = (double)T->hpf_w[2];

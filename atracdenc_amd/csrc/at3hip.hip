@@ -37,7 +37,11 @@ struct DevBuf {
 
 // AT3HIP_TAP_CLOCK: 16 header words, 2 x 256 rows of 12 per-phase cycle sums (k_alloc_pack, k_gain_analysis1), then, in profiling
 // builds, the entry and exit times (100 MHz) of k_alloc_pack's first 16384 workgroups
+#ifdef AT3HIP_DEBUG_KNOBS
 constexpr size_t kClkWords = 16 + 2 * 256 * 12 + 2 * 16384 + 12 * 16384;   // (... and their own per-phase cycles)
+#else
+constexpr size_t kClkWords = 16;   // release builds write words 0 and 1 only (the phase rows exist in profiling builds)
+#endif
 struct at3hip_ctx {
     at3hip_config cfg;
     int frame_sz = 0;
@@ -85,8 +89,8 @@ struct at3hip_ctx {
     char err[256] = {0};
     long long blocks_fed = 0;   // per stream
     int runs_override = 0;   // AT3HIP_OPT_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
-    int flat_literal = 0;    // AT3HIP_OPT_FLATNESS_LITERAL
-    int gain_two_waves = 0;  // AT3HIP_OPT_GAIN_TWO_WAVES: 0 / 1 = the two-wavefront workgroups of rounds 2 - 3 (default), 2 = one wavefront per item (k_gain_analysis1)
+    int flat_literal = 0;    // AT3HIP_OPT_LITERAL_FORMS
+    int gain_form = AT3HIP_GAIN_FORM_TWO_WAVES;   // AT3HIP_OPT_GAIN_FORM: the two-wavefront workgroups (default) or one wavefront per item (k_gain_analysis1)
     int gain_wgs_per_cu = 0; // AT3HIP_OPT_GAIN_WGS_PER_CU: k_gain_analysis1 workgroups per CU (dynamic LDS padding; 0 = chosen per launch)
     int n_cus = 256;
     size_t lds_per_cu = 0;     // hipDeviceProp_t::maxSharedMemoryPerMultiProcessor; the whole-round LDS padding below is tuned for 160 KB
@@ -114,6 +118,7 @@ struct at3hip_ctx {
     uint8_t* d_out = nullptr;
     QuantRec* d_quant = nullptr;     // allocated by AT3HIP_OPT_QUANT_TAP
     unsigned long long* d_clk = nullptr;   // AT3HIP_TAP_CLOCK (kClkWords)
+    unsigned long long* d_counters = nullptr;   // at3hip_get_counters: [0] "Scale error" blocks, [1] "clipping" values (k_psy adds)
     at3hip_timings tm = {};
     // grow-only device staging of the stage-level entry points (at3hip_mdct, at3hip_gain_energy_scale) for host buffers
     void* d_stage = nullptr;
@@ -284,6 +289,7 @@ int reset_state(at3hip_ctx* c)
     HIPCHK(c, hipMemsetAsync(c->d_hist[1], 0, S * kHist * 2 * sizeof(float), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_state, 0, S * 8 * sizeof(BandState), c->stream));
     if (c->d_sub_tail) HIPCHK(c, hipMemsetAsync(c->d_sub_tail, 0, S * 8 * 512 * sizeof(float), c->stream));   // silence before the stream
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), c->stream));
     float* init = (float*)malloc(S * sizeof(float));
     if (!init) return fail(c, AT3HIP_ENOMEM, "malloc");
     for (size_t i = 0; i < S; ++i) init[i] = 0.006f;  // LoudFactor, atrac3denc.h:115-116
@@ -300,7 +306,7 @@ int reset_state(at3hip_ctx* c)
 
 extern "C" {
 
-uint32_t at3hip_version(void) { return (1u << 16) | 1u; }
+uint32_t at3hip_version(void) { return (uint32_t)AT3HIP_VERSION; }
 
 int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
 {
@@ -419,6 +425,7 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     if ((rc = dev_alloc(c, &c->d_out, S * B * (size_t)c->frame_sz)) != AT3HIP_OK) return bail(rc);
     if ((rc = dev_alloc(c, &c->d_clk, kClkWords)) != AT3HIP_OK) return bail(rc);
     if (hipMemsetAsync(c->d_clk, 0, (kClkWords) * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(AT3HIP_EDEVICE);   // (reset_state below waits for the stream)
+    if ((rc = dev_alloc(c, &c->d_counters, 2)) != AT3HIP_OK) return bail(rc);   // (zeroed by reset_state)
     if ((rc = reset_state(c)) != AT3HIP_OK) return bail(rc);
     hipDeviceProp_t prop;
     const bool have_prop = hipGetDeviceProperties(&prop, c->device) == hipSuccess;
@@ -453,7 +460,7 @@ void at3hip_destroy(at3hip_ctx* c)
     if (c->d_sub_b[1]) (void)hipFree(c->d_sub_b[1]);
     void* bufs[] = {c->d_tables,    c->d_pcm_in,    c->d_hist[0],  c->d_hist[1],  c->d_sub,    c->d_rec,    c->d_state, c->d_curves[0],
                     c->d_curves[1], c->d_specs[0],  c->d_specs[1], c->d_ges[0],   c->d_ges[1], c->d_psy,    c->d_loud,  c->d_loud_state,
-                    c->d_out,       c->d_quant,     c->d_stage,    c->d_sub_tail, c->d_bins,     c->d_clk};
+                    c->d_out,       c->d_quant,     c->d_stage,    c->d_sub_tail, c->d_bins,     c->d_clk,      c->d_counters};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (auto& row : c->ev)
@@ -555,17 +562,21 @@ int at3hip_set_option(at3hip_ctx* c, int32_t option, int32_t value)
             if (value < 0) return fail(c, AT3HIP_EINVAL, "runs must be >= 0");
             c->runs_override = value;
             return AT3HIP_OK;
-        case AT3HIP_OPT_FLATNESS_LITERAL:
-            c->flat_literal = value != 0;
+        case AT3HIP_OPT_LITERAL_FORMS:
+            if (value != 0 && value != 1) return fail(c, AT3HIP_EINVAL, "literal forms: 0 or 1");
+            c->flat_literal = value;
             return AT3HIP_OK;
-        case AT3HIP_OPT_GAIN_TWO_WAVES:
-            c->gain_two_waves = value;
+        case AT3HIP_OPT_GAIN_FORM:
+            if (value != AT3HIP_GAIN_FORM_TWO_WAVES && value != AT3HIP_GAIN_FORM_ONE_WAVE)
+                return fail(c, AT3HIP_EINVAL, "gain form: AT3HIP_GAIN_FORM_TWO_WAVES or AT3HIP_GAIN_FORM_ONE_WAVE");
+            c->gain_form = value;
             return AT3HIP_OK;
         case AT3HIP_OPT_GAIN_WGS_PER_CU:
             if (value < 0 || (value > 16 && value < 256) || value > 64 * 1024) return fail(c, AT3HIP_EINVAL, "workgroups per CU must be 0 .. 16 (or a pad of 256 .. 65536 bytes)");
             c->gain_wgs_per_cu = value;
             return AT3HIP_OK;
         case AT3HIP_OPT_QUANT_TAP: {
+            if (value != 0 && value != 1) return fail(c, AT3HIP_EINVAL, "quant tap: 0 or 1");
             at3host::DeviceGuard guard(c->device);
             HIPCHK(c, guard.error());
             const int rc = drain(c);
@@ -628,6 +639,8 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
     const int f0 = (c->blocks_fed == 0) ? 1 : 0;
     const int n_out = n_blocks - f0;
     if (n_out > 0 && !out_frames) return fail(c, AT3HIP_EINVAL, "out_frames is null");
+    // k_s16_to_f32 reads the caller's device pointer sixteen bytes at a time
+    if (s16 && (flags & AT3HIP_PCM_ON_DEVICE) && ((uintptr_t)pcm_any & 15u) != 0) return fail(c, AT3HIP_EINVAL, "16-bit device PCM must be 16-byte aligned");
     hipStream_t st = c->stream;
     const bool gain = !c->cfg.no_gain_control;
 
@@ -768,7 +781,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(64), spec_lds_pad(c, ((long long)S * n_out * 6 + 3) / 4), st, gp, c->d_tables, S * n_out * 6);
             // default: the two-wavefront form. The one-wavefront form is 11 % faster alone (89 against 101 us at 4096 frames) and
             // leaves the pipelined step 2 % slower at that size, equal at the 1024 x 128 shard (profiles/EXPERIMENTS.md)
-            if (c->gain_two_waves != 2) hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), analysis_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);
+            if (c->gain_form != AT3HIP_GAIN_FORM_ONE_WAVE) hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), analysis_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);
             else hipLaunchKernelGGL(k_gain_analysis1, dim3(S * n_out * 6), dim3(64), analysis1_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);   // one wavefront per item
             HIPCHK(c, hipEventRecord(ev[2], st));
             HIPCHK(c, hipStreamWaitEvent(md, ev[2], 0));   // the light stage starts when this call's heavy stage is done
@@ -835,6 +848,8 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         bp.debug_stop = c->dbg_stop;
         bp.quant = c->d_quant;
         bp.clk = c->d_clk;
+        bp.counters = c->d_counters;
+        bp.one_channel = c->cfg.channels == 1 ? 1 : 0;
         hipLaunchKernelGGL(k_loud_sum, dim3((unsigned)((S * n_out * 2 + kLoudCf - 1) / kLoudCf)), dim3(256), (size_t)c->dbg_pad[5], bk, bp, c->d_tables, S * n_out * 2);
         hipLaunchKernelGGL(k_psy, dim3((S * n_out * 2 + kPsyCf - 1) / kPsyCf), dim3(256), (size_t)c->dbg_pad[6], bk, bp, c->d_tables, S * n_out * 2);
         HIPCHK(c, hipEventRecord(ev[6], bk));
@@ -911,6 +926,21 @@ int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
     }
     if (!src || bytes > cap) return fail(c, AT3HIP_EINVAL, "tap not available or request too large");
     HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return AT3HIP_OK;
+}
+
+int at3hip_get_counters(at3hip_ctx* c, at3hip_counters* out, int32_t reset)
+{
+    if (!c || !out) return AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
+    const int rc = drain(c);
+    if (rc != AT3HIP_OK) return rc;
+    unsigned long long v[2] = {0ull, 0ull};
+    HIPCHK(c, hipMemcpy(v, c->d_counters, sizeof(v), hipMemcpyDeviceToHost));
+    out->scale_overflow = v[0];
+    out->clipped_values = v[1];
+    if (reset) HIPCHK(c, hipMemset(c->d_counters, 0, sizeof(v)));
     return AT3HIP_OK;
 }
 

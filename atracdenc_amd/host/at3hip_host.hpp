@@ -64,6 +64,17 @@ struct TGainPoint {                  // TAtrac3Data::SubbandInfo::TGainPoint (at
     uint32_t Location;
 };
 
+// The library this header runs against must implement at least the ABI minor number the header was written for (at3hip.h lists
+// what each one added: three calls in flight need the four-deep wait ring of 1.2, Counters() needs 1.3). Called by every class
+// below before its first at3hip_create.
+inline void CheckLibraryVersion()
+{
+    const uint32_t have = at3hip_version();
+    if ((have >> 16) != (uint32_t)AT3HIP_VERSION_MAJOR || have < (uint32_t)AT3HIP_VERSION)
+        throw std::runtime_error("libat3hip.so implements at3hip ABI " + std::to_string(have >> 16) + "." + std::to_string(have & 0xffffu) +
+                                 ", this host layer needs " + std::to_string(AT3HIP_VERSION_MAJOR) + "." + std::to_string(AT3HIP_VERSION_MINOR));
+}
+
 inline void Check(int rc, at3hip_ctx* ctx, const char* what)
 {
     if (rc != AT3HIP_OK)
@@ -83,6 +94,7 @@ public:
         cfg.max_blocks = 2;
         cfg.device_id = deviceId;
         cfg.no_gain_control = 1;
+        CheckLibraryVersion();
         Check(at3hip_create(&cfg, &Ctx), nullptr, "at3hip_create");
     }
     ~TAtrac3MDCT() { at3hip_destroy(Ctx); }
@@ -176,6 +188,7 @@ public:
         cfg.n_streams = nStreams;
         cfg.max_blocks = maxBlocks;
         cfg.device_id = deviceId;
+        CheckLibraryVersion();
         Check(at3hip_create(&cfg, &Ctx), nullptr, "at3hip_create");
         FrameSz = at3hip_frame_size(Ctx);
     }
@@ -204,6 +217,14 @@ public:
     }
     void Reset() { Check(at3hip_reset(Ctx), Ctx, "at3hip_reset"); }
     at3hip_ctx* Handle() { return Ctx; }
+    // What the reference's TScaler::Scale would have written to stderr for these streams since construction / Reset()
+    // ("Scale error: absSpec > MAX_SCALE" per block, "clipping, scaled value" per value; atrac_scale.cpp:150-153, 163-167)
+    at3hip_counters Counters(bool reset = false)
+    {
+        at3hip_counters c{};
+        Check(at3hip_get_counters(Ctx, &c, reset ? 1 : 0), Ctx, "at3hip_get_counters");
+        return c;
+    }
 
     // A long input fed call by call with the copies hidden: two page-locked PCM buffers and two frame buffers alternate, the
     // calls are asynchronous, so while the GPU encodes call k the host thread fills call k + 1's buffer (`fill`), the copy
@@ -342,6 +363,11 @@ public:
     // The same for a long input: pcm [nStreams][nBlocksTotal][1024][SourceChannels] is cut into calls of `blocksPerCall`
     // blocks; every device's host thread runs TAtrac3EncoderBatch::EncodePipelined on its slice (page-locked staging, copies
     // and kernels of consecutive calls overlapping). frames [nStreams][nFrames][FrameSize()]; returns nFrames per stream.
+    // STARTS A NEW STREAM: the node is Reset() first - unlike TAtrac3EncoderBatch::EncodePipelined, which continues whatever its
+    // context has been fed - because `frames` is laid out for exactly nBlocksTotal - 1 frames per stream, which only holds from
+    // start of stream. Blocks fed through Encode() before this call are therefore NOT continued; callers that feed one stream in
+    // pieces use Encode() throughout, or TAtrac3EncoderBatch::EncodePipelined on a part. `frames` is resized before any frame
+    // arrives, so when a device's thread throws (e.g. the frame-count guard below) its content is unspecified.
     int EncodePipelined(const float* pcm, int nBlocksTotal, int blocksPerCall, std::vector<uint8_t>& frames)
     {
         const size_t blockFloats = (size_t)1024 * Channels;

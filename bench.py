@@ -143,9 +143,9 @@ class DeviceJob:
         if DeviceJob.runs:
             from atracdenc_amd import binding as B
             self.enc.set_option(B.OPT_RUNS, DeviceJob.runs)
-        if DeviceJob.gain_two_waves:
+        if DeviceJob.gain_form:
             from atracdenc_amd import binding as B
-            self.enc.set_option(B.OPT_GAIN_TWO_WAVES, DeviceJob.gain_two_waves)
+            self.enc.set_option(B.OPT_GAIN_FORM, DeviceJob.gain_form)
         if DeviceJob.gain_wgs:
             from atracdenc_amd import binding as B
             self.enc.set_option(B.OPT_GAIN_WGS_PER_CU, DeviceJob.gain_wgs)
@@ -174,7 +174,7 @@ class DeviceJob:
 
     sync_steps = False   # --sync-steps (profiling aid)
     runs = 0             # --runs (tuning aid: AT3HIP_OPT_RUNS)
-    gain_two_waves = 0   # --gain-two-waves (A/B aid: AT3HIP_OPT_GAIN_TWO_WAVES)
+    gain_form = 0        # --gain-form (A/B aid: AT3HIP_OPT_GAIN_FORM)
     gain_wgs = 0         # --gain-wgs (tuning aid: AT3HIP_OPT_GAIN_WGS_PER_CU)
 
     def replay(self, n_steps):
@@ -303,6 +303,19 @@ def roofline_of(k1_avg_ms, frames_per_launch):
     return round(achieved, 2), round(achieved / HBM_PEAK_GBS, 5)
 
 
+# algorithmic flops of the QMF + MDCT work per stereo frame (QMF 2 x 100 352 + MDCT 2 x ~26 000), against the fp32
+# vector peak WITHOUT FMA: 157.3 TFLOP/s counts a fused multiply-add as two flops; the bit-exactness contract (-ffp-contract=off)
+# issues the multiply and the add separately, so the usable peak is half of it. Spec-derived: needs no micro-benchmark.
+ALGO_FLOPS_PER_FRAME_K1 = 2 * 100352 + 2 * 26000
+FP32_VECTOR_PEAK_TF = 157.3
+FP32_NO_FMA_PEAK_TF = FP32_VECTOR_PEAK_TF / 2.0
+
+
+def flops_of(k1_ms, frames_per_launch):
+    tf = ALGO_FLOPS_PER_FRAME_K1 * frames_per_launch / (k1_ms * 1e-3) / 1e12
+    return round(tf, 3), round(tf / FP32_NO_FMA_PEAK_TF, 4)
+
+
 def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
     """One of SURVEY 8(d)'s other workloads on device 0, after the headline: whole-pipeline rate + K1 launch time."""
     out = {"workload": name}
@@ -323,6 +336,7 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
                     "frames_per_step": S * F, "frame_bytes": job.fsz, "input": kind,
                     "k1_avg_launch_ms": round(k1, 5), "k1_GBps": ach, "k1_frac": frac,
                     "k1_isolated_ms": round(iso, 5), "k1_isolated_GBps": ach_i, "k1_isolated_frac": frac_i,
+                    "k1_isolated_TFLOPs": flops_of(iso, S * F)[0], "k1_isolated_flops_frac": flops_of(iso, S * F)[1],
                     "k1_kernels": "k_qmf_mdct8 (fused QMF + MDCT, one launch)" if getattr(job, "k1_launches", 2) == 1 else "k_qmf_sub8 + k_mdct_sub (two launches)",
                     "gain_control": not no_gain,
                     "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(stage.items())}})
@@ -458,8 +472,8 @@ def main():
     ap.add_argument("--region-ms", type=float, default=50.0)
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the frames after the timed regions")
     ap.add_argument("--runs", type=int, default=0, help="TUNING AID: AT3HIP_OPT_RUNS (runs per stream and channel of the QMF / MDCT kernels)")
-    ap.add_argument("--gain-two-waves", type=int, default=0, help="A/B AID: AT3HIP_OPT_GAIN_TWO_WAVES (the upsampler / AnalyzeGain kernel as the two-wavefront "
-                                                                  "workgroups of rounds 2 - 3; same results)")
+    ap.add_argument("--gain-form", type=int, default=0, help="A/B AID: AT3HIP_OPT_GAIN_FORM (0 = the two-wavefront workgroups of the upsampler / "
+                                                             "AnalyzeGain kernel, 1 = one wavefront per item; same results)")
     ap.add_argument("--gain-wgs", type=int, default=0, help="TUNING AID: AT3HIP_OPT_GAIN_WGS_PER_CU")
     ap.add_argument("--sync-steps", action="store_true", help="PROFILING AID: run the timed steps synchronously (no overlap of "
                                                               "consecutive calls) so that rocprofv3 sees every kernel alone; "
@@ -472,7 +486,7 @@ def main():
 
     DeviceJob.sync_steps = args.sync_steps
     DeviceJob.runs = args.runs
-    DeviceJob.gain_two_waves = int(args.gain_two_waves)
+    DeviceJob.gain_form = int(args.gain_form)
     DeviceJob.gain_wgs = args.gain_wgs
     from atracdenc_amd import dist as at3dist
     rank, local_rank, world = at3dist.env_world()
@@ -553,17 +567,27 @@ def main():
     k1_ms, stage_ms = j0.k1_stats(min(region_steps, 28), 0)      # the last region's launches
     iso_ms = j0.isolated_k1()                       # 3 synchronous steps after the timed regions
     parity = None
-    if rank == 0 and not args.no_parity and not args.sync_steps:
-        # (1) the whole timed sequence again from start of stream: same final frames (determinism); (2) the start of that
-        # sequence against the CPU oracle. Both after the timing, on the buffers the timed regions used.
-        same = None
-        if steps_done * S * F <= 64 * 1024 * 1024:
-            same = (j0.replay(steps_done) == checksum)
-        try:
-            parity = j0.parity_sample()
-            parity["timed_sequence_replayed_identically"] = same
-        except Exception as ex:   # noqa: BLE001 - reported in the line, parity_in_run stays false
-            parity = {"error": repr(ex)}
+    contexts = []
+    if not args.no_parity and not args.sync_steps:
+        # EVERY context of the run (one per device; on every rank): (1) the whole timed sequence again from start of stream - same
+        # final frames (determinism); (2) the start of that sequence against the CPU oracle. Both after the timing, on the buffers the
+        # timed regions used. Seeds differ per context, so the checksums must all differ (a context fed another one's shard shows).
+        for i, j in enumerate(jobs):
+            rep = {"rank": rank, "device": j.device, "seed": 1 + rank * 64 + i, "steps": j.calls, "checksum": j.checksum()}
+            same = None
+            if j.calls * S * F <= 64 * 1024 * 1024:
+                same = (j.replay(j.calls) == rep["checksum"])
+            try:
+                chk = j.parity_sample(n_check=4 if n_gpus == 1 else 2)
+                chk["timed_sequence_replayed_identically"] = same
+            except Exception as ex:   # noqa: BLE001 - reported in the line, parity_in_run stays false
+                chk = {"error": repr(ex)}
+            rep["parity_check"] = chk
+            rep["ok"] = bool(chk.get("mismatching_frames", 1) == 0 and same is not False)
+            contexts.append(rep)
+        contexts = [c for part in at3dist.gather_objects(contexts, dist) for c in part]
+        if rank == 0:
+            parity = contexts[0]["parity_check"]
 
     if rank == 0:
         med_ms = float(np.median(region_ms))
@@ -680,6 +704,15 @@ def main():
                                  "three streams and share the GPU with the neighbouring steps' gain analysis and rate loop - on purpose: "
                                  "that overlap is what shortens the step - so each launch takes longer than it does alone; `isolated` is "
                                  "the same launches with the GPU to themselves",
+                         "flops": {"algorithmic_flops_per_frame": ALGO_FLOPS_PER_FRAME_K1, "peak_TF": round(FP32_NO_FMA_PEAK_TF, 2),
+                                   "peak_is": "fp32 vector peak 157.3 TFLOP/s / 2: the arithmetic contract forbids FMA contraction, so a multiply-add is two "
+                                              "instructions (SURVEY 8(d)); spec-derived, no micro-benchmark involved",
+                                   "achieved_TF": flops_of(k1_avg_ms, S * F)[0], "frac": flops_of(k1_avg_ms, S * F)[1],
+                                   "isolated_achieved_TF": flops_of(iso_ms, S * F)[0], "isolated_frac": flops_of(iso_ms, S * F)[1],
+                                   "hbm_frac_at_this_ceiling": round(FP32_NO_FMA_PEAK_TF * 1e12 / ALGO_FLOPS_PER_FRAME_K1 * ALGO_BYTES_PER_FRAME_K1 / 1e9 / HBM_PEAK_GBS, 4),
+                                   "note": "the compute-side view of the same launches (HIP-event durations as for `achieved`): at 100 % of this peak the QMF + "
+                                           "MDCT work would run at hbm_frac_at_this_ceiling of the HBM peak, so north_star's 50 % of HBM asks for 78 % of "
+                                           "the FMA-free vector peak"},
                          "sclk_mhz_observed": None if sclk_mhz is None else round(sclk_mhz, 1),
                          "sclk_note": "shader clock under the rate loop of the last timed step: s_memtime cycles / s_memrealtime (100 MHz) ticks over the "
                                       "life of k_alloc_pack's workgroup 0 (AT3HIP_TAP_CLOCK)",
@@ -704,8 +737,11 @@ def main():
             "checksum": checksum,
         }
         if parity is not None:
-            line["parity_in_run"] = bool(parity.get("mismatching_frames", 1) == 0 and parity.get("timed_sequence_replayed_identically") is not False)
+            sums = [c["checksum"] for c in contexts]
+            line["parity_in_run"] = bool(len(contexts) == n_gpus and all(c["ok"] for c in contexts) and len(set(sums)) == len(sums))
             line["parity_check"] = parity
+            if n_gpus > 1:
+                line["contexts"] = contexts   # one record per device / rank: seed, checksum, replay and oracle check of ITS shard
         if args.sync_steps:
             line["INVALID_profiling_run"] = "--sync-steps: calls were not pipelined; not a throughput measurement"
         if one_gpu_ref is not None:

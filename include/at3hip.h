@@ -101,7 +101,8 @@ int at3hip_encode(at3hip_ctx* ctx, const float* pcm, int32_t n_blocks, uint8_t* 
  * s / 32768.0f on the device - what libsndfile's sf_readf_float hands the reference's TPCMEngine for a 16-bit WAV
  * (pcm_io_sndfile.cpp:111-113, pcmengin.h:173-184) - so the frames equal at3hip_encode's on those floats byte for byte.
  * Half the bytes per frame cross the bus: a host-fed context is bound by them ("Host buffers"). Same
- * flags, same stream state (calls of both kinds may alternate on one context). */
+ * flags, same stream state (calls of both kinds may alternate on one context). With AT3HIP_PCM_ON_DEVICE the pointer must be
+ * 16-byte aligned (the conversion kernel reads eight samples per load; hipMalloc'ed memory is): AT3HIP_EINVAL otherwise. */
 int at3hip_encode_s16(at3hip_ctx* ctx, const int16_t* pcm, int32_t n_blocks, uint8_t* out_frames, int32_t* n_frames_out,
                       uint32_t flags);
 
@@ -190,28 +191,52 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
 
 /* Options that never change a result: how the work is cut up, or which of two equivalent forms computes it.
  *   AT3HIP_OPT_RUNS              wavefronts ("runs" of consecutive blocks) per (stream, channel) of the QMF / MDCT kernels;
- *                                0 = chosen per call from the batch geometry (default). A run re-derives its FIR history and
- *                                overlap from the samples before its first block, so any cut gives the same bytes.
- *   AT3HIP_OPT_FLATNESS_LITERAL  1 = every spectral-flatness measure (CalcSpectralFlatnessPerBfu,
- *                                atrac_psy_common.cpp:158-199) by the literal per-line form; 0 (default) = the short form
- *                                with the literal one as fall-back where rounding could matter. Same values either way.
- *                                The same switch governs the other guarded short form of the path: highFreqRatio
- *                                (transient_spectral_upsampler.cpp:99-118), whose two 257-term f64 energy sums are added in
- *                                lane order and whose f32 is kept only when an error bound (4e-13 against a provable
- *                                1.15e-13) says the reference's chains round to the same f32; 1 = the chains for every item.
+ *                                0 = chosen per call from the batch geometry (default), otherwise >= 1. A run re-derives its FIR
+ *                                history and overlap from the samples before its first block, so any cut gives the same bytes.
+ *   AT3HIP_OPT_LITERAL_FORMS     0 (default) / 1. The path has two guarded SHORT forms of reference arithmetic; 1 makes both run in
+ *                                their LITERAL form for every item (a test and diagnosis aid: same values either way):
+ *                                (a) the spectral-flatness measure (CalcSpectralFlatnessPerBfu, atrac_psy_common.cpp:158-199): one
+ *                                    log per BFU over a product of mantissas instead of a log per line, literal per-line form as
+ *                                    fall-back where rounding could matter;
+ *                                (b) highFreqRatio (transient_spectral_upsampler.cpp:99-118): its two 257-term f64 energy sums added
+ *                                    in lane order, the f32 kept only when an error bound (4e-13 against a provable 1.15e-13) says
+ *                                    the reference's chains round to the same f32, the chains otherwise.
+ *                                AT3HIP_OPT_FLATNESS_LITERAL is the former name of this option (same number, kept for source
+ *                                compatibility).
  *                                SUPPORTED REFERENCE PLATFORM: both forms restate glibc 2.35's f64 log / exp (and log2f) in the
  *                                variants its ifunc picks on an x86-64 host WITH FMA; glibc selects per CPU, so on a host without
  *                                FMA the reference itself rounds differently in rare last-bit cases and "bit-identical" then means
  *                                identical to the reference run on an FMA host (every box in play). tests/test_libm64.py and the
  *                                gpu-marked pin check the host's libm against the restatement.
- *   AT3HIP_OPT_QUANT_TAP         1 = keep the AT3HIP_TAP_QUANT records (3.5 KB written per frame; off by default). */
+ *   AT3HIP_OPT_QUANT_TAP         0 (default) / 1 = keep the AT3HIP_TAP_QUANT records (3.5 KB written per frame).
+ *   AT3HIP_OPT_GAIN_FORM         which form of the spectral upsampler / AnalyzeGain kernel runs (same results):
+ *                                AT3HIP_GAIN_FORM_TWO_WAVES (0, default) = a two-wavefront workgroup per item,
+ *                                AT3HIP_GAIN_FORM_ONE_WAVE (1) = one wavefront per item (faster alone, not in the pipelined step).
+ *   AT3HIP_OPT_GAIN_WGS_PER_CU   tuning aid: workgroups per CU of that kernel by LDS padding: 0 = chosen per launch (default),
+ *                                1 .. 16 = that many, 256 .. 65536 = the pad itself in bytes.
+ * Values outside the ranges above are rejected with AT3HIP_EINVAL (nothing is stored). */
 #define AT3HIP_OPT_RUNS 1
-#define AT3HIP_OPT_FLATNESS_LITERAL 2
+#define AT3HIP_OPT_LITERAL_FORMS 2
+#define AT3HIP_OPT_FLATNESS_LITERAL AT3HIP_OPT_LITERAL_FORMS
 #define AT3HIP_OPT_QUANT_TAP 3
-#define AT3HIP_OPT_GAIN_WGS_PER_CU 5  /* tuning aid: workgroups per CU of the upsampler kernel (1 .. 16: by LDS padding; from 256: the pad in bytes), 0 = chosen per launch */
-#define AT3HIP_OPT_GAIN_TWO_WAVES 4   /* which form of the upsampler / AnalyzeGain kernel runs (same results): 0 / 1 = two-wavefront
-                                        * workgroups (default), 2 = one wavefront per item (faster alone, not in the pipelined step) */
+#define AT3HIP_OPT_GAIN_FORM 4
+#define AT3HIP_OPT_GAIN_WGS_PER_CU 5
+#define AT3HIP_GAIN_FORM_TWO_WAVES 0
+#define AT3HIP_GAIN_FORM_ONE_WAVE 1
 int at3hip_set_option(at3hip_ctx* ctx, int32_t option, int32_t value);
+
+/* The reference's overflow diagnostics as counters ("these conditions become counters, not prints").
+ * TScaler::Scale (atrac_scale.cpp:141-172) prints "Scale error: absSpec > MAX_SCALE" once per block (BFU or tonal component) whose
+ * largest magnitude exceeds 1.0 and "clipping, scaled value: ..." once per value whose scaled magnitude exceeds 1.0; the results
+ * are clamped either way (and are bit-identical here). The counters accumulate over every frame this context has encoded since
+ * at3hip_create / at3hip_reset / the last at3hip_get_counters(..., reset = 1), summed over streams, and count what ONE
+ * TAtrac3Encoder per stream would have printed (a one-channel stream is scaled once, like the reference's single channel).
+ * Waits for queued work. */
+typedef struct at3hip_counters {
+    uint64_t scale_overflow;   /* "Scale error" lines: blocks with max |spectrum| > MAX_SCALE (1.0) */
+    uint64_t clipped_values;   /* "clipping" lines: values with |value / scale factor| > 1.0 */
+} at3hip_counters;
+int at3hip_get_counters(at3hip_ctx* ctx, at3hip_counters* out, int32_t reset);
 
 /* Host-buffer pipeline. The reference's caller hands host floats (TPCMEngine::ApplyProcess, pcmengin.h:152-192): with
  * page-locked buffers from at3hip_host_alloc and AT3HIP_ASYNC calls that alternate between two input and two output
@@ -234,7 +259,16 @@ int at3hip_wait_frames(at3hip_ctx* ctx, int32_t ago);
  * suite prove, on the machine that runs the encoder, that the tables equal the reference's. */
 int at3hip_host_tables(void* dst, size_t bytes);
 
-/* Library/ABI version: (major << 16) | minor. */
+/* Library/ABI version: (major << 16) | minor. The minor number grows with every addition to this header:
+ *   1.1  rounds 1 - 3 (two calls in flight: at3hip_wait_* accept ago 0 .. 1)
+ *   1.2  at3hip_encode_s16, at3hip_wait_* with ago 0 .. 3 (three calls in flight), AT3HIP_TAP_CLOCK / AT3HIP_TAP_GAIN_ANALYSIS,
+ *        AT3HIP_OPT_GAIN_FORM / AT3HIP_OPT_GAIN_WGS_PER_CU / AT3HIP_OPT_LITERAL_FORMS with validated values
+ *   1.3  at3hip_get_counters
+ * A host layer compiled against this header checks at3hip_version() >= AT3HIP_VERSION before it relies on them
+ * (atracdenc_amd/host/at3hip_host.hpp and the ctypes stub do). */
+#define AT3HIP_VERSION_MAJOR 1
+#define AT3HIP_VERSION_MINOR 3
+#define AT3HIP_VERSION ((AT3HIP_VERSION_MAJOR << 16) | AT3HIP_VERSION_MINOR)
 uint32_t at3hip_version(void);
 
 #if defined(__GNUC__)

@@ -1006,6 +1006,15 @@ static void create_band_curve(const float* up, int band, curve_ctx* ctx, curve_t
  * Scaling and quantisation (atrac/atrac_scale.cpp)
  * ---------------------------------------------------------------------------------------- */
 /* atrac_scale.cpp:141-172; lower_bound on the (strictly increasing) ScaleTable */
+/* what the reference prints to stderr here, as counts (process-wide; read and reset through at3o_diag_counts):
+ * [0] "Scale error: absSpec > MAX_SCALE" (:150-153), [1] "clipping, scaled value" (:163-167) */
+static unsigned long long g_diag[2];
+void at3o_diag_counts(unsigned long long* out2, int reset)
+{
+    if (out2) { out2[0] = g_diag[0]; out2[1] = g_diag[1]; }
+    if (reset) g_diag[0] = g_diag[1] = 0;
+}
+
 static int scale_block(const float* in, int len, float* values, float* energy)
 {
     float maxAbs = 0;
@@ -1013,7 +1022,10 @@ static int scale_block(const float* in, int len, float* values, float* energy)
         const float a = fabsf(in[i]);
         if (a > maxAbs) maxAbs = a;
     }
-    if (maxAbs > 1.0f) maxAbs = 1.0f;
+    if (maxAbs > 1.0f) {
+        g_diag[0]++;
+        maxAbs = 1.0f;
+    }
     int sfi = 0;
     while (sfi < 63 && T.scale[sfi] < maxAbs) ++sfi;
     const float sf = T.scale[sfi];
@@ -1021,7 +1033,10 @@ static int scale_block(const float* in, int len, float* values, float* energy)
     for (int i = 0; i < len; ++i) {
         float v = in[i] / sf;
         e += in[i] * in[i];
-        if (fabsf(v) >= 1.0) v = (v > 0) ? 0.99999 : -0.99999;
+        if (fabsf(v) >= 1.0) {
+            if (fabsf(v) > 1.0) g_diag[1]++;
+            v = (v > 0) ? 0.99999 : -0.99999;
+        }
         values[i] = v;
     }
     *energy = e;

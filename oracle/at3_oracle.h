@@ -67,6 +67,9 @@ int at3o_calc_curve(const float* gain32, float* ctx, float minScore, const float
 int at3o_relation_to_idx_hdr(float x);
 float at3o_quant_mantisas(const float* in, int n, float mul, int ea, int32_t* mant);
 void at3o_scale_frame(const float* specs, int32_t* sfi, float* energy, float* values);
+/* TScaler::Scale's stderr diagnostics as process-wide counts since the last reset: out2[0] = "Scale error" lines
+ * (atrac_scale.cpp:150-153), out2[1] = "clipping" lines (:163-167). */
+void at3o_diag_counts(unsigned long long* out2, int reset);
 void at3o_flatness(const float* energy1024, float* flat32);
 float at3o_log2f(float x);
 void at3o_tables(float* scale64, float* encwin256, float* gainlevel16, float* gaininterp31,

@@ -306,6 +306,44 @@ def pcm_stress(nblocks, seed=3):
     return (s16.astype(np.float32) / np.float32(32768.0)).reshape(nblocks, 1024, 2).astype(np.float32)
 
 
+def pcm_hot(nblocks, seed=5, gain=40.0):
+    """Input ABOVE full scale (what a float WAV may hold): the stress signal and a few loud sines, times `gain`, unquantised -
+    spectra beyond MAX_SCALE = 1.0, so TScaler::Scale clamps scale factors and clips values (atrac_scale.cpp:150-167: the
+    reference's "Scale error" / "clipping" diagnostics), in residual BFUs and in tonal components alike."""
+    x = pcm_stress(nblocks, seed=seed).astype(np.float64).reshape(-1, 2)
+    t = np.arange(x.shape[0], dtype=np.float64)
+    for i, f in enumerate((700.0, 2500.0, 6100.0, 9000.0)):
+        x[:, i & 1] += 0.4 * np.sin(2 * np.pi * f * t / 44100.0 + i)
+    return (x * gain).astype(np.float32).reshape(nblocks, 1024, 2)
+
+
+def capture_ref_diagnostics(fn):
+    """Runs fn() with file descriptor 2 redirected and returns (fn's result, "Scale error" lines, "clipping" lines): the
+    reference reports TScaler::Scale's overflow conditions on std::cerr only (atrac_scale.cpp:150-153, 163-167)."""
+    import sys
+    import tempfile
+    sys.stderr.flush()
+    saved = os.dup(2)
+    with tempfile.TemporaryFile() as tmp:
+        os.dup2(tmp.fileno(), 2)
+        try:
+            res = fn()
+        finally:
+            os.dup2(saved, 2)
+            os.close(saved)
+        tmp.seek(0)
+        text = tmp.read().decode(errors="replace")
+    return res, text.count("Scale error: absSpec > MAX_SCALE"), text.count("clipping, scaled value")
+
+
+def oracle_diag_counts(reset=False):
+    """(scale errors, clipped values) the oracle has counted since the last reset (at3o_diag_counts; process-wide)."""
+    o = oracle()
+    out = (ctypes.c_ulonglong * 2)()
+    o.lib.at3o_diag_counts(out, int(bool(reset)))
+    return int(out[0]), int(out[1])
+
+
 SIGNALS = {
     "noise": pcm_noise,
     "burst": pcm_burst,

@@ -185,6 +185,38 @@ int main()
         }
         printf("TAtrac3EncoderBatch::EncodeS16 / EncodePipelinedS16 compared with the float path\n");
     }
+    // ---- TAtrac3EncoderNode with EIGHT parts (what a full node runs; this box has one device, so all eight on device 0): the
+    // shards' bytes equal ONE context's on the same streams, through Encode and through the pinned pipeline; the overflow
+    // counters of a part report what the oracle counts for that part's streams ----
+    {
+        const int S = 19, n = 7;   // 19 streams over 8 parts: shards of 3, 3, 3, 2, 2, 2, 2, 2
+        std::vector<float> batch((size_t)S * n * 2048);
+        for (int s = 0; s < S; ++s)
+            for (int i = 0; i < n * 2048; ++i)
+                batch[(size_t)s * n * 2048 + i] = pcm[(size_t)((i + 2048 * s) % (nb * 2048))] * (s == 4 ? 30.0f : 1.0f);   // stream 4: above full scale
+        TAtrac3EncoderSettings st;
+        TAtrac3EncoderBatch one(st, S, n);
+        std::vector<uint8_t> ref1, got8, piped8;
+        const int nf1 = one.Encode(batch.data(), n, ref1);
+        TAtrac3EncoderNode node(st, S, n, {0, 0, 0, 0, 0, 0, 0, 0});
+        EXPECT(node.Devices() == 8);
+        EXPECT(node.Encode(batch.data(), n, got8) == nf1 && got8 == ref1);
+        EXPECT(node.EncodePipelined(batch.data(), n, 3, piped8) == nf1 && piped8 == ref1);
+        unsigned long long want[2] = {0, 0};
+        at3o_diag_counts(nullptr, 1);
+        for (int s = 0; s < S; ++s) {
+            std::vector<unsigned char> exp((size_t)n * 1024);
+            int fsz = 0;
+            EXPECT(at3o_encode(132300, 2, 0, 0, 0, batch.data() + (size_t)s * n * 2048, n, exp.data(), &fsz, nullptr) == nf1);
+            EXPECT(memcmp(ref1.data() + (size_t)s * nf1 * fsz, exp.data(), (size_t)nf1 * fsz) == 0);
+        }
+        at3o_diag_counts(want, 1);
+        const at3hip_counters c = one.Counters();
+        EXPECT(want[0] > 0 && c.scale_overflow == want[0] && c.clipped_values == want[1]);
+        EXPECT(one.Counters(true).scale_overflow == want[0] && one.Counters().scale_overflow == 0);
+        printf("TAtrac3EncoderNode (8 contexts on one device) equals one context; overflow counters %llu / %llu\n", (unsigned long long)c.scale_overflow,
+               (unsigned long long)c.clipped_values);
+    }
     // ---- TAt3PEncoder: 5 stereo frames of 2048 samples through a batch of 2; look-ahead call, silent first frame ----
     {
         const int nfr = 5;

@@ -5,7 +5,7 @@ too (the kernels keep the reference's fp32 operation order, contraction off), wh
 import numpy as np
 import pytest
 
-from at3_testlib import LP2, LP4, SIGNALS, pcm_stress
+from at3_testlib import LP2, LP4, SIGNALS, capture_ref_diagnostics, have_ref, oracle_diag_counts, pcm_hot, pcm_stress, ref
 
 pytestmark = pytest.mark.gpu
 
@@ -127,7 +127,7 @@ def test_stage_taps(hip, oracle, br):
 
 @pytest.mark.parametrize("br", [LP2, LP4])
 def test_gain_analysis_forms_agree(hip, oracle, br):
-    """AT3HIP_OPT_GAIN_TWO_WAVES: the upsampler / AnalyzeGain kernel as two-wavefront workgroups (default) and as one wavefront
+    """AT3HIP_OPT_GAIN_FORM: the upsampler / AnalyzeGain kernel as two-wavefront workgroups (default) and as one wavefront
     per item (k_gain_analysis1: leaves in registers, v_permlane swaps across the rows) - same curves, same frames, both
     equal to the oracle's, on the signals that drive the gain-control path."""
     from atracdenc_amd import binding as B
@@ -137,16 +137,16 @@ def test_gain_analysis_forms_agree(hip, oracle, br):
     pcm = np.stack([sig[n](nb) for n in names])
     exp = oracle_frames(oracle, pcm, br)
     got = {}
-    for form in (1, 2):
+    for form in (B.GAIN_FORM_TWO_WAVES, B.GAIN_FORM_ONE_WAVE):
         enc = hip.At3Hip(n_streams=len(names), max_blocks=nb, bitrate=br)
-        enc.set_option(B.OPT_GAIN_TWO_WAVES, form)
+        enc.set_option(B.OPT_GAIN_FORM, form)
         frames = np.concatenate([enc.encode(pcm[:, :7]), enc.encode(pcm[:, 7:])], axis=1)   # two calls: carried context
         curves = enc.read_tap(B.TAP_CURVES, np.uint8, (len(names), nb - 7, 2, 4, 16))
         enc.close()
         assert np.array_equal(frames, exp), form
         got[form] = curves
-    assert np.array_equal(got[1], got[2])
-    assert got[1][..., 0].any()          # the material does produce gain curves
+    assert np.array_equal(got[B.GAIN_FORM_TWO_WAVES], got[B.GAIN_FORM_ONE_WAVE])
+    assert got[B.GAIN_FORM_TWO_WAVES][..., 0].any()          # the material does produce gain curves
 
 
 @pytest.mark.parametrize("br", [LP2, LP4])
@@ -219,7 +219,7 @@ def _check_flat_values(oracle, psy, specs):
 def test_flatness_values(hip, oracle, literal):
     """CalcSpectralFlatnessPerBfu (atrac_psy_common.cpp:158-199) by VALUE: the f32 the device hands to `flat < 0.01f` equals
     the reference's for every BFU the extraction looks at - in the default form (one log of the lines' mantissa product,
-    guarded by an error bound, literal fall-back) and with AT3HIP_OPT_FLATNESS_LITERAL (a restated glibc log per line, the
+    guarded by an error bound, literal fall-back) and with AT3HIP_OPT_LITERAL_FORMS (a restated glibc log per line, the
     reference's ordered sums, the restated exp: atracdenc_amd/csrc/at3_libm64.hpp). Frames equal either way."""
     from atracdenc_amd import binding as B
     nb = 12
@@ -228,7 +228,7 @@ def test_flatness_values(hip, oracle, literal):
     S = pcm.shape[0]
     specs = _raw_spectra(hip, pcm)
     enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2, no_gain=True)
-    enc.set_option(B.OPT_FLATNESS_LITERAL, literal)
+    enc.set_option(B.OPT_LITERAL_FORMS, literal)
     got = enc.encode(pcm)
     psy = enc.read_tap(B.TAP_PSY, B.At3Hip.PSY_DTYPE, (S, nb - 1, 2))
     enc.close()
@@ -248,7 +248,7 @@ def test_flatness_threshold_adversarial(hip, oracle, literal):
     S, nb = pcm.shape[0], pcm.shape[1]
     specs = _raw_spectra(hip, pcm)
     enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2, no_gain=True)
-    enc.set_option(B.OPT_FLATNESS_LITERAL, literal)
+    enc.set_option(B.OPT_LITERAL_FORMS, literal)
     got = enc.encode(pcm)
     psy = enc.read_tap(B.TAP_PSY, B.At3Hip.PSY_DTYPE, (S, nb - 1, 2))
     enc.close()
@@ -262,7 +262,7 @@ def test_flatness_threshold_adversarial(hip, oracle, literal):
 def test_high_freq_ratio_short_form(hip, oracle):
     """highFreqRatio (transient_spectral_upsampler.cpp:99-118) gates the gain analysis (`< 0.05`, `< 0.3`). k_gain_spec adds the
     two f64 energy sums in lane order and keeps the f32 of the quotient only when an error bound says the reference's 257-term
-    chains round to the same f32; AT3HIP_OPT_FLATNESS_LITERAL walks the chains for every item. The ratios of both forms are
+    chains round to the same f32; AT3HIP_OPT_LITERAL_FORMS walks the chains for every item. The ratios of both forms are
     equal bit for bit over every item of a mixed batch, and the frames equal the oracle's in both forms."""
     from atracdenc_amd import binding as B
     nb = 10
@@ -273,7 +273,7 @@ def test_high_freq_ratio_short_form(hip, oracle):
     ratios = []
     for literal in (0, 1):
         enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=LP2)
-        enc.set_option(B.OPT_FLATNESS_LITERAL, literal)
+        enc.set_option(B.OPT_LITERAL_FORMS, literal)
         got = enc.encode(pcm)
         rec = enc.read_tap(B.TAP_GAIN_ANALYSIS, np.uint32, (S, nb, 2, 3, 104))
         enc.close()
@@ -730,6 +730,39 @@ def test_bench_contract_and_two_context_paths(tmp_path):
     assert d3["n_gpus"] == 2 and "ranks" in d3["config"]["launch"] and d3["value"] > 1e5
 
 
+@pytest.mark.parametrize("launch", ["one_process", "ranks"])
+def test_eight_context_readiness(launch):
+    """What runs the day an 8-GPU node is available, on this box's single GPU through --device-map 0,0,0,0,0,0,0,0: bench.py
+    --gpus 8 as ONE process (eight contexts, eight host threads, the one_gpu_same_workload regions, the replay of every context's
+    call sequence) and as eight torch.distributed.run ranks (gloo barrier, MAX of the elapsed time, checksums gathered). Every
+    context checks its own shard against the oracle and replays its own sequence; eight seeds give eight distinct checksums."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    tail = [bench, "--gpus", "8", "--device-map", "0,0,0,0,0,0,0,0", "--steps", "3", "--warmup", "1", "--streams", "64", "--frames", "16",
+            "--regions", "1", "--region-ms", "1", "--no-side-workloads", "--no-cpu-baseline"]
+    cmd = [sys.executable] + tail if launch == "one_process" else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29541"] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["frames_per_step_all_gpus"] == 8 * 64 * 16
+    assert d["parity_in_run"] is True
+    ctx = d["contexts"]
+    assert len(ctx) == 8 and all(c["ok"] and c["parity_check"]["mismatching_frames"] == 0 for c in ctx)
+    assert all(c["parity_check"]["timed_sequence_replayed_identically"] is True for c in ctx)
+    assert len({c["seed"] for c in ctx}) == 8 and len({c["checksum"] for c in ctx}) == 8
+    if launch == "one_process":
+        assert d["one_gpu_same_workload"]["value"] > 1e5 and sorted(c["rank"] for c in ctx) == [0] * 8
+    else:
+        assert sorted(c["rank"] for c in ctx) == list(range(8))
+
+
 def wild_spread_pcm(nb, seed):
     """Full-scale noise below 3.5 kHz and float rounding dust above it: half of the BFUs scale near the top of the table, the
     other half at its bottom - a spread of the scale-factor indices that no ordinary material has."""
@@ -837,4 +870,64 @@ def test_options_and_quant_tap(hip, oracle):
     assert np.array_equal(enc.encode(pcm), exp)
     with pytest.raises(hip.At3HipError):
         enc.set_option(99, 1)
+    enc.close()
+
+
+@pytest.mark.parametrize("br,channels", [(LP2, 2), (LP4, 2), (LP2, 1), (LP4, 1)])
+def test_overflow_counters(hip, oracle, br, channels):
+    """at3hip_get_counters: TScaler::Scale's stderr diagnostics as counters (atrac_scale.cpp:150-153 "Scale error" per block,
+    :163-167 "clipping" per value). Input above full scale: frames equal the oracle's and the counters equal
+    what the oracle counts - and, where the real reference is present, the lines it prints. They accumulate over calls and
+    streams, a one-channel stream counts like the reference's single channel, ordinary material counts nothing, reset clears."""
+    nb = 14
+    pcm = np.stack([pcm_hot(nb, seed=5), pcm_hot(nb, seed=9, gain=12.0), SIGNALS["mix"](nb)])[..., :channels]
+    pcm = np.ascontiguousarray(pcm)
+    oracle_diag_counts(reset=True)
+    exp = oracle_frames(oracle, pcm, br)
+    want = oracle_diag_counts(reset=True)
+    assert want[0] > 100 and want[1] >= want[0]
+    if have_ref():
+        _, n_scale, n_clip = capture_ref_diagnostics(lambda: [ref().encode(pcm[i], br) for i in range(pcm.shape[0])])
+        assert (n_scale, n_clip) == want
+    enc = hip.At3Hip(n_streams=3, max_blocks=nb, bitrate=br, channels=channels)
+    assert enc.counters() == {"scale_overflow": 0, "clipped_values": 0}
+    got = np.concatenate([enc.encode(pcm[:, :5]), enc.encode(pcm[:, 5:])], axis=1)     # two calls: the counters accumulate
+    assert np.array_equal(got, exp)
+    c = enc.counters(reset=True)
+    assert (c["scale_overflow"], c["clipped_values"]) == want
+    assert enc.counters() == {"scale_overflow": 0, "clipped_values": 0}
+    enc.reset()
+    quiet = np.ascontiguousarray(np.stack([SIGNALS[n](6) for n in ("mix", "burst", "noise")])[..., :channels])
+    enc.encode(quiet)
+    assert enc.counters() == {"scale_overflow": 0, "clipped_values": 0}
+    enc.encode(pcm[:, :4])
+    assert enc.counters()["scale_overflow"] > 0
+    enc.reset()                                                                          # a fresh TAtrac3Encoder has printed nothing
+    assert enc.counters() == {"scale_overflow": 0, "clipped_values": 0}
+    enc.close()
+
+
+def test_option_values_are_validated_and_version(hip):
+    """at3hip_set_option rejects values outside an option's range and stores nothing; a 16-bit device pointer that
+    the conversion kernel cannot read sixteen bytes at a time is refused; the library reports the ABI the binding was written for."""
+    import torch
+    from atracdenc_amd import binding as B
+    lib = B.load_library()
+    assert lib.at3hip_version() == B.AT3HIP_VERSION and B.AT3HIP_VERSION >> 16 == 1
+    enc = hip.At3Hip(n_streams=1, max_blocks=4)
+    for opt, bad in ((B.OPT_RUNS, -1), (B.OPT_LITERAL_FORMS, 2), (B.OPT_LITERAL_FORMS, -1), (B.OPT_QUANT_TAP, 2), (B.OPT_GAIN_FORM, 2),
+                     (B.OPT_GAIN_FORM, -1), (B.OPT_GAIN_WGS_PER_CU, 17), (B.OPT_GAIN_WGS_PER_CU, 100000), (0, 0), (6, 0)):
+        with pytest.raises(hip.At3HipError):
+            enc.set_option(opt, bad)
+    for opt, good in ((B.OPT_RUNS, 2), (B.OPT_RUNS, 0), (B.OPT_LITERAL_FORMS, 1), (B.OPT_LITERAL_FORMS, 0), (B.OPT_GAIN_FORM, B.GAIN_FORM_ONE_WAVE),
+                      (B.OPT_GAIN_FORM, B.GAIN_FORM_TWO_WAVES), (B.OPT_GAIN_WGS_PER_CU, 6), (B.OPT_GAIN_WGS_PER_CU, 0)):
+        enc.set_option(opt, good)
+    assert B.OPT_FLATNESS_LITERAL == B.OPT_LITERAL_FORMS
+    dev = torch.device("cuda", 0)
+    raw = torch.zeros(4 * 2048 + 16, dtype=torch.int16, device=dev)
+    out = torch.zeros(4 * 384, dtype=torch.uint8, device=dev)
+    assert raw.data_ptr() % 16 == 0
+    with pytest.raises(hip.At3HipError):
+        enc.encode_device_s16(raw.data_ptr() + 2, 4, out.data_ptr())      # misaligned by one sample
+    assert enc.encode_device_s16(raw.data_ptr(), 4, out.data_ptr()) == 3
     enc.close()

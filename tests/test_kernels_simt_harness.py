@@ -44,23 +44,32 @@ def harness():
 
 def test_atrac3_kernels(harness):
     """Six signals x LP2 / LP4 x (all tools, no gain, no gain + no tonal), two streams, two calls (carried state)."""
-    _assert_clean(_run("run_emu.py", "--strict", "--nobuild"), 36)
+    _assert_clean(_run("run_emu.py", "--strict", "--nobuild"), 72)   # (frames and overflow counters per case)
+
+
+def test_atrac3_overflow_counters(harness):
+    """Input above full scale: frames and at3hip_get_counters (TScaler::Scale's "Scale error" / "clipping" diagnostics,
+    atrac_scale.cpp:150-167, counted by k_psy) against the oracle, which tests/test_oracle_vs_ref.py pins to the lines the
+    reference prints."""
+    out = _run("run_emu.py", "--strict", "--nobuild", "hot")
+    _assert_clean(out, 12)
+    assert re.search(r"overflow counters [1-9]\d+, [1-9]\d+ ", out), out[-2000:]
 
 
 def test_atrac3_gain_analysis_one_wavefront_form(harness):
-    """AT3HIP_OPT_GAIN_TWO_WAVES = 2 (k_gain_analysis1, incl. the restated v_permlane32/16_swap, which tools/ubench/permlane_check
+    """AT3HIP_OPT_GAIN_FORM = AT3HIP_GAIN_FORM_ONE_WAVE (k_gain_analysis1, incl. the restated v_permlane32/16_swap, which tools/ubench/permlane_check
     compares with the hardware): the signals with gain curves x LP2 / LP4 x three option sets."""
-    _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--gain-form=2", "burst", "stress"), 12)
+    _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--gain-form=1", "burst", "stress"), 24)
 
 
 def test_atrac3_literal_forms(harness):
-    """AT3HIP_OPT_FLATNESS_LITERAL: the flatness measure per line and k_gain_spec's energy sums as the reference's chains."""
-    _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--literal", "mix", "stress"), 12)
+    """AT3HIP_OPT_LITERAL_FORMS: the flatness measure per line and k_gain_spec's energy sums as the reference's chains."""
+    _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--literal", "mix", "stress"), 24)
 
 
 def test_atrac3_s16_entry_point(harness):
     """at3hip_encode_s16 (k_s16_to_f32 + the unchanged pipeline), calls of both kinds alternating on one context."""
-    _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--s16", "mix"), 6)
+    _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "--s16", "mix"), 12)
 
 
 def test_atrac1_kernels(harness):

@@ -3,7 +3,8 @@
 import numpy as np
 import pytest
 
-from at3_testlib import LP2, LP4, SIGNALS, TAP_DTYPE, flatness_threshold_walk, have_ref, pcm_stress, ref
+from at3_testlib import (LP2, LP4, SIGNALS, TAP_DTYPE, capture_ref_diagnostics, flatness_threshold_walk, have_ref, oracle_diag_counts, pcm_hot,
+                         pcm_stress, ref)
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
 
@@ -144,3 +145,18 @@ def test_sort_tie_order_matches_libstdcxx(oracle):
         m2, e2 = r.quant_mantisas(v, mul, 1)
         assert np.array_equal(m1, m2)
         assert e1.view(np.uint32) == e2.view(np.uint32) or (np.isnan(e1) and np.isnan(e2))
+
+
+@pytest.mark.parametrize("br,nch", [(LP2, 2), (LP4, 2), (LP2, 1), (LP4, 1)])
+def test_scale_diagnostics_counted_like_the_reference_prints_them(oracle, br, nch):
+    """TScaler::Scale reports a block above MAX_SCALE ("Scale error") and every value it clips ("clipping") on stderr only
+    (atrac_scale.cpp:150-153, 163-167). The oracle counts them (at3o_diag_counts): equal to the reference's lines on input
+    above full scale, zero on ordinary material, frames equal either way. These counts are what at3hip_get_counters returns."""
+    for pcm, want_some in ((pcm_hot(14), True), (SIGNALS["mix"](8), False)):
+        pcm = np.ascontiguousarray(pcm[:, :, :nch])
+        (fr, _), n_scale, n_clip = capture_ref_diagnostics(lambda: ref().encode(pcm, br))
+        oracle_diag_counts(reset=True)
+        fo, _ = oracle.encode(pcm, br)
+        assert np.array_equal(fo, fr)
+        assert oracle_diag_counts(reset=True) == (n_scale, n_clip)
+        assert (n_scale > 0 and n_clip >= n_scale) if want_some else (n_scale == 0 and n_clip == 0)

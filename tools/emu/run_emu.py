@@ -5,8 +5,8 @@ import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from at3_testlib import SIGNALS, LP2, LP4, oracle, pcm_stress
-SIGNALS = dict(SIGNALS, stress=lambda nb: pcm_stress(nb, seed=7))
+from at3_testlib import SIGNALS, LP2, LP4, oracle, oracle_diag_counts, pcm_hot, pcm_stress
+SIGNALS = dict(SIGNALS, stress=lambda nb: pcm_stress(nb, seed=7), hot=lambda nb: pcm_hot(nb))   # hot: above full scale (overflow counters)
 from atracdenc_amd.binding import At3Hip
 
 EMU = os.path.join(ROOT, "tools", "emu", "libat3hip_emu.so")
@@ -26,7 +26,7 @@ if __name__ == "__main__":
     strict = "--strict" in sys.argv
     if strict: os.environ["EMU_STRICT"] = "1"
     if "--nobuild" not in sys.argv: build(strict)
-    gain_form = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--gain-form=")), 0)   # AT3HIP_OPT_GAIN_TWO_WAVES
+    gain_form = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--gain-form=")), 0)   # AT3HIP_OPT_GAIN_FORM
     names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["noise", "burst", "tones", "silence", "mix", "stress"]
     nb = 6
     o = oracle()
@@ -37,11 +37,11 @@ if __name__ == "__main__":
                 t = time.time()
                 enc = At3Hip(n_streams=2, max_blocks=nb, bitrate=br, no_gain=ng, no_tonal=nt, lib_path=EMU)
                 if gain_form:
-                    from atracdenc_amd.binding import OPT_GAIN_TWO_WAVES
-                    enc.set_option(OPT_GAIN_TWO_WAVES, gain_form)
-                if "--literal" in sys.argv:   # AT3HIP_OPT_FLATNESS_LITERAL: the guarded short forms (flatness, highFreqRatio) take their literal paths
-                    from atracdenc_amd.binding import OPT_FLATNESS_LITERAL
-                    enc.set_option(OPT_FLATNESS_LITERAL, 1)
+                    from atracdenc_amd.binding import OPT_GAIN_FORM
+                    enc.set_option(OPT_GAIN_FORM, gain_form)
+                if "--literal" in sys.argv:   # AT3HIP_OPT_LITERAL_FORMS: the guarded short forms (flatness, highFreqRatio) take their literal paths
+                    from atracdenc_amd.binding import OPT_LITERAL_FORMS
+                    enc.set_option(OPT_LITERAL_FORMS, 1)
                 # feed in two pieces to exercise the carried state
                 if "--s16" in sys.argv:   # at3hip_encode_s16: the same samples as 16-bit integers, converted on the "device"
                     p16 = np.round(np.clip(pcm, -1.0, 32767.0 / 32768.0) * 32768.0).astype(np.int16)
@@ -49,8 +49,14 @@ if __name__ == "__main__":
                     got = np.concatenate([enc.encode_s16(p16[:, :4]), enc.encode(pcm[:, 4:5]), enc.encode_s16(p16[:, 5:])], axis=1)
                 else:
                     got = np.concatenate([enc.encode(pcm[:, :4]), enc.encode(pcm[:, 4:])], axis=1)
+                cnt = enc.counters()
                 enc.close()
+                oracle_diag_counts(reset=True)
                 exp = np.stack([o.encode(pcm[i], br, ng, nt)[0] for i in range(2)])
+                want = oracle_diag_counts(reset=True)
+                # at3hip_get_counters against the oracle's count of TScaler::Scale's diagnostics (zero on everything but `hot`)
+                print(f"{name:8s} overflow counters {cnt['scale_overflow']}, {cnt['clipped_values']} (oracle {want[0]}, {want[1]}): "
+                      f"bad {int((cnt['scale_overflow'], cnt['clipped_values']) != want)}")
                 bad = (got != exp).any(axis=2)
                 print(f"{name:8s} br={br} nogain={ng} notonal={nt}: shape {got.shape} mismatching frames "
                       f"{int(bad.sum())}/{bad.size} {np.argwhere(bad)[:6].tolist()} ({time.time()-t:.1f}s)")

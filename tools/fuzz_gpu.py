@@ -85,8 +85,8 @@ def main():
         for br in (LP2, LP4):
             for ng, nt in ((0, 0), (1, 0), (0, 1)):
                 enc = atracdenc_amd.At3Hip(n_streams=S, max_blocks=nb, bitrate=br, no_gain=ng, no_tonal=nt)
-                if os.environ.get("FUZZ_GAIN_FORM"):   # AT3HIP_OPT_GAIN_TWO_WAVES: 2 = the one-wavefront upsampler kernel
-                    enc.set_option(atracdenc_amd.binding.OPT_GAIN_TWO_WAVES, int(os.environ["FUZZ_GAIN_FORM"]))
+                if os.environ.get("FUZZ_GAIN_FORM"):   # AT3HIP_OPT_GAIN_FORM: 1 = the one-wavefront upsampler kernel
+                    enc.set_option(atracdenc_amd.binding.OPT_GAIN_FORM, int(os.environ["FUZZ_GAIN_FORM"]))
                 got = enc.encode(pcm)
                 enc.close()
                 exp = list(pool.map(lambda i: o.encode(pcm[i], br, ng, nt)[0], range(S)))
