@@ -259,14 +259,22 @@ private:
             ~TPinned() { at3hip_host_free(Ctx, P); }
         };
         const size_t inFloats = (size_t)NStreams * blocksPerCall * 1024 * channels, outBytes = (size_t)NStreams * blocksPerCall * FrameSz;
-        // kDepth calls in flight: the device overlaps three stages of consecutive calls, so two calls leave it idle between them
-        // once the copies are as short as the kernels (16-bit samples); at3hip_wait_* reach three calls back
-        constexpr int kDepth = 3;
-        TPinned in0(Ctx, inFloats * sizeof(TSample)), in1(Ctx, inFloats * sizeof(TSample)), in2(Ctx, inFloats * sizeof(TSample));
-        TPinned out0(Ctx, outBytes), out1(Ctx, outBytes), out2(Ctx, outBytes);
-        TSample* in[kDepth] = {(TSample*)in0.P, (TSample*)in1.P, (TSample*)in2.P};
-        uint8_t* out[kDepth] = {(uint8_t*)out0.P, (uint8_t*)out1.P, (uint8_t*)out2.P};
-        int32_t nf[kDepth] = {0, 0, 0};
+        // kDepth calls in flight (at3hip_wait_* reach three calls back, so at most four). Measured on configs[1] (64 x 64 frames per
+        // call, profiles/EXPERIMENTS.md round 5): 16-bit samples - the copy of a call is as short as its kernels, and the device
+        // overlaps three stages of consecutive calls - 9.6 / 11.5 / 12.4 M frames/s at two / three / four calls in flight (92 % of
+        // the bus with four); float samples are bound by the bus at any depth (6.6 / 6.5 / 6.5 M = 95 % of it), so they keep two
+        // calls and 64 MB less page-locked memory.
+        constexpr int kDepth = sizeof(TSample) == 2 ? 4 : 2;
+        std::unique_ptr<TPinned> inBuf[kDepth], outBuf[kDepth];
+        TSample* in[kDepth];
+        uint8_t* out[kDepth];
+        for (int q = 0; q < kDepth; ++q) {
+            inBuf[q].reset(new TPinned(Ctx, inFloats * sizeof(TSample)));
+            outBuf[q].reset(new TPinned(Ctx, outBytes));
+            in[q] = (TSample*)inBuf[q]->P;
+            out[q] = (uint8_t*)outBuf[q]->P;
+        }
+        int32_t nf[kDepth] = {};
         long long total = 0;
         int call = 0, drained = 0;   // calls queued / calls whose frames were handed over
         auto drain_next = [&] {

@@ -349,17 +349,22 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
     return out
 
 
-def host_pipeline_workload(S, F, steps=400, warmup=24, s16=False):
+HOST_PIPELINE_DEPTH = {False: 2, True: 4}   # float32 / 16-bit samples: calls in flight (mirrors TAtrac3EncoderBatch::EncodePipelined)
+
+
+def host_pipeline_workload(S, F, steps=400, warmup=24, s16=False, depth=0):
     """configs[1] fed from HOST memory the way the reference's caller hands it over (pcmengin.h:152-192), PCIe included: two
     page-locked PCM buffers and two frame buffers alternate, the calls are asynchronous, so the H2D copy of call k + 1, the
     kernels of call k and the D2H copy of call k - 1 overlap (at3hip_host_alloc / at3hip_wait_*). Never part of `value`."""
-    out = {"workload": f"configs[1] from host memory: {S} x {F} frames per call, pinned buffers, three calls in flight, H2D + kernels + D2H overlapped"
+    out = {"workload": f"configs[1] from host memory: {S} x {F} frames per call, pinned buffers, {depth or HOST_PIPELINE_DEPTH[bool(s16)]} calls in flight, H2D + kernels + D2H overlapped"
                        + (", 16-bit samples (at3hip_encode_s16: converted on the device)" if s16 else ", float32 samples")}
     try:
         import torch
         import atracdenc_amd
         enc = atracdenc_amd.At3Hip(n_streams=S, max_blocks=F + 1, bitrate=LP2, device_id=0)
-        D = 3   # calls in flight (at3hip_wait_* reach three calls back): buffers alternate D ways
+        # calls in flight (at3hip_wait_* reach three calls back; buffers alternate D ways): what TAtrac3EncoderBatch::EncodePipelined uses
+        # for the sample format (kDepthOf in at3hip_host.hpp) unless the caller asks for another depth
+        D = depth or HOST_PIPELINE_DEPTH[bool(s16)]
         ins = [enc.host_alloc((S, F, 1024, 2), np.int16 if s16 else np.float32) for _ in range(D)]
         outs = [enc.host_alloc((S, F, enc.frame_size), np.uint8) for _ in range(D)]
         rng = np.random.RandomState(5)
@@ -621,34 +626,40 @@ def main():
                                 "algorithmic_bytes_per_frame": pj["algorithmic_bytes_per_frame"],
                                 "source": "profiles/pipeline_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE summed over the pipeline's "
                                           "kernels, separate passes, this workload - not measured in this run"}
-                # Issue floors. SQ_INSTS_VALU per kernel (profiles/pipeline_traffic.json) priced with the measured issue costs
-                # (tools/ubench, profiles/r04_ubench_instruction_rates.txt: resident wavefronts counted, shader clock 2.1 - 2.4 GHz under
-                # load): ~1.3 ns (2.5 - 3.2 cycles) per plain wave-instruction and SIMD, ~2.1 ns (4.3 - 4.6 cycles) per packed fp32 one; the packed share of a kernel comes from the compiler's assembly (profiles/valu_mix.json)
-                mix = {}
+                # Issue floors. SQ_INSTS_VALU per kernel (profiles/pipeline_traffic.json) priced with the issue costs tools/ubench/valu_issue
+                # measured with four and eight wavefronts PROVABLY on every SIMD (profiles/r05_ubench_valu_issue.txt): a 32-bit encoded
+                # vector instruction (VOP1 / VOP2 / VOPC) holds a SIMD for 2.15 cycles, a 64-bit encoded one (VOP3, the packed fp32 forms,
+                # DPP / SDWA) for 4.2; a kernel's share of the second class comes from the compiler's assembly (profiles/valu_mix.json)
+                mix, cyc32, cyc64, ghz = {}, 2.15, 4.2, 2.4
                 mp = os.path.join(ROOT, "profiles", "valu_mix.json")
                 if os.path.exists(mp):
-                    mix = {k: v.get("packed_share", 0.0) for k, v in json.load(open(mp)).get("kernels", {}).items()}
+                    mj = json.load(open(mp))
+                    mix = {k: v.get("wide_share", v.get("packed_share", 0.0)) for k, v in mj.get("kernels", {}).items()}
+                    cj = mj.get("cycles_per_wave_instruction_per_simd", {})
+                    cyc32, cyc64, ghz = cj.get("encoded_32_bit", cyc32), cj.get("encoded_64_bit", cyc64), cj.get("clock_ghz", ghz)
                 n_simd = 1024
 
                 def floor_ms(counts):
-                    return sum(n * (mix.get(k, 0.0) * 2.1e-6 + (1.0 - mix.get(k, 0.0)) * 1.3e-6) for k, n in counts.items()) / n_simd
+                    return sum(n * (mix.get(k, 0.0) * cyc64 + (1.0 - mix.get(k, 0.0)) * cyc32) / ghz * 1e-6 for k, n in counts.items()) / n_simd
 
                 k1_counts = pj.get("valu_wave_insts_per_launch", {})
                 if k1_counts:
                     valu_floor_ms = floor_ms(k1_counts)
                     valu_note = (f"{int(sum(k1_counts.values()))} vector wave-instructions per launch pair (SQ_INSTS_VALU, profiles/pipeline_traffic.json) / "
-                                 f"{n_simd} SIMDs, a plain fp32 instruction priced at its measured 1.3 ns of issue (2.5 - 3.2 cycles at the observed 2.1 - 2.4 GHz) and a packed one at 2.1 ns "
-                                 "(packed share per kernel from the compiler's assembly, profiles/valu_mix.json; the arithmetic contract "
-                                 "forbids FMA, so the multiply-add pairs of the FIR are two packed instructions each)")
+                                 f"{n_simd} SIMDs, a 32-bit encoded instruction priced at {cyc32} cycles of its SIMD and a 64-bit encoded one (VOP3, packed fp32, DPP) at {cyc64} "
+                                 f"(tools/ubench/valu_issue with 4 and 8 wavefronts per SIMD by construction, profiles/r05_ubench_valu_issue.txt), at {ghz} GHz; the share of 64-bit "
+                                 "encodings per kernel from the compiler's assembly (profiles/valu_mix.json); the arithmetic contract forbids FMA, so the "
+                                 "multiply-add pairs of the FIR are two packed instructions each")
                 all_counts = pj.get("valu_wave_insts_per_launch_all", {})
                 if all_counts:
                     step_floor = floor_ms(all_counts)
                     pipe_valu = {"floor_ms_per_step": round(step_floor, 4), "frac": round(step_floor / med_ms, 4),
                                  "vector_wave_instructions_per_step": int(sum(all_counts.values())),
                                  "note": "the whole step against the issue floor of its own vector instruction streams (every kernel of the pipeline, "
-                                         "same pricing as roofline.valu_floor_ms; f64 instructions priced as plain ones, so the true floor is "
-                                         "slightly higher): frac = floor / ms_per_step. This, not HBM, is the roofline that bounds the encoder "
-                                         "under the FMA-free arithmetic contract"}
+                                         "same pricing as roofline.valu_floor_ms; f64 instructions priced like the others, so the true floor is "
+                                         "slightly higher): frac = floor / ms_per_step = the share of the step during which the vector ALUs would be busy "
+                                         "if nothing else ever stalled a wavefront. A wavefront also issues at most one instruction of ANY kind every ~6.4 "
+                                         "cycles (same table), and the scalar unit of a CU one instruction per cycle for its four SIMDs"}
             except Exception:
                 pipe_traffic = None
         # the same launches as rocprofv3 saw them alone (kernel begin to kernel end, without the event and launch gaps of the

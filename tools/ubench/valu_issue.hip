@@ -191,12 +191,21 @@ void run(const char* name, int instr_per_trip, int valu_per_trip, int wgs_per_cu
     std::vector<WaveRec> r((size_t)grid * 16);
     hipMemcpy(r.data(), d_rec, r.size() * sizeof(WaveRec), hipMemcpyDeviceToHost);
     std::map<unsigned long long, int> per_simd;
+    std::map<unsigned long long, std::pair<unsigned long long, unsigned long long>> simd_span;   // first begin, last end of the SIMD's wavefronts
+    std::vector<unsigned long long> starts;
     double sum_cyc = 0, sum_rt = 0;
     unsigned long long first = r[0].r0, last = r[0].r1;
     for (const WaveRec& w : r) {
         // HW_ID (gfx9): WAVE_ID [3:0], SIMD_ID [5:4], PIPE_ID [7:6], CU_ID [11:8], SH_ID [12], SE_ID [15:13]; XCC_ID [3:0] of its own register
         const unsigned long long key = ((unsigned long long)(w.xcc_id & 15u) << 16) | (w.hw_id & 0xff30u);
         per_simd[key]++;
+        auto it = simd_span.find(key);
+        if (it == simd_span.end()) simd_span[key] = std::make_pair(w.r0, w.r1);
+        else {
+            it->second.first = std::min(it->second.first, w.r0);
+            it->second.second = std::max(it->second.second, w.r1);
+        }
+        starts.push_back(w.r0);
         sum_cyc += (double)w.cycles;
         sum_rt += (double)(w.r1 - w.r0);
         first = std::min(first, w.r0);
@@ -208,16 +217,24 @@ void run(const char* name, int instr_per_trip, int valu_per_trip, int wgs_per_cu
         max_w = std::max(max_w, kv.second);
     }
     const double simds = (double)per_simd.size();
+    // per SIMD: the span from its first wavefront's loop begin to its last one's end (100 MHz ticks); a SIMD's throughput is its
+    // wavefronts' instructions over THAT span - the device-wide span also holds the skew between the workgroups' starts
+    double sum_simd_span = 0;
+    for (auto& kv : simd_span) sum_simd_span += (double)(kv.second.second - kv.second.first);
+    std::sort(starts.begin(), starts.end());
+    const double skew_p50 = (double)(starts[starts.size() / 2] - starts[0]) / 100.0, skew_max = (double)(starts.back() - starts[0]) / 100.0;
     const double by_id = (double)r.size() / simds;
     const double by_time = sum_rt / ((double)(last - first) * simds);
     const double cyc_wave = sum_cyc / (double)r.size();
     const double mhz = sum_cyc / sum_rt * 100.0;
     const double n = (double)iters * instr_per_trip, nv = (double)iters * valu_per_trip;
     // cycles per instruction as the SIMD sees them: a wavefront's cycles per instruction / the wavefronts sharing the SIMD in time
-    printf("%-34s asked %d  SIMDs %4.0f  resident by id %4.2f (min %d max %d) by time %4.2f  sclk %4.0f MHz  cyc/instr: wave %6.2f  SIMD %5.2f"
-           "  cyc/VALU/SIMD %5.2f  kernel %7.1f us\n",
-           name, 4 * wgs_per_cu, simds, by_id, min_w, max_w, by_time, mhz, cyc_wave / n, cyc_wave / n / by_time, valu_per_trip ? cyc_wave / nv / by_time : 0.0,
-           ms * 1e3);
+    // cycles per instruction of a SIMD over its OWN busy span: (span in ticks x sclk / 100 MHz) / (its wavefronts x instructions each)
+    const double simd_cyc = (sum_simd_span / simds) * (mhz / 100.0) / (by_id * n);
+    printf("%-34s asked %d  SIMDs %4.0f  resident by id %4.2f (min %d max %d) by time %4.2f  sclk %4.0f MHz  cyc/instr: wave %6.2f  SIMD(device span) %5.2f"
+           "  SIMD(own span) %5.2f  cyc/VALU/SIMD(own span) %5.2f  start skew p50 %6.1f max %6.1f us  kernel %8.1f us\n",
+           name, 4 * wgs_per_cu, simds, by_id, min_w, max_w, by_time, mhz, cyc_wave / n, cyc_wave / n / by_time, simd_cyc,
+           valu_per_trip ? simd_cyc * n / nv : 0.0, skew_p50, skew_max, ms * 1e3);
 }
 
 int main()
@@ -246,6 +263,14 @@ int main()
         run<K_BRANCH_TAKEN>("v_add_u32 + s_branch (taken)", 128, 64, w, d_out, d_rec);
         run<K_IF_SKELETON>("if-skeleton: cmp saveexec cbr add or", 160, 64, w, d_out, d_rec);
         run<K_WAITCNT>("v_add_u32 + s_waitcnt (idle)", 128, 64, w, d_out, d_rec);
+    }
+    // the same with loops sixteen times as long: a fixed start-up skew between workgroups no longer weighs on the device-wide span
+    for (int w : {1, 2}) {
+        run<K_MUL>("LONG v_mul_f32", 128, 128, w, d_out, d_rec, 16384);
+        run<K_FMA>("LONG v_fma_f32 (not used)", 128, 128, w, d_out, d_rec, 16384);
+        run<K_PK_FMA>("LONG v_pk_fma_f32 (not used)", 128, 128, w, d_out, d_rec, 16384);
+        run<K_MUL_ADD_DEP>("LONG v_mul_f32 -> v_add_f32 pair", 128, 128, w, d_out, d_rec, 16384);
+        run<K_SALU_ONLY>("LONG s_add / s_xor only", 128, 0, w, d_out, d_rec, 16384);
     }
     return 0;
 }
