@@ -316,36 +316,43 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             const int start = kEaLine0 + 32 * (bfu - 19), ustart = start - kEaLine0, line = start + l;   // == bfu_start(bfu) for BFUs 19..25
             const uint32_t want = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)my_want);
             const float mul = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * bfu, (int)__float_as_uint(my_mul)));   // == max_quant(wordlen of the unit)
-            // (the line's value and mantissa are requested with its code, not behind the ballot: one LDS round trip less per pass)
+            // The pass is written WITHOUT lane conditions around its stores (a condition costs the wavefront a compare, two exec-mask
+            // instructions and a branch - ~50 cycles, tools/ubench/valu_issue - and this pass had five): every lane of a half stores ONE
+            // key and ONE record. Candidates store their |delta| at their slot and their record at their rank; the other lanes store +inf
+            // behind the candidates (the key list comes out padded to 32: no second store) and a zero record behind the ranks. A half
+            // without a unit (the odd unit out) walks unit A's lines again and stores into spare bytes behind the key lists.
             const float val_l = L.val[line];
             const int m0_l = (int)L.bm[line - kTermLine0];
-            const bool flag = has && ((L.code[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;
+            const uint32_t cbyte = L.code[(line - kEaLine0) >> 2];
+            const bool flag = has & (((cbyte >> (2 * (line & 3))) & 3u) == want);
             const unsigned long long mask = __ballot(flag);
             const uint32_t hm = half ? (uint32_t)(mask >> 32) : (uint32_t)mask;
-            const int cnt = __popc(hm);
+            const int cnt = __popc(hm), below = __popc(hm & ((1u << l) - 1u));
+            const int pos = flag ? below : cnt + (l - below);   // a permutation of 0..31 per half
             float* uk = L.uk + 64 * half;
-            float key = 0.0f;
-            uint32_t recv = 0u;
-            if (flag) {
-                const int slot = __popc(hm & ((1u << l) - 1u));
-                const float t = val_l * mul;
-                key = fabsf(t - (truncf(t) + 0.5f));
-                uk[slot] = key;
-                const int m0 = m0_l;
-                const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
-                recv = (uint32_t)l | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12);
-            }
-            if (l < 8 && cnt + l < ((cnt + 7) & ~7)) uk[cnt + l] = __builtin_huge_valf();   // pad the list to eight
+            const float t = val_l * mul;
+            const float key = fabsf(t - (truncf(t) + 0.5f));
+            uk[pos] = flag ? key : __builtin_huge_valf();
+            const int m0 = m0_l;
+            const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
+            const uint32_t recv = flag ? ((uint32_t)l | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12)) : 0u;
             wave_sync();
+            // rank = keys of the own list below the own key, eight per step (most units list eight candidates or fewer: 5.5 on average
+            // on white noise); the trip count is the longer list's (uniform), the shorter one reads its padding
+            const int cnt_lo = __popc((uint32_t)mask), cnt_hi = __popc((uint32_t)(mask >> 32));
+            const int cmax = cnt_lo > cnt_hi ? cnt_lo : cnt_hi;
             int rr = 0;
-            if (flag) {
-                // eight keys per step: most units list eight candidates or fewer (5.5 on average on white noise)
+            {
                 const float4* t4 = reinterpret_cast<const float4*>(uk);
-                for (int q = 0; q < cnt; q += 8) rr = count_below8(t4[(q >> 2)], t4[(q >> 2) + 1], key, rr);
-                L.rec[ustart + rr] = (uint16_t)recv;
+                for (int q = 0; q < cmax; q += 8) rr = count_below8(t4[(q >> 2)], t4[(q >> 2) + 1], key, rr);
             }
+            uint16_t* recw = has ? L.rec + ustart : reinterpret_cast<uint16_t*>(L.uk + 128);
+            const int wpos = flag ? rr : pos;
+            recw[wpos] = (uint16_t)recv;
             wave_sync();
-            const unsigned long long lost = __ballot(flag && L.rec[ustart + rr] != (uint16_t)recv);
+            // equal keys collide on a rank; the loser notices on read-back and the unit goes to the exact path (a lane that is no
+            // candidate reads its own zero back)
+            const unsigned long long lost = __ballot(recw[wpos] != (uint16_t)recv);
             if ((uint32_t)lost) tie_units |= 1u << ubA;
             if ((uint32_t)(lost >> 32)) tie_units |= 1u << (ubB >= 0 ? ubB : ubA);
             if (lane == 19 + ubA) my_nc = __popc((uint32_t)mask);
@@ -354,55 +361,60 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
         }
         for (uint32_t rem = (ea_need >> 19) & ~0x7fu; rem; rem &= rem - 1u) {
             const int ub = __builtin_ctz(rem), bfu = 19 + ub;
-            const int start = bfu_start(bfu), n = bfu_start(bfu + 1) - start, ustart = start - kEaLine0;
+            const bool two = ub >= 11;   // (uniform) BFUs 30 and 31 are 128 lines long: a second round of 64 lines
+            const int start = two ? 768 + 128 * (ub - 11) : 512 + 64 * (ub - 7), ustart = start - kEaLine0;   // == bfu_start(bfu) for BFUs 26..31
             const uint32_t want = (uint32_t)__builtin_amdgcn_readlane((int)my_want, bfu);
             const float mul = readlane_f(my_mul, bfu);
+            // as above: every lane stores one key and one record per round, without lane conditions - candidates at their slots and
+            // ranks, the others +inf / zero behind them (the list comes out padded to the unit's length)
             bool flag[2];
             float key[2];
             uint32_t recv[2];
-            int cnt_u = 0;
+            int below[2];
+            unsigned long long mask[2] = {0ull, 0ull};
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 flag[r] = false;
                 key[r] = 0.0f;
                 recv[r] = 0u;
-                if (r == 1 && n <= 64) continue;   // (uniform) only the two 128-line units have a second round
+                below[r] = 0;
+                if (r == 1 && !two) continue;
                 const int j = 64 * r + lane, line = start + j;
                 const float val_l = L.val[line];
-                const int m0_l = (int)L.bm[line - kTermLine0];
-                flag[r] = j < n && ((L.code[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;
-                const unsigned long long mask = __ballot(flag[r]);
-                if (flag[r]) {
-                    const int slot = cnt_u + __popcll(mask & ((1ull << lane) - 1ull));
-                    const float t = val_l * mul;
-                    key[r] = fabsf(t - (truncf(t) + 0.5f));   // sort key |delta|
-                    L.uk[slot] = key[r];
-                    const int m0 = m0_l;
-                    const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
-                    recv[r] = (uint32_t)j | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12);
-                }
-                cnt_u += __popcll(mask);
+                const int m0 = (int)L.bm[line - kTermLine0];
+                flag[r] = ((L.code[(line - kEaLine0) >> 2] >> (2 * (line & 3))) & 3u) == want;   // (64 r + lane < n in the rounds that run)
+                mask[r] = __ballot(flag[r]);
+                below[r] = __popcll(mask[r] & ((1ull << lane) - 1ull));
+                const float t = val_l * mul;
+                key[r] = fabsf(t - (truncf(t) + 0.5f));   // sort key |delta|
+                const bool neg = m0 < 0 || (m0 == 0 && !(t > 0));
+                recv[r] = flag[r] ? ((uint32_t)j | ((uint32_t)(m0 < 0 ? -m0 : m0) << 7) | ((uint32_t)neg << 12)) : 0u;
             }
-            if (lane < 16 && cnt_u + lane < ((cnt_u + 15) & ~15)) L.uk[cnt_u + lane] = __builtin_huge_valf();   // pad the list to sixteen
+            const int c0 = __popcll(mask[0]), cnt_u = c0 + __popcll(mask[1]);
+            // positions: round 0's candidates, round 1's, then the lanes that list nothing (round 0's, round 1's) - a permutation of 0..n-1
+            int pos[2];
+            pos[0] = flag[0] ? below[0] : cnt_u + (lane - below[0]);
+            pos[1] = flag[1] ? c0 + below[1] : cnt_u + (64 - c0) + (lane - below[1]);
+            L.uk[pos[0]] = flag[0] ? key[0] : __builtin_huge_valf();
+            if (two) L.uk[pos[1]] = flag[1] ? key[1] : __builtin_huge_valf();
             wave_sync();
-            int rank[2] = {0, 0};
+            int wpos[2] = {pos[0], pos[1]};
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                if (r == 1 && n <= 64) continue;
-                if (flag[r]) {
-                    const float4* t4 = reinterpret_cast<const float4*>(L.uk);
-                    int rr = 0;
-                    for (int q = 0; q < cnt_u; q += 16) {
-                        rr = count_below8(t4[(q >> 2)], t4[(q >> 2) + 1], key[r], rr);
-                        rr = count_below8(t4[(q >> 2) + 2], t4[(q >> 2) + 3], key[r], rr);
-                    }
-                    rank[r] = rr;
-                    L.rec[ustart + rr] = (uint16_t)recv[r];
+                if (r == 1 && !two) continue;
+                const float4* t4 = reinterpret_cast<const float4*>(L.uk);
+                int rr = 0;
+                for (int q = 0; q < cnt_u; q += 16) {
+                    rr = count_below8(t4[(q >> 2)], t4[(q >> 2) + 1], key[r], rr);
+                    rr = count_below8(t4[(q >> 2) + 2], t4[(q >> 2) + 3], key[r], rr);
                 }
+                wpos[r] = flag[r] ? rr : pos[r];
+                L.rec[ustart + wpos[r]] = (uint16_t)recv[r];
             }
             wave_sync();
             // equal keys collide on a rank; the loser notices on read-back and the unit goes to the exact path
-            const bool lost = (flag[0] && L.rec[ustart + rank[0]] != (uint16_t)recv[0]) || (flag[1] && L.rec[ustart + rank[1]] != (uint16_t)recv[1]);
+            bool lost = L.rec[ustart + wpos[0]] != (uint16_t)recv[0];
+            if (two) lost = lost || L.rec[ustart + wpos[1]] != (uint16_t)recv[1];
             if (__ballot(lost) != 0ull) tie_units |= 1u << ub;
             if (lane == bfu) my_nc = cnt_u;
             wave_sync();   // the key list is reused by the next unit
@@ -706,16 +718,14 @@ __device__ __forceinline__ int tonal_emit_parallel(const PsyRec* rec, const uint
 // CalcBitsAllocation for one BFU (atrac3_bitstream.cpp:272-336) followed by ConsiderEnergyErr's closure `gmap`
 __device__ __forceinline__ int alloc_bits(float A, bool gate, int tcount, uint32_t gmap, float lam)
 {
-    int bits = 0;
-    if (!gate) {
-        const int tmp = (int)(A - lam);
-        if (tmp > 7) bits = 7;
-        else if (tmp < 0) bits = 0;
-        else if (tmp == 0) bits = 1;
-        else bits = tmp;
-    }
+    // (selects, no lane conditions: the rate loop forms an allocation per trip, and a condition around five instructions costs
+    // the wavefront more than the five)
+    const int tmp = (int)(A - lam);
+    int bits = tmp > 7 ? 7 : tmp < 1 ? 1 : tmp;   // 7 above seven, 1 for zero, tmp between
+    bits = (gate || tmp < 0) ? 0 : bits;            // nothing below the threshold in quiet, nothing for a negative difference
     // one decrement per tonal block in this BFU while the wordlen is above 2 (:325-333)
-    if (bits > 2 && tcount) bits = (bits - tcount > 2) ? bits - tcount : 2;
+    const int dec = bits - tcount > 2 ? bits - tcount : 2;
+    bits = (bits > 2 && tcount) ? dec : bits;
     return (int)((gmap >> (3 * bits)) & 7u);
 }
 
@@ -1201,8 +1211,11 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     } else {
                         const int b = alloc_bits(readlane_f(A, t), __builtin_amdgcn_readlane((int)gate, t) != 0, 0,
                                                  (uint32_t)__builtin_amdgcn_readlane((int)gmap, t), m_lam);
+                        // (the BFU's line count from the lane that owns it: bfu_start() of a wavefront-uniform index is a chain of scalar
+                        // compares and branches, some forty instructions per dropped BFU)
+                        const int n_t = __builtin_amdgcn_readlane(n_i, t);
                         if (lane < memo_n && b) {
-                            m_acc -= clc_bits(b, bfu_start(t + 1) - bfu_start(t)) | ((uint32_t)s_cost[(b - 1) * 32 + t] << 13);
+                            m_acc -= clc_bits(b, n_t) | ((uint32_t)s_cost[(b - 1) * 32 + t] << 13);
                             m_nz -= 1u;
                         }
                     }
