@@ -213,9 +213,12 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float t = v[k] * mul;
-                const int m = __float2int_rn(t);
+                // (the square of the mantissa as a product of floats: |m| <= 31, so m and m * m are exact in fp32 and (float)(m * m) is
+                // the same number - an integer multiply is a slow 64-bit encoded instruction here, a float one is not)
+                const float r = rintf(t);
+                const int m = (int)r;
                 pk |= (uint32_t)(uint8_t)m << (8 * k);
-                tm[k] = (float)(m * m) * inv2;
+                tm[k] = (r * r) * inv2;
                 // the pass may re-round a line only when it is close to a rounding boundary (|delta| < 0.25) AND lies on the
                 // side the pass moves: rounded towards zero and below the top code (pass taken when e2 < e1) or rounded
                 // away from zero (e2 > e1), atrac_scale.cpp:66-126; which pass runs is known after the energy sums
@@ -470,11 +473,13 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             float dist = fabsf(e2 - e1);
             const uint16_t* rp = L.rec + (my_start - kEaLine0);
             int8_t* mant = L.bm + (my_start - kTermLine0);
-            unsigned long long ch_lo = 0ull, ch_hi = 0ull;   // the lines re-rounded below (bit = line in the unit)
+            // what the emission needs to form this unit's mantissas again: plain rounding plus the lines moved by one below - a bit per
+            // line in the row of this wordlen (a unit is quantised once per wordlen and the rows were cleared before the rate loop, so
+            // OR-ing a bit in is storing it: untouched units stay zero)
+            uint32_t* cw = L.chg + (bits - 1) * kChgWords + ((my_start - kEaLine0) >> 5);
             uint2 r4 = *reinterpret_cast<const uint2*>(rp);
             for (int c0 = 0; c0 < my_nc; c0 += 4) {
-                uint2 n4 = r4;
-                if (c0 + 4 < my_nc) n4 = *reinterpret_cast<const uint2*>(rp + c0 + 4);
+                const uint2 n4 = *reinterpret_cast<const uint2*>(rp + (c0 + 4 < my_nc ? c0 + 4 : c0));   // (the next four, requested now)
                 float d0[4], d1[4];
                 int idx[4], mnew[4];
 #pragma unroll
@@ -484,39 +489,28 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                     const int a1 = grow ? a0 + 1 : (a0 > 0 ? a0 - 1 : 0);
                     idx[k] = (int)(rc & 127u);
                     mnew[k] = ((rc >> 12) & 1u) ? -a1 : a1;
-                    d0[k] = (float)(a0 * a0) * my_inv2;
-                    d1[k] = (float)(a1 * a1) * my_inv2;
+                    const float fa0 = (float)a0, fa1 = (float)a1;   // (exact, as their squares are: values up to 32)
+                    d0[k] = (fa0 * fa0) * my_inv2;
+                    d1[k] = (fa1 * fa1) * my_inv2;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (c0 + k < my_nc) {
-                        float ex = e2;
-                        ex -= d0[k];
-                        ex += d1[k];
-                        const float nd = fabsf(ex - e1);
-                        if (nd < dist) {
-                            mant[idx[k]] = (int8_t)mnew[k];
-                            if (idx[k] < 64) ch_lo |= 1ull << idx[k];
-                            else ch_hi |= 1ull << (idx[k] - 64);
-                            e2 = ex;
-                            dist = nd;
-                        }
+                    // (one lane condition per candidate, around the two stores only: the chain itself runs on selects)
+                    float ex = e2;
+                    ex -= d0[k];
+                    ex += d1[k];
+                    const float nd = fabsf(ex - e1);
+                    const bool take = (c0 + k < my_nc) & (nd < dist);
+                    if (take) {
+                        mant[idx[k]] = (int8_t)mnew[k];
+                        atomicOr(cw + (idx[k] >> 5), 1u << (idx[k] & 31));
                     }
+                    e2 = take ? ex : e2;
+                    dist = take ? nd : dist;
                 }
                 r4 = n4;
             }
             my_e2 = e2;
-            // what the emission needs to form this unit's mantissas again: plain rounding plus these lines moved by one (a
-            // unit is quantised once per wordlen and its rows were cleared before the rate loop: untouched units stay zero)
-            uint32_t* cw = L.chg + (bits - 1) * kChgWords + ((my_start - kEaLine0) >> 5);
-            if (ch_lo | ch_hi) {
-                cw[0] = (uint32_t)ch_lo;
-                if (my_n > 32) cw[1] = (uint32_t)(ch_lo >> 32);
-                if (my_n > 64) {
-                    cw[2] = (uint32_t)ch_hi;
-                    cw[3] = (uint32_t)(ch_hi >> 32);
-                }
-            }
         }
     }
     wave_sync();
@@ -612,11 +606,15 @@ __device__ __forceinline__ void small_units(AllocLds& L, const LaneTab& tab, int
             const float4 va = *reinterpret_cast<const float4*>(L.val + line0), vb4 = *reinterpret_cast<const float4*>(L.val + line0 + 4);
             const float v[8] = {va.x, va.y, va.z, va.w, vb4.x, vb4.y, vb4.z, vb4.w};
             int m[8];
+            float r[8];   // (the rounded products as floats: their squares are exact in fp32, see compute_units)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) m[k] = __float2int_rn(v[k] * mul);
+            for (int k = 0; k < 8; ++k) {
+                r[k] = rintf(v[k] * mul);
+                m[k] = (int)r[k];
+            }
             float e2 = own ? e2A : e2B;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) e2 += (float)(m[k] * m[k]) * inv2;
+            for (int k = 0; k < 8; ++k) e2 += (r[k] * r[k]) * inv2;
             const uint32_t vb = vlc_bits8(wl, row, m);
             if (own) {
                 e2A = e2;
@@ -1115,13 +1113,15 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
                 }
             }
-            const uint32_t clc_i = (tab_u(tab.misc, bits) & 7u) * (uint32_t)n_i;   // == clc_bits(bits, n_i)
-            const uint32_t mine = (lane < num_bfu && bits) ? (clc_i | ((uint32_t)s_cost[(bits - 1) * 32 + i] << 13)) : 0u;
+            const uint32_t clc_i = __umul24(tab_u(tab.misc, bits) & 7u, (uint32_t)n_i);   // == clc_bits(bits, n_i)
+            // (bits is zero from num_bfu on; the cost is read at a clamped index and dropped rather than read under a lane condition)
+            const uint32_t vlc_i = s_cost[(bits ? bits - 1 : 0) * 32 + i];
+            const uint32_t mine = clc_i | ((bits ? vlc_i : 0u) << 13);
             const uint32_t rsum = row_allreduce_add(mine);
             acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
             // the count of non-zero BFUs comes from a ballot: summed as a third field it would need six bits at
             // 32 of 32 (and silently wrapped to zero when every BFU of the frame was coded)
-            nz = (uint32_t)__popcll(__ballot(lane < num_bfu && bits != 0));
+            nz = (uint32_t)__popcll(__ballot(bits != 0));
             if (n_tonal > 0 && tonal_serial) {
                 if (lane < 32) s_alloc[lane] = (uint8_t)bits;
                 __syncthreads();

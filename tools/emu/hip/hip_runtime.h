@@ -58,6 +58,7 @@ void emu_syncthreads();
 
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned int __umul24(unsigned int a, unsigned int b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int __float2int_rn(float f) { return (int)lrintf(f); }
 static inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 static inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
