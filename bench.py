@@ -551,6 +551,10 @@ def main():
     elapsed = timed_region(jobs, args.steps, dist)
     elapsed = at3dist.max_over_ranks(elapsed, dist, device="cpu")
     j0 = jobs[0]
+    try:
+        sclk_contract = j0.enc.sclk_mhz()   # the shader clock under the rate loop of the contract region's last step
+    except Exception:   # noqa: BLE001 - diagnostic only
+        sclk_contract = None
     # median of >= 10 runs. Further regions bracketed the same way, each long enough (>= --region-ms) that a
     # launch hiccup or a clock ramp does not decide the figure; the steps they run are the same steps.
     region_ms = [elapsed / args.steps * 1e3]
@@ -744,6 +748,11 @@ def main():
                        "regions": len(region_ms), "steps_per_region": [args.steps] + [region_steps] * (len(region_ms) - 1),
                        "ms_per_step_median": round(med_ms, 4), "ms_per_step_min": round(min(region_ms), 4), "ms_per_step_max": round(max(region_ms), 4),
                        "ms_per_step_contract_region": round(region_ms[0], 4),
+                       "sclk_mhz_contract_region": None if sclk_contract is None else round(sclk_contract, 1),
+                       "contract_region_note": "region 0 starts --warmup steps (a few milliseconds of work) after an idle device and lasts --steps steps: it is read "
+                                               "while the part is still stepping its clocks up (compare sclk_mhz_contract_region with roofline.sclk_mhz_observed, "
+                                               "taken after the last region) and every launch-ordering hiccup of the first steps weighs 1 / --steps; the later regions "
+                                               "(>= 50 ms each) are what a batch service sees",
                        "value_contract_region": round(n_gpus * S * F / (region_ms[0] * 1e-3), 1)},
             "checksum": checksum,
         }
