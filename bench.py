@@ -168,8 +168,11 @@ class DeviceJob:
         return n
 
     def warmup(self, w):
+        # queued like the timed steps (AT3HIP_ASYNC, one sync at the end): the same launch pattern the timed regions run, so the
+        # clocks and the three-stage overlap are what they will be - a synchronous warm-up left the device idle between its steps
         for _ in range(w):
-            assert self.step(False) == self.F
+            assert self.step(not DeviceJob.sync_steps) == self.F
+        self.enc.sync()
         self.torch.cuda.synchronize(self.dev)
 
     sync_steps = False   # --sync-steps (profiling aid)
@@ -749,10 +752,11 @@ def main():
                        "ms_per_step_median": round(med_ms, 4), "ms_per_step_min": round(min(region_ms), 4), "ms_per_step_max": round(max(region_ms), 4),
                        "ms_per_step_contract_region": round(region_ms[0], 4),
                        "sclk_mhz_contract_region": None if sclk_contract is None else round(sclk_contract, 1),
-                       "contract_region_note": "region 0 starts --warmup steps (a few milliseconds of work) after an idle device and lasts --steps steps: it is read "
-                                               "while the part is still stepping its clocks up (compare sclk_mhz_contract_region with roofline.sclk_mhz_observed, "
-                                               "taken after the last region) and every launch-ordering hiccup of the first steps weighs 1 / --steps; the later regions "
-                                               "(>= 50 ms each) are what a batch service sees",
+                       "contract_region_note": "every timed region starts with an empty pipeline and ends with a drain (barrier + synchronize on both sides): one call's "
+                                               "latency (~0.8 ms, stage_ms_per_step.total_ms) less one step is paid once per region - ~0.5 ms, i.e. 6 % of a 30-step "
+                                               "region and 1 % of a 165-step one; region 0 also starts --warmup steps (a few milliseconds) after an idle device, while "
+                                               "the part is still stepping its clock up (sclk_mhz_contract_region against roofline.sclk_mhz_observed, taken after the "
+                                               "last region: ~4 %). The later regions (>= 50 ms each) are what a batch service sees",
                        "value_contract_region": round(n_gpus * S * F / (region_ms[0] * 1e-3), 1)},
             "checksum": checksum,
         }
