@@ -76,7 +76,11 @@ __device__ __forceinline__ void cell_divisors_packed(uint64_t lo, uint64_t hi, c
 constexpr int kGesRow = 260;   // row stride of the term lists: the ten chain lanes read ten rows at once, in different banks
 __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const Tables* T, int n_frames_total)
 {
-    __shared__ __attribute__((aligned(16))) float s_terms[2][5][kGesRow];
+    // FOUR ordered sums per band, not the reference's five: its prevStoredEnergy (sum of prevOverlap[i]^2, prevOverlap[i] = EncodeWindow[i] x the
+    // previous block's modulated sample) and the previous block's nextModulatedEnergy (sum of (mod x winNext)^2) add the squares of the SAME
+    // products in the same order - one chain serves both (s0 below). With five rows of terms the block was 10 784 bytes: fifteen workgroups
+    // per CU, 3840 slots for the 4096 workgroups of configs[1] - a second round for the last 256; four rows are 8704 bytes: eighteen per CU.
+    __shared__ __attribute__((aligned(16))) float s_terms[2][4][kGesRow];
     __shared__ __attribute__((aligned(16))) Curve s_cv[8][2];
     __shared__ float s_gi[32];
     const int lane = threadIdx.x;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
     const float wn[4] = {wn4.x, wn4.y, wn4.z, wn4.w}, wc[4] = {wr4.w, wr4.z, wr4.y, wr4.x};
     wave_sync();
     const size_t sublen = (size_t)(p.n_blocks + 2) * 256;
-    const int cj = lane / 5, kk = lane % 5;   // chain lanes 0..9: band cj of the pair, sum kk
+    const int cj = lane >> 2, kk = lane & 3;   // chain lanes 0..7: band cj of the pair, sum kk
     uint32_t todo = active;
     while (todo) {   // wave-uniform
         int cpair[2];
@@ -145,25 +149,24 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
                 dc4[0] = hi_half ? dc8[4] : dc8[0]; dc4[1] = hi_half ? dc8[5] : dc8[1]; dc4[2] = hi_half ? dc8[6] : dc8[2]; dc4[3] = hi_half ? dc8[7] : dc8[3];
                 dp4[0] = hi_half ? dp8[4] : dp8[0]; dp4[1] = hi_half ? dp8[5] : dp8[1]; dp4[2] = hi_half ? dp8[6] : dp8[2]; dp4[3] = hi_half ? dp8[7] : dp8[3];
             }
-            float t[5][4];
+            float t[4][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float mc = xc[k] / dc4[k];
                 const float mp = xp[k] / dp4[k];
                 const float pv = wn[k] * mp;                // the overlap this block inherited: EncodeWindow[i] * modulated sample
-                const float cw = xc[k] * wc[k], mw = mc * wc[k], nw = xp[k] * wn[k], mnw = mp * wn[k];
+                const float cw = xc[k] * wc[k], mw = mc * wc[k], nw = xp[k] * wn[k];   // (mod x winNext of the previous block IS pv: multiplication commutes)
                 t[0][k] = pv * pv;
                 t[1][k] = cw * cw;
                 t[2][k] = mw * mw;
                 t[3][k] = nw * nw;
-                t[4][k] = mnw * mnw;
             }
 #pragma unroll
-            for (int r = 0; r < 5; ++r) *reinterpret_cast<float4*>(&s_terms[j][r][4 * lane]) = float4{t[r][0], t[r][1], t[r][2], t[r][3]};
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(&s_terms[j][r][4 * lane]) = float4{t[r][0], t[r][1], t[r][2], t[r][3]};
         }
         wave_sync();
         const int cc = cj == 0 ? cpair[0] : (cj == 1 ? cpair[1] : -1);
-        const bool chain = lane < 10 && cc >= 0;
+        const bool chain = lane < 8 && cc >= 0;
         float acc = 0.0f;
         if (chain) {
             const float4* t4 = reinterpret_cast<const float4*>(s_terms[cj][kk]);
@@ -180,17 +183,16 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
                 }
             }
         }
-        // the five sums of a band sit in lanes 5 cj .. 5 cj + 4; the first of them closes the formula
+        // the four sums of a band sit in lanes 4 cj .. 4 cj + 3; the first of them closes the formula
         const float s1 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 1), (int)__float_as_uint(acc)));
         const float s2 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 2), (int)__float_as_uint(acc)));
         const float s3 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 3), (int)__float_as_uint(acc)));
-        const float s4 = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane + 4), (int)__float_as_uint(acc)));
         if (chain && kk == 0) {
             const Curve& q_cur = s_cv[cc][0];
             const bool h_cur = q_cur.n > 0, h_prev = s_cv[cc][1].n > 0;
             const float s0 = acc;
             // PrevOverlapGainScale: the previous block's NextOverlapScale, 1 when that block had no curve (equal sums)
-            float ps = h_prev ? safe_energy_scale(s3, s4) : 1.0f;
+            float ps = h_prev ? safe_energy_scale(s3, s0) : 1.0f;   // (nextModulatedEnergy of the previous block == s0, see s_terms)
             float frame_scale = 1.0f;
             if (h_cur || ps != 1.0f) {
                 if (!isfinite(ps) || ps <= 0.0f) ps = 1.0f;
