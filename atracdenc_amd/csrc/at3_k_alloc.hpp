@@ -43,6 +43,12 @@ struct PhaseClock {};
 #define AT3_PH_END(pc, k) ((void)0)
 #endif
 
+#ifdef AT3_EMU_STATS
+extern "C" unsigned long long g_alloc_stats[16];
+#define AT3_STAT(k, n) do { if (lane == 0) g_alloc_stats[k] += (n); } while (0)
+#else
+#define AT3_STAT(k, n) ((void)0)
+#endif
 constexpr int kTermLine0 = 96;   // BFUs 0..9 (lines 0..95) are quantised by small_units: no batch ever lists their lines
 constexpr int kChgWords = kEaLines / 32;   // 23: one bit per line from BFU 19 on (every such BFU covers whole words)
 struct AllocLds {
@@ -128,6 +134,30 @@ __device__ __forceinline__ uint32_t vlc_len(const VlcRow& r, int m)
 }
 __device__ __forceinline__ uint32_t vlc_len(int wl, int m) { return vlc_len(vlc_row(wl), m); }
 
+// unit_bounds' rows (described there): nibble x = min(len(x), len(x + 1))
+constexpr unsigned long long lb_row(unsigned long long row, int top, unsigned next)   // nibble x: min(len(x), len(x + 1)), x + 1 <= top
+{
+    unsigned long long r = 0;
+    for (int x = 0; x < 16; ++x) {
+        const unsigned a = (unsigned)((row >> (4 * x)) & 15u);
+        const unsigned b = x == 15 ? next : (unsigned)((row >> (4 * (x + 1))) & 15u);
+        r |= (unsigned long long)((x + 1 <= top && b < a) ? b : a) << (4 * x);
+    }
+    return r;
+}
+constexpr unsigned long long kVlcHi7 = 0x4888888888877777ull;                     // wordlen 7, |m| = 16..31 (vlc_row)
+constexpr unsigned long long kLbHi7 = lb_row(kVlcHi7, 15, 0u);                    // (x = 31 is the top code: no x + 1)
+__device__ __forceinline__ unsigned long long lb_row_of(int wl)
+{
+    switch (wl) {
+        case 2: return lb_row(0x331ull, 1, 0u);
+        case 3: return lb_row(0x4431ull, 3, 0u);
+        case 4: return lb_row(0x55431ull, 4, 0u);
+        case 5: return lb_row(0x46654432ull, 7, 0u);
+        case 6: return lb_row(0x4777766665554443ull, 15, 0u);
+        default: return lb_row(0x7766666666555553ull, 31, (unsigned)(kVlcHi7 & 15ull));   // wl 7, |m| <= 15: x + 1 = 16 is the first code of the upper row
+    }
+}
 // Per-wordlen constants as a table ACROSS the lanes (lane k & 7 holds the entries of wordlen k): the wordlen differs from
 // lane to lane wherever these are needed, where a `switch` is a chain of compares and selects per constant; a cross-lane
 // read (ds_bpermute, no LDS storage, not a vector-ALU instruction) fetches all of them with one address. Every lane must
@@ -142,11 +172,12 @@ __device__ __forceinline__ LaneTab lane_tab(int lane)
 {
     const int k = lane & 7;
     const VlcRow r = vlc_row(k);
+    const unsigned long long lo = (lane & 8) ? lb_row_of(k) : r.lo;   // lanes 8..15: the rows of unit_bounds' lower bound
     LaneTab t;
     t.mq = max_quant(k);
     t.inv = inv_mul2(k);
-    t.lo0 = (uint32_t)r.lo;
-    t.lo1 = (uint32_t)(r.lo >> 32);
+    t.lo0 = (uint32_t)lo;
+    t.lo1 = (uint32_t)(lo >> 32);
     t.bfus = (uint32_t)opaque_lane_value(bfu_of_line(4 * lane) | (bfu_of_line(256 + 4 * lane) << 8) | (bfu_of_line(512 + 4 * lane) << 16) |
                                          (bfu_of_line(768 + 4 * lane) << 24));
     t.misc = (uint32_t)(k == 1 ? 2 : clc_len(k)) | ((uint32_t)huff_off(k) << 8);
@@ -175,6 +206,113 @@ __device__ __forceinline__ uint32_t vlc_bits8(int wl, const VlcRow& row, const i
         for (int k = 0; k < 8; k += 2) vb += vlc_pair_len(m[k], m[k + 1]);
     }
     return vb;
+}
+
+// The VLC bit count of the units of round h (lines 256 h + 4 lane .. + 3 per lane) from every lane's four-line count `vb`: a unit's
+// lines sit in 4, 8, 16 or 32 NEIGHBOURING lanes of one round (16-, 32-, 64-, 128-line BFUs from line 96 on, all aligned to their
+// own size), so its bit count is a sum over a quad, a half row, a row or two rows: DPP adds, no LDS traffic (the first version added
+// every lane's count to a per-BFU LDS counter: up to 32 lanes on one address). The unit's first lane stores it in the cache.
+__device__ __forceinline__ void unit_cost_store(AllocLds& L, const LaneTab& tab, int h, int wl, uint32_t vb, int lane)
+{
+    vb += (uint32_t)AT3_DPP(vb, 0xB1, false);   // quad_perm [1, 0, 3, 2]
+    vb += (uint32_t)AT3_DPP(vb, 0x4E, false);   // quad_perm [2, 3, 0, 1]: every lane of a quad holds the quad's 16 lines
+    bool lead = (lane & 3) == 0;
+    if (h == 0) {   // lines 96..191: 16-line BFUs, lines 192..255: two 32-line BFUs
+        const uint32_t v8 = vb + (uint32_t)AT3_DPP(vb, 0x141, false);   // row_half_mirror
+        if (lane >= 48) {
+            vb = v8;
+            lead = (lane & 7) == 0;
+        }
+    } else {
+        vb += (uint32_t)AT3_DPP(vb, 0x141, false);
+        lead = (lane & 7) == 0;
+        if (h >= 2) {   // 64-line BFUs: a row each
+            vb += (uint32_t)AT3_DPP(vb, 0x140, false);   // row_mirror
+            lead = (lane & 15) == 0;
+        }
+        if (h == 3) {   // 128-line BFUs: two rows each
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)vb, 0) + (uint32_t)__builtin_amdgcn_readlane((int)vb, 16);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)vb, 32) + (uint32_t)__builtin_amdgcn_readlane((int)vb, 48);
+            vb = lane < 32 ? lo : hi;
+            lead = (lane & 31) == 0;
+        }
+    }
+    if (wl && lead) L.cost[(wl - 1) * 32 + (int)((tab.bfus >> (8 * h)) & 0xffu)] = (uint16_t)vb;
+}
+
+// A LOWER BOUND of the VLC bits of the units {(b, wl_b) : bit b of `need`} without the energy-adaptive pass - and below BFU 19,
+// where there is no such pass, the bits themselves. The bisection compares a total with the target (lib/bs_encode/encode.cpp:
+// 57-129): when the comparison is already decided by a bound of the total, the exact bits are never needed, and the pass (two fifths
+// of what a unit costs: candidate lists, ranks, the sequential walk, plus the ordered energy sum it starts from) is only run for the
+// units of the few allocations whose totals come too close to the target to call - in practice the final one's.
+//   * The pass moves a line by ONE code, only a line close to a rounding boundary (|delta| < 0.25) and only in the direction AWAY
+//     from where rounding took it (atrac_scale.cpp:66-126): a line rounded away from zero (|m| > |t|) may end at |m| - 1, a line
+//     rounded towards zero at |m| + 1, whatever else the pass asks of it (which of the two passes runs, the top code, the energy
+//     test): the set allowed for here contains the set it moves.
+//   * A code's length depends on |m| only. With lb(x) = min(len(x), len(x + 1)) a line rounded away from zero costs at least
+//     lb(|m| - 1) if it is such a candidate, any other line at least lb(|m|): ONE look-up per line in the row of lb. The tables grow with |m| except for the
+//     top code of wordlens 5..7, so lb(x) = len(x) but for the code below the top one: the bound is the plain-rounding bits less a
+//     bit or two per line that was rounded up across a length step - within a per cent of the final bits on white noise.
+//     (Pairs at wordlen 1: the pair table grows with either |m|, so the pair of the smaller magnitudes bounds it.)
+// Rounding and lengths in one go, sixteen lines per lane in registers: nothing is stored but the counts; no lane conditions.
+// The rows of lb sit in lanes 8..15 of the lane table's length words (tab_row reads lanes 0..7). Wave-uniform call.
+__device__ __forceinline__ void unit_bounds(AllocLds& L, const LaneTab& tab, uint32_t need, int bits, int lane_, PhaseClock& pc)
+{
+    AT3_PH_END(pc, 4);
+    // (the lane conditions below are formed here, where they are used: hoisted in front of the rate loop they would sit in scalar
+    // registers the loop does not have - it already parks some of its masks in vector lanes)
+    const int lane = opaque_lane_value(lane_);
+    int wl_h[4];
+    float mul_h[4];
+    unsigned long long row_h[4];
+    {
+        int wl_r[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) wl_r[h] = __builtin_amdgcn_ds_bpermute(4 * (int)((tab.bfus >> (8 * h)) & 0xffu), bits);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            mul_h[h] = tab_f(tab.mq, wl_r[h]);
+            // lines below BFU 19 (round 0, lanes 0..7 of round 1) are final as rounded: their lengths come from the table itself
+            const int src = (h == 0 || (h == 1 && lane < 8)) ? wl_r[h] : wl_r[h] + 8;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * src, (int)tab.lo0), b = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * src, (int)tab.lo1);
+            row_h[h] = (unsigned long long)a | ((unsigned long long)b << 32);
+            wl_h[h] = ((need >> ((tab.bfus >> (8 * h)) & 0xffu)) & 1u) ? wl_r[h] : 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int line0 = 256 * h + 4 * lane;
+        const int wl = wl_h[h];
+        const float mul = mul_h[h];
+        const unsigned long long row = row_h[h];
+        const bool ea = h > 1 || (h == 1 && lane >= 8);
+        const unsigned long long hi = ea ? kLbHi7 : kVlcHi7;   // (only wordlen 7 has codes from 16 on)
+        uint32_t vb = 0;
+        const bool any_pairs = __ballot(wl == 1) != 0ull;   // (most rounds have no unit at wordlen 1: its pair look-ups are branched over)
+        if (wl) {   // (one condition per round - a call for a few units skips whole rounds -, none per line)
+            const float4 va = *reinterpret_cast<const float4*>(L.val + line0);
+            const float v[4] = {va.x, va.y, va.z, va.w};
+            int ap[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = v[k] * mul;
+                const float am = fabsf(rintf(t));
+                const int a = (int)am;
+                const float delta = t - (truncf(t) + 0.5f);
+                // (bitwise: `&&` would be compiled into a branch around the second test - a lane condition per line)
+                ap[k] = a - (int)((int)ea & (int)(am > fabsf(t)) & (int)(fabsf(delta) < 0.25f));
+                vb += (uint32_t)((ap[k] < 16 ? row : hi) >> (4 * (ap[k] & 15))) & 15u;
+            }
+            if (any_pairs) {   // (wave-uniform; at wordlen 1 |m| <= 1)
+                const uint32_t vp = vlc_pair_len(ap[0] & 1, ap[1] & 1) + vlc_pair_len(ap[2] & 1, ap[3] & 1);
+                vb = wl == 1 ? vp : vb;
+            }
+        }
+        unit_cost_store(L, tab, h, wl, vb, lane);
+    }
+    wave_sync();
+    AT3_PH_END(pc, 5);
 }
 
 // Quantise the units {(b, wl_b) : bit b of `need`}, wl_b = lane b's `bits` (QuantMantisas + CLC/VLC cost,
@@ -516,9 +654,6 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
     wave_sync();
     AT3_PH_END(pc, 8);
     // ---- (4) VLC cost of the final mantissas; (5) cache entries ----
-    // A unit's lines sit in 4, 8, 16 or 32 NEIGHBOURING lanes of one round (16-, 32-, 64-, 128-line BFUs from line 96 on, all
-    // aligned to their own size), so its bit count is a sum over a quad, a half row, a row or two rows: DPP adds, no
-    // LDS traffic (the first version added every lane's count to a per-BFU LDS counter: up to 32 lanes on one address).
     VlcRow row_h[4];   // (the four rounds' length rows requested together)
 #pragma unroll
     for (int h = 0; h < 4; ++h) row_h[h] = tab_row(tab, wl_h[h]);
@@ -541,30 +676,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
                 vb = vlc_pair_len(m[0], m[1]) + vlc_pair_len(m[2], m[3]);
             }
         }
-        vb += (uint32_t)AT3_DPP(vb, 0xB1, false);   // quad_perm [1, 0, 3, 2]
-        vb += (uint32_t)AT3_DPP(vb, 0x4E, false);   // quad_perm [2, 3, 0, 1]: every lane of a quad holds the quad's 16 lines
-        bool lead = (lane & 3) == 0;
-        if (h == 0) {   // lines 96..191: 16-line BFUs, lines 192..255: two 32-line BFUs
-            const uint32_t v8 = vb + (uint32_t)AT3_DPP(vb, 0x141, false);   // row_half_mirror
-            if (lane >= 48) {
-                vb = v8;
-                lead = (lane & 7) == 0;
-            }
-        } else {
-            vb += (uint32_t)AT3_DPP(vb, 0x141, false);
-            lead = (lane & 7) == 0;
-            if (h >= 2) {   // 64-line BFUs: a row each
-                vb += (uint32_t)AT3_DPP(vb, 0x140, false);   // row_mirror
-                lead = (lane & 15) == 0;
-            }
-            if (h == 3) {   // 128-line BFUs: two rows each
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)vb, 0) + (uint32_t)__builtin_amdgcn_readlane((int)vb, 16);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)vb, 32) + (uint32_t)__builtin_amdgcn_readlane((int)vb, 48);
-                vb = lane < 32 ? lo : hi;
-                lead = (lane & 31) == 0;
-            }
-        }
-        if (wl && lead) L.cost[(wl - 1) * 32 + (int)((tab.bfus >> (8 * h)) & 0xffu)] = (uint16_t)vb;
+        unit_cost_store(L, tab, h, wl, vb, lane);
     }
     if (mine && qerr) qerr[(bits - 1) * 32 + lane] = my_e1 / my_e2;   // BFUs >= 10: nothing but the QUANT tap looks at their energy error
     wave_sync();
@@ -922,7 +1034,8 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 2) return;
 #endif
-    uint32_t valid = lane < 10 ? 0xfeu : 0u;   // lane i: bit wl set = unit (BFU i, wl) is in the cache
+    // lane i: bit wl set = the cache holds the VLC bits of unit (BFU i, wl); bit 8 + wl set = it holds them or a lower bound (unit_bounds)
+    uint32_t valid = lane < 10 ? 0xfefeu : 0u;
     // ---- TConfigure: spread (sequential float sums, every lane computes the same value) ----
     const int i = lane & 31;   // BFU owned by this lane (lanes 32..63 mirror 0..31 but never contribute)
     const int n_i = opaque_lane_value(bfu_start(i + 1) - bfu_start(i));   // (computed once: not re-derived inside the rate loop)
@@ -1049,6 +1162,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     }
     int mode = 1;
     int bits = 0;
+    AT3_STAT(10, 1);
     // Evaluations already made, one per lane: lambda -> the CLC | VLC << 13 sums, the count of coded BFUs and the tonal
     // bits for the CURRENT number of BFUs. The reference repeats the whole bisection with one BFU less whenever the last
     // BFU ended without bits (three times per channel-frame on white noise, eleven on the burst input), and each repeat
@@ -1062,8 +1176,9 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     // that changed - or at the last one when none did. Anything else (a hit outside that order, a full memo) turns the
     // shortcut off for the frame and the repeat is walked as before.
     float m_lam = 0.0f, m_min = 0.0f, m_max = 0.0f, m_last = 0.0f;
+    // m_nz: the count of coded BFUs | kind of the record << 8 (0: the bits, 1 / 2: a bound that decided the comparison, set where the
+    // record is made) | the way the comparison went << 10 (0: below the target, 1: above, 2: on it - the pass ended there);
     uint32_t m_acc = 0u, m_nz = 0u, m_ton = 0u;
-    int m_dir = 0;   // 0: below the target, 1: above, 2: on it (the pass ended there)
     int memo_n = 0;
     unsigned long long path = 0ull;
     bool skip_ok = true;
@@ -1091,34 +1206,23 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             uint32_t acc, nz, tonal_bits = 5;
             int rec_lane = -1;   // the record of this evaluation
             const unsigned long long hit = __ballot(lane < memo_n && m_lam == lam);
-            if (hit) {
-                const int k = __builtin_ctzll(hit);
-                acc = (uint32_t)__builtin_amdgcn_readlane((int)m_acc, k);
-                nz = (uint32_t)__builtin_amdgcn_readlane((int)m_nz, k);
-                tonal_bits = (uint32_t)__builtin_amdgcn_readlane((int)m_ton, k);
-                rec_lane = k;
+            const int hit_k = hit ? __builtin_ctzll(hit) : 0;
+            // (a record whose comparison was decided by a bound of its total holds that bound: good for the comparison it
+            // decided - and for the same one after BFUs were dropped, as long as it still decides it - but not for an
+            // evaluation that ends the bisection, which needs the bits themselves: those are evaluated again, in place)
+            const uint32_t hit_nz = hit ? (uint32_t)__builtin_amdgcn_readlane((int)m_nz, hit_k) : 0u;
+            AT3_STAT(0, 1);
+            if (hit && (hit_nz >> 8) == 0u) {
+                acc = (uint32_t)__builtin_amdgcn_readlane((int)m_acc, hit_k);
+                nz = hit_nz;
+                tonal_bits = (uint32_t)__builtin_amdgcn_readlane((int)m_ton, hit_k);
+                rec_lane = hit_k;
                 bits_current = false;
+                AT3_STAT(1, 1);
             } else {
+            AT3_STAT(3, 1); if (hit) AT3_STAT(2, 1);
             bits = (lane < num_bfu) ? alloc_bits(A, gate, tcount, gmap, lam) : 0;
-            // quantise what this allocation asks for and the cache does not hold yet (TEncCache, atrac_enc_cache.cpp)
-            {
-                const uint32_t need = (uint32_t)__ballot(lane < 32 && bits != 0 && !((valid >> bits) & 1u));
-#ifdef AT3HIP_DEBUG_KNOBS
-                if (need && p.debug_stop == 4) {   // the loop without the units (their cache entries stay zero)
-                    if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
-                } else
-#endif
-                if (need) {
-                    compute_units(L, tab, need, bits, my_e1, lane, qerr, pc, p.debug_stop);
-                    if (lane < 32 && ((need >> lane) & 1u)) valid |= 1u << bits;
-                }
-            }
             const uint32_t clc_i = __umul24(tab_u(tab.misc, bits) & 7u, (uint32_t)n_i);   // == clc_bits(bits, n_i)
-            // (bits is zero from num_bfu on; the cost is read at a clamped index and dropped rather than read under a lane condition)
-            const uint32_t vlc_i = s_cost[(bits ? bits - 1 : 0) * 32 + i];
-            const uint32_t mine = clc_i | ((bits ? vlc_i : 0u) << 13);
-            const uint32_t rsum = row_allreduce_add(mine);
-            acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
             // the count of non-zero BFUs comes from a ballot: summed as a third field it would need six bits at
             // 32 of 32 (and silently wrapped to zero when every BFU of the frame was coded)
             nz = (uint32_t)__popcll(__ballot(bits != 0));
@@ -1151,15 +1255,59 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 const uint32_t group_bands = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
                 if (groups) tonal_bits = 5u + 2u + 10u * groups + 12u * group_bands + members;
             }
-            if (memo_n < 64) {
-                if (lane == memo_n) {
+            // The units this allocation asks for (TEncCache, atrac_enc_cache.cpp) are brought in only as far as the comparison with
+            // the target needs them: spec bits = 3 per BFU + 6 per coded BFU + min(CLC, VLC) are at most the CLC bits (known from the
+            // wordlens alone) and at least min(CLC, a lower bound of the VLC bits). unit_bounds gives a close lower bound of a new
+            // unit's VLC bits - below BFU 19 the bits themselves -, compute_units, with the energy-adaptive pass, the bits. An
+            // evaluation that ends the bisection (`exhausted`, or a total on the target - which only bits can show) always gets the
+            // bits: the frame is coded from it.
+            {
+                const uint32_t need = (uint32_t)__ballot(lane < 32 && bits != 0 && !((valid >> (8 + bits)) & 1u));
+#ifdef AT3HIP_DEBUG_KNOBS
+                if (need && p.debug_stop == 4) {   // the loop without the units (their cache entries stay zero)
+                    if (lane < 32 && ((need >> lane) & 1u)) valid |= 0x101u << bits;
+                } else
+#endif
+                if (need) {
+                    unit_bounds(L, tab, need, bits, lane, pc);
+                    AT3_STAT(4, 1); AT3_STAT(5, __popc(need));
+                    if (lane < 32 && ((need >> lane) & 1u)) valid |= (lane < 19 ? 0x101u : 0x100u) << bits;
+                }
+            }
+            // (bits is zero from num_bfu on; the cost is read at a clamped index and dropped rather than read under a lane condition)
+            const int cost_at = (bits ? bits - 1 : 0) * 32 + i;
+            uint32_t rsum = row_allreduce_add(clc_i | ((bits ? (uint32_t)s_cost[cost_at] : 0u) << 13));
+            acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
+            uint32_t kind = 0u;   // 0: acc holds the bits, 1: the total is below the target whatever the units cost, 2: above it
+            const uint32_t inexact = (uint32_t)__ballot(lane < 32 && bits != 0 && !((valid >> bits) & 1u));
+            if (inexact) {
+                if (!exhausted) {
+                    const uint32_t base = (uint32_t)num_bfu * 3 + 6 * nz + tonal_bits;
+                    const uint32_t clc_b = acc & 0x1fffu, vlb = (acc >> 13) & 0x3fffu;
+                    if (base + clc_b < (uint32_t)target) {
+                        kind = 1u; AT3_STAT(8, 1);
+                        acc = clc_b | (0x3fffu << 13);   // (read as min(CLC, VLC) = CLC below)
+                    } else if (base + (clc_b <= vlb ? clc_b : vlb) > (uint32_t)target) {
+                        kind = 2u; AT3_STAT(9, 1);
+                    }
+                }
+                if (kind == 0u) {
+                    compute_units(L, tab, inexact, bits, my_e1, lane, qerr, pc, p.debug_stop);
+                    AT3_STAT(6, 1); AT3_STAT(7, __popc(inexact));
+                    if (lane < 32 && ((inexact >> lane) & 1u)) valid |= 1u << bits;
+                    rsum = row_allreduce_add(clc_i | ((bits ? (uint32_t)s_cost[cost_at] : 0u) << 13));
+                    acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
+                }
+            }
+            if (hit || memo_n < 64) {
+                rec_lane = hit ? hit_k : memo_n;
+                if (lane == rec_lane) {
                     m_lam = lam;
                     m_acc = acc;
-                    m_nz = nz;
+                    m_nz = (m_nz & 0xc00u) | nz | (kind << 8);
                     m_ton = tonal_bits;
                 }
-                rec_lane = memo_n;
-                ++memo_n;
+                if (!hit) ++memo_n;
             }
             bits_current = true;
             }
@@ -1193,7 +1341,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                         m_min = pre_min;
                         m_max = pre_max;
                         m_last = pre_last;
-                        m_dir = dir;
+                        m_nz = (m_nz & ~0xc00u) | ((uint32_t)dir << 10);
                     }
                 }
             }
@@ -1215,7 +1363,10 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                         // compares and branches, some forty instructions per dropped BFU)
                         const int n_t = __builtin_amdgcn_readlane(n_i, t);
                         if (lane < memo_n && b) {
-                            m_acc -= clc_bits(b, n_t) | ((uint32_t)s_cost[(b - 1) * 32 + t] << 13);
+                            // (a bound record was summed with the unit's bound where the cache may hold its bits by now: taking out no less
+                            // than went in, never below zero, leaves a bound; exact records take out what went in)
+                            const uint32_t went = (uint32_t)s_cost[(b - 1) * 32 + t], have = (m_acc >> 13) & 0x3fffu;
+                            m_acc -= clc_bits(b, n_t) | ((went < have ? went : have) << 13);
                             m_nz -= 1u;
                         }
                     }
@@ -1225,9 +1376,10 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     bool unchanged = false;
                     if (skip_ok && memo_n > 0 && path) {
                         const uint32_t c1 = m_acc & 0x1fffu, v1 = (m_acc >> 13) & 0x3fffu;
-                        const uint32_t tot = (uint32_t)num_bfu * 3 + 6 * m_nz + (c1 <= v1 ? c1 : v1) + m_ton;
+                        // (for a bound record `tot` is that bound of its total: unchanged while it still decides the comparison the way it did)
+                        const uint32_t tot = (uint32_t)num_bfu * 3 + 6 * (m_nz & 0xffu) + (c1 <= v1 ? c1 : v1) + m_ton;
                         const int nd = tot < (uint32_t)target ? 0 : tot > (uint32_t)target ? 1 : 2;
-                        const unsigned long long changed = __ballot(nd != m_dir) & path;
+                        const unsigned long long changed = __ballot((uint32_t)nd != ((m_nz >> 10) & 3u)) & path;
                         unchanged = changed == 0ull;
                         resume = changed ? __builtin_ctzll(changed) : 63 - __builtin_clzll(path);
                         path &= (2ull << resume) - 1ull;
@@ -1257,16 +1409,18 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 3) return;
 #endif
-    if (p.quant) {   // the QUANT tap: what the cache holds at the end (err e1 / e2, cost CLC | VLC << 13; zero = never computed)
+    if (p.quant) {   // the QUANT tap: the units whose bits the cache holds at the end (err e1 / e2, cost CLC | VLC << 13; zero = not computed, or a bound only)
         QuantRec* qr = p.quant + cf;
+        if (lane < 32) s_alloc[lane] = (uint8_t)(valid & 0xfeu);
+        wave_sync();
         for (int k = lane; k < 7 * 32; k += 64) {
-            const uint32_t vb = s_cost[k];
+            const uint32_t vb = ((s_alloc[k & 31] >> (1 + (k >> 5))) & 1u) ? s_cost[k] : 0u;
             qr->cost[k >> 5][k & 31] = vb ? (clc_bits(1 + (k >> 5), bfu_start((k & 31) + 1) - bfu_start(k & 31)) | (vb << 13)) : 0u;
         }
     }
     // requested now, wanted after the mantissas below have been formed: the frame's curves (lanes 0..7, for the header) and
     // the code tables (their LDS storage was the key lists' until here)
-    const uint4 cw = *reinterpret_cast<const uint4*>(curves + (lane & 7));   // (every lane asks: a load inside `if (lane < 8)` is waited for where the paths join)
+    const uint4 cw = *reinterpret_cast<const uint4*>(curves + (opaque_lane_value(lane) & 7));   // (the address is formed here: as the head's, it would be held across the rate loop)   // (every lane asks: a load inside `if (lane < 8)` is waited for where the paths join)
     const uint32_t huff_a = c_huff[lane], huff_b = c_huff[64 + lane], huff_c = lane < 2 ? c_huff[128 + lane] : 0u;
     if (lane < 32) s_alloc[lane] = (uint8_t)bits;
     for (int k = lane; k < kBitWords; k += 64) s_words[k] = 0;   // the key lists are dead: their storage becomes the bit buffer
