@@ -42,6 +42,15 @@ struct PhaseClock {
 struct PhaseClock {};
 #define AT3_PH_END(pc, k) ((void)0)
 #endif
+// -DAT3_LOOP_PHASES (with AT3HIP_DEBUG_KNOBS; tools/alloc_loop_phases.sh): the rate loop's own parts instead of the units' - slots 5..9 =
+// trip head + memo look-up, allocation + tonal side information, sums + decision, record + comparison + interval, BFU drops; slot 10 = units + emission
+#ifdef AT3_LOOP_PHASES
+#define AT3_UPH(pc, k, kl) do { if ((kl) >= 0) AT3_PH_END(pc, kl); } while (0)
+#define AT3_LPH(pc, k) AT3_PH_END(pc, k)
+#else
+#define AT3_UPH(pc, k, kl) AT3_PH_END(pc, k)
+#define AT3_LPH(pc, k) ((void)0)
+#endif
 
 #ifdef AT3_EMU_STATS
 extern "C" unsigned long long g_alloc_stats[16];
@@ -240,15 +249,37 @@ __device__ __forceinline__ void unit_cost_store(AllocLds& L, const LaneTab& tab,
     if (wl && lead) L.cost[(wl - 1) * 32 + (int)((tab.bfus >> (8 * h)) & 0xffu)] = (uint16_t)vb;
 }
 
+// sum of v[i]^2, i = 0 .. n - 1 in that order (QuantMantisas' e1, atrac_scale.cpp:42-58), n a multiple of 8: eight values per step,
+// the next eight requested before this step's chain of additions runs (every step used to wait for its own LDS reads)
+__device__ __forceinline__ float ordered_square_sum(const float* v, int n)
+{
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    float acc = 0.0f;
+    float4 a = v4[0], b = v4[1];
+    for (int off = 0; off < n; off += 8) {
+        float4 na = a, nb = b;
+        if (off + 8 < n) {
+            na = v4[(off >> 2) + 2];
+            nb = v4[(off >> 2) + 3];
+        }
+        const float term[8] = {a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w, b.x * b.x, b.y * b.y, b.z * b.z, b.w * b.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += term[k];
+        a = na;
+        b = nb;
+    }
+    return acc;
+}
+
 // A LOWER BOUND of the VLC bits of the units {(b, wl_b) : bit b of `need`} without the energy-adaptive pass - and below BFU 19,
 // where there is no such pass, the bits themselves. The bisection compares a total with the target (lib/bs_encode/encode.cpp:
 // 57-129): when the comparison is already decided by a bound of the total, the exact bits are never needed, and the pass (two fifths
 // of what a unit costs: candidate lists, ranks, the sequential walk, plus the ordered energy sum it starts from) is only run for the
 // units of the few allocations whose totals come too close to the target to call - in practice the final one's.
-//   * The pass moves a line by ONE code, only a line close to a rounding boundary (|delta| < 0.25) and only in the direction AWAY
-//     from where rounding took it (atrac_scale.cpp:66-126): a line rounded away from zero (|m| > |t|) may end at |m| - 1, a line
-//     rounded towards zero at |m| + 1, whatever else the pass asks of it (which of the two passes runs, the top code, the energy
-//     test): the set allowed for here contains the set it moves.
+//   * The pass moves a line by ONE code, only a line close to a rounding boundary (|delta| < 0.25: as the reference forms delta,
+//     positive lines only) and only in the direction AWAY from where rounding took it (atrac_scale.cpp:66-126): a line rounded
+//     away from zero (|m| > |t|) may end at |m| - 1, a line rounded towards zero at |m| + 1, whatever else the pass asks of it
+//     (which of the two passes runs, the top code, the energy test): the set allowed for here contains the set it moves.
 //   * A code's length depends on |m| only. With lb(x) = min(len(x), len(x + 1)) a line rounded away from zero costs at least
 //     lb(|m| - 1) if it is such a candidate, any other line at least lb(|m|): ONE look-up per line in the row of lb. The tables grow with |m| except for the
 //     top code of wordlens 5..7, so lb(x) = len(x) but for the code below the top one: the bound is the plain-rounding bits less a
@@ -258,7 +289,7 @@ __device__ __forceinline__ void unit_cost_store(AllocLds& L, const LaneTab& tab,
 // The rows of lb sit in lanes 8..15 of the lane table's length words (tab_row reads lanes 0..7). Wave-uniform call.
 __device__ __forceinline__ void unit_bounds(AllocLds& L, const LaneTab& tab, uint32_t need, int bits, int lane_, PhaseClock& pc)
 {
-    AT3_PH_END(pc, 4);
+    AT3_UPH(pc, 4, 7);
     // (the lane conditions below are formed here, where they are used: hoisted in front of the rate loop they would sit in scalar
     // registers the loop does not have - it already parks some of its masks in vector lanes)
     const int lane = opaque_lane_value(lane_);
@@ -299,9 +330,11 @@ __device__ __forceinline__ void unit_bounds(AllocLds& L, const LaneTab& tab, uin
                 const float t = v[k] * mul;
                 const float am = fabsf(rintf(t));
                 const int a = (int)am;
-                const float delta = t - (truncf(t) + 0.5f);
+                // A candidate that was rounded away from zero: the reference's delta = t - (trunc(t) + 0.5) is formed with the SIGNED t, so
+                // |delta| >= 0.5 for every negative t (no negative line is ever a candidate); for t > 0 rounded up to m, f = t - m is in
+                // [-0.5, 0) (exact: both are multiples of t's last place) and |delta| = f + 0.5 < 0.25 means f < -0.25.
                 // (bitwise: `&&` would be compiled into a branch around the second test - a lane condition per line)
-                ap[k] = a - (int)((int)ea & (int)(am > fabsf(t)) & (int)(fabsf(delta) < 0.25f));
+                ap[k] = a - (int)((int)ea & (int)(t - am < -0.25f) & (int)(t > 0.0f));
                 vb += (uint32_t)((ap[k] < 16 ? row : hi) >> (4 * (ap[k] & 15))) & 15u;
             }
             if (any_pairs) {   // (wave-uniform; at wordlen 1 |m| <= 1)
@@ -312,14 +345,17 @@ __device__ __forceinline__ void unit_bounds(AllocLds& L, const LaneTab& tab, uin
         unit_cost_store(L, tab, h, wl, vb, lane);
     }
     wave_sync();
-    AT3_PH_END(pc, 5);
+    AT3_UPH(pc, 5, 10);
 }
 
 // Quantise the units {(b, wl_b) : bit b of `need`}, wl_b = lane b's `bits` (QuantMantisas + CLC/VLC cost,
-// atrac3_bitstream.cpp:154-173, atrac_scale.cpp:40-130). Lane b < 32 passes BFU b's e1 in `my_e1`. Wave-uniform call.
-__device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, uint32_t need, int bits, float my_e1, int lane, float* qerr, PhaseClock& pc, int dbg = 0)
+// atrac3_bitstream.cpp:154-173, atrac_scale.cpp:40-130). Lane b keeps BFU b's e1 in `my_e1` (from BFU 19 on formed here, on first use). Wave-uniform call.
+__device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, uint32_t need, int bits, float& my_e1, int lane_, float* qerr, PhaseClock& pc, int dbg = 0)
 {
-    AT3_PH_END(pc, 4);
+    // (lane constants - addresses, masks - are formed where they are used: since the bounds the call is rare (once or twice per channel-frame), and
+    // hoisted in front of the rate loop they would hold registers across it that the loop's own code is short of)
+    const int lane = opaque_lane_value(lane_);
+    AT3_UPH(pc, 4, 7);
     // ---- (1) mantissa = lrint(value * MaxQuant[wl]) for the lines of the needed BFUs; energy-adaptive candidate codes ----
     // Four rounds of four lines per lane, line0 = 256 round + 4 lane: a wavefront's 16-byte LDS accesses are one contiguous
     // kilobyte (sixteen lines per lane, the first layout, put every fourth lane on the same banks).
@@ -373,7 +409,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
         }
     }
     wave_sync();
-    AT3_PH_END(pc, 5);
+    AT3_UPH(pc, 5, -1);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (dbg == 9) return;
 #endif
@@ -381,6 +417,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
     const bool mine = lane < 32 && ((need >> lane) & 1u);
     const int my_start = bfu_start(lane & 31), my_n = bfu_start((lane & 31) + 1) - my_start;
     float my_inv2 = tab_f(tab.inv, bits), my_e2 = 0.0f;
+    if (mine && lane > 18 && my_e1 < 0.0f) my_e1 = ordered_square_sum(L.val + my_start, my_n);   // (the first unit of this BFU to need the pass)
     if (mine && (lane > 18 || qerr)) {   // below BFU 19 nothing but the QUANT tap reads a unit's quantised energy
         const float4* t4 = reinterpret_cast<const float4*>(L.term + (my_start - kTermLine0));
         float acc = 0.0f;
@@ -419,7 +456,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
         my_e2 = acc;
     }
     wave_sync();   // the terms' storage becomes the key list and the candidate records
-    AT3_PH_END(pc, 6);
+    AT3_UPH(pc, 6, -1);
 #ifdef AT3HIP_DEBUG_KNOBS
     if (dbg == 10) return;
 #endif
@@ -560,7 +597,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
             if (lane == bfu) my_nc = cnt_u;
             wave_sync();   // the key list is reused by the next unit
         }
-        AT3_PH_END(pc, 7);
+        AT3_UPH(pc, 7, -1);
         // equal keys among listed candidates: libstdc++'s std::sort order decides (rare). The order of equal elements
         // depends on the whole array the reference sorts, so the full |delta| < 0.25 list is rebuilt, sorted with the
         // restated algorithm and then filtered.
@@ -652,7 +689,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
         }
     }
     wave_sync();
-    AT3_PH_END(pc, 8);
+    AT3_UPH(pc, 8, -1);
     // ---- (4) VLC cost of the final mantissas; (5) cache entries ----
     VlcRow row_h[4];   // (the four rounds' length rows requested together)
 #pragma unroll
@@ -680,7 +717,7 @@ __device__ __forceinline__ void compute_units(AllocLds& L, const LaneTab& tab, u
     }
     if (mine && qerr) qerr[(bits - 1) * 32 + lane] = my_e1 / my_e2;   // BFUs >= 10: nothing but the QUANT tap looks at their energy error
     wave_sync();
-    AT3_PH_END(pc, 9);
+    AT3_UPH(pc, 9, 10);
 }
 
 // The 70 units of BFUs 0..9 (8 or 16 lines each, no energy-adaptive pass below BFU 19), one lane per unit: ConsiderEnergyErr
@@ -999,28 +1036,11 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     }
     __syncthreads();
     AT3_PH_END(pc, 0);
-    float my_e1 = 0.0f;   // lane b < 32: e1 of BFU b
-    if (lane < 32) {
-        // eight values per step, the next eight requested before this step's chain of additions runs (the chain of the 128-line
-        // BFUs is sixteen steps long: every step used to wait for its own LDS reads)
-        const int start = bfu_start(lane), n = bfu_start(lane + 1) - start;
-        const float4* v4 = reinterpret_cast<const float4*>(L.val + start);
-        float acc = 0.0f;
-        float4 a = v4[0], b = v4[1];
-        for (int off = 0; off < n; off += 8) {
-            float4 na = a, nb = b;
-            if (off + 8 < n) {
-                na = v4[(off >> 2) + 2];
-                nb = v4[(off >> 2) + 3];
-            }
-            const float term[8] = {a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w, b.x * b.x, b.y * b.y, b.z * b.z, b.w * b.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc += term[k];
-            a = na;
-            b = nb;
-        }
-        my_e1 = acc;
-    }
+    // lane b < 19: e1 of BFU b. From BFU 19 on e1 is only read by the energy-adaptive pass of one of the BFU's units (its lane
+    // forms it then, compute_units; -1 = not yet) - the pass runs for the final allocation's units and few others, the two 128-line
+    // BFUs are mostly dropped before that, and their chain of additions is four times the longest one here
+    float my_e1 = -1.0f;
+    if (lane < 19) my_e1 = ordered_square_sum(L.val + bfu_start(lane), bfu_start(lane + 1) - bfu_start(lane));
     __syncthreads();
     AT3_PH_END(pc, 1);
     // units of the first ten BFUs at every wordlen: ConsiderEnergyErr (atrac3_bitstream.cpp:241-257) looks at their energy
@@ -1211,6 +1231,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             // decided - and for the same one after BFUs were dropped, as long as it still decides it - but not for an
             // evaluation that ends the bisection, which needs the bits themselves: those are evaluated again, in place)
             const uint32_t hit_nz = hit ? (uint32_t)__builtin_amdgcn_readlane((int)m_nz, hit_k) : 0u;
+            AT3_LPH(pc, 5);
             AT3_STAT(0, 1);
             if (hit && (hit_nz >> 8) == 0u) {
                 acc = (uint32_t)__builtin_amdgcn_readlane((int)m_acc, hit_k);
@@ -1255,6 +1276,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                 const uint32_t group_bands = (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
                 if (groups) tonal_bits = 5u + 2u + 10u * groups + 12u * group_bands + members;
             }
+            AT3_LPH(pc, 6);
             // The units this allocation asks for (TEncCache, atrac_enc_cache.cpp) are brought in only as far as the comparison with
             // the target needs them: spec bits = 3 per BFU + 6 per coded BFU + min(CLC, VLC) are at most the CLC bits (known from the
             // wordlens alone) and at least min(CLC, a lower bound of the VLC bits). unit_bounds gives a close lower bound of a new
@@ -1299,6 +1321,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);
                 }
             }
+            AT3_LPH(pc, 7);
             if (hit || memo_n < 64) {
                 rec_lane = hit ? hit_k : memo_n;
                 if (lane == rec_lane) {
@@ -1345,6 +1368,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     }
                 }
             }
+            AT3_LPH(pc, 8);
             if (!done) continue;
             final_lam = lam;
             const int last_alloc = (p.bfu_idx_const || num_bfu <= 1) ? 1
@@ -1402,6 +1426,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             }
             break;
         }
+        AT3_LPH(pc, 9);
         if (!restart) break;
     }
     if (!bits_current) bits = (lane < num_bfu) ? alloc_bits(A, gate, tcount, gmap, final_lam) : 0;   // (mode is the last evaluation's)
@@ -1418,15 +1443,17 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             qr->cost[k >> 5][k & 31] = vb ? (clc_bits(1 + (k >> 5), bfu_start((k & 31) + 1) - bfu_start(k & 31)) | (vb << 13)) : 0u;
         }
     }
+    // (the emission's lane constants are formed here, behind the rate loop, not held across it)
+    const int elane = opaque_lane_value(lane);
     // requested now, wanted after the mantissas below have been formed: the frame's curves (lanes 0..7, for the header) and
     // the code tables (their LDS storage was the key lists' until here)
-    const uint4 cw = *reinterpret_cast<const uint4*>(curves + (opaque_lane_value(lane) & 7));   // (the address is formed here: as the head's, it would be held across the rate loop)   // (every lane asks: a load inside `if (lane < 8)` is waited for where the paths join)
-    const uint32_t huff_a = c_huff[lane], huff_b = c_huff[64 + lane], huff_c = lane < 2 ? c_huff[128 + lane] : 0u;
-    if (lane < 32) s_alloc[lane] = (uint8_t)bits;
-    for (int k = lane; k < kBitWords; k += 64) s_words[k] = 0;   // the key lists are dead: their storage becomes the bit buffer
+    const uint4 cw = *reinterpret_cast<const uint4*>(curves + (elane & 7));   // (the address is formed here: as the head's, it would be held across the rate loop)   // (every elane asks: a load inside `if (elane < 8)` is waited for where the paths join)
+    const uint32_t huff_a = c_huff[elane], huff_b = c_huff[64 + elane], huff_c = elane < 2 ? c_huff[128 + elane] : 0u;
+    if (elane < 32) s_alloc[elane] = (uint8_t)bits;
+    for (int k = elane; k < kBitWords; k += 64) s_words[k] = 0;   // the key lists are dead: their storage becomes the bit buffer
 
     // ---- emission (WriteSoundUnit header, EncodeSpecs) ----
-    // mantissas: 16 spectral lines per lane (BFU sizes are multiples of 8, so at most two BFUs per lane), formed AGAIN from
+    // mantissas: 16 spectral lines per elane (BFU sizes are multiples of 8, so at most two BFUs per elane), formed AGAIN from
     // the scaled values instead of being kept for every unit the rate loop ever asked for: plain rounding, and from BFU 19
     // on the lines the energy-adaptive pass moved by one (its record, one bit per line and wordlen). Which way a recorded
     // line went can be read off the line itself: the pass that adds lists only lines rounded towards zero, the pass that
@@ -1435,7 +1462,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     int m_h[2][8];
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
-        const int i0 = lane * 16 + 8 * hlf;
+        const int i0 = elane * 16 + 8 * hlf;
         const int b = bfu_of_line(i0);
         const int wl = __builtin_amdgcn_ds_bpermute(4 * b, bits);   // (zero from num_bfu on)
         wl_h[hlf] = wl;
@@ -1457,12 +1484,12 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
             m_h[hlf][k] = wl ? m : 0;
         }
     }
-    s_huff[lane] = (uint16_t)huff_a;
-    s_huff[64 + lane] = (uint16_t)huff_b;
-    if (lane < 2) s_huff[128 + lane] = (uint16_t)huff_c;
+    s_huff[elane] = (uint16_t)huff_a;
+    s_huff[64 + elane] = (uint16_t)huff_b;
+    if (elane < 2) s_huff[128 + elane] = (uint16_t)huff_c;
     __syncthreads();
     int pos = (p.js && ch == 1) ? 14 : 6;
-    if (lane == 0) {
+    if (elane == 0) {
         if (p.js && ch == 1) {
             put_bits(s_words, 0, 0, 1);
             put_bits(s_words, 1, 7, 3);
@@ -1474,10 +1501,10 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         put_bits(s_words, pos, 3, 2);
     }
     pos += 2;
-    {   // gain points: lane ch * 4 + b writes band b's count and (level, location) pairs out of its registers
+    {   // gain points: elane ch * 4 + b writes band b's count and (level, location) pairs out of its registers
         const int n0 = __builtin_amdgcn_readlane(curve_n, ch * 4), n1 = __builtin_amdgcn_readlane(curve_n, ch * 4 + 1);
         const int n2 = __builtin_amdgcn_readlane(curve_n, ch * 4 + 2), n3 = __builtin_amdgcn_readlane(curve_n, ch * 4 + 3);
-        const int b = lane - ch * 4;
+        const int b = elane - ch * 4;
         if (b >= 0 && b < 4) {
             int at = pos + 3 * b + 9 * ((b > 0 ? n0 : 0) + (b > 1 ? n1 : 0) + (b > 2 ? n2 : 0));
             put_bits(s_words, at, (uint32_t)curve_n, 3);
@@ -1495,13 +1522,13 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     if (n_tonal == 0) {   // EncodeTonalComponents without components: five zero bits (atrac3_bitstream.cpp:382-400)
         pos += 5;
     } else if (!tonal_serial) {
-        pos += tonal_emit_parallel(rec, s_tbits, s_huff, s_words, pos, lane, n_tonal, num_bfu, bits, tb_bfu, tb_len, tb_blk);
+        pos += tonal_emit_parallel(rec, s_tbits, s_huff, s_words, pos, elane, n_tonal, num_bfu, bits, tb_bfu, tb_len, tb_blk);
     } else {
-        if (lane == 0) s_misc[1] = tonal_encode<true>(rec, s_tbits, s_alloc, num_bfu, s_words, pos, tonal_scr);
+        if (elane == 0) s_misc[1] = tonal_encode<true>(rec, s_tbits, s_alloc, num_bfu, s_words, pos, tonal_scr);
         __syncthreads();
         pos += s_misc[1];
     }
-    if (lane == 0) {
+    if (elane == 0) {
         put_bits(s_words, pos, (uint32_t)num_bfu - 1, 5);
         put_bits(s_words, pos + 5, (uint32_t)mode, 1);
     }
@@ -1509,14 +1536,14 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
 #ifdef AT3HIP_DEBUG_KNOBS
     if (p.debug_stop == 7) return;
 #endif
-    const unsigned long long nzmask = __ballot(lane < num_bfu && bits != 0);
-    if (lane < num_bfu) put_bits(s_words, pos + 3 * lane, (uint32_t)bits, 3);
+    const unsigned long long nzmask = __ballot(elane < num_bfu && bits != 0);
+    if (elane < num_bfu) put_bits(s_words, pos + 3 * elane, (uint32_t)bits, 3);
     pos += 3 * num_bfu;
-    if (lane < num_bfu && bits)
-        put_bits(s_words, pos + 6 * __popcll(nzmask & ((1ull << lane) - 1ull)), (uint32_t)my_sfi, 6);
+    if (elane < num_bfu && bits)
+        put_bits(s_words, pos + 6 * __popcll(nzmask & ((1ull << elane) - 1ull)), (uint32_t)my_sfi, 6);
     pos += 6 * __popcll(nzmask);
     {
-        // The lane's codes are strung together in registers, most significant bit first: first into groups of at most 30
+        // The elane's codes are strung together in registers, most significant bit first: first into groups of at most 30
         // bits (four fixed-length codes, or three / three / two Huffman codes per eight lines), then group by group into
         // a 64-bit window that reaches the shared bit buffer one 32-bit word at a time.
         uint32_t grp[6], glen[6];
@@ -1570,7 +1597,7 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
         int sum = 0;
 #pragma unroll
         for (int k = 0; k < 6; ++k) sum += (int)glen[k];
-        const int off = pos + wave_inclusive_scan(sum, lane) - sum;
+        const int off = pos + wave_inclusive_scan(sum, elane) - sum;
         int cur = off >> 5, fill = off & 31;
         uint64_t acc = 0;
 #pragma unroll
@@ -1598,16 +1625,16 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
     uint8_t* frame = p.out + ((size_t)s * n_out + fo) * p.frame_sz;
     const int dst0 = (ch == 0) ? 0 : half + shift;
     if (!p.js && ((p.frame_sz | half) & 3) == 0) {   // whole big-endian words
-        for (int j = lane; j < (nbytes >> 2); j += 64)
+        for (int j = elane; j < (nbytes >> 2); j += 64)
             *reinterpret_cast<uint32_t*>(frame + dst0 + 4 * j) = (j < kBitWords) ? __builtin_bswap32(s_words[j]) : 0u;
     } else {
-        for (int j = lane; j < nbytes; j += 64) {
+        for (int j = elane; j < nbytes; j += 64) {
             const int src = (p.js && ch == 1) ? (nbytes - 1 - j) : j;
             const uint8_t byte = (src < kBitWords * 4) ? (uint8_t)(s_words[src >> 2] >> (24 - 8 * (src & 3))) : 0;
             frame[dst0 + j] = byte;
         }
     }
-    if (clk_probe && lane == 0) {
+    if (clk_probe && elane == 0) {
         p.clk[0] = __builtin_amdgcn_s_memtime() - clk_t0;
         p.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
     }
