@@ -52,7 +52,12 @@ struct PhaseClock {};
 #define AT3_LPH(pc, k) ((void)0)
 #endif
 
-#ifdef AT3_EMU_STATS
+// SIMT harness only (tools/emu, AT3_EMU_HOST): the rate loop counts what it does - and checks every lower bound of unit_bounds
+// against the bits compute_units finds later - in g_alloc_stats (tools/emu/emu_runtime.cpp; printed and asserted by run_emu.py):
+// 0 trips, 1 hits of exact records, 2 evaluations in place of bound records, 3 evaluations, 4 unit_bounds calls, 5 their units,
+// 6 compute_units calls, 7 their units, 8 / 9 comparisons decided by the upper / lower bound, 10 channel-frames,
+// 11 bounds compared with the bits, 12 bounds ABOVE the bits (must stay zero)
+#ifdef AT3_EMU_HOST
 extern "C" unsigned long long g_alloc_stats[16];
 #define AT3_STAT(k, n) do { if (lane == 0) g_alloc_stats[k] += (n); } while (0)
 #else
@@ -1314,8 +1319,16 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     }
                 }
                 if (kind == 0u) {
+#ifdef AT3_EMU_HOST
+                    const uint32_t bound_i = s_cost[cost_at];
+#endif
                     compute_units(L, tab, inexact, bits, my_e1, lane, qerr, pc, p.debug_stop);
                     AT3_STAT(6, 1); AT3_STAT(7, __popc(inexact));
+#ifdef AT3_EMU_HOST
+                    AT3_STAT(11, __popc(inexact));
+                    const unsigned long long above = __ballot(lane < 32 && ((inexact >> lane) & 1u) && bound_i > (uint32_t)s_cost[cost_at]);
+                    AT3_STAT(12, __popcll(above));
+#endif
                     if (lane < 32 && ((inexact >> lane) & 1u)) valid |= 1u << bits;
                     rsum = row_allreduce_add(clc_i | ((bits ? (uint32_t)s_cost[cost_at] : 0u) << 13));
                     acc = (uint32_t)__builtin_amdgcn_readlane((int)rsum, 0) + (uint32_t)__builtin_amdgcn_readlane((int)rsum, 16);

@@ -1,6 +1,8 @@
 // DEVELOPMENT HARNESS ONLY - see hip/hip_runtime.h in this directory.
 #include "hip/hip_runtime.h"
 #include <dlfcn.h>
+// k_alloc_pack's harness-only counters (at3_k_alloc.hpp: AT3_STAT)
+extern "C" { unsigned long long g_alloc_stats[16] = {0}; }
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 

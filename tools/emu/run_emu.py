@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """DEVELOPMENT HARNESS: run the kernel sources through the CPU SIMT emulator (tools/emu) and diff
 against the oracle. Not a test, not a benchmark - only a debugging aid for a GPU-less container."""
-import os, subprocess, sys, time
+import ctypes, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -57,6 +57,12 @@ if __name__ == "__main__":
                 # at3hip_get_counters against the oracle's count of TScaler::Scale's diagnostics (zero on everything but `hot`)
                 print(f"{name:8s} overflow counters {cnt['scale_overflow']}, {cnt['clipped_values']} (oracle {want[0]}, {want[1]}): "
                       f"bad {int((cnt['scale_overflow'], cnt['clipped_values']) != want)}")
+                # k_alloc_pack's own account of its rate loop (AT3_STAT): every lower bound that was later replaced by the bits must not exceed them
+                st = (ctypes.c_ulonglong * 16).in_dll(ctypes.CDLL(EMU), "g_alloc_stats")
+                cf = max(1, st[10])
+                print(f"{name:8s} rate loop per channel-frame: {st[0] / cf:.1f} trips, {st[3] / cf:.1f} evaluations ({st[8] / cf:.1f} / {st[9] / cf:.1f} decided by the upper / "
+                      f"lower bound), {st[5] / cf:.1f} units bounded, {st[7] / cf:.1f} quantised; {st[11]} bounds checked against the bits: bad {st[12]}")
+                for k in range(16): st[k] = 0
                 bad = (got != exp).any(axis=2)
                 print(f"{name:8s} br={br} nogain={ng} notonal={nt}: shape {got.shape} mismatching frames "
                       f"{int(bad.sum())}/{bad.size} {np.argwhere(bad)[:6].tolist()} ({time.time()-t:.1f}s)")
