@@ -161,7 +161,9 @@ int at3hip_sync(at3hip_ctx* ctx);
  *                 CalcSpectralFlatnessPerBfu of BFUs 8..28 (0 elsewhere and with NoTonalComponents)  (T4, T5, T6)
  *   LOUDNESS      float [n_streams][F] tracked loudness                                             (T6)
  *   QUANT         1792-byte records [n_streams][F][2]: float err[7][32] (e1/e2), u32 cost[7][32] (CLC | VLC << 13) of the
- *                 quantised units the rate loop asked for (zero = never computed); only with AT3HIP_OPT_QUANT_TAP */
+ *                 units the rate loop quantised (zero = never, or only bounded: the loop brings a unit's bits in when a bound of
+ *                 them does not decide its comparison; err is kept for BFUs 0..9 - ConsiderEnergyErr's - and for the units that
+ *                 went through the energy-adaptive pass); only with AT3HIP_OPT_QUANT_TAP */
 #define AT3HIP_TAP_SPECTRA 1
 #define AT3HIP_TAP_CURVES 2
 #define AT3HIP_TAP_ENERGY_SCALE 3
