@@ -276,14 +276,20 @@ __global__ __launch_bounds__(64) void k_gain_spec(GainParams p, const Tables* T,
     const int lane = threadIdx.x, row = lane >> 4, L = lane & 15;
     SpecItemLds& S = s_item[row];
     const int nfr = p.n_blocks - p.f0;
-    int item = blockIdx.x * 4 + row;
-    const bool valid = item < n_items;
-    if (!valid) item = n_items - 1;   // (keeps the wavefront uniform; nothing is stored)
-    int wg = item;
+    // The four rows of a wavefront take four CONSECUTIVE frames of one (stream, channel, band): an item's 512 samples are its frame's
+    // block and the next one, so row r's second half is row r + 1's first - five blocks per wavefront instead of eight come from
+    // memory (items in index order put the two readers of a block in different workgroups, mostly on different XCDs' L2s).
+    // workgroup = ((stream * quads + quad) * 2 + channel) * 3 + band, quads = ceil(frames / 4); a stream's last quad may be ragged
+    const int quads = (nfr + 3) >> 2;
+    int wg = blockIdx.x;
     const int band = wg % 3; wg /= 3;
     const int ch = wg % 2; wg /= 2;
-    const int f = p.f0 + wg % nfr;
-    const int s = wg / nfr;
+    const int fr = 4 * (wg % quads) + row;
+    const int s = wg / quads;
+    const bool valid = fr < nfr;
+    const int f = p.f0 + (valid ? fr : nfr - 1);   // (a row past the end repeats the last frame: the wavefront stays uniform, nothing is stored)
+    const int item = (((s * nfr) + (f - p.f0)) * 2 + ch) * 3 + band;
+    (void)n_items;
     const int cb = f - 1;  // current block
     const size_t sublen = (size_t)(p.n_blocks + 2) * 256;
     const float* sb0 = p.sub + ((size_t)s * 8 + 0 * 4 + band) * sublen + (size_t)(cb + 2) * 256 - 128;

@@ -778,7 +778,10 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             launch_qmf_sub();
             HIPCHK(c, hipEventRecord(ev[1], st));
             launch_state(st, 1);   // PCM history and subband tail: the next call's heavy stage needs nothing else from this one
-            hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)((S * n_out * 6 + 3) / 4)), dim3(64), spec_lds_pad(c, ((long long)S * n_out * 6 + 3) / 4), st, gp, c->d_tables, S * n_out * 6);
+            {
+                const long long spec_wgs = (long long)S * ((n_out + 3) / 4) * 6;   // (four consecutive frames of one (stream, channel, band) per wavefront)
+                hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)spec_wgs), dim3(64), spec_lds_pad(c, spec_wgs), st, gp, c->d_tables, S * n_out * 6);
+            }
             // default: the two-wavefront form. The one-wavefront form is 11 % faster alone (89 against 101 us at 4096 frames) and
             // leaves the pipelined step 2 % slower at that size, equal at the 1024 x 128 shard (profiles/EXPERIMENTS.md)
             if (c->gain_form != AT3HIP_GAIN_FORM_ONE_WAVE) hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), analysis_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);
