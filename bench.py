@@ -352,6 +352,26 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
     return out
 
 
+def side_workload_fresh(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
+    """side_workload in a process of its own, as the headline has. Why: the FIRST context a process creates runs `tones` at 16.2 M frames/s,
+    any later one of the same process at 12.2 - 14.9 M (same kernels, same isolated kernel times; where the buffers lie and the number of
+    hardware queues do not matter; white noise does not show it) - so figures taken from the second .. seventh context of the bench
+    process said more about their position in the list than about the workload. Falls back to the in-process
+    measurement, and says so, if the child fails."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-side-workload", json.dumps([name, S, F, bitrate, kind, steps, warmup, bool(no_gain)])],
+                           capture_output=True, text=True, timeout=600)
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["fresh_process"] = True
+        return out
+    except Exception as ex:   # noqa: BLE001
+        out = side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=no_gain)
+        out["fresh_process"] = False
+        out["fresh_process_error"] = repr(ex)
+        return out
+
+
 HOST_PIPELINE_DEPTH = {False: 2, True: 4}   # float32 / 16-bit samples: calls in flight (mirrors TAtrac3EncoderBatch::EncodePipelined)
 
 
@@ -488,7 +508,13 @@ def main():
                                                               "the line is marked and is not a valid throughput result")
     ap.add_argument("--device-map", default="", help="TEST AID: comma list of device ordinals to use instead of 0..N-1 (e.g. 0,0 runs the "
                                                      "two-device code path on one GPU); recorded in the JSON line, never a valid N-GPU result")
+    ap.add_argument("--one-side-workload", default="", help="INTERNAL: JSON [name, S, F, bitrate, kind, steps, warmup, no_gain] - measure that one side workload in this "
+                    "(fresh) process and print its record (what `other_workloads` calls for each entry)")
     args = ap.parse_args()
+    if args.one_side_workload:
+        name, S, F, br, kind, steps, warmup, no_gain = json.loads(args.one_side_workload)
+        print(json.dumps(side_workload(name, S, F, br, kind, steps, warmup, no_gain=bool(no_gain))))
+        return
 
     import torch
 
@@ -779,12 +805,12 @@ def main():
                 line["cpu_baseline"] = cpu_baseline()
             if not args.no_side_workloads:
                 line["other_workloads"] = [
-                    side_workload("configs[1] shape, 'burst' input (gain-control path busy)", 64, 64, LP2, "burst", 30, 3),
-                    side_workload("configs[1] shape, 'tones' input (tonal extraction busy)", 64, 64, LP2, "tones", 30, 3),
-                    side_workload("configs[3]: LP4 66 kbps joint stereo, configs[1] shape, 'noise'", 64, 64, LP4, "noise", 30, 3),
-                    side_workload("shard_1024x128: per-GPU shard of configs[2] (1024 streams x 128 frames) on one GPU, 'noise'", 1024, 128, LP2, "noise", 10, 2),
-                    side_workload("configs[1] shape, 'noise', --nogaincontrol: the FUSED QMF + MDCT kernel k_qmf_mdct8 (north_star's kernel)", 64, 64, LP2, "noise", 30, 3, no_gain=True),
-                    side_workload("shard_1024x128, 'noise', --nogaincontrol: k_qmf_mdct8 at the per-GPU shard", 1024, 128, LP2, "noise", 10, 2, no_gain=True),
+                    side_workload_fresh("configs[1] shape, 'burst' input (gain-control path busy)", 64, 64, LP2, "burst", 30, 3),
+                    side_workload_fresh("configs[1] shape, 'tones' input (tonal extraction busy)", 64, 64, LP2, "tones", 30, 3),
+                    side_workload_fresh("configs[3]: LP4 66 kbps joint stereo, configs[1] shape, 'noise'", 64, 64, LP4, "noise", 30, 3),
+                    side_workload_fresh("shard_1024x128: per-GPU shard of configs[2] (1024 streams x 128 frames) on one GPU, 'noise'", 1024, 128, LP2, "noise", 10, 2),
+                    side_workload_fresh("configs[1] shape, 'noise', --nogaincontrol: the FUSED QMF + MDCT kernel k_qmf_mdct8 (north_star's kernel)", 64, 64, LP2, "noise", 30, 3, no_gain=True),
+                    side_workload_fresh("shard_1024x128, 'noise', --nogaincontrol: k_qmf_mdct8 at the per-GPU shard", 1024, 128, LP2, "noise", 10, 2, no_gain=True),
                 ]
                 line["host_pipeline"] = host_pipeline_workload(64, 64)
                 line["host_pipeline_s16"] = host_pipeline_workload(64, 64, s16=True)
