@@ -9,8 +9,11 @@
 //
 // The rate loop asks for quantised (BFU, wordlen) units as its bisection walks: on typical material about 100 of the
 // 224 possible units and a third of their spectral lines (a quarter of the lines that need the energy-adaptive pass).
-// The first version quantised all 224 up front in a separate kernel; here a unit is computed the first time an
-// allocation asks for it, exactly as the reference's cache does, by the wavefront that runs the loop:
+// The first version quantised all 224 up front in a separate kernel; then a unit was computed the first time an
+// allocation asked for it, as the reference's cache does; now it is brought in only as far as the bisection's comparison
+// needs it: as a LOWER BOUND of its VLC bits first (unit_bounds: rounding + one length look-up per line), and through
+// QuantMantisas' energy-adaptive pass only when no bound decides the comparison or the evaluation ends the bisection
+// (compute_units; on white noise a third of the units the reference quantises). By the wavefront that runs the loop:
 //   rounding and code lengths of the batch's lines       16 lines per lane
 //   the ordered energy sum of every new unit              one lane per unit
 //   energy-adaptive candidates (BFU > 18): compaction by ballot, rank by counting smaller keys, exact std::sort order
