@@ -317,19 +317,23 @@ struct MdctTab {
 struct MdctTabRegs {
     float4 a, b;
 };
+// (NT = work-items of the workgroup, 192 or 256: the table has 288 entries, so the first 288 - NT work-items take a second one)
+template <int NT = 256>
 __device__ __forceinline__ MdctTabRegs mdct_tab_request(const Tables* T, int tid)
 {
+    static_assert(NT >= 144 && NT <= 288 && (288 - NT) % 32 == 0, "one or two entries per work-item");
     const float4* flat = reinterpret_cast<const float4*>(&T->mdct_tab[0][0][0]);
     MdctTabRegs r;
     r.a = flat[tid];
-    r.b = flat[256 + (tid & 31)];
+    r.b = flat[NT + (tid < 288 - NT ? tid : 0)];
     return r;
 }
+template <int NT = 256>
 __device__ __forceinline__ void mdct_tab_store(MdctTab& tab, const MdctTabRegs& r, int tid)
 {
     float4* flat = &tab.e[0][0];
     flat[tid] = r.a;
-    if (tid < 32) flat[256 + tid] = r.b;
+    if (tid < 288 - NT) flat[NT + tid] = r.b;
 }
 
 // The lane's sixteen samples from its row's 256. The lane reads the even-index pairs (x[i], x[i+1]) at i = e and
@@ -559,18 +563,20 @@ __device__ __forceinline__ void rows_request(const float* sb_own, const float* s
     }
 }
 
-template <bool JS>
-__global__ __launch_bounds__(256) void k_mdct_sub(MdctSubParams p, const Tables* T)
+// NW wavefronts per workgroup: four (25.5 KB of LDS, one table copy per four runs) or three (20.3 KB: a workgroup then fits the 22.5 KB slot ONE retiring
+// k_gain_analysis workgroup frees when that kernel's launch is padded to seven per CU; at 25.5 KB it needed 26 KB slots, six per CU - EXPERIMENTS round 5)
+template <bool JS, int NW>
+__global__ __launch_bounds__(64 * NW) void k_mdct_sub(MdctSubParams p, const Tables* T)
 {
     __shared__ __attribute__((aligned(16))) MdctTab s_tab;
-    __shared__ __attribute__((aligned(16))) float4 s_x[4][4 * kRowScratch4];   // exchange scratch; also the rows' divisor tables
-    __shared__ __attribute__((aligned(16))) Curve s_cv[4][4];
+    __shared__ __attribute__((aligned(16))) float4 s_x[NW][4 * kRowScratch4];   // exchange scratch; also the rows' divisor tables
+    __shared__ __attribute__((aligned(16))) Curve s_cv[NW][4];
     __shared__ float s_gi[32];
     static_assert(kRowScratch4 * 4 >= 256, "a row's 256 divisors share its exchange scratch");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // (a wavefront beyond the batch stays for the rendezvous below with the last run's indices and leaves after it)
-    const bool live = blockIdx.x * 4 + wave < p.n_waves;
-    const int W = live ? blockIdx.x * 4 + wave : p.n_waves - 1;
+    const bool live = (int)blockIdx.x * NW + wave < p.n_waves;
+    const int W = live ? (int)blockIdx.x * NW + wave : p.n_waves - 1;
     const int n_out = p.n_blocks - p.f0;
     const int nchunks = p.frame_runs;   // runs per (stream, channel): the n_out frames are dealt out as evenly as possible
     const int chunk = W % nchunks;
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(256) void k_mdct_sub(MdctSubParams p, const Tables*
     float* spec_base = p.specs + ((size_t)s * n_out * 2 + ch) * 1024 + band * 256;
     // block f - 1 is frame f's new half; block fa - 2 primes the overlap of the run (modulated by frame fa - 1's curve).
     // The subbands of the next block are requested before the current one is transformed: a wavefront waits for HBM once.
-    const MdctTabRegs tab_regs = mdct_tab_request(T, tid);
+    const MdctTabRegs tab_regs = mdct_tab_request<64 * NW>(T, tid);
     const float gi_v = T->gain_interp[(tid & 31) < 31 ? (tid & 31) : 30];
     __builtin_amdgcn_sched_barrier(0);   // (the workgroup's tables are asked for FIRST: see mdct_tab_request)
     RowRaw raw_a, raw_b;
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(256) void k_mdct_sub(MdctSubParams p, const Tables*
     __builtin_amdgcn_sched_barrier(0);
     // the run's first subbands and curve are on their way while the workgroup stores its tables
     if (tid < 32) s_gi[tid] = gi_v;
-    mdct_tab_store(s_tab, tab_regs, tid);
+    mdct_tab_store<64 * NW>(s_tab, tab_regs, tid);
     __syncthreads();   // the only workgroup-level rendezvous: the shared tables
     if (!live) return;
     for (int f = fa - 1; f < fb; ++f) {

@@ -260,7 +260,11 @@ size_t analysis_lds_pad(const at3hip_ctx* c, long long n_wgs)
     if (c->gain_wgs_per_cu >= 9) return 0;
     // (six per CU at 26 KB each leave 4 KB of the CU's LDS: with the 8704-byte pad of round 3 they left exactly the 10 KB of one
     // k_alloc_pack wavefront, and the step was 0.8 % slower for every CU carrying that lodger - tools/ab_step.sh, --gain-wgs)
-    static const LdsChoice kChoice[3] = {{9, 0}, {8, 3328}, {6, 9728}};
+    // Since k_mdct_sub's workgroups are three wavefronts (20.3 KB) the fat slot is 22.5 KB, SEVEN per CU: what counts is that the slot ONE retiring
+    // analysis workgroup frees takes a workgroup of the light stage - with mdct at 25.5 KB that needed the 26 KB slots of six per CU (a 2 KB larger
+    // mdct block cost the step 5 %: AT3HIP_PAD_MDCT, EXPERIMENTS round 5), now seven fit the same launches (+1.2 % on the step, `tones` +2 %;
+    // 23.3 KB slots, which leave under 1 KB of the CU, lose 7 %). The choice is still scored as the six-per-CU one it replaces.
+    static const LdsChoice kChoice[3] = {{9, 0}, {8, 3328}, {6, 5632}};
     return whole_rounds_pad(c, n_wgs, kChoice, 3, true);   // (equally whole rounds: the fewer, fatter slots measured better)
 }
 // The one-wavefront form (k_gain_analysis1, 9.5 KB per workgroup): sixteen per CU without padding.
@@ -438,8 +442,8 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_mdct8, 256, 0);
         c->wgs_per_cu = (e == hipSuccess && nb > 0) ? nb : 3;
         nb = 0;
-        c->wgs_per_cu_mdct = ((c->js ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mdct_sub<true>, 256, 0)
-                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mdct_sub<false>, 256, 0)) == hipSuccess && nb > 0) ? nb : 3;
+        c->wgs_per_cu_mdct = ((c->js ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_mdct_sub<true, 4>), 256, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_mdct_sub<false, 4>), 256, 0)) == hipSuccess && nb > 0) ? nb : 3;   // (wavefronts per SIMD, pick_runs' unit: the same three for the three-wavefront form, four workgroups per CU)
     }
     *out = c;
     return AT3HIP_OK;
@@ -810,8 +814,16 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             mp.js = c->js;
             mp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu_mdct, 0.3);
             mp.n_waves = S * 2 * mp.frame_runs;
-            if (c->js) hipLaunchKernelGGL(k_mdct_sub<true>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, md, mp, c->d_tables);
-            else hipLaunchKernelGGL(k_mdct_sub<false>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), (size_t)c->dbg_pad[1], md, mp, c->d_tables);
+            // three wavefronts per workgroup (20.3 KB) where k_gain_analysis' launch is padded to fat slots - a light-stage workgroup must fit the slot
+            // one retiring analysis workgroup frees (analysis_lds_pad) -, four (25.5 KB; one table copy per four runs) where it fills the chip unpadded
+            const bool fat_slots = analysis_lds_pad(c, (long long)S * n_out * 6) != 0;
+            if (fat_slots) {
+                if (c->js) hipLaunchKernelGGL((k_mdct_sub<true, 3>), dim3((unsigned)((mp.n_waves + 2) / 3)), dim3(192), 0, md, mp, c->d_tables);
+                else hipLaunchKernelGGL((k_mdct_sub<false, 3>), dim3((unsigned)((mp.n_waves + 2) / 3)), dim3(192), (size_t)c->dbg_pad[1], md, mp, c->d_tables);
+            } else {
+                if (c->js) hipLaunchKernelGGL((k_mdct_sub<true, 4>), dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, md, mp, c->d_tables);
+                else hipLaunchKernelGGL((k_mdct_sub<false, 4>), dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), (size_t)c->dbg_pad[1], md, mp, c->d_tables);
+            }
         } else {
             const int n_waves = S * 2 * fp.frame_runs;
             hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
@@ -1148,7 +1160,7 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
         mp.js = 1;
         mp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu_mdct, 0.3);
         mp.n_waves = S * 2 * mp.frame_runs;
-        hipLaunchKernelGGL(k_mdct_sub<true>, dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, st, mp, c->d_tables);
+        hipLaunchKernelGGL((k_mdct_sub<true, 4>), dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, st, mp, c->d_tables);
     } else {
         const int n_waves = S * 2 * fp.frame_runs;
         hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
