@@ -32,8 +32,14 @@ namespace at3 {
 // so one read instruction (fixed group offset) touches consecutive slots in consecutive work-items: conflict free.
 // Inside a group the two floats of a pair are swapped, (x[2k+1], x[2k]): the operand order of the packed tap product.
 constexpr int kHist8 = 48;
-constexpr int kPcmH8 = 74;    // slots per plane, >= 67 and = 2 mod 8 (planes 32 bytes out of phase for the 16-byte stores)
-constexpr int kS1H8 = 42;     // >= 35
+#ifndef K1_PCM_H
+#define K1_PCM_H 74
+#endif
+#ifndef K1_S1_H
+#define K1_S1_H 42
+#endif
+constexpr int kPcmH8 = K1_PCM_H;    // slots per plane, >= 67 and = 2 mod 8 (planes 32 bytes out of phase for the 16-byte stores)
+constexpr int kS1H8 = K1_S1_H;     // >= 35
 constexpr int kPcmRing8 = 16 * kPcmH8;   // floats per channel
 constexpr int kS1Ring8 = 16 * kS1H8;     // floats per (channel, half)
 
@@ -191,10 +197,10 @@ __device__ __forceinline__ void s1_hist_store(QmfLdsW& S, const QmfRunW& q, int 
     if (lane < 24) reinterpret_cast<float4*>(S.s1 + (lane / 12) * kS1Ring8)[ring8_slot<kS1H8>(lane % 12)] = q.s1_keep;
 }
 
-// The prologue's 144 floats of scratch sit in the body of the first stage-1 ring (behind its history slots, in front of
-// the second plane), which the first stage 1 overwrites afterwards.
+// The prologue's 144 floats of scratch sit in the body of the PCM ring's first plane (behind its three history slots, in
+// front of the second plane), which the tile store that ends the prologue overwrites afterwards.
 constexpr int kPrologueTmp = 16;
-static_assert(kPrologueTmp >= 12 && kPrologueTmp + 144 <= 4 * kS1H8, "prologue scratch must fit between the history and plane 1");
+static_assert(kPrologueTmp >= 12 && kPrologueTmp + 144 <= 4 * kPcmH8, "prologue scratch must fit between the history and plane 1");
 
 // Prologue of a run that starts with block b0: PCM history and stage-1 history of that block, then its tile.
 // `tmp` = 144 floats of scratch. On return the tile of block b0 is in the ring; with PREFETCH block b0 + 1 is being fetched.
@@ -225,6 +231,7 @@ __device__ __forceinline__ void qmf_prologue(QmfLdsW& S, QmfRunW& q, float* tmp,
         S.s1[kS1Ring8 + ring8_at<kS1H8>(lane)] = lo - hi;
         S.pcm[ring8_at<kPcmH8>(lane)] = tmp[96 + lane];   // samples -48 .. -1
     }
+    wave_sync();   // (the tile overwrites the scratch)
     tile_store(S, q, lane);
     if (PREFETCH && b0 + 1 <= b_last) tile_fetch(q, b0 + 1, lane);
     wave_sync();
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256) void k_qmf_sub8(FrontParams p, const Tables* T
     q.hist2 = reinterpret_cast<const float2*>(p.hist) + (size_t)s * kHist;
     q.ch = ch;
     q.s1_keep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    qmf_prologue<true>(S, q, S.s1 + kPrologueTmp, Wp, ba, bb - 1, lane);
+    qmf_prologue<true>(S, q, S.pcm + kPrologueTmp, Wp, ba, bb - 1, lane);
     const int which = lane >> 5, g = lane & 31;
     float* out_lo = p.sub + ((size_t)s * 8 + ch * 4 + (which ? 3 : 0)) * sublen + 8 * g;
     float* out_up = p.sub + ((size_t)s * 8 + ch * 4 + (which ? 2 : 1)) * sublen + 8 * g;
@@ -298,6 +305,12 @@ __device__ __forceinline__ float dpp_row_mirror(float v)
 {
     return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xf, 0xf, false));
 }
+// `v` of the mirror lane in the rows of ROWS (bit r = row r of the wavefront), `old` in the others
+template <int ROWS>
+__device__ __forceinline__ float dpp_row_mirror_rows(float old, float v)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(v), 0x140, ROWS, 0xf, false));
+}
 
 // Per-lane constants of the row transform. They depend on the lane's position in its row only (L = 4 q1 + q2), so one
 // table of 18 sixteen-byte entries per L serves every row of a workgroup; entry e of lane L sits at [e][L], which a
@@ -321,19 +334,28 @@ struct MdctTabRegs {
 template <int NT = 256>
 __device__ __forceinline__ MdctTabRegs mdct_tab_request(const Tables* T, int tid)
 {
-    static_assert(NT >= 144 && NT <= 288 && (288 - NT) % 32 == 0, "one or two entries per work-item");
+    static_assert(NT >= 144 && (NT >= 288 || (288 - NT) % 32 == 0), "one or two entries per work-item");
     const float4* flat = reinterpret_cast<const float4*>(&T->mdct_tab[0][0][0]);
     MdctTabRegs r;
-    r.a = flat[tid];
-    r.b = flat[NT + (tid < 288 - NT ? tid : 0)];
+    if (NT >= 288) {
+        r.a = flat[tid < 288 ? tid : 0];
+        r.b = r.a;
+    } else {
+        r.a = flat[tid];
+        r.b = flat[NT + (tid < 288 - NT ? tid : 0)];
+    }
     return r;
 }
 template <int NT = 256>
 __device__ __forceinline__ void mdct_tab_store(MdctTab& tab, const MdctTabRegs& r, int tid)
 {
     float4* flat = &tab.e[0][0];
-    flat[tid] = r.a;
-    if (tid < 288 - NT) flat[NT + tid] = r.b;
+    if (NT >= 288) {
+        if (tid < 288) flat[tid] = r.a;
+    } else {
+        flat[tid] = r.a;
+        if (tid < 288 - NT) flat[NT + tid] = r.b;
+    }
 }
 
 // The lane's sixteen samples from its row's 256. The lane reads the even-index pairs (x[i], x[i+1]) at i = e and
@@ -419,10 +441,18 @@ __device__ __forceinline__ f2 rot_pre(f2 a, f2 cs)
 // 127-e, 255-e}]; pw = the windowed overlap, same indexing, carried in registers from frame to frame; `inv_scale` =
 // 1 / GainLevel[first point] when the frame's curve is non-empty (the overlap half is divided by that level,
 // gain_processor.h:87-121), else 1. `scratch` = the row's kRowScratch4 16-byte slots. Returns the lane's sixteen
-// spectral lines as four runs of four consecutive lines: run i' starts at line 16 q1 + 4 q2 + 64 i' (natural order).
+// spectral lines as the four 16-byte stores of mdct_rows_store (odd bands already reversed: see the end of the function).
 // WAVE-UNIFORM: every lane of the wavefront must call (DPP and wave-level rendezvous inside).
+// XORS: the exchange scratch without its spare chunks - quad q's sixteen slots at 16 q, slot index ^ 4 in odd quads (the
+// same bank phase the padded layout gets from its 20-slot stride) - 64 instead of 80 slots per row.
+template <bool XORS>
+__device__ __forceinline__ int xslot(int quad, int idx)
+{
+    return XORS ? 16 * quad + (idx ^ ((quad & 1) << 2)) : 20 * quad + idx;
+}
+template <bool XORS = false>
 __device__ __forceinline__ void mdct_row_frame(const MdctTab& tab, const f2 (&tw2)[3], float (&pw)[4][4], const float (&X)[4][4], float inv_scale,
-                                               float4* scratch, int L, bool emit, float4 (&lines)[4])
+                                               float4* scratch, int L, bool emit, float4 (&slots)[4])
 {
     const int q1 = L >> 2, q2 = L & 3;
     f2 z[8];   // element j = 2 q3 + q4 of the lane's 8-point sub-transform
@@ -457,15 +487,14 @@ __device__ __forceinline__ void mdct_row_frame(const MdctTab& tab, const f2 (&tw
     }
     // exchange 1: butterfly k = 2 q2 + kappa of the m = 8 pass takes element k of the four lanes of the quad
     {
-        float4* w = scratch + 20 * q1 + 4 * q2;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) w[jj ^ q2] = make_float4(z[2 * jj].x, z[2 * jj].y, z[2 * jj + 1].x, z[2 * jj + 1].y);
+        for (int jj = 0; jj < 4; ++jj) scratch[xslot<XORS>(q1, 4 * q2 + (jj ^ q2))] = make_float4(z[2 * jj].x, z[2 * jj].y, z[2 * jj + 1].x, z[2 * jj + 1].y);
     }
     wave_sync();
     f2 y[2][4];   // [kappa][i]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float4 v = scratch[20 * q1 + 4 * i + (q2 ^ i)];
+        const float4 v = scratch[xslot<XORS>(q1, 4 * i + (q2 ^ i))];
         y[0][i] = f2lo(v);
         y[1][i] = f2hi(v);
     }
@@ -477,15 +506,14 @@ __device__ __forceinline__ void mdct_row_frame(const MdctTab& tab, const f2 (&tw
     }
     // exchange 2: butterfly k = 8 a + 2 q2 + kappa of the m = 32 pass takes (kappa, i = a) of the lanes (i', q2)
     {
-        float4* w = scratch + 20 * q2 + 4 * q1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i ^ q1] = make_float4(y[0][i].x, y[0][i].y, y[1][i].x, y[1][i].y);
+        for (int i = 0; i < 4; ++i) scratch[xslot<XORS>(q2, 4 * q1 + (i ^ q1))] = make_float4(y[0][i].x, y[0][i].y, y[1][i].x, y[1][i].y);
     }
     wave_sync();
     f2 u[2][4];   // [kappa][i']
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip) {
-        const float4 v = scratch[20 * q2 + 4 * ip + (q1 ^ ip)];
+        const float4 v = scratch[xslot<XORS>(q2, 4 * ip + (q1 ^ ip))];
         u[0][ip] = f2lo(v);
         u[1][ip] = f2hi(v);
     }
@@ -508,26 +536,32 @@ __device__ __forceinline__ void mdct_row_frame(const MdctTab& tab, const f2 (&tw
             O[kap][ip] = -r0 * ss + i0 * cc;
         }
     }
-    // lines 2B + 64 i' .. + 3 (B = 8 q1 + 2 q2) = E[0][i'], mirror O[1][3 - i'], E[1][i'], mirror O[0][3 - i']
+    // Lines 2B + 64 i' .. + 3 (B = 8 q1 + 2 q2) = E[0][i'], mirror O[1][3 - i'], E[1][i'], mirror O[0][3 - i'] - and odd bands are stored
+    // reversed (atrac3denc.cpp:53-55): the run of i' = 3 - j goes, back to front, to lines 252 - (2B + 64 i') .. + 3 = (60 - 2B) + 64 j .. + 3.
+    // So slot j of the lane's store order is, in even rows, the run i' = j and, in odd rows, the reversed run i' = 3 - j:
+    //   even rows  E[0][j],         mirror O[1][3 - j], E[1][j],         mirror O[0][3 - j]
+    //   odd rows   mirror O[0][j],  E[1][3 - j],        mirror O[1][j],  E[0][3 - j]
+    // - one row_mirror move per value with a ROW MASK (the rows that do not take the mirror lane's value keep `old`): no per-lane selects,
+    // no lane conditions round the stores, one store address per lane.
 #pragma unroll
-    for (int ip = 0; ip < 4; ++ip) {
-        const float o1 = dpp_row_mirror(O[1][3 - ip]);
-        const float o0 = dpp_row_mirror(O[0][3 - ip]);
-        lines[ip] = make_float4(E[0][ip], o1, E[1][ip], o0);
+    for (int j = 0; j < 4; ++j) {
+        slots[j].x = dpp_row_mirror_rows<0xA>(E[0][j], O[0][j]);
+        slots[j].y = dpp_row_mirror_rows<0x5>(E[1][3 - j], O[1][3 - j]);
+        slots[j].z = dpp_row_mirror_rows<0xA>(E[1][j], O[1][j]);
+        slots[j].w = dpp_row_mirror_rows<0x5>(E[0][3 - j], O[0][3 - j]);
     }
 }
 
-// Store a row's spectrum: odd bands are reversed (atrac3denc.cpp:53-55).
-__device__ __forceinline__ void mdct_row_store(float* dst256, const float4 (&lines)[4], int L, bool odd)
+// Store a wavefront's four spectra (row = band) of one channel-frame: `frame_ch` = the channel-frame's 1024 lines (wave-uniform),
+// slots as mdct_row_frame returns them. Slot j of lane (band, L) starts at line 256 band + 64 j + (band odd ? 60 - 2B : 2B).
+__device__ __forceinline__ void mdct_rows_store(float* frame_ch, const float4 (&slots)[4], int lane)
 {
-    const int base = 16 * (L >> 2) + 4 * (L & 3);
+    const int band = lane >> 4, L = lane & 15;
+    const int line0 = 16 * (L >> 2) + 4 * (L & 3);
+    const unsigned off = (unsigned)(256 * band + ((band & 1) ? 60 - line0 : line0));
+    float4* dst = reinterpret_cast<float4*>(frame_ch + off);
 #pragma unroll
-    for (int ip = 0; ip < 4; ++ip) {
-        const int line = base + 64 * ip;
-        const float4 v = lines[ip];
-        if (odd) *reinterpret_cast<float4*>(dst256 + 252 - line) = make_float4(v.w, v.z, v.y, v.x);
-        else *reinterpret_cast<float4*>(dst256 + line) = v;
-    }
+    for (int j = 0; j < 4; ++j) dst[16 * j] = slots[j];
 }
 
 // ---- MDCT from subbands in HBM (the gain-control path: k_qmf_sub8 wrote them for the gain analysis anyway) -----------
@@ -573,7 +607,8 @@ __global__ __launch_bounds__(64 * NW) void k_mdct_sub(MdctSubParams p, const Tab
     __shared__ __attribute__((aligned(16))) Curve s_cv[NW][4];
     __shared__ float s_gi[32];
     static_assert(kRowScratch4 * 4 >= 256, "a row's 256 divisors share its exchange scratch");
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((unsigned)tid >> 6);   // (uniform: the run's indices and base addresses live in scalar registers)
     // (a wavefront beyond the batch stays for the rendezvous below with the last run's indices and leaves after it)
     const bool live = (int)blockIdx.x * NW + wave < p.n_waves;
     const int W = live ? (int)blockIdx.x * NW + wave : p.n_waves - 1;
@@ -601,7 +636,7 @@ __global__ __launch_bounds__(64 * NW) void k_mdct_sub(MdctSubParams p, const Tab
     float4* scratch = s_x[wave] + band * kRowScratch4;
     float* divs = reinterpret_cast<float*>(scratch);
     Curve& cv = s_cv[wave][band];
-    float* spec_base = p.specs + ((size_t)s * n_out * 2 + ch) * 1024 + band * 256;
+    float* spec_base = p.specs + ((size_t)s * n_out * 2 + ch) * 1024;   // (uniform)
     // block f - 1 is frame f's new half; block fa - 2 primes the overlap of the run (modulated by frame fa - 1's curve).
     // The subbands of the next block are requested before the current one is transformed: a wavefront waits for HBM once.
     const MdctTabRegs tab_regs = mdct_tab_request<64 * NW>(T, tid);
@@ -671,9 +706,9 @@ __global__ __launch_bounds__(64 * NW) void k_mdct_sub(MdctSubParams p, const Tab
                 }
             }
         }
-        float4 lines[4];
-        mdct_row_frame(s_tab, tw2, pw, X, emit ? inv_scale : 1.0f, scratch, L, emit, lines);
-        if (emit) mdct_row_store(spec_base + (size_t)(f - p.f0) * 2048, lines, L, band & 1);
+        float4 slots[4];
+        mdct_row_frame(s_tab, tw2, pw, X, emit ? inv_scale : 1.0f, scratch, L, emit, slots);
+        if (emit) mdct_rows_store(spec_base + (size_t)(f - p.f0) * 2048, slots, lane);
     }
 }
 
@@ -682,19 +717,67 @@ __global__ __launch_bounds__(64 * NW) void k_mdct_sub(MdctSubParams p, const Tab
 // overlap. The wavefront runs stage 1, stage 2 and the four bands' transforms of a block back to back; its subbands
 // and exchange scratch reuse the rings that are dead at that point (the PCM ring after stage 1, the stage-1 rings after
 // stage 2), 10 KB of LDS per wavefront in all. A workgroup is four independent wavefronts sharing the MDCT table.
-__global__ __launch_bounds__(256) void k_qmf_mdct8(FrontParams p, const Tables* T, int n_waves)
+#ifndef K1_ATTR
+#define K1_ATTR
+#endif
+#ifndef K1_NW
+#define K1_NW 4
+#endif
+#ifndef K1_EARLY
+#define K1_EARLY 0
+#endif
+#ifndef K1_XOR
+#define K1_XOR 0
+#endif
+#ifndef K1_FETCH_AT
+#define K1_FETCH_AT 0
+#endif
+#ifndef K1_OPAQUE
+#define K1_OPAQUE (K1_NW > 4)
+#endif
+#if K1_OPAQUE
+#define K1_LANE(l) opaque_lane_value(l)
+#else
+#define K1_LANE(l) (l)
+#endif
+constexpr int kFusedWaves = K1_NW;          // wavefronts per workgroup of the fused kernel (they share the MDCT table)
+constexpr bool kFusedEarlyTile = K1_EARLY;  // the next tile moves into the PCM ring as soon as the subbands were gathered
+constexpr bool kFusedXor = K1_XOR;          // exchange scratch without spare chunks (64 slots per row)
+constexpr int kFusedRowScratch4 = kFusedXor ? 64 : kRowScratch4;
+// Where the exchange scratch of the four rows starts (in floats from the PCM ring's start): behind the block's subbands when
+// it may use the ring's tail, at the stage-1 rings when the next tile moves into the PCM ring before the transform.
+constexpr int kFusedScratchAt = kFusedEarlyTile ? kPcmRing8 : 4 * 264;
+static_assert(kPcmRing8 >= 4 * 264, "the block's subbands reuse the PCM ring");
+static_assert((kPcmRing8 + 2 * kS1Ring8 - kFusedScratchAt) * sizeof(float) >= sizeof(float4) * 4 * kFusedRowScratch4, "the exchange scratch reuses the rings");
+#ifdef K1_STAMPS
+#define K1_STAMP(k) do { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); ph[k] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define K1_STAMP(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(64 * kFusedWaves) K1_ATTR void k_qmf_mdct8(FrontParams p, const Tables* T, int n_waves)
 {
+    constexpr int NW = kFusedWaves;
+#ifdef K1_TAB_GLOBAL
+    const MdctTab& s_tab = *reinterpret_cast<const MdctTab*>(&T->mdct_tab[0][0][0]);
+#else
     __shared__ __attribute__((aligned(16))) MdctTab s_tab;
-    __shared__ __attribute__((aligned(16))) QmfLdsW s_q[4];
-    static_assert(sizeof(float) * kPcmRing8 >= sizeof(float) * 4 * 264, "the block's subbands reuse the PCM ring");
-    static_assert(sizeof(float) * 2 * kS1Ring8 >= sizeof(float4) * 4 * kRowScratch4, "the exchange scratch reuses the stage-1 rings");
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#endif
+    __shared__ __attribute__((aligned(16))) QmfLdsW s_q[NW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane((unsigned)tid >> 6);   // (uniform: the run's indices, bounds and base addresses live in scalar registers)
     // The shared table is asked for first and stored behind the run's prologue - the wavefront's first PCM requests do not queue up
     // behind a workgroup rendezvous. (A wavefront past the end of the launch runs the last run's prologue, which writes nothing but
     // its own LDS, and leaves after the rendezvous.)
-    const MdctTabRegs tab_regs = mdct_tab_request(T, tid);
+#ifndef K1_TAB_GLOBAL
+    const MdctTabRegs tab_regs = mdct_tab_request<64 * NW>(T, tid);
     __builtin_amdgcn_sched_barrier(0);
-    const int W0 = blockIdx.x * 4 + wave;
+#endif
+#ifdef K1_STAMPS
+    unsigned ph[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime(), r_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned t_prev = (unsigned)t_begin;
+#endif
+    const int W0 = blockIdx.x * NW + wave;
     const bool live = W0 < n_waves;
     const int W = live ? W0 : n_waves - 1;
     QmfLdsW& S = s_q[wave];
@@ -712,8 +795,6 @@ __global__ __launch_bounds__(256) void k_qmf_mdct8(FrontParams p, const Tables* 
     q.hist2 = reinterpret_cast<const float2*>(p.hist) + (size_t)s * kHist;
     q.ch = ch;
     q.s1_keep = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const int band = lane >> 4, L = lane & 15;
-    const int b = (L >> 2) + 4 * (L & 3);
     float pw[4][4];
 #pragma unroll
     for (int q3 = 0; q3 < 4; ++q3)
@@ -723,30 +804,47 @@ __global__ __launch_bounds__(256) void k_qmf_mdct8(FrontParams p, const Tables* 
 #pragma unroll
     for (int j = 0; j < 3; ++j) tw2[j] = ld2(T->tw128 + 16 * (j + 1));
     float (*sub)[264] = reinterpret_cast<float (*)[264]>(S.pcm);            // [band][256 + pad], after stage 1
-    float4* scratch = reinterpret_cast<float4*>(S.s1) + band * kRowScratch4;   // after stage 2
     const int b0 = fa - 2, b_last = fb - 2;
-    qmf_prologue<false>(S, q, S.s1 + kPrologueTmp, Wp, b0, b_last, lane);
-    mdct_tab_store(s_tab, tab_regs, tid);
+    qmf_prologue<false>(S, q, S.pcm + kPrologueTmp, Wp, b0, b_last, lane);
+#ifndef K1_TAB_GLOBAL
+    mdct_tab_store<64 * NW>(s_tab, tab_regs, tid);
     __syncthreads();   // the only workgroup-level rendezvous: the shared table
+#endif
     if (!live) return;
-    float* spec_base = p.specs + ((size_t)s * n_out * 2 + ch) * 1024 + band * 256;
-    const int which = lane >> 5, g = lane & 31;
+    K1_STAMP(0);
+    // Per-lane LDS and HBM offsets are formed again in every block, phase by phase, from a lane index the optimiser cannot see
+    // through (opaque_lane_value): hoisted in front of the loop - where the compiler puts anything loop-invariant - they were
+    // fifty registers held for the whole run, the difference between three and four wavefronts per SIMD.
+    const float* frame_base = p.specs + ((size_t)s * n_out * 2 + ch) * 1024;
     for (int blk = b0; blk <= b_last; ++blk) {
-        if (blk > b0) {
-            // the ring held the previous block's subbands until its transform had gathered them: now the tile
-            // (fetched one block ago) and the FIR histories move in
-            pcm_hist_store(S, q, lane);   // the tail of the previous tile, before tile_store replaces the copy in registers
-            tile_store(S, q, lane);
-            s1_hist_store(S, q, lane);
-            wave_sync();
-        }
-        if (blk + 1 <= b_last) tile_fetch(q, blk + 1, lane);   // lands during this block's arithmetic
-        qmf_stage1(S, Wp, lane);
-        wave_sync();
-        s1_hist_fetch(S, q, lane);
         {
+            const int ln = K1_LANE(lane);
+            if (!kFusedEarlyTile && blk > b0) {
+                // the ring held the previous block's subbands until its transform had gathered them: now the tile
+                // (fetched one block ago) and the FIR histories move in
+                pcm_hist_store(S, q, ln);   // the tail of the previous tile, before tile_store replaces the copy in registers
+                tile_store(S, q, ln);
+            }
+            if (blk > b0) {
+                s1_hist_store(S, q, ln);
+                wave_sync();
+            }
+            if (K1_FETCH_AT == 0 && blk + 1 <= b_last) tile_fetch(q, blk + 1, ln);   // lands during this block's arithmetic
+        }
+        K1_STAMP(1);
+        {
+            const int ln = K1_LANE(lane);
+            qmf_stage1(S, Wp, ln);
+            wave_sync();
+            s1_hist_fetch(S, q, ln);
+            if (K1_FETCH_AT == 1 && blk + 1 <= b_last) tile_fetch(q, blk + 1, ln);   // lands during stage 2
+        }
+        K1_STAMP(2);
+        {
+            const int ln = K1_LANE(lane);
+            const int which = ln >> 5, g = ln & 31;
             float lo[8], up[8];
-            qmf_stage2(S, Wp, lane, lo, up);
+            qmf_stage2(S, Wp, ln, lo, up);
             wave_sync();   // every lane is done with the rings (the exchange scratch and the subbands overwrite them)
             float4* o0 = reinterpret_cast<float4*>(&sub[which ? 3 : 0][8 * g]);
             float4* o1 = reinterpret_cast<float4*>(&sub[which ? 2 : 1][8 * g]);
@@ -756,17 +854,45 @@ __global__ __launch_bounds__(256) void k_qmf_mdct8(FrontParams p, const Tables* 
             o1[1] = make_float4(up[4], up[5], up[6], up[7]);
         }
         wave_sync();
+        K1_STAMP(3);
         {
             const int f = blk + 1;
             float X[4][4];
-            row_gather([&](int i) { return *reinterpret_cast<const f2*>(&sub[band][i]); }, b, X);
-            wave_sync();
+            {
+                const int ln = K1_LANE(lane);
+                const int band = ln >> 4, L = ln & 15;
+                const int b = (L >> 2) + 4 * (L & 3);
+                row_gather([&](int i) { return *reinterpret_cast<const f2*>(&sub[band][i]); }, b, X);
+                wave_sync();
+                if (kFusedEarlyTile && blk < b_last) {
+                    // the subbands are in registers: the next tile (requested earlier in this block) and the tail of this one move into the ring
+                    pcm_hist_store(S, q, ln);
+                    tile_store(S, q, ln);
+                }
+            }
+            K1_STAMP(4);
             const bool emit = f >= fa;
-            float4 lines[4];
-            mdct_row_frame(s_tab, tw2, pw, X, 1.0f, scratch, L, emit, lines);
-            if (emit) mdct_row_store(spec_base + (size_t)(f - p.f0) * 2048, lines, L, band & 1);
+            float4 slots[4];
+            {
+                const int ln = K1_LANE(lane);
+                const int band = ln >> 4, L = ln & 15;
+                float4* scratch = reinterpret_cast<float4*>(S.pcm + kFusedScratchAt) + band * kFusedRowScratch4;   // after stage 2 (and the gather)
+                mdct_row_frame<kFusedXor>(s_tab, tw2, pw, X, 1.0f, scratch, L, emit, slots);
+            }
+            if (emit) mdct_rows_store(const_cast<float*>(frame_base) + (size_t)(f - p.f0) * 2048, slots, K1_LANE(lane));
+            K1_STAMP(5);
         }
     }
+#ifdef K1_STAMPS
+    if (p.clk && lane == 0) {
+        unsigned long long* row = p.clk + 16 + (W0 & 255) * 12;
+        for (int k = 0; k < 6; ++k) atomicAdd(row + k, (unsigned long long)ph[k]);
+        atomicAdd(row + 6, __builtin_amdgcn_s_memtime() - t_begin);
+        atomicAdd(row + 7, __builtin_amdgcn_s_memrealtime() - r_begin);
+        atomicAdd(row + 8, 1ull);
+        atomicAdd(row + 9, (unsigned long long)(b_last - b0 + 1));
+    }
+#endif
 }
 
 }  // namespace at3

@@ -27,6 +27,7 @@ struct FrontParams {
     int js;
     int sub_runs;            // k_qmf_sub8: runs per (stream, channel) the n_blocks + 2 blocks are cut into
     int debug;               // profiling aid (env AT3HIP_DEBUG_FRONT, debug builds): 3 = skip the energy-scale chains
+    unsigned long long* clk; // profiling builds (-DK1_STAMPS): per-phase cycle sums of the fused kernel's wavefronts (AT3HIP_TAP_CLOCK), else null
 };
 
 // The divisors of the eight samples of cell `cell / 8` under a curve given as its two 8-byte halves (n, level[7] |

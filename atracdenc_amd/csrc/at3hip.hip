@@ -439,8 +439,9 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
         int nb = 0;
         const bool gain = !c->cfg.no_gain_control;
         const hipError_t e = (gain || c->js) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_sub8, 256, 0)
-                                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_mdct8, 256, 0);
-        c->wgs_per_cu = (e == hipSuccess && nb > 0) ? nb : 3;
+                                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_qmf_mdct8, 64 * kFusedWaves, 0);
+        // (pick_runs' unit is resident wavefronts per SIMD: a four-wavefront workgroup is one per SIMD)
+        c->wgs_per_cu = (e == hipSuccess && nb > 0) ? ((gain || c->js) ? nb : nb * kFusedWaves / 4) : 3;
         nb = 0;
         c->wgs_per_cu_mdct = ((c->js ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_mdct_sub<true, 4>), 256, 0)
                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_mdct_sub<false, 4>), 256, 0)) == hipSuccess && nb > 0) ? nb : 3;   // (wavefronts per SIMD, pick_runs' unit: the same three for the three-wavefront form, four workgroups per CU)
@@ -758,6 +759,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         fp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu, 1.35);
         fp.sub_runs = 0;
         fp.debug = c->dbg_front;
+        fp.clk = nullptr;
         fp.js = c->js;
         const bool split = gain || c->js;   // QMF and MDCT as two kernels with the subbands in HBM between them
         auto launch_qmf_sub = [&] {
@@ -826,7 +828,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             }
         } else {
             const int n_waves = S * 2 * fp.frame_runs;
-            hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
+            hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + kFusedWaves - 1) / kFusedWaves)), dim3(64 * kFusedWaves), 0, st, fp, c->d_tables, n_waves);
         }
         HIPCHK(c, hipEventRecord(ev[4], md));
         c->slot_k1_launches[slot] = split ? 2 : 1;
@@ -923,7 +925,7 @@ int at3hip_read_tap(at3hip_ctx* c, int32_t kind, void* dst, size_t bytes)
     HIPCHK(c, guard.error());
     const int rc = drain(c);
     if (rc != AT3HIP_OK) return rc;
-    if (c->enc_calls == 0) return fail(c, AT3HIP_EINVAL, "no encode call yet");
+    if (c->enc_calls == 0 && kind != AT3HIP_TAP_CLOCK) return fail(c, AT3HIP_EINVAL, "no encode call yet");
     const int par = (int)((c->enc_calls - 1) & 1);
     const size_t S = c->cfg.n_streams, B = c->cfg.max_blocks;
     const void* src = nullptr;
@@ -1134,6 +1136,11 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
     fp.sub = nullptr;
     fp.sub_runs = 0;
     fp.debug = 0;
+#ifdef K1_STAMPS
+    fp.clk = c->d_clk;
+#else
+    fp.clk = nullptr;
+#endif
     fp.n_blocks = n_blocks;
     fp.f0 = 1;
     const int n_out = n_blocks - 1;
@@ -1163,7 +1170,7 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
         hipLaunchKernelGGL((k_mdct_sub<true, 4>), dim3((unsigned)((mp.n_waves + 3) / 4)), dim3(256), 0, st, mp, c->d_tables);
     } else {
         const int n_waves = S * 2 * fp.frame_runs;
-        hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
+        hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + kFusedWaves - 1) / kFusedWaves)), dim3(64 * kFusedWaves), 0, st, fp, c->d_tables, n_waves);
     }
     HIPCHK(c, hipEventRecord(c->ev[0][1], st));
     HIPCHK(c, hipGetLastError());

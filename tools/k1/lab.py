@@ -1,0 +1,65 @@
+"""GPU box: the fused QMF + MDCT kernel alone (at3hip_qmf_mdct: HIP events round the one launch) for several builds of the library,
+alternating on the same box, at configs[1]'s size and at the per-GPU shard of configs[2]; a checksum of the spectra says whether a
+variant still produces the baseline's bits.   usage: python tools/k1/lab.py [--sizes 64x64,1024x128] [--runs R,..] lib1.so lib2.so ..."""
+import os, sys, ctypes
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/../..")
+import torch
+from atracdenc_amd import binding as B
+
+def main():
+    a = sys.argv[1:]
+    sizes = "64x64,1024x128"
+    runs = [0]
+    reps = 3
+    libs = []
+    i = 0
+    while i < len(a):
+        if a[i] == "--sizes": sizes = a[i + 1]; i += 2
+        elif a[i] == "--runs": runs = [int(x) for x in a[i + 1].split(",")]; i += 2
+        elif a[i] == "--reps": reps = int(a[i + 1]); i += 2
+        else: libs.append(a[i]); i += 1
+    sizes = [tuple(int(x) for x in s.split("x")) for s in sizes.split(",")]
+    res = {}
+    sums = {}
+    for S, F in sizes:
+        nb = F + 1
+        g = torch.Generator(device="cuda"); g.manual_seed(1)
+        pcm = (torch.randint(-8192, 8192, (S, nb, 1024, 2), generator=g, device="cuda", dtype=torch.int32).to(torch.float32) / 32768.0).contiguous()
+        specs = torch.zeros((S, F, 2, 1024), dtype=torch.float32, device="cuda")
+        n_iter = 400 if S * F <= 8192 else 80   # (the first launches of a burst run in the power manager's transient: only the second half is kept)
+        for rep in range(reps):
+            for lib in libs:
+                for r in runs:
+                    enc = B.At3Hip(n_streams=S, max_blocks=nb, no_gain=True, lib_path=os.path.abspath(lib))
+                    if r: enc.set_option(1, r)
+                    specs.zero_()
+                    ms = []
+                    for it in range(n_iter):
+                        enc.qmf_mdct_device(pcm.data_ptr(), nb, specs.data_ptr())
+                        ms.append(enc.timings()["qmf_mdct_ms"])
+                    torch.cuda.synchronize()
+                    v = specs.view(torch.int32).to(torch.int64)
+                    cs = int((v * (torch.arange(v.numel(), device="cuda").view(v.shape) % 1000003 + 1)).sum().item()) & 0xffffffffffff
+                    if "stamps" in lib and rep == 0:
+                        c = enc.read_tap(B.TAP_CLOCK, np.uint64, (16 + 256 * 12,)).astype(np.float64)[16:].reshape(256, 12).sum(axis=0)
+                        waves, blocks = c[8], c[9]
+                        names = ["prologue", "hist/tile in, fetch", "stage 1", "stage 2 + subbands out", "gather (+ early tile)", "MDCT + store"]
+                        print("  %s %dx%d runs=%d: %d wavefront-launches, %.1f blocks per wavefront, life %.0f cycles, sclk %.0f MHz" % (
+                            os.path.basename(lib), S, F, r, waves, blocks / waves, c[6] / waves, 100.0 * c[6] / max(c[7], 1)))
+                        for k in range(6):
+                            print("    %-24s %9.0f cycles per wavefront  %8.0f per block  %5.1f %%" % (names[k], c[k] / waves, c[k] / blocks, 100 * c[k] / c[:6].sum()))
+                    enc.close()
+                    key = (S, F, os.path.basename(lib), r)
+                    res.setdefault(key, []).extend(ms[len(ms) // 2:])
+                    sums[key] = cs
+    base = {}
+    for (S, F, lib, r), ms in res.items():
+        ms = np.array(ms) * 1e3
+        cs = sums[(S, F, lib, r)]
+        base.setdefault((S, F), cs)
+        by = S * F * 16384
+        print("%5dx%-4d %-34s runs=%-3d min %8.2f us  med %8.2f us  hbm_frac(med) %.3f  %s" % (
+            S, F, lib, r, ms.min(), np.median(ms), by / (np.median(ms) * 1e-6) / 8e12, "same-bits" if cs == base[(S, F)] else "BITS-DIFFER"))
+
+main()
