@@ -130,26 +130,40 @@ __device__ __forceinline__ float pcm_at(const QmfRunW& q, int g)   // sample g (
 // Fetch the tile of block b into registers: group u = samples 4u .. 4u+3 arrive as two 16-byte loads of (L, R) pairs.
 __device__ __forceinline__ void tile_fetch(QmfRunW& q, int b, int lane)
 {
+    // (a block never straddles the history boundary - block starts are multiples of 1024 samples -, so the block's base is
+    // wave-uniform: one scalar base and one 32-bit lane offset serve the eight loads)
+    const float4* base = (b >= 0) ? reinterpret_cast<const float4*>(q.pcm2 + (ptrdiff_t)b * 1024) : reinterpret_cast<const float4*>(q.hist2 + (kHist + b * 1024));
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const int g = b * 1024 + 4 * (lane + 64 * w);
-        // (a block never straddles the history boundary: block starts are multiples of 1024 samples)
-        const float4* p4 = (g >= 0) ? reinterpret_cast<const float4*>(q.pcm2 + g) : reinterpret_cast<const float4*>(q.hist2 + (kHist + g));
-        q.nxt[2 * w] = p4[0];
-        q.nxt[2 * w + 1] = p4[1];
+        const unsigned u = 2u * (unsigned)(lane + 64 * w);
+        q.nxt[2 * w] = base[u];
+        q.nxt[2 * w + 1] = base[u + 1];
     }
 }
 
 // Store the fetched tile into the ring (data / 4.0, exact) and keep the last 48 samples for the history.
 __device__ __forceinline__ void tile_store(QmfLdsW& S, QmfRunW& q, int lane)
 {
+    // (the channel is wave-uniform: ONE scalar branch picks between two straight sequences of sixteen multiplies and four stores;
+    // written as a select per value the compiler copied the chosen half of every register pair first)
+    float4* ring = reinterpret_cast<float4*>(S.pcm) + ring8_slot<kPcmH8>(kHist8 / 4 + lane);
+    // (sixty-four groups on are sixteen slots on in the same plane)
+    if (q.ch) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const float4 a = q.nxt[2 * w], b = q.nxt[2 * w + 1];   // (L0, R0, L1, R1), (L2, R2, L3, R3)
-        const float4 v = q.ch ? make_float4(a.w * 0.25f, a.y * 0.25f, b.w * 0.25f, b.y * 0.25f)
-                              : make_float4(a.z * 0.25f, a.x * 0.25f, b.z * 0.25f, b.x * 0.25f);
-        reinterpret_cast<float4*>(S.pcm)[ring8_slot<kPcmH8>(kHist8 / 4 + lane + 64 * w)] = v;
-        if (w == 3) q.hist_keep = v;
+        for (int w = 0; w < 4; ++w) {
+            const float4 a = q.nxt[2 * w], b = q.nxt[2 * w + 1];   // (L0, R0, L1, R1), (L2, R2, L3, R3)
+            const float4 v = make_float4(a.w * 0.25f, a.y * 0.25f, b.w * 0.25f, b.y * 0.25f);
+            ring[16 * w] = v;
+            if (w == 3) q.hist_keep = v;
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float4 a = q.nxt[2 * w], b = q.nxt[2 * w + 1];
+            const float4 v = make_float4(a.z * 0.25f, a.x * 0.25f, b.z * 0.25f, b.x * 0.25f);
+            ring[16 * w] = v;
+            if (w == 3) q.hist_keep = v;
+        }
     }
 }
 
@@ -244,7 +258,8 @@ __device__ __forceinline__ void qmf_prologue(QmfLdsW& S, QmfRunW& q, float* tmp,
 __global__ __launch_bounds__(256) void k_qmf_sub8(FrontParams p, const Tables* T, int n_waves)
 {
     __shared__ __attribute__((aligned(16))) QmfLdsW s_q[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the run's indices and base addresses live in scalar registers)
     const int W = blockIdx.x * 4 + wave;
     if (W >= n_waves) return;
     QmfLdsW& S = s_q[wave];
@@ -450,33 +465,60 @@ __device__ __forceinline__ int xslot(int quad, int idx)
 {
     return XORS ? 16 * quad + (idx ^ ((quad & 1) << 2)) : 20 * quad + idx;
 }
+// The fold of mdct.h:64-86 in its two halves. A frame's FFT inputs are sums and differences of products of the NEW half's samples
+// (A = (r0a, i0b) per q3) and of the windowed OVERLAP (B = (i0a, r0b) per q3): a run that starts in the middle of a stream can form A
+// of its first frame at once and B only when the run before it has finished its last block (k_qmf_mdct8's chained runs).
+// fold_new also leaves the next frame's overlap = EncodeWindow[i] * new[i] (atrac3denc.cpp:47) in pw.
+__device__ __forceinline__ void mdct_fold_old(const float (&pw)[4][4], float inv_scale, float (&B)[4][2])
+{
+#pragma unroll
+    for (int q3 = 0; q3 < 4; ++q3) {
+        const float p0 = pw[q3][0] * inv_scale, p1 = pw[q3][1] * inv_scale, p2 = pw[q3][2] * inv_scale, p3 = pw[q3][3] * inv_scale;
+        B[q3][0] = p1 - p2;   // i0a
+        B[q3][1] = p3 - p0;   // r0b
+    }
+}
+__device__ __forceinline__ void mdct_fold_new(const MdctTab& tab, float (&pw)[4][4], const float (&X)[4][4], int L, bool want_a, float (&A)[4][2])
+{
+#pragma unroll
+    for (int q3 = 0; q3 < 4; ++q3) {
+        const float4 w = tab.e[q3][L];
+        pw[q3][0] = w.x * X[q3][0];
+        pw[q3][1] = w.y * X[q3][1];
+        pw[q3][2] = w.z * X[q3][2];
+        pw[q3][3] = w.w * X[q3][3];
+        if (want_a) {
+            A[q3][0] = w.y * X[q3][2] + w.z * X[q3][1];   // r0a
+            A[q3][1] = w.w * X[q3][0] + w.x * X[q3][3];   // i0b
+        }
+    }
+}
+template <bool XORS>
+__device__ __forceinline__ void mdct_row_transform(const MdctTab& tab, const f2 (&tw2)[3], const float (&A)[4][2], const float (&B)[4][2], float4* scratch, int L, float4 (&slots)[4]);
+
 template <bool XORS = false>
 __device__ __forceinline__ void mdct_row_frame(const MdctTab& tab, const f2 (&tw2)[3], float (&pw)[4][4], const float (&X)[4][4], float inv_scale,
                                                float4* scratch, int L, bool emit, float4 (&slots)[4])
+{
+    float A[4][2], B[4][2];
+    if (emit) mdct_fold_old(pw, inv_scale, B);
+    mdct_fold_new(tab, pw, X, L, emit, A);
+    if (!emit) return;   // priming block: only the overlap is wanted (uniform per wavefront)
+    mdct_row_transform<XORS>(tab, tw2, A, B, scratch, L, slots);
+}
+
+// The transform proper: pre-rotation (mdct.h:76-86), the 128-point FFT in the row's sixteen lanes, post-rotation, store order.
+template <bool XORS>
+__device__ __forceinline__ void mdct_row_transform(const MdctTab& tab, const f2 (&tw2)[3], const float (&A)[4][2], const float (&B)[4][2], float4* scratch, int L, float4 (&slots)[4])
 {
     const int q1 = L >> 2, q2 = L & 3;
     f2 z[8];   // element j = 2 q3 + q4 of the lane's 8-point sub-transform
 #pragma unroll
     for (int q3 = 0; q3 < 4; ++q3) {
-        const float4 w = tab.e[q3][L];
-        const float p0 = pw[q3][0] * inv_scale, p1 = pw[q3][1] * inv_scale, p2 = pw[q3][2] * inv_scale, p3 = pw[q3][3] * inv_scale;
-        // next frame's overlap = EncodeWindow[i] * new[i] (atrac3denc.cpp:47)
-        pw[q3][0] = w.x * X[q3][0];
-        pw[q3][1] = w.y * X[q3][1];
-        pw[q3][2] = w.z * X[q3][2];
-        pw[q3][3] = w.w * X[q3][3];
-        if (emit) {
-            // fold (mdct.h:64-86): n = e < 128 and n = 128 + e
-            const float r0a = w.y * X[q3][2] + w.z * X[q3][1];
-            const float i0a = p1 - p2;
-            const float r0b = p3 - p0;
-            const float i0b = w.w * X[q3][0] + w.x * X[q3][3];
-            const float4 cs = tab.e[4 + q3][L];
-            z[2 * q3] = rot_pre(mk2(r0a, i0a), f2lo(cs));
-            z[2 * q3 + 1] = rot_pre(mk2(r0b, i0b), f2hi(cs));
-        }
+        const float4 cs = tab.e[4 + q3][L];
+        z[2 * q3] = rot_pre(mk2(A[q3][0], B[q3][0]), f2lo(cs));       // n = e < 128: (r0a, i0a)
+        z[2 * q3 + 1] = rot_pre(mk2(B[q3][1], A[q3][1]), f2hi(cs));   // n = 128 + e: (r0b, i0b)
     }
-    if (!emit) return;   // priming block: only the overlap is wanted (uniform per wavefront)
     // radix-2 leaves (m = 1, twiddle tw[0]) and the m = 2 pass (butterfly k on elements k, k+2, k+4, k+6)
     {
         const f2 w0 = mk2(1.0f, 0.0f);   // tw128[0] = (cos 0, sin 0)
@@ -773,7 +815,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) K1_ATTR void k_qmf_mdct8(FrontPar
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifdef K1_STAMPS
-    unsigned ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned ph[7] = {0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime(), r_begin = __builtin_amdgcn_s_memrealtime();
     unsigned t_prev = (unsigned)t_begin;
 #endif
@@ -786,8 +828,26 @@ __global__ __launch_bounds__(64 * kFusedWaves) K1_ATTR void k_qmf_mdct8(FrontPar
     const int chunk = W % nchunks;
     const int ch = (W / nchunks) & 1;
     const int s = W / (2 * nchunks);
-    const int fa = p.f0 + (chunk * n_out) / nchunks;
-    const int fb = p.f0 + ((chunk + 1) * n_out) / nchunks;
+    // Blocks b0 .. b_last of the run; block b carries frame b + 1, whose overlap is block b - 1. The run's FIRST block only leaves its
+    // windowed samples behind as the next frame's overlap. Unchained (p.chain == 0) that block is one the run before this one computes as
+    // well: every run pays a whole block's FIR to prime its overlap. CHAINED (p.chain != 0; the host picks it when a run is a few frames
+    // long, then frame_runs is a multiple of NW), the NW wavefronts of a workgroup are NW consecutive runs of one (stream, channel) that cut
+    // the group's frames + ONE priming block between them: wavefront j > 0 starts with a block whose frame it owns, forms the half of that
+    // frame's fold that needs the new samples at once (parked in the frame's own slot of the spectra), and finishes the frame after the
+    // rendezvous at the end, when wavefront j - 1 has left the other half - the differences of ITS last windowed samples - in LDS.
+    int b0, b_last;
+    bool deferred = false;
+    if (p.chain) {
+        const int groups = nchunks / NW, grp = chunk / NW;
+        const int ga = p.f0 + (grp * n_out) / groups, gb = p.f0 + ((grp + 1) * n_out) / groups;   // the group's frames
+        const int nblk = gb - ga + 1;                                                              // + the priming block ga - 2
+        b0 = ga - 2 + (wave * nblk) / NW;
+        b_last = ga - 2 + ((wave + 1) * nblk) / NW - 1;
+        deferred = wave > 0;
+    } else {
+        b0 = p.f0 + (chunk * n_out) / nchunks - 2;
+        b_last = p.f0 + ((chunk + 1) * n_out) / nchunks - 2;
+    }
     f2 Wp[24];
     load_taps(T, Wp);
     QmfRunW q;
@@ -804,13 +864,12 @@ __global__ __launch_bounds__(64 * kFusedWaves) K1_ATTR void k_qmf_mdct8(FrontPar
 #pragma unroll
     for (int j = 0; j < 3; ++j) tw2[j] = ld2(T->tw128 + 16 * (j + 1));
     float (*sub)[264] = reinterpret_cast<float (*)[264]>(S.pcm);            // [band][256 + pad], after stage 1
-    const int b0 = fa - 2, b_last = fb - 2;
     qmf_prologue<false>(S, q, S.pcm + kPrologueTmp, Wp, b0, b_last, lane);
 #ifndef K1_TAB_GLOBAL
     mdct_tab_store<64 * NW>(s_tab, tab_regs, tid);
     __syncthreads();   // the only workgroup-level rendezvous: the shared table
 #endif
-    if (!live) return;
+    if (!live) return;   // (never in a chained launch: its grid is whole groups)
     K1_STAMP(0);
     // Per-lane LDS and HBM offsets are formed again in every block, phase by phase, from a lane index the optimiser cannot see
     // through (opaque_lane_value): hoisted in front of the loop - where the compiler puts anything loop-invariant - they were
@@ -871,18 +930,63 @@ __global__ __launch_bounds__(64 * kFusedWaves) K1_ATTR void k_qmf_mdct8(FrontPar
                 }
             }
             K1_STAMP(4);
-            const bool emit = f >= fa;
-            float4 slots[4];
-            {
-                const int ln = K1_LANE(lane);
-                const int band = ln >> 4, L = ln & 15;
-                float4* scratch = reinterpret_cast<float4*>(S.pcm + kFusedScratchAt) + band * kFusedRowScratch4;   // after stage 2 (and the gather)
-                mdct_row_frame<kFusedXor>(s_tab, tw2, pw, X, 1.0f, scratch, L, emit, slots);
+            const bool emit = blk > b0;
+            float* frame_ch = const_cast<float*>(frame_base) + (size_t)(f - p.f0) * 2048;
+            if (emit) {
+                float4 slots[4];
+                {
+                    const int ln = K1_LANE(lane);
+                    const int band = ln >> 4, L = ln & 15;
+                    float4* scratch = reinterpret_cast<float4*>(S.pcm + kFusedScratchAt) + band * kFusedRowScratch4;   // after stage 2 (and the gather)
+                    mdct_row_frame<kFusedXor>(s_tab, tw2, pw, X, 1.0f, scratch, L, true, slots);
+                }
+                mdct_rows_store(frame_ch, slots, K1_LANE(lane));
+            } else {
+                float A[4][2];
+                mdct_fold_new(s_tab, pw, X, K1_LANE(lane) & 15, deferred, A);
+                if (deferred) {
+                    float4* park = reinterpret_cast<float4*>(frame_ch) + 2 * K1_LANE(lane);
+                    park[0] = make_float4(A[0][0], A[0][1], A[1][0], A[1][1]);
+                    park[1] = make_float4(A[2][0], A[2][1], A[3][0], A[3][1]);
+                }
             }
-            if (emit) mdct_rows_store(const_cast<float*>(frame_base) + (size_t)(f - p.f0) * 2048, slots, K1_LANE(lane));
             K1_STAMP(5);
         }
     }
+    if (p.chain) {
+        // hand the overlap half of the next run's first frame on: (i0a, r0b) of this run's last windowed samples, lane for lane
+        // (the rings are dead; every wavefront of the group - this is the same for all - arrives here)
+        float4* hand = reinterpret_cast<float4*>(S.pcm) + 2 * lane;
+        if (wave + 1 < NW) {
+            float B[4][2];
+            mdct_fold_old(pw, 1.0f, B);
+            hand[0] = make_float4(B[0][0], B[0][1], B[1][0], B[1][1]);
+            hand[1] = make_float4(B[2][0], B[2][1], B[3][0], B[3][1]);
+        }
+        __syncthreads();
+        if (deferred) {
+            const float4* from = reinterpret_cast<const float4*>(s_q[wave - 1].pcm) + 2 * lane;
+            const float4 h0 = from[0], h1 = from[1];
+            float* frame_ch = const_cast<float*>(frame_base) + (size_t)(b0 + 1 - p.f0) * 2048;
+            const float4* park = reinterpret_cast<const float4*>(frame_ch) + 2 * lane;
+            const float4 a0 = park[0], a1 = park[1];
+            const float A[4][2] = {{a0.x, a0.y}, {a0.z, a0.w}, {a1.x, a1.y}, {a1.z, a1.w}};
+#ifdef K1_SABOTAGE
+            const float B[4][2] = {{h0.x, h0.y}, {h0.z, h0.w}, {h1.x, h1.y}, {h1.z, 0.0f}};
+#else
+            const float B[4][2] = {{h0.x, h0.y}, {h0.z, h0.w}, {h1.x, h1.y}, {h1.z, h1.w}};
+#endif
+            // (the exchange scratch lies behind the hand-over in this wavefront's own rings; the lane's stores below come after its own loads of
+            // the parked half: the compiler keeps that order - they may alias - and a lane only overwrites what it and its mirror lane parked)
+            float4 slots[4];
+            const int band = lane >> 4, L = lane & 15;
+            float4* scratch = reinterpret_cast<float4*>(S.pcm + kFusedScratchAt) + band * kFusedRowScratch4;
+            wave_sync();
+            mdct_row_transform<kFusedXor>(s_tab, tw2, A, B, scratch, L, slots);
+            mdct_rows_store(frame_ch, slots, lane);
+        }
+    }
+    K1_STAMP(6);
 #ifdef K1_STAMPS
     if (p.clk && lane == 0) {
         unsigned long long* row = p.clk + 16 + (W0 & 255) * 12;
@@ -891,6 +995,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) K1_ATTR void k_qmf_mdct8(FrontPar
         atomicAdd(row + 7, __builtin_amdgcn_s_memrealtime() - r_begin);
         atomicAdd(row + 8, 1ull);
         atomicAdd(row + 9, (unsigned long long)(b_last - b0 + 1));
+        atomicAdd(row + 10, (unsigned long long)ph[6]);
     }
 #endif
 }

@@ -27,6 +27,7 @@ struct FrontParams {
     int js;
     int sub_runs;            // k_qmf_sub8: runs per (stream, channel) the n_blocks + 2 blocks are cut into
     int debug;               // profiling aid (env AT3HIP_DEBUG_FRONT, debug builds): 3 = skip the energy-scale chains
+    int chain;               // fused kernel: runs of one (stream, channel) chained in workgroups (see k_qmf_mdct8), frame_runs a multiple of the workgroup's wavefronts
     unsigned long long* clk; // profiling builds (-DK1_STAMPS): per-phase cycle sums of the fused kernel's wavefronts (AT3HIP_TAP_CLOCK), else null
 };
 

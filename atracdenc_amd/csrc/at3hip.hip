@@ -88,6 +88,7 @@ struct at3hip_ctx {
     int slot_k1_launches[kSlots] = {};   // kernels the QMF + MDCT work of the slot's call was spread over (1 = fused, 2)
     char err[256] = {0};
     long long blocks_fed = 0;   // per stream
+    int chain_mode = 0;      // AT3HIP_OPT_CHAIN: 0 = chosen per call, 1 = never, 2 = whenever the geometry allows
     int runs_override = 0;   // AT3HIP_OPT_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
     int flat_literal = 0;    // AT3HIP_OPT_LITERAL_FORMS
     int gain_form = AT3HIP_GAIN_FORM_TWO_WAVES;   // AT3HIP_OPT_GAIN_FORM: the two-wavefront workgroups (default) or one wavefront per item (k_gain_analysis1)
@@ -221,6 +222,49 @@ int pick_runs(const at3hip_ctx* c, int items, int wgs_per_cu, double prologue)
         }
     }
     return best;
+}
+
+// The fused kernel's cut: runs per (stream, channel) and whether the runs of a workgroup are CHAINED (k_qmf_mdct8: kFusedWaves consecutive
+// runs share one priming block and hand their overlap on through LDS instead of each re-deriving it from a whole block of PCM). A chained
+// wavefront costs its share of (the group's frames + 1) blocks, its FIR prologue and the hand-over with the deferred transform (~0.65 block);
+// an unchained one its frames + 1.35. Same time model as pick_runs; chaining wins whenever runs are short (small batches).
+struct FusedCut {
+    int runs, chain;
+};
+FusedCut pick_fused(const at3hip_ctx* c, int items)
+{
+    const int NW = kFusedWaves;
+    FusedCut cut = {pick_runs(c, items, c->wgs_per_cu, 1.35), 0};
+    if (c->chain_mode == 1 || items < NW) return cut;
+    const long long pairs = 2LL * c->cfg.n_streams;
+    const long long simds = (long long)c->n_cus * 4;
+    const int cap = c->wgs_per_cu;
+    static const double eff[5] = {0.0, 0.55, 0.85, 0.95, 1.0};
+    auto cost = [&](int r, double work) {
+        const long long waves = pairs * r;
+        const long long per_simd = (waves + simds - 1) / simds;
+        const long long resident = per_simd < cap ? per_simd : cap;
+        return (double)per_simd * work / eff[resident > 4 ? 4 : resident];
+    };
+    if (c->runs_override > 0) {
+        // a forced run count is chained when it can be: a multiple of NW with at least NW frames per group
+        const int r = cut.runs;
+        if (r % NW == 0 && items / (r / NW) >= NW) cut.chain = 1;
+        return cut;
+    }
+    const double t_plain = cost(cut.runs, (double)((items + cut.runs - 1) / cut.runs) + 1.35);
+    double best_t = c->chain_mode == 2 ? 1e300 : t_plain;
+    const int g_min = (items + 32 * NW - 1) / (32 * NW);   // (a run holds at most ~32 blocks)
+    for (int g = g_min; g <= items / NW && g <= 64; ++g) {
+        const int per_group = (items + g - 1) / g + 1;      // the longest group's frames + its priming block
+        const double t = cost(g * NW, (double)((per_group + NW - 1) / NW) + 0.65);
+        if (t < best_t * 0.999) {
+            best_t = t;
+            cut.runs = g * NW;
+            cut.chain = 1;
+        }
+    }
+    return cut;
 }
 
 // Dynamic LDS added to k_gain_analysis' launch: it decides how many of its 17 KB workgroups share a CU (nine without). A
@@ -567,11 +611,16 @@ int at3hip_set_option(at3hip_ctx* c, int32_t option, int32_t value)
             if (value < 0) return fail(c, AT3HIP_EINVAL, "runs must be >= 0");
             c->runs_override = value;
             return AT3HIP_OK;
+        case AT3HIP_OPT_CHAIN:
+            if (value < 0 || value > 2) return fail(c, AT3HIP_EINVAL, "chain: 0 (per call), 1 (never) or 2 (whenever possible)");
+            c->chain_mode = value;
+            return AT3HIP_OK;
         case AT3HIP_OPT_LITERAL_FORMS:
             if (value != 0 && value != 1) return fail(c, AT3HIP_EINVAL, "literal forms: 0 or 1");
             c->flat_literal = value;
             return AT3HIP_OK;
         case AT3HIP_OPT_GAIN_FORM:
+            if (value == 2) value = AT3HIP_GAIN_FORM_ONE_WAVE;   // (ABI 1.2's number for the one-wavefront form)
             if (value != AT3HIP_GAIN_FORM_TWO_WAVES && value != AT3HIP_GAIN_FORM_ONE_WAVE)
                 return fail(c, AT3HIP_EINVAL, "gain form: AT3HIP_GAIN_FORM_TWO_WAVES or AT3HIP_GAIN_FORM_ONE_WAVE");
             c->gain_form = value;
@@ -756,12 +805,16 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         fp.sub_tail = c->d_sub_tail;
         fp.n_blocks = n_blocks;
         fp.f0 = f0;
-        fp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu, 1.35);
+        const bool split = gain || c->js;   // QMF and MDCT as two kernels with the subbands in HBM between them
+        {
+            const FusedCut cut = split ? FusedCut{0, 0} : pick_fused(c, n_out);
+            fp.frame_runs = cut.runs;
+            fp.chain = cut.chain;
+        }
         fp.sub_runs = 0;
         fp.debug = c->dbg_front;
         fp.clk = nullptr;
         fp.js = c->js;
-        const bool split = gain || c->js;   // QMF and MDCT as two kernels with the subbands in HBM between them
         auto launch_qmf_sub = [&] {
             fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35);
             const int n_waves = S * 2 * fp.sub_runs;   // one wavefront per (stream, channel, run)
@@ -1145,7 +1198,11 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
     fp.f0 = 1;
     const int n_out = n_blocks - 1;
     fp.js = c->js;
-    fp.frame_runs = pick_runs(c, n_out, c->wgs_per_cu, 1.35);
+    {
+        const FusedCut cut = c->js ? FusedCut{0, 0} : pick_fused(c, n_out);
+        fp.frame_runs = cut.runs;
+        fp.chain = cut.chain;
+    }
     HIPCHK(c, hipEventRecord(c->ev[0][0], st));
     if (c->js) {
         // joint stereo: the M/S matrixing needs both channels' subbands, which go through HBM (as in at3hip_encode)

@@ -216,13 +216,18 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
  *                                AT3HIP_GAIN_FORM_ONE_WAVE (1) = one wavefront per item (faster alone, not in the pipelined step).
  *   AT3HIP_OPT_GAIN_WGS_PER_CU   tuning aid: workgroups per CU of that kernel by LDS padding: 0 = chosen per launch (default),
  *                                1 .. 16 = that many, 256 .. 65536 = the pad itself in bytes.
+ *   AT3HIP_OPT_CHAIN             tuning aid for the fused QMF + MDCT kernel (no gain control, discrete stereo): whether the runs of a
+ *                                workgroup hand their MDCT overlap on to each other instead of each priming its own from a block of
+ *                                PCM: 0 = chosen per call (default), 1 = never, 2 = whenever the cut allows it. Same bytes either way.
  * Values outside the ranges above are rejected with AT3HIP_EINVAL (nothing is stored). */
 #define AT3HIP_OPT_RUNS 1
 #define AT3HIP_OPT_LITERAL_FORMS 2
 #define AT3HIP_OPT_FLATNESS_LITERAL AT3HIP_OPT_LITERAL_FORMS
 #define AT3HIP_OPT_QUANT_TAP 3
 #define AT3HIP_OPT_GAIN_FORM 4
+#define AT3HIP_OPT_GAIN_TWO_WAVES AT3HIP_OPT_GAIN_FORM   /* the option's former name (same number; its former value 2 = AT3HIP_GAIN_FORM_ONE_WAVE is still accepted) */
 #define AT3HIP_OPT_GAIN_WGS_PER_CU 5
+#define AT3HIP_OPT_CHAIN 6
 #define AT3HIP_GAIN_FORM_TWO_WAVES 0
 #define AT3HIP_GAIN_FORM_ONE_WAVE 1
 int at3hip_set_option(at3hip_ctx* ctx, int32_t option, int32_t value);
@@ -265,11 +270,13 @@ int at3hip_host_tables(void* dst, size_t bytes);
  *   1.1  rounds 1 - 3 (two calls in flight: at3hip_wait_* accept ago 0 .. 1)
  *   1.2  at3hip_encode_s16, at3hip_wait_* with ago 0 .. 3 (three calls in flight), AT3HIP_TAP_CLOCK / AT3HIP_TAP_GAIN_ANALYSIS,
  *        AT3HIP_OPT_GAIN_FORM / AT3HIP_OPT_GAIN_WGS_PER_CU / AT3HIP_OPT_LITERAL_FORMS with validated values
- *   1.3  at3hip_get_counters
+ *   1.3  at3hip_get_counters; AT3HIP_OPT_GAIN_FORM's values renumbered (the former AT3HIP_OPT_GAIN_TWO_WAVES: 0 = one workgroup of two
+ *        wavefronts per item, 1 = the one-wavefront form, formerly 2 - the legacy value 2 is still accepted and means ONE_WAVE)
+ *   1.4  AT3HIP_OPT_CHAIN
  * A host layer compiled against this header checks at3hip_version() >= AT3HIP_VERSION before it relies on them
  * (atracdenc_amd/host/at3hip_host.hpp and the ctypes stub do). */
 #define AT3HIP_VERSION_MAJOR 1
-#define AT3HIP_VERSION_MINOR 3
+#define AT3HIP_VERSION_MINOR 4
 #define AT3HIP_VERSION ((AT3HIP_VERSION_MAJOR << 16) | AT3HIP_VERSION_MINOR)
 uint32_t at3hip_version(void);
 

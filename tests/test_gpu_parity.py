@@ -433,13 +433,20 @@ def _oracle_spectra(oracle, pcm):
     return out
 
 
-def test_fused_qmf_mdct_kernel(hip, oracle):
+@pytest.mark.parametrize("nb,runs,chain", [(9, 0, 0), (9, 3, 1), (9, 4, 2), (9, 8, 2), (18, 4, 2), (18, 16, 2), (18, 0, 2), (6, 4, 2), (2, 0, 0)])
+def test_fused_qmf_mdct_kernel(hip, oracle, nb, runs, chain):
+    """k_qmf_mdct8 alone (at3hip_qmf_mdct) against the oracle's QMF tree + MDCT, spectra as bit patterns - for the cut the library picks
+    and for forced cuts: unchained runs (every run primes its own overlap) and CHAINED ones (AT3HIP_OPT_CHAIN: the runs of a workgroup
+    hand the overlap on and finish their first frame after the group's rendezvous)."""
     torch = pytest.importorskip("torch")
-    nb, S = 9, 3
+    from atracdenc_amd import binding as B
+    S = 3
     pcm = np.stack([SIGNALS["noise"](nb, seed=4), SIGNALS["mix"](nb), SIGNALS["tones"](nb)])
     enc = hip.At3Hip(n_streams=S, max_blocks=nb, no_gain=True)
+    if runs: enc.set_option(B.OPT_RUNS, runs)
+    if chain: enc.set_option(B.OPT_CHAIN, chain)
     d_pcm = torch.from_numpy(pcm).cuda()
-    d_specs = torch.zeros((S, nb - 1, 2, 1024), dtype=torch.float32, device="cuda")
+    d_specs = torch.full((S, nb - 1, 2, 1024), float("nan"), dtype=torch.float32, device="cuda")
     enc.qmf_mdct_device(d_pcm.data_ptr(), nb, d_specs.data_ptr())
     got = d_specs.cpu().numpy()
     enc.close()
@@ -915,12 +922,13 @@ def test_option_values_are_validated_and_version(hip):
     lib = B.load_library()
     assert lib.at3hip_version() == B.AT3HIP_VERSION and B.AT3HIP_VERSION >> 16 == 1
     enc = hip.At3Hip(n_streams=1, max_blocks=4)
-    for opt, bad in ((B.OPT_RUNS, -1), (B.OPT_LITERAL_FORMS, 2), (B.OPT_LITERAL_FORMS, -1), (B.OPT_QUANT_TAP, 2), (B.OPT_GAIN_FORM, 2),
-                     (B.OPT_GAIN_FORM, -1), (B.OPT_GAIN_WGS_PER_CU, 17), (B.OPT_GAIN_WGS_PER_CU, 100000), (0, 0), (6, 0)):
+    for opt, bad in ((B.OPT_RUNS, -1), (B.OPT_LITERAL_FORMS, 2), (B.OPT_LITERAL_FORMS, -1), (B.OPT_QUANT_TAP, 2), (B.OPT_GAIN_FORM, 3),
+                     (B.OPT_GAIN_FORM, -1), (B.OPT_GAIN_WGS_PER_CU, 17), (B.OPT_GAIN_WGS_PER_CU, 100000), (B.OPT_CHAIN, 3), (B.OPT_CHAIN, -1), (0, 0), (7, 0)):
         with pytest.raises(hip.At3HipError):
             enc.set_option(opt, bad)
     for opt, good in ((B.OPT_RUNS, 2), (B.OPT_RUNS, 0), (B.OPT_LITERAL_FORMS, 1), (B.OPT_LITERAL_FORMS, 0), (B.OPT_GAIN_FORM, B.GAIN_FORM_ONE_WAVE),
-                      (B.OPT_GAIN_FORM, B.GAIN_FORM_TWO_WAVES), (B.OPT_GAIN_WGS_PER_CU, 6), (B.OPT_GAIN_WGS_PER_CU, 0)):
+                      (B.OPT_GAIN_FORM, 2), (B.OPT_GAIN_FORM, B.GAIN_FORM_TWO_WAVES), (B.OPT_GAIN_WGS_PER_CU, 6), (B.OPT_GAIN_WGS_PER_CU, 0), (B.OPT_CHAIN, 2), (B.OPT_CHAIN, 1),
+                      (B.OPT_CHAIN, 0)):
         enc.set_option(opt, good)
     assert B.OPT_FLATNESS_LITERAL == B.OPT_LITERAL_FORMS
     dev = torch.device("cuda", 0)

@@ -32,11 +32,13 @@ def oracle_spectra(pcm):
     return out
 
 bad_total = 0
-for nb, S, runs in ((9, 3, 0), (9, 3, 1), (9, 3, 3), (9, 3, 8), (12, 5, 5), (3, 2, 0), (2, 1, 0)):
+for nb, S, runs, chain in ((9, 3, 0, 0), (9, 3, 1, 0), (9, 3, 3, 1), (9, 3, 8, 1), (12, 5, 5, 0), (3, 2, 0, 0), (2, 1, 0, 0),
+                            (9, 3, 4, 2), (9, 3, 8, 2), (17, 2, 4, 2), (17, 2, 8, 2), (17, 2, 16, 2), (12, 3, 0, 2), (6, 2, 4, 2), (5, 2, 4, 2)):
     names = ["noise", "mix", "tones", "burst", "stress"][:S] if S <= 3 else ["noise", "mix", "tones", "burst", "noise"]
     pcm = np.stack([SIGNALS[n](nb, seed=4 + i) if n == "noise" else SIGNALS[n](nb) for i, n in enumerate(names)]).astype(np.float32)
     enc = At3Hip(n_streams=S, max_blocks=nb, no_gain=True, lib_path=EMU)
     if runs: enc.set_option(1, runs)
+    if chain: enc.set_option(6, chain)
     specs = np.full((S, nb - 1, 2, 1024), np.nan, np.float32)
     enc.qmf_mdct_device(pcm.ctypes.data, nb, specs.ctypes.data)
     enc.close()
@@ -45,5 +47,5 @@ for nb, S, runs in ((9, 3, 0), (9, 3, 1), (9, 3, 3), (9, 3, 8), (12, 5, 5), (3, 
         exp = oracle_spectra(pcm[i])
         bad += int((specs[i].view(np.uint32) != exp.view(np.uint32)).sum())
     bad_total += bad
-    print(f"flags {' '.join(flags) or '(none)'}: {S} streams x {nb} blocks, runs {runs or 'auto'}: mismatching words {bad}")
+    print(f"flags {' '.join(flags) or '(none)'}: {S} streams x {nb} blocks, runs {runs or 'auto'} chain {chain}: mismatching words {bad}")
 sys.exit(1 if bad_total else 0)

@@ -6,11 +6,13 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/../..")
 import torch
 from atracdenc_amd import binding as B
+B.AT3HIP_VERSION = (1 << 16) | 3   # (the lab also loads builds of earlier rounds for same-box comparisons)
 
 def main():
     a = sys.argv[1:]
     sizes = "64x64,1024x128"
     runs = [0]
+    chains = [0]
     reps = 3
     libs = []
     i = 0
@@ -18,6 +20,7 @@ def main():
         if a[i] == "--sizes": sizes = a[i + 1]; i += 2
         elif a[i] == "--runs": runs = [int(x) for x in a[i + 1].split(",")]; i += 2
         elif a[i] == "--reps": reps = int(a[i + 1]); i += 2
+        elif a[i] == "--chain": chains = [int(x) for x in a[i + 1].split(",")]; i += 2
         else: libs.append(a[i]); i += 1
     sizes = [tuple(int(x) for x in s.split("x")) for s in sizes.split(",")]
     res = {}
@@ -30,9 +33,13 @@ def main():
         n_iter = 400 if S * F <= 8192 else 80   # (the first launches of a burst run in the power manager's transient: only the second half is kept)
         for rep in range(reps):
             for lib in libs:
-                for r in runs:
+                for r, cm in [(r, cm) for r in runs for cm in chains]:
                     enc = B.At3Hip(n_streams=S, max_blocks=nb, no_gain=True, lib_path=os.path.abspath(lib))
                     if r: enc.set_option(1, r)
+                    if cm:
+                        try: enc.set_option(6, cm)
+                        except Exception: pass
+                    r = r * 10 + cm
                     specs.zero_()
                     ms = []
                     for it in range(n_iter):
@@ -47,8 +54,10 @@ def main():
                         names = ["prologue", "hist/tile in, fetch", "stage 1", "stage 2 + subbands out", "gather (+ early tile)", "MDCT + store"]
                         print("  %s %dx%d runs=%d: %d wavefront-launches, %.1f blocks per wavefront, life %.0f cycles, sclk %.0f MHz" % (
                             os.path.basename(lib), S, F, r, waves, blocks / waves, c[6] / waves, 100.0 * c[6] / max(c[7], 1)))
-                        for k in range(6):
-                            print("    %-24s %9.0f cycles per wavefront  %8.0f per block  %5.1f %%" % (names[k], c[k] / waves, c[k] / blocks, 100 * c[k] / c[:6].sum()))
+                        names.append("hand-over + deferred frame")
+                        ph = list(c[:6]) + [c[10]]
+                        for k in range(7):
+                            print("    %-26s %9.0f cycles per wavefront  %8.0f per block  %5.1f %%" % (names[k], ph[k] / waves, ph[k] / blocks, 100 * ph[k] / sum(ph)))
                     enc.close()
                     key = (S, F, os.path.basename(lib), r)
                     res.setdefault(key, []).extend(ms[len(ms) // 2:])
@@ -59,7 +68,7 @@ def main():
         cs = sums[(S, F, lib, r)]
         base.setdefault((S, F), cs)
         by = S * F * 16384
-        print("%5dx%-4d %-34s runs=%-3d min %8.2f us  med %8.2f us  hbm_frac(med) %.3f  %s" % (
+        print("%5dx%-4d %-34s runs*10+chain=%-4d min %8.2f us  med %8.2f us  hbm_frac(med) %.3f  %s" % (
             S, F, lib, r, ms.min(), np.median(ms), by / (np.median(ms) * 1e-6) / 8e12, "same-bits" if cs == base[(S, F)] else "BITS-DIFFER"))
 
 main()
