@@ -759,6 +759,23 @@ __global__ __launch_bounds__(64 * NW) void k_mdct_sub(MdctSubParams p, const Tab
 // overlap. The wavefront runs stage 1, stage 2 and the four bands' transforms of a block back to back; its subbands
 // and exchange scratch reuse the rings that are dead at that point (the PCM ring after stage 1, the stage-1 rings after
 // stage 2), 10 KB of LDS per wavefront in all. A workgroup is four independent wavefronts sharing the MDCT table.
+// Workgroup b of a launch of 2 n workgroups -> (unit u in [0, n), channel). The two channels of a unit read the SAME interleaved PCM, so
+// they should meet in one L2: workgroups go round the eight XCDs in turn, hence b and b + 8 run on the same XCD one dispatch step apart.
+// (Units beyond the last whole set of eight take neighbouring workgroups: correct, only without the shared L2.)
+__device__ __forceinline__ void xcd_pair(int b, int n, int& u, int& ch)
+{
+    const int full = (n >> 3) << 4;
+    if (b < full) {
+        const int k = b >> 3;
+        ch = k & 1;
+        u = ((k >> 1) << 3) | (b & 7);
+    } else {
+        const int t = b - full;
+        ch = t & 1;
+        u = (full >> 1) + (t >> 1);
+    }
+}
+
 #ifndef K1_ATTR
 #define K1_ATTR
 #endif
@@ -821,13 +838,23 @@ __global__ __launch_bounds__(64 * kFusedWaves) K1_ATTR void k_qmf_mdct8(FrontPar
 #endif
     const int W0 = blockIdx.x * NW + wave;
     const bool live = W0 < n_waves;
-    const int W = live ? W0 : n_waves - 1;
     QmfLdsW& S = s_q[wave];
     const int n_out = p.n_blocks - p.f0;
     const int nchunks = p.frame_runs;   // runs per (stream, channel): the n_out frames are dealt out as evenly as possible
-    const int chunk = W % nchunks;
-    const int ch = (W / nchunks) & 1;
-    const int s = W / (2 * nchunks);
+    int chunk, ch, s;
+    if (nchunks % NW == 0) {
+        // a workgroup is NW consecutive runs of ONE (stream, channel): the two channels of a piece of a stream go to the same XCD (xcd_pair)
+        const int per = nchunks / NW;
+        int u;
+        xcd_pair((int)blockIdx.x, n_waves / (2 * nchunks) * per, u, ch);
+        s = u / per;
+        chunk = (u % per) * NW + wave;
+    } else {
+        const int W = live ? W0 : n_waves - 1;
+        chunk = W % nchunks;
+        ch = (W / nchunks) & 1;
+        s = W / (2 * nchunks);
+    }
     // Blocks b0 .. b_last of the run; block b carries frame b + 1, whose overlap is block b - 1. The run's FIRST block only leaves its
     // windowed samples behind as the next frame's overlap. Unchained (p.chain == 0) that block is one the run before this one computes as
     // well: every run pays a whole block's FIR to prime its overlap. CHAINED (p.chain != 0; the host picks it when a run is a few frames
@@ -989,13 +1016,19 @@ __global__ __launch_bounds__(64 * kFusedWaves) K1_ATTR void k_qmf_mdct8(FrontPar
     K1_STAMP(6);
 #ifdef K1_STAMPS
     if (p.clk && lane == 0) {
-        unsigned long long* row = p.clk + 16 + (W0 & 255) * 12;
+        unsigned long long* row = p.clk + 16 + (W0 & 255) * 24;   // (256 rows of 24 words: the space of k_alloc_pack's and k_gain_analysis1's phase rows)
         for (int k = 0; k < 6; ++k) atomicAdd(row + k, (unsigned long long)ph[k]);
         atomicAdd(row + 6, __builtin_amdgcn_s_memtime() - t_begin);
         atomicAdd(row + 7, __builtin_amdgcn_s_memrealtime() - r_begin);
         atomicAdd(row + 8, 1ull);
         atomicAdd(row + 9, (unsigned long long)(b_last - b0 + 1));
         atomicAdd(row + 10, (unsigned long long)ph[6]);
+        // when the row's wavefronts of this launch started and ended (100 MHz): words 12 .. 15 keep max(~first start), max(last start), max(~first end), max(last end)
+        const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
+        atomicMax(row + 12, ~r_begin);
+        atomicMax(row + 13, r_begin);
+        atomicMax(row + 14, ~r_end);
+        atomicMax(row + 15, r_end);
     }
 #endif
 }

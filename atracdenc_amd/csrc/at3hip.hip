@@ -235,7 +235,13 @@ FusedCut pick_fused(const at3hip_ctx* c, int items)
 {
     const int NW = kFusedWaves;
     FusedCut cut = {pick_runs(c, items, c->wgs_per_cu, 1.35), 0};
-    if (c->chain_mode == 1 || items < NW) return cut;
+    if (items < NW) return cut;
+    if (c->runs_override > 0) {
+        // a forced run count is chained when it can be: a multiple of NW with at least NW frames per group
+        const int r = cut.runs;
+        if (c->chain_mode != 1 && r % NW == 0 && items / (r / NW) >= NW) cut.chain = 1;
+        return cut;
+    }
     const long long pairs = 2LL * c->cfg.n_streams;
     const long long simds = (long long)c->n_cus * 4;
     const int cap = c->wgs_per_cu;
@@ -246,22 +252,26 @@ FusedCut pick_fused(const at3hip_ctx* c, int items)
         const long long resident = per_simd < cap ? per_simd : cap;
         return (double)per_simd * work / eff[resident > 4 ? 4 : resident];
     };
-    if (c->runs_override > 0) {
-        // a forced run count is chained when it can be: a multiple of NW with at least NW frames per group
-        const int r = cut.runs;
-        if (r % NW == 0 && items / (r / NW) >= NW) cut.chain = 1;
-        return cut;
-    }
-    const double t_plain = cost(cut.runs, (double)((items + cut.runs - 1) / cut.runs) + 1.35);
-    double best_t = c->chain_mode == 2 ? 1e300 : t_plain;
+    // Whole workgroups of one (stream, channel) - run counts that are multiples of NW - let the kernel put a stream's two channels on
+    // the same XCD (xcd_pair): its interleaved PCM then crosses the fabric once instead of twice. Only such cuts are considered.
     const int g_min = (items + 32 * NW - 1) / (32 * NW);   // (a run holds at most ~32 blocks)
-    for (int g = g_min; g <= items / NW && g <= 64; ++g) {
-        const int per_group = (items + g - 1) / g + 1;      // the longest group's frames + its priming block
-        const double t = cost(g * NW, (double)((per_group + NW - 1) / NW) + 0.65);
-        if (t < best_t * 0.999) {
-            best_t = t;
-            cut.runs = g * NW;
-            cut.chain = 1;
+    double best_t = 1e300;
+    for (int g = g_min; g * NW <= items && g <= 64; ++g) {
+        const int r = g * NW;
+        if (c->chain_mode != 2) {
+            const double t = cost(r, (double)((items + r - 1) / r) + 1.35);
+            if (t < best_t * 0.999) {
+                best_t = t;
+                cut = {r, 0};
+            }
+        }
+        if (c->chain_mode != 1 && items / g >= NW) {
+            const int per_group = (items + g - 1) / g + 1;      // the longest group's frames + its priming block
+            const double t = cost(r, (double)((per_group + NW - 1) / NW) + 0.65);
+            if (t < best_t * 0.999) {
+                best_t = t;
+                cut = {r, 1};
+            }
         }
     }
     return cut;
@@ -1191,6 +1201,8 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
     fp.debug = 0;
 #ifdef K1_STAMPS
     fp.clk = c->d_clk;
+    for (int r = 0; r < 256; r += 64)   // (the launch's own first / last starts and ends: words 12 .. 15 of every row)
+        HIPCHK(c, hipMemset2DAsync(c->d_clk + 16 + 12 + r * 24, 24 * sizeof(unsigned long long), 0, 4 * sizeof(unsigned long long), 64, st));
 #else
     fp.clk = nullptr;
 #endif
