@@ -98,7 +98,9 @@ def load_library(path=None):
     lib.at3hip_version.restype = ctypes.c_uint32
     have = lib.at3hip_version()
     # same major number, and every entry point / option / wait depth this stub relies on (at3hip.h lists them per minor number)
-    if have >> 16 != AT3HIP_VERSION >> 16 or have < AT3HIP_VERSION:
+    # (AT3HIP_MIN_MINOR=<n>: same-box A/B runs against a build of an earlier round that lacks only options the run does not set)
+    need = (AT3HIP_VERSION & ~0xffff) | int(os.environ["AT3HIP_MIN_MINOR"]) if "AT3HIP_MIN_MINOR" in os.environ else AT3HIP_VERSION
+    if have >> 16 != AT3HIP_VERSION >> 16 or have < need:
         raise At3HipError(f"{path} implements at3hip ABI {have >> 16}.{have & 0xffff}, this binding needs {AT3HIP_VERSION >> 16}.{AT3HIP_VERSION & 0xffff}: rebuild it")
     lib.at3hip_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
     lib.at3hip_create.restype = ctypes.c_int

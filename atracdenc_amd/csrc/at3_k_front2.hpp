@@ -251,6 +251,23 @@ __device__ __forceinline__ void qmf_prologue(QmfLdsW& S, QmfRunW& q, float* tmp,
     wave_sync();
 }
 
+// Workgroup b of a launch of 2 n workgroups -> (unit u in [0, n), channel). The two channels of a unit read the SAME interleaved PCM, so
+// they should meet in one L2: workgroups go round the eight XCDs in turn, hence b and b + 8 run on the same XCD one dispatch step apart.
+// (Units beyond the last whole set of eight take neighbouring workgroups: correct, only without the shared L2.)
+__device__ __forceinline__ void xcd_pair(int b, int n, int& u, int& ch)
+{
+    const int full = (n >> 3) << 4;
+    if (b < full) {
+        const int k = b >> 3;
+        ch = k & 1;
+        u = ((k >> 1) << 3) | (b & 7);
+    } else {
+        const int t = b - full;
+        ch = t & 1;
+        u = (full >> 1) + (t >> 1);
+    }
+}
+
 // ---- subband analysis only (feeds the gain-control kernels and the MDCT-from-subbands kernel) ----------------------
 // Raw L/R subbands of blocks 0 .. n_blocks-1 to HBM; blocks -2 and -1 (look-back of the gain analysis, overlap of the
 // first frame) are the previous call's last two, carried in `sub_tail` and copied in front by the (stream, channel)'s runs
@@ -265,9 +282,19 @@ __global__ __launch_bounds__(256) void k_qmf_sub8(FrontParams p, const Tables* T
     QmfLdsW& S = s_q[wave];
     const int nb2 = p.n_blocks + 2;
     const int nchunks = p.sub_runs;   // runs per (stream, channel): the blocks are dealt out as evenly as possible
-    const int chunk = W % nchunks;
-    const int ch = (W / nchunks) & 1;
-    const int s = W / (2 * nchunks);
+    int chunk, ch, s;
+    if (nchunks % 4 == 0) {
+        // a workgroup is four consecutive runs of ONE (stream, channel): the two channels of a piece of a stream go to the same XCD (xcd_pair)
+        const int per = nchunks / 4;
+        int u;
+        xcd_pair((int)blockIdx.x, n_waves / (2 * nchunks) * per, u, ch);
+        s = u / per;
+        chunk = (u % per) * 4 + wave;
+    } else {
+        chunk = W % nchunks;
+        ch = (W / nchunks) & 1;
+        s = W / (2 * nchunks);
+    }
     const int ba = (chunk * p.n_blocks) / nchunks;
     const int bb = ((chunk + 1) * p.n_blocks) / nchunks;
     const size_t sublen = (size_t)nb2 * 256;
@@ -759,23 +786,6 @@ __global__ __launch_bounds__(64 * NW) void k_mdct_sub(MdctSubParams p, const Tab
 // overlap. The wavefront runs stage 1, stage 2 and the four bands' transforms of a block back to back; its subbands
 // and exchange scratch reuse the rings that are dead at that point (the PCM ring after stage 1, the stage-1 rings after
 // stage 2), 10 KB of LDS per wavefront in all. A workgroup is four independent wavefronts sharing the MDCT table.
-// Workgroup b of a launch of 2 n workgroups -> (unit u in [0, n), channel). The two channels of a unit read the SAME interleaved PCM, so
-// they should meet in one L2: workgroups go round the eight XCDs in turn, hence b and b + 8 run on the same XCD one dispatch step apart.
-// (Units beyond the last whole set of eight take neighbouring workgroups: correct, only without the shared L2.)
-__device__ __forceinline__ void xcd_pair(int b, int n, int& u, int& ch)
-{
-    const int full = (n >> 3) << 4;
-    if (b < full) {
-        const int k = b >> 3;
-        ch = k & 1;
-        u = ((k >> 1) << 3) | (b & 7);
-    } else {
-        const int t = b - full;
-        ch = t & 1;
-        u = (full >> 1) + (t >> 1);
-    }
-}
-
 #ifndef K1_ATTR
 #define K1_ATTR
 #endif

@@ -199,9 +199,10 @@ void read_timings(const at3hip_ctx* c, int slot, at3hip_timings* tm)
 // overlap priming); a SIMD with w resident wavefronts issues at roughly eff(w) of its peak. The run count with the
 // smallest estimated time wins: small batches get as many equal runs as one round of the grid holds, large batches long
 // runs.
-int pick_runs(const at3hip_ctx* c, int items, int wgs_per_cu, double prologue)
+int pick_runs(const at3hip_ctx* c, int items, int wgs_per_cu, double prologue, int step = 1)
 {
     if (c->runs_override > 0) return c->runs_override < items ? c->runs_override : items;
+    if (items < step) step = 1;   // (`step`: only multiples of it are considered - whole workgroups per (stream, channel), see xcd_pair)
     const long long pairs = 2LL * c->cfg.n_streams;   // (stream, channel)
     const long long simds = (long long)c->n_cus * 4;
     const int cap = wgs_per_cu;                        // resident wavefronts per SIMD (a workgroup is one per SIMD)
@@ -210,7 +211,7 @@ int pick_runs(const at3hip_ctx* c, int items, int wgs_per_cu, double prologue)
     double best_t = 1e300;
     const int r_min = (items + 31) / 32;
     const int r_max = r_min > 128 ? r_min + 16 : 128;   // (a run holds at most 32 items: long calls need more than 128 runs)
-    for (int r = r_min; r <= items && r <= r_max; ++r) {
+    for (int r = (r_min + step - 1) / step * step; r <= items && r <= r_max; r += step) {
         const long long waves = pairs * r;
         const long long per_simd = (waves + simds - 1) / simds;   // the fullest SIMD
         const double work = (double)((items + r - 1) / r) + prologue;   // the longest run
@@ -799,7 +800,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         fp.n_blocks = n_blocks;
         fp.f0 = f0;
         fp.js = c->js;
-        fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35);
+        fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35, 4);
         const int n_waves = S * 2 * fp.sub_runs;
         hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), (size_t)c->dbg_pad[0], st, fp, c->d_tables, n_waves);
     }
@@ -826,7 +827,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         fp.clk = nullptr;
         fp.js = c->js;
         auto launch_qmf_sub = [&] {
-            fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35);
+            fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35, 4);
             const int n_waves = S * 2 * fp.sub_runs;   // one wavefront per (stream, channel, run)
             hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), (size_t)c->dbg_pad[0], st, fp, c->d_tables, n_waves);
         };
@@ -846,7 +847,10 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             gp.clk = c->d_clk + 16 + 256 * 12;
             launch_qmf_sub();
             HIPCHK(c, hipEventRecord(ev[1], st));
-            launch_state(st, 1);   // PCM history and subband tail: the next call's heavy stage needs nothing else from this one
+            // PCM history and subband tail: the next call's heavy stage needs nothing else from this one. (Round 6: moved behind the gain analysis - off the
+            // chain QMF -> spectra -> analysis - it cost the step 8 %: the next call's QMF kernel follows it on this stream and then misses the window
+            // between the analysis and the next rate loop in which it gets its only undisturbed microseconds. EXPERIMENTS.md.)
+            launch_state(st, 1);
             {
                 const long long spec_wgs = (long long)S * ((n_out + 3) / 4) * 6;   // (four consecutive frames of one (stream, channel, band) per wavefront)
                 hipLaunchKernelGGL(k_gain_spec, dim3((unsigned)spec_wgs), dim3(64), spec_lds_pad(c, spec_wgs), st, gp, c->d_tables, S * n_out * 6);
@@ -1223,7 +1227,7 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
         if (c->blocks_fed != 0) return fail(c, AT3HIP_EINVAL, "qmf_mdct on a joint-stereo context needs a fresh or reset context");
         fp.sub = c->d_sub;
         fp.sub_tail = c->d_sub_tail;
-        fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35);
+        fp.sub_runs = pick_runs(c, n_blocks, c->wgs_per_cu, 0.35, 4);
         const int n_waves = S * 2 * fp.sub_runs;
         hipLaunchKernelGGL(k_qmf_sub8, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, st, fp, c->d_tables, n_waves);
         MdctSubParams mp;
