@@ -43,7 +43,7 @@ SYMBOLS = ["at3hip_encode_s16", "at3hip_create", "at3hip_destroy", "at3hip_frame
            "at3hip_encode", "at3hip_reset", "at3hip_mdct", "at3hip_qmf_mdct", "at3hip_get_timings",
            "at3hip_set_stream", "at3hip_version", "at3hip_sync", "at3hip_get_timings_ago", "at3hip_read_tap",
            "at3hip_mdct_levels", "at3hip_gain_energy_scale", "at3hip_set_option", "at3hip_host_tables", "at3hip_host_alloc",
-           "at3hip_host_free", "at3hip_wait_input", "at3hip_wait_frames", "at3hip_get_counters"]
+           "at3hip_host_free", "at3hip_wait_input", "at3hip_wait_frames", "at3hip_get_counters", "at3hip_device_numa_node"]
 # include/at1hip.h
 AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_encode", "at1hip_reset", "at1hip_get_timings",
                "at1hip_read_tap", "at1hip_host_tables"]
@@ -122,6 +122,8 @@ def load_library(path=None):
     lib.at3hip_sync.argtypes = [vp]
     lib.at3hip_set_option.argtypes = [vp, i32, i32]
     lib.at3hip_host_tables.argtypes = [vp, ctypes.c_size_t]
+    lib.at3hip_device_numa_node.argtypes = [i32]
+    lib.at3hip_device_numa_node.restype = ctypes.c_int
     lib.at3hip_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.at3hip_host_free.argtypes = [vp, vp]
     lib.at3hip_wait_input.argtypes = [vp, i32]

@@ -128,20 +128,24 @@ __device__ __forceinline__ uint32_t vlc_pair_index(int m0, int m1) { return (uin
 struct VlcRow {
     unsigned long long lo, hi;   // lengths of |m| = 0..15 and 16..31 (the same row twice below wordlen 7)
 };
+// The rows, ONE definition for the code lengths (vlc_row) and for unit_bounds' lower-bound rows derived from them (lb_row_of):
+constexpr unsigned long long kVlcLo[8] = {0ull, 0ull, 0x331ull, 0x4431ull, 0x55431ull, 0x46654432ull, 0x4777766665554443ull, 0x7766666666555553ull};   // selector wl, |m| = 0..15
+constexpr unsigned long long kVlcHi7 = 0x4888888888877777ull;   // selector 7, |m| = 16..31
+constexpr int kVlcTop[8] = {0, 0, 1, 3, 4, 7, 15, 31};          // largest |m| rounding produces at wordlen wl (MaxQuant: 1.5, 3.5, 4.5, 7.5, 15.5, 31.5 -> wordlen 2 stops at 1)
 __device__ __forceinline__ VlcRow vlc_row(int wl)
 {
     unsigned long long k;
-    switch (wl) {
-        case 2: k = 0x331ull; break;
-        case 3: k = 0x4431ull; break;
-        case 4: k = 0x55431ull; break;
-        case 5: k = 0x46654432ull; break;
-        case 6: k = 0x4777766665554443ull; break;
-        default: k = 0x7766666666555553ull; break;   // wl 7, |m| <= 15
+    switch (wl) {   // (a switch over compile-time constants: the rows stay immediates, indexing the array would be a memory look-up)
+        case 2: k = kVlcLo[2]; break;
+        case 3: k = kVlcLo[3]; break;
+        case 4: k = kVlcLo[4]; break;
+        case 5: k = kVlcLo[5]; break;
+        case 6: k = kVlcLo[6]; break;
+        default: k = kVlcLo[7]; break;   // wl 7, |m| <= 15
     }
     VlcRow r;
     r.lo = k;
-    r.hi = wl == 7 ? 0x4888888888877777ull : k;   // wl 7, 16 <= |m| <= 31
+    r.hi = wl == 7 ? kVlcHi7 : k;   // wl 7, 16 <= |m| <= 31
     return r;
 }
 __device__ __forceinline__ uint32_t vlc_len(const VlcRow& r, int m)
@@ -162,17 +166,16 @@ constexpr unsigned long long lb_row(unsigned long long row, int top, unsigned ne
     }
     return r;
 }
-constexpr unsigned long long kVlcHi7 = 0x4888888888877777ull;                     // wordlen 7, |m| = 16..31 (vlc_row)
 constexpr unsigned long long kLbHi7 = lb_row(kVlcHi7, 15, 0u);                    // (x = 31 is the top code: no x + 1)
 __device__ __forceinline__ unsigned long long lb_row_of(int wl)
 {
     switch (wl) {
-        case 2: return lb_row(0x331ull, 1, 0u);
-        case 3: return lb_row(0x4431ull, 3, 0u);
-        case 4: return lb_row(0x55431ull, 4, 0u);
-        case 5: return lb_row(0x46654432ull, 7, 0u);
-        case 6: return lb_row(0x4777766665554443ull, 15, 0u);
-        default: return lb_row(0x7766666666555553ull, 31, (unsigned)(kVlcHi7 & 15ull));   // wl 7, |m| <= 15: x + 1 = 16 is the first code of the upper row
+        case 2: return lb_row(kVlcLo[2], kVlcTop[2], 0u);
+        case 3: return lb_row(kVlcLo[3], kVlcTop[3], 0u);
+        case 4: return lb_row(kVlcLo[4], kVlcTop[4], 0u);
+        case 5: return lb_row(kVlcLo[5], kVlcTop[5], 0u);
+        case 6: return lb_row(kVlcLo[6], kVlcTop[6], 0u);
+        default: return lb_row(kVlcLo[7], kVlcTop[7], (unsigned)(kVlcHi7 & 15ull));   // wl 7, |m| <= 15: x + 1 = 16 is the first code of the upper row
     }
 }
 // Per-wordlen constants as a table ACROSS the lanes (lane k & 7 holds the entries of wordlen k): the wordlen differs from
@@ -207,7 +210,7 @@ __device__ __forceinline__ VlcRow tab_row(const LaneTab& t, int wl)
     const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * wl, (int)t.lo0), b = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * wl, (int)t.lo1);
     VlcRow r;
     r.lo = (unsigned long long)a | ((unsigned long long)b << 32);
-    r.hi = wl == 7 ? 0x4888888888877777ull : r.lo;
+    r.hi = wl == 7 ? kVlcHi7 : r.lo;
     return r;
 }
 __device__ __forceinline__ uint32_t vlc_pair_len(int m0, int m1) { return (uint32_t)((0x545313545ull >> (4 * (3 * (m0 + 1) + (m1 + 1)))) & 15ull); }
@@ -1322,15 +1325,23 @@ __global__ __launch_bounds__(64) AT3_WAVES_PER_EU(4) void k_alloc_pack(BackParam
                     }
                 }
                 if (kind == 0u) {
-#ifdef AT3_EMU_HOST
+#if defined(AT3_EMU_HOST) || defined(AT3HIP_DEBUG_KNOBS)
                     const uint32_t bound_i = s_cost[cost_at];
 #endif
                     compute_units(L, tab, inexact, bits, my_e1, lane, qerr, pc, p.debug_stop);
                     AT3_STAT(6, 1); AT3_STAT(7, __popc(inexact));
-#ifdef AT3_EMU_HOST
-                    AT3_STAT(11, __popc(inexact));
+#if defined(AT3_EMU_HOST) || defined(AT3HIP_DEBUG_KNOBS)
+                    // every lower bound the loop decided with against the bits that now replace it: none may exceed them (the SIMT harness
+                    // asserts `bad 0`; profiling builds count the same on the hardware - AT3HIP_TAP_CLOCK words 13 / 14, tools/fuzz_gpu.py --bounds)
                     const unsigned long long above = __ballot(lane < 32 && ((inexact >> lane) & 1u) && bound_i > (uint32_t)s_cost[cost_at]);
+                    AT3_STAT(11, __popc(inexact));
                     AT3_STAT(12, __popcll(above));
+#ifndef AT3_EMU_HOST
+                    if (p.clk && lane == 0) {
+                        atomicAdd(p.clk + 13, (unsigned long long)__popc(inexact));
+                        if (above) atomicAdd(p.clk + 14, (unsigned long long)__popcll(above));
+                    }
+#endif
 #endif
                     if (lane < 32 && ((inexact >> lane) & 1u)) valid |= 1u << bits;
                     rsum = row_allreduce_add(clc_i | ((bits ? (uint32_t)s_cost[cost_at] : 0u) << 13));

@@ -31,7 +31,9 @@ struct BackParams {
     int frame_sz;
     int bfu_idx_const;
     int mono_js;             // one input channel in a joint-stereo container: empty second sound unit (atrac3denc.cpp:843-849)
-    struct QuantRec* quant;  // [S][n_out][2] the unit cache's final content, for the QUANT tap (zero for units never asked for); null unless AT3HIP_OPT_QUANT_TAP
+    struct QuantRec* quant;  // [S][n_out][2] the unit cache's final content, for the QUANT tap; null unless AT3HIP_OPT_QUANT_TAP. cost is zero for units never asked
+                             // for; err is zero for those AND for units of BFUs >= 10 whose cost the rate loop only ever needed as unit_bounds gives it (exact below
+                             // BFU 19, where there is no energy-adaptive pass): compute_units, which forms e1 / e2, never ran for them (include/at3hip.h)
     int flat_literal;        // AT3HIP_OPT_LITERAL_FORMS: every flatness measure by the literal per-line form (test aid; same results)
     int debug_stop;          // profiling aid (env AT3HIP_DEBUG_STOP, -DAT3HIP_DEBUG_KNOBS builds): stage exits of k_alloc_pack
     unsigned long long* counters;   // [2] at3hip_get_counters: blocks TScaler::Scale would report as "Scale error", values it would report as

@@ -577,6 +577,22 @@ int at3hip_host_alloc(at3hip_ctx* c, size_t bytes, void** out)
     return AT3HIP_OK;
 }
 
+int at3hip_device_numa_node(int32_t device_id)
+{
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device_id) != hipSuccess || !bus[0]) return -1;
+    for (char* q = bus; *q; ++q)
+        if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');   // sysfs spells the address in lower case
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
 int at3hip_host_free(at3hip_ctx* c, void* p)
 {
     if (!c) return AT3HIP_EINVAL;
@@ -885,7 +901,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             mp.n_waves = S * 2 * mp.frame_runs;
             // three wavefronts per workgroup (20.3 KB) where k_gain_analysis' launch is padded to fat slots - a light-stage workgroup must fit the slot
             // one retiring analysis workgroup frees (analysis_lds_pad) -, four (25.5 KB; one table copy per four runs) where it fills the chip unpadded
-            const bool fat_slots = analysis_lds_pad(c, (long long)S * n_out * 6) != 0;
+            const bool fat_slots = c->gain_form != AT3HIP_GAIN_FORM_ONE_WAVE && analysis_lds_pad(c, (long long)S * n_out * 6) != 0;   // (the one-wavefront form's launch has no fat slots)
             if (fat_slots) {
                 if (c->js) hipLaunchKernelGGL((k_mdct_sub<true, 3>), dim3((unsigned)((mp.n_waves + 2) / 3)), dim3(192), 0, md, mp, c->d_tables);
                 else hipLaunchKernelGGL((k_mdct_sub<false, 3>), dim3((unsigned)((mp.n_waves + 2) / 3)), dim3(192), (size_t)c->dbg_pad[1], md, mp, c->d_tables);

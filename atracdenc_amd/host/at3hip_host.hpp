@@ -27,6 +27,10 @@
 #include <string>
 #include <thread>
 #include <vector>
+#if defined(__linux__)
+#include <sched.h>
+#include <cstdio>
+#endif
 
 #include "../../include/at1hip.h"
 #include "../../include/at3hip.h"
@@ -321,6 +325,45 @@ inline std::pair<int, int> ShardStreams(int total, int parts, int idx)
     return {idx * base + (idx < rem ? idx : rem), base + (idx < rem ? 1 : 0)};
 }
 
+// Pin the calling thread to the host NUMA node of a device (at3hip_device_numa_node; the node's CPUs from
+// /sys/devices/system/node/node<N>/cpulist). Memory the thread touches first afterwards - the page-locked staging buffers of
+// TAtrac3EncoderBatch::EncodePipelined among it - then lies on that node. Returns the node, or -1 when nothing was changed (unknown
+// node, no sysfs, not Linux): a missing pin costs bandwidth on a multi-socket host, never correctness.
+inline int PinThreadToDeviceNode(int deviceId)
+{
+#if defined(__linux__)
+    const int node = at3hip_device_numa_node(deviceId);
+    if (node < 0) return -1;
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0, a = 0, b = 0;
+    for (;;) {   // "0-15,128-143"
+        if (fscanf(f, "%d", &a) != 1) break;
+        b = a;
+        int c = fgetc(f);
+        if (c == '-') {
+            if (fscanf(f, "%d", &b) != 1) break;
+            c = fgetc(f);
+        }
+        for (int cpu = a; cpu <= b && cpu < CPU_SETSIZE; ++cpu) {
+            CPU_SET(cpu, &set);
+            ++n;
+        }
+        if (c != ',') break;
+    }
+    fclose(f);
+    if (n == 0 || sched_setaffinity(0, sizeof(set), &set) != 0) return -1;
+    return node;
+#else
+    (void)deviceId;
+    return -1;
+#endif
+}
+
 class TAtrac3EncoderNode {
 public:
     // deviceIds: the HIP ordinals to use (e.g. {0,1,...,7}); streams [first, first + count) of ShardStreams go to deviceIds[i]
@@ -333,6 +376,7 @@ public:
             First.push_back(part.first);
             Count.push_back(part.second);
             Parts.emplace_back(new TAtrac3EncoderBatch(s, part.second, maxBlocks, deviceIds[i]));
+            DeviceIds.push_back(deviceIds[i]);
         }
         FrameSz = Parts[0]->FrameSize();
     }
@@ -350,6 +394,7 @@ public:
         for (size_t i = 0; i < Parts.size(); ++i)
             th.emplace_back([&, i] {
                 try {
+                    PinThreadToDeviceNode(DeviceIds[i]);   // (the device's feeder thread and what it allocates: on the device's NUMA node)
                     nf[i] = Parts[i]->Encode(pcm + (size_t)First[i] * nBlocks * blockFloats, nBlocks, out[i]);
                 } catch (const std::exception& e) {
                     err[i] = e.what();
@@ -390,6 +435,7 @@ public:
         for (size_t i = 0; i < Parts.size(); ++i)
             th.emplace_back([&, i] {
                 try {
+                    PinThreadToDeviceNode(DeviceIds[i]);   // before EncodePipelined allocates its page-locked staging: first touch on the device's node
                     int fed = 0, written = 0;
                     got[i] = Parts[i]->EncodePipelined(
                         blocksPerCall, Channels,
@@ -420,7 +466,7 @@ public:
 
 private:
     std::vector<std::unique_ptr<TAtrac3EncoderBatch>> Parts;
-    std::vector<int> First, Count;
+    std::vector<int> First, Count, DeviceIds;
     int NStreams;
     int Channels;
     int FrameSz = 0;

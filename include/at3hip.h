@@ -256,6 +256,11 @@ int at3hip_get_counters(at3hip_ctx* ctx, at3hip_counters* out, int32_t reset);
  *                       waits for all of them)
  * Pageable host memory works too (the copies then block the calling thread, as hipMemcpyAsync does for such memory). */
 int at3hip_host_alloc(at3hip_ctx* ctx, size_t bytes, void** out);
+/* The host NUMA node the device's PCIe link hangs off (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<id>/numa_node), or -1 when the
+ * platform does not say (single-node hosts, containers without sysfs). A node-level driver pins the host thread that feeds a device -
+ * and with it the first-touch placement of the page-locked buffers it allocates - to that node: eight host-fed devices pull ~50 GB/s
+ * each, which a single node's memory controllers do not deliver (atracdenc_amd/host/at3hip_host.hpp: TAtrac3EncoderNode). Needs no ctx. */
+int at3hip_device_numa_node(int32_t device_id);
 int at3hip_host_free(at3hip_ctx* ctx, void* p);
 int at3hip_wait_input(at3hip_ctx* ctx, int32_t ago);
 int at3hip_wait_frames(at3hip_ctx* ctx, int32_t ago);
@@ -272,7 +277,7 @@ int at3hip_host_tables(void* dst, size_t bytes);
  *        AT3HIP_OPT_GAIN_FORM / AT3HIP_OPT_GAIN_WGS_PER_CU / AT3HIP_OPT_LITERAL_FORMS with validated values
  *   1.3  at3hip_get_counters; AT3HIP_OPT_GAIN_FORM's values renumbered (the former AT3HIP_OPT_GAIN_TWO_WAVES: 0 = one workgroup of two
  *        wavefronts per item, 1 = the one-wavefront form, formerly 2 - the legacy value 2 is still accepted and means ONE_WAVE)
- *   1.4  AT3HIP_OPT_CHAIN
+ *   1.4  AT3HIP_OPT_CHAIN, at3hip_device_numa_node
  * A host layer compiled against this header checks at3hip_version() >= AT3HIP_VERSION before it relies on them
  * (atracdenc_amd/host/at3hip_host.hpp and the ctypes stub do). */
 #define AT3HIP_VERSION_MAJOR 1

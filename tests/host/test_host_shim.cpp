@@ -136,7 +136,7 @@ int main()
             EXPECT(enf == nf && fsz == node.FrameSize());
             EXPECT(memcmp(frames.data() + (size_t)s * nf * fsz, exp.data(), (size_t)nf * fsz) == 0);
         }
-        printf("TAtrac3EncoderNode (2 contexts) compared\n");
+        printf("TAtrac3EncoderNode (2 contexts) compared; device 0 sits on host NUMA node %d (at3hip_device_numa_node; -1 = the platform does not say)\n", at3hip_device_numa_node(0));
         // the same input through the page-locked, double-buffered pipeline: calls of 2 blocks, copies and kernels overlapping
         node.Reset();
         std::vector<uint8_t> piped;

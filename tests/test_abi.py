@@ -67,6 +67,13 @@ def test_vlc_length_constants():
     off = {2: 9, 3: 14, 4: 0, 5: 21, 6: 36, 7: 67}
     maxabs = {2: 2, 3: 3, 4: 4, 5: 7, 6: 15, 7: 31}
     alloc = open(os.path.join(root, "at3_k_alloc.hpp")).read()
+    # ONE definition of the rows: kVlcLo / kVlcHi7 / kVlcTop - vlc_row and unit_bounds' lb_row_of both read them, no second copy of a literal
+    lo_txt = re.search(r"constexpr unsigned long long kVlcLo\[8\] = \{([^}]*)\}", alloc).group(1)
+    k_lo = [int(x.strip().rstrip("ul"), 16) for x in lo_txt.split(",")]
+    k_hi7 = int(re.search(r"constexpr unsigned long long kVlcHi7 = (0x[0-9a-fA-F]+)ull", alloc).group(1), 16)
+    k_top = [int(x) for x in re.search(r"constexpr int kVlcTop\[8\] = \{([^}]*)\}", alloc).group(1).split(",")]
+    assert len(k_lo) == 8 and len(k_top) == 8 and k_lo[0] == k_lo[1] == 0
+    assert len(re.findall(r"0x4888888888877777", alloc)) == 1 and len(re.findall(r"0x7766666666555553", alloc)) == 1   # (no stray copies)
     for sel in range(2, 8):
         k = 0
         for m in range(maxabs[sel] + 1):
@@ -76,11 +83,17 @@ def test_vlc_length_constants():
                 ln = bits[off[sel] + (m << 1) - 1]
                 assert ln == bits[off[sel] + (m << 1)]      # +m and -m: same length
             k |= ln << (4 * m)
+        assert k_top[sel] == (1 if sel == 2 else maxabs[sel])   # (wordlen 2 rounds to |m| <= 1: its table's third length is never a neighbour)
         if sel < 7:
-            assert f"case {sel}: k = {hex(k)}ull" in alloc, sel
+            assert k_lo[sel] == k, sel
         else:
-            lo, hi = k & ((1 << 64) - 1), k >> 64
-            assert f"default: k = {hex(lo)}ull" in alloc and f"wl == 7 ? {hex(hi)}ull : k" in alloc
+            assert k_lo[7] == k & ((1 << 64) - 1) and k_hi7 == k >> 64
+        assert f"case {sel}: k = kVlcLo[{sel}]" in alloc or sel == 7
+        assert f"lb_row(kVlcLo[{sel}], kVlcTop[{sel}]" in alloc
+        # the property unit_bounds' lower bound rests on: a code's length never shrinks with |m|, but for the top code of wordlens 5 .. 7
+        lens = [(k >> (4 * m)) & 15 for m in range(maxabs[sel] + 1)]
+        drops = [m for m in range(1, len(lens)) if lens[m] < lens[m - 1]]
+        assert drops == ([maxabs[sel]] if sel >= 5 else []), (sel, lens)
     rt9 = [8, 4, 7, 2, 0, 1, 6, 3, 5]
     kp = sum(bits[rt9[i]] << (4 * i) for i in range(9))
     assert f"({hex(kp)}ull >> (4 * (3 * (m0 + 1) + (m1 + 1))))" in alloc

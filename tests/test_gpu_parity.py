@@ -871,6 +871,17 @@ def test_options_and_quant_tap(hip, oracle):
     lines = np.array([8] * 8 + [16] * 2)
     clc = np.array([2, 3, 3, 4, 4, 5, 6])[:, None] * lines[None, :]          # CLC bits per unit: clc_len(wordlen) x lines (pairs of 4 bits at wordlen 1)
     assert ((cost & 0x1fff) == clc).all() and ((cost >> 13) > 0).all()
+    # BFUs 10 .. 31: a unit the rate loop asked for has its cost (CLC bits of its wordlen and line count | VLC bits << 13) but its energy
+    # error only if the energy-adaptive pass had to run for it - cost != 0 with err == 0 is a unit whose bits unit_bounds alone supplied -, and a unit
+    # never asked for is zero in both
+    err_hi, cost_hi = q["err"][..., 10:], q["cost"][..., 10:]
+    asked = cost_hi != 0
+    assert asked.any() and (~asked).any()
+    assert np.isfinite(err_hi).all() and (err_hi >= 0).all() and (err_hi[~asked] == 0).all()
+    lines_hi = np.array([16] * 6 + [32] * 10 + [64] * 4 + [128] * 2)
+    clc_hi = np.array([2, 3, 3, 4, 4, 5, 6])[:, None] * lines_hi[None, :]
+    assert ((cost_hi & 0x1fff)[asked] == np.broadcast_to(clc_hi, cost_hi.shape)[asked]).all()
+    assert (asked & (err_hi == 0)).any()      # the bounds-only units exist on this material: the contract above is exercised
     enc.reset()
     enc.set_option(B.OPT_QUANT_TAP, 0)
     enc.set_option(B.OPT_RUNS, 0)

@@ -104,6 +104,7 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); 
 struct hipDeviceProp_t { int multiProcessorCount; size_t maxSharedMemoryPerMultiProcessor; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 4; p->maxSharedMemoryPerMultiProcessor = 160u * 1024u; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipDeviceGetPCIBusId(char* id, int len, int) { if (len > 0) id[0] = 0; return hipErrorUnknown; }
 
 // ---- wave-level (64 lanes) cross-lane primitives: implemented with a wave-wide rendezvous ----
 unsigned emu_wave_exchange(unsigned value, unsigned* all64);   // deposit `value`, returns active mask lo; all64 = values

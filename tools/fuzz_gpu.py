@@ -88,6 +88,13 @@ def main():
                 if os.environ.get("FUZZ_GAIN_FORM"):   # AT3HIP_OPT_GAIN_FORM: 1 = the one-wavefront upsampler kernel
                     enc.set_option(atracdenc_amd.binding.OPT_GAIN_FORM, int(os.environ["FUZZ_GAIN_FORM"]))
                 got = enc.encode(pcm)
+                if os.environ.get("FUZZ_BOUNDS"):   # a -DAT3HIP_DEBUG_KNOBS build (AT3HIP_LIB): k_alloc_pack counts the lower bounds its rate loop decided with
+                    clk = enc.read_tap(atracdenc_amd.binding.TAP_CLOCK, np.uint64, (16,))      # ... that were later replaced by bits (word 13) and those above them (14)
+                    bounds_seen = globals().setdefault("_bounds", [0, 0])
+                    bounds_seen[0] += int(clk[13]); bounds_seen[1] += int(clk[14])
+                    if int(clk[14]):
+                        bad_total += 1
+                        print(f"BOUND ABOVE BITS round {rd} br {br} nogain {ng} notonal {nt}: {int(clk[14])} of {int(clk[13])}")
                 enc.close()
                 exp = list(pool.map(lambda i: o.encode(pcm[i], br, ng, nt)[0], range(S)))
                 if have_ref():   # the oracle itself against the real reference on a slice of the same material
@@ -104,6 +111,8 @@ def main():
                         bad_total += len(bad)
                         print(f"MISMATCH round {rd} br {br} nogain {ng} notonal {nt} stream {i} family {items[i][0]} frames {bad[:8].tolist()}")
         print(f"round {rd}: {total} frames checked, {bad_total} mismatching, {time.time() - t0:.1f}s", flush=True)
+    if os.environ.get("FUZZ_BOUNDS"):
+        print("bounds checked against the bits that replaced them:", globals().get("_bounds", [0, 0])[0], "above them:", globals().get("_bounds", [0, 0])[1])
     print("FUZZ", "CLEAN" if bad_total == 0 else "FAILED", total, "frames")
 
 if __name__ == "__main__":
