@@ -422,7 +422,8 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
         // slots the heavy stage's workgroups free (+3 % on the step; a middle priority does nothing).
         if (!cfg->no_gain_control && hipStreamCreateWithPriority(&c->mid_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(AT3HIP_EDEVICE);
     }
-    if (hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    // (the copy stream is created by the first call that copies from host memory: a context fed from device memory keeps the process one stream - one claim on the
+    // runtime's few hardware queues - smaller; with it, later contexts of a process wandered between 12.5 and 14.9 M frames/s on `tones`, without it they sit at 14.8)
     for (int q = 0; q < 2; ++q)
         if (hipEventCreateWithFlags(&c->ev_h2d[q], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_pcm_free[q], hipEventDisableTiming) != hipSuccess)
@@ -744,6 +745,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             const int rc = dev_alloc(c, &c->d_s16_b[par], (size_t)S * c->cfg.max_blocks * 1024 * c->cfg.channels);
             if (rc != AT3HIP_OK) return rc;
         }
+        if (!c->h2d_stream && hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess) return fail(c, AT3HIP_EDEVICE, "hipStreamCreateWithFlags (copy stream)");
         if (c->pcm_free_valid[par]) HIPCHK(c, hipStreamWaitEvent(c->h2d_stream, c->ev_pcm_free[par], 0));
         if (s16) HIPCHK(c, hipMemcpyAsync(c->d_s16_b[par], pcm_any, n_in * sizeof(int16_t), hipMemcpyHostToDevice, c->h2d_stream));
         else HIPCHK(c, hipMemcpyAsync(c->d_pcm_in_b[par], pcm, n_in * sizeof(float), hipMemcpyHostToDevice, c->h2d_stream));
@@ -926,6 +928,10 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
     }
     if (n_out > 0) {
         // ---- back half, on its own stream, after the fused kernel of THIS call ----
+        // (Round 6, each an 8 - 11 % LOSS on the step although it shortens a chain: the loudness sums and k_psy queued behind the MDCT on the light stage's stream
+        // (no event hop between the streams in front of them); k_gain_energy_scale on this stream beside the MDCT; TrackLoudness inside k_psy (no k_loudness
+        // launch); k_loud_sum in 22 KB blocks that fit a slot one retiring analysis workgroup frees. EXPERIMENTS.md: the step's schedule is one of several
+        // stable ones, tools/event_timeline.py shows which.)
         HIPCHK(c, hipStreamWaitEvent(bk, ev[4], 0));
         HIPCHK(c, hipEventRecord(ev[5], bk));
         BackParams bp;
@@ -1043,6 +1049,24 @@ int at3hip_get_counters(at3hip_ctx* c, at3hip_counters* out, int32_t reset)
     if (reset) HIPCHK(c, hipMemset(c->d_counters, 0, sizeof(v)));
     return AT3HIP_OK;
 }
+
+#if defined(AT3HIP_DEBUG_KNOBS) || defined(AT3HIP_DEBUG_EVENTS)
+// PROFILING BUILDS ONLY (-DAT3HIP_DEBUG_EVENTS: the release kernels + this entry point; not in include/at3hip.h): milliseconds from event `ia` of the call
+// `ago_a` calls back to event `ib` of the call `ago_b` calls back (events 0 .. 7 of a call: before QMF, after QMF, after the gain analysis, after the curves /
+// energy scales, after the MDCT, back half's start, after k_psy, after the rate loop) - the pipelined step's timeline WITHOUT a tracer (tools/event_timeline.py):
+// rocprofv3 serialises what it traces, and this pipeline's schedule does not survive that.
+__attribute__((visibility("default"))) int at3hip_debug_event_ms(at3hip_ctx* c, int32_t ago_a, int32_t ia, int32_t ago_b, int32_t ib, float* ms)
+{
+    if (!c || !ms || ago_a < 0 || ago_b < 0 || ago_a >= at3hip_ctx::kSlots || ago_b >= at3hip_ctx::kSlots || ago_a >= c->enc_calls || ago_b >= c->enc_calls ||
+        ia < 0 || ia > 7 || ib < 0 || ib > 7)
+        return AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    const int rc = drain(c);
+    if (rc != AT3HIP_OK) return rc;
+    const int sa = (int)((c->enc_calls - 1 - ago_a) % at3hip_ctx::kSlots), sb = (int)((c->enc_calls - 1 - ago_b) % at3hip_ctx::kSlots);
+    return hipEventElapsedTime(ms, c->ev[sa][ia], c->ev[sb][ib]) == hipSuccess ? AT3HIP_OK : AT3HIP_EDEVICE;
+}
+#endif
 
 int at3hip_get_timings_ago(at3hip_ctx* c, int32_t ago, at3hip_timings* out)
 {
