@@ -422,8 +422,10 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
         // slots the heavy stage's workgroups free (+3 % on the step; a middle priority does nothing).
         if (!cfg->no_gain_control && hipStreamCreateWithPriority(&c->mid_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(AT3HIP_EDEVICE);
     }
-    // (the copy stream is created by the first call that copies from host memory: a context fed from device memory keeps the process one stream - one claim on the
-    // runtime's few hardware queues - smaller; with it, later contexts of a process wandered between 12.5 and 14.9 M frames/s on `tones`, without it they sit at 14.8)
+    // (Round 6 tried creating the copy stream only at the first call that copies from host memory - one claim less on the runtime's few hardware queues for
+    // contexts fed from device memory. Created that late it shares a hardware queue with one of the kernel streams and the host-fed pipeline halves:
+    // 12.4 -> 6.3 M frames/s with 16-bit samples. It is created here, right behind the kernel streams.)
+    if (hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess) return bail(AT3HIP_EDEVICE);
     for (int q = 0; q < 2; ++q)
         if (hipEventCreateWithFlags(&c->ev_h2d[q], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_pcm_free[q], hipEventDisableTiming) != hipSuccess)
@@ -745,7 +747,6 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             const int rc = dev_alloc(c, &c->d_s16_b[par], (size_t)S * c->cfg.max_blocks * 1024 * c->cfg.channels);
             if (rc != AT3HIP_OK) return rc;
         }
-        if (!c->h2d_stream && hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess) return fail(c, AT3HIP_EDEVICE, "hipStreamCreateWithFlags (copy stream)");
         if (c->pcm_free_valid[par]) HIPCHK(c, hipStreamWaitEvent(c->h2d_stream, c->ev_pcm_free[par], 0));
         if (s16) HIPCHK(c, hipMemcpyAsync(c->d_s16_b[par], pcm_any, n_in * sizeof(int16_t), hipMemcpyHostToDevice, c->h2d_stream));
         else HIPCHK(c, hipMemcpyAsync(c->d_pcm_in_b[par], pcm, n_in * sizeof(float), hipMemcpyHostToDevice, c->h2d_stream));
