@@ -742,8 +742,10 @@ def main():
                          "avg_launch_ms": round(k1_avg_ms, 5), "launches_per_step": getattr(j0, "k1_launches", 1),
                          "timing": "HIP events on the context's stream around the kernel(s); they include the launch gaps that "
                                    "rocprofv3's kernel durations (profiles/) do not",
-                         "limiter": "VALU issue + LDS (FMA-free fp32 arithmetic contract), not HBM: see DESIGN.md section 5; the HBM "
-                                    "fraction is reported because it is the roofline north_star names",
+                         "limiter": "the vector pipe (FMA-free fp32 arithmetic contract: the FIR's multiplies and adds are two packed instructions "
+                                    "each), not HBM - and for the fused kernel running back to back on white noise the board's 1400 W power cap, which holds "
+                                    "the shader clock at 2.0 - 2.1 GHz instead of 2.4 (profiles/r06_k1_power_probe.txt, not measured in this run): see "
+                                    "DESIGN.md section 5; the HBM fraction is reported because it is the roofline north_star names",
                          "note": "launches of the timed region (device 0). In the timed region the two kernels run on two of the context's "
                                  "three streams and share the GPU with the neighbouring steps' gain analysis and rate loop - on purpose: "
                                  "that overlap is what shortens the step - so each launch takes longer than it does alone; `isolated` is "

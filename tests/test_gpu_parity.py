@@ -950,3 +950,16 @@ def test_option_values_are_validated_and_version(hip):
         enc.encode_device_s16(raw.data_ptr() + 2, 4, out.data_ptr())      # misaligned by one sample
     assert enc.encode_device_s16(raw.data_ptr(), 4, out.data_ptr()) == 3
     enc.close()
+
+
+def test_device_numa_node_query(hip):
+    """at3hip_device_numa_node (ABI 1.4): the host NUMA node of a device's PCIe link from sysfs, -1 where the platform does not say;
+    an ordinal the runtime does not know is -1 too (never an error: a missing pin only costs bandwidth)."""
+    import os
+    from atracdenc_amd import binding as B
+    lib = B.load_library()
+    node = lib.at3hip_device_numa_node(0)
+    assert -1 <= node < 64
+    if node >= 0:
+        assert os.path.exists(f"/sys/devices/system/node/node{node}/cpulist")
+    assert lib.at3hip_device_numa_node(1000) == -1
