@@ -12,10 +12,10 @@ CSRC = os.path.join(HERE, "csrc")
 AT3HIP_PCM_ON_DEVICE = 1
 AT3HIP_OUT_ON_DEVICE = 2
 AT3HIP_ASYNC = 4
-OPT_RUNS, OPT_LITERAL_FORMS, OPT_QUANT_TAP, OPT_GAIN_FORM, OPT_GAIN_WGS_PER_CU, OPT_CHAIN = 1, 2, 3, 4, 5, 6
+OPT_RUNS, OPT_LITERAL_FORMS, OPT_QUANT_TAP, OPT_GAIN_FORM, OPT_GAIN_WGS_PER_CU, OPT_CHAIN, OPT_TIMING_EVERY = 1, 2, 3, 4, 5, 6, 7
 OPT_FLATNESS_LITERAL = OPT_LITERAL_FORMS           # (former name, same number)
 GAIN_FORM_TWO_WAVES, GAIN_FORM_ONE_WAVE = 0, 1
-AT3HIP_VERSION = (1 << 16) | 4                     # include/at3hip.h this stub mirrors: load_library refuses an older library
+AT3HIP_VERSION = (1 << 16) | 5                     # include/at3hip.h this stub mirrors: load_library refuses an older library
 TAP_SPECTRA, TAP_CURVES, TAP_ENERGY_SCALE, TAP_PSY, TAP_LOUDNESS, TAP_QUANT, TAP_CLOCK, TAP_GAIN_ANALYSIS = 1, 2, 3, 4, 5, 6, 7, 8
 LP2 = 132300
 LP4 = 66150

@@ -59,6 +59,7 @@ struct at3hip_ctx {
     GainRec* d_rec_b[2] = {nullptr, nullptr};
     hipEvent_t ev_mid_done[2] = {};              // light stage finished with the parity's subbands and gain records
     bool mid_done_valid[2] = {false, false};
+    hipEvent_t mid_done_of[2] = {};              // the event that says so for the parity's last call: its ev_mdct_done, or ev_mid_done (not owned)
     // The back half of call N only consumes what the front half of call N produced (spectra, curves, energy scales),
     // and the front half of call N+1 only depends on the front half of call N (carried state): the two halves run on
     // HIP streams of their own (three with gain control, see mid_stream below), buffers that cross between them are double-buffered by call parity, and consecutive calls overlap.
@@ -75,7 +76,7 @@ struct at3hip_ctx {
     hipEvent_t ev_pcm_free[2] = {};                 // the parity's staging has been consumed (front half done with it)
     bool pcm_free_valid[2] = {false, false};
     bool h2d_valid[2] = {false, false};
-    hipEvent_t ev_back_done[2] = {};     // back half finished with the parity's cross buffers
+    hipEvent_t ev_back_done[2] = {};     // back half finished with the parity's cross buffers (the ev_host_out of that call: not owned)
     // what the HOST waits for (at3hip_wait_input / at3hip_wait_frames), per call in a ring of four: the parity events above are
     // re-recorded by the call after next, so a caller with three calls in flight would wait for the newest of them
     static constexpr int kHostRing = 4;
@@ -89,6 +90,10 @@ struct at3hip_ctx {
     char err[256] = {0};
     long long blocks_fed = 0;   // per stream
     int chain_mode = 0;      // AT3HIP_OPT_CHAIN: 0 = chosen per call, 1 = never, 2 = whenever the geometry allows
+    int timing_every = 1;    // AT3HIP_OPT_TIMING_EVERY: stage timings on every Nth call with frames (0 = never)
+    unsigned timing_tick = 0;
+    bool slot_timed[kSlots] = {};
+    hipEvent_t ev_heavy_done[kSlots] = {}, ev_mdct_done[kSlots] = {};   // a call's own hand-overs between its streams (no timestamps)
     int runs_override = 0;   // AT3HIP_OPT_RUNS: runs per (stream, channel) of the front-end kernels (tuning aid; output is invariant)
     int flat_literal = 0;    // AT3HIP_OPT_LITERAL_FORMS
     int gain_form = AT3HIP_GAIN_FORM_TWO_WAVES;   // AT3HIP_OPT_GAIN_FORM: the two-wavefront workgroups (default) or one wavefront per item (k_gain_analysis1)
@@ -181,7 +186,7 @@ int drain(at3hip_ctx* c)
 void read_timings(const at3hip_ctx* c, int slot, at3hip_timings* tm)
 {
     memset(tm, 0, sizeof(*tm));
-    if (slot < 0 || !c->slot_has_frames[slot]) return;
+    if (slot < 0 || !c->slot_has_frames[slot] || !c->slot_timed[slot]) return;   // (all zero, qmf_mdct_launches 0: the call was not timed)
     hipEvent_t const* ev = c->ev[slot];
     float ms = 0.0f;
     (void)hipEventElapsedTime(&ms, ev[0], ev[1]); tm->qmf_ms = ms;
@@ -435,8 +440,10 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
         for (auto& e : row)
             if (hipEventCreate(&e) != hipSuccess) return bail(AT3HIP_EDEVICE);
     if (hipEventCreateWithFlags(&c->ev_front_done, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
-    for (auto& e : c->ev_back_done)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(AT3HIP_EDEVICE);
+    for (int q = 0; q < at3hip_ctx::kSlots; ++q)
+        if (hipEventCreateWithFlags(&c->ev_heavy_done[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_mdct_done[q], hipEventDisableTiming) != hipSuccess)
+            return bail(AT3HIP_EDEVICE);
     for (int q = 0; q < at3hip_ctx::kHostRing; ++q)
         if (hipEventCreateWithFlags(&c->ev_host_in[q], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_host_out[q], hipEventDisableTiming) != hipSuccess)
@@ -538,7 +545,9 @@ void at3hip_destroy(at3hip_ctx* c)
     }
     if (c->h2d_stream) (void)hipStreamDestroy(c->h2d_stream);
     if (c->ev_front_done) (void)hipEventDestroy(c->ev_front_done);
-    for (auto& e : c->ev_back_done)
+    for (auto& e : c->ev_heavy_done)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_mdct_done)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_host_in)
         if (e) (void)hipEventDestroy(e);
@@ -644,6 +653,11 @@ int at3hip_set_option(at3hip_ctx* c, int32_t option, int32_t value)
         case AT3HIP_OPT_CHAIN:
             if (value < 0 || value > 2) return fail(c, AT3HIP_EINVAL, "chain: 0 (per call), 1 (never) or 2 (whenever possible)");
             c->chain_mode = value;
+            return AT3HIP_OK;
+        case AT3HIP_OPT_TIMING_EVERY:
+            if (value < 0) return fail(c, AT3HIP_EINVAL, "timing every: 0 (never) or N >= 1 (every Nth call with frames)");
+            c->timing_every = value;
+            c->timing_tick = 0;
             return AT3HIP_OK;
         case AT3HIP_OPT_LITERAL_FORMS:
             if (value != 0 && value != 1) return fail(c, AT3HIP_EINVAL, "literal forms: 0 or 1");
@@ -784,6 +798,10 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
     float* d_specs = c->d_specs[par];
     float* d_ges = c->d_ges[par];
     c->slot_has_frames[slot] = false;
+    // The timing events sit between the kernels of the three streams; at 4096 frames a step recording all eight takes 3.3 % longer than one recording none
+    // (EXPERIMENTS.md, round 6), so a caller that only samples the stage timings asks for every Nth call.
+    const bool timed = n_out > 0 && c->timing_every > 0 && (c->timing_tick++ % (unsigned)c->timing_every) == 0;
+    c->slot_timed[slot] = timed;
     auto launch_state = [&](hipStream_t on, int parts) {
         StateParams sp;
         sp.pcm = d_pcm;
@@ -804,8 +822,8 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
     float* d_sub = gain ? c->d_sub_b[par] : c->d_sub;
     GainRec* d_rec = gain ? c->d_rec_b[par] : c->d_rec;
     // the light stage of the call before the previous one must be done with this parity's subbands and gain records
-    if (gain && c->mid_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_mid_done[par], 0));
-    HIPCHK(c, hipEventRecord(ev[0], st));
+    if (gain && c->mid_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(st, c->mid_done_of[par], 0));
+    if (timed) HIPCHK(c, hipEventRecord(ev[0], st));
     // the back half of the call before the previous one must be done with this parity's spectra / curves / scales
     if (c->back_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(md, c->ev_back_done[par], 0));
     HIPCHK(c, hipMemsetAsync(d_curves, 0, (size_t)S * n_blocks * 8 * sizeof(Curve), md));
@@ -865,7 +883,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             gp.literal = c->flat_literal;
             gp.clk = c->d_clk + 16 + 256 * 12;
             launch_qmf_sub();
-            HIPCHK(c, hipEventRecord(ev[1], st));
+            if (timed) HIPCHK(c, hipEventRecord(ev[1], st));
             // PCM history and subband tail: the next call's heavy stage needs nothing else from this one. (Round 6: moved behind the gain analysis - off the
             // chain QMF -> spectra -> analysis - it cost the step 8 %: the next call's QMF kernel follows it on this stream and then misses the window
             // between the analysis and the next rate loop in which it gets its only undisturbed microseconds. EXPERIMENTS.md.)
@@ -878,18 +896,19 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             // leaves the pipelined step 2 % slower at that size, equal at the 1024 x 128 shard (profiles/EXPERIMENTS.md)
             if (c->gain_form != AT3HIP_GAIN_FORM_ONE_WAVE) hipLaunchKernelGGL(k_gain_analysis, dim3(S * n_out * 6), dim3(128), analysis_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);
             else hipLaunchKernelGGL(k_gain_analysis1, dim3(S * n_out * 6), dim3(64), analysis1_lds_pad(c, (long long)S * n_out * 6), st, gp, c->d_tables);   // one wavefront per item
-            HIPCHK(c, hipEventRecord(ev[2], st));
-            HIPCHK(c, hipStreamWaitEvent(md, ev[2], 0));   // the light stage starts when this call's heavy stage is done
+            if (timed) HIPCHK(c, hipEventRecord(ev[2], st));
+            HIPCHK(c, hipEventRecord(c->ev_heavy_done[slot], st));
+            HIPCHK(c, hipStreamWaitEvent(md, c->ev_heavy_done[slot], 0));   // the light stage starts when this call's heavy stage is done
             hipLaunchKernelGGL(k_gain_tail, dim3((unsigned)((S * n_out * 6 + 7) / 8)), dim3(256), (size_t)c->dbg_pad[4], md, gp, S * n_out * 6);
             hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), (size_t)c->dbg_pad[7], md, gp, S);
             hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), (size_t)c->dbg_pad[2], md, gp, c->d_tables, S);
             hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), (size_t)c->dbg_pad[3], md, fp, c->d_tables, S * n_out);
         } else {
             if (split) launch_qmf_sub();   // joint stereo without gain control: the QMF kernel, timed as qmf_ms
-            HIPCHK(c, hipEventRecord(ev[1], st));
-            HIPCHK(c, hipEventRecord(ev[2], st));
+            if (timed) HIPCHK(c, hipEventRecord(ev[1], st));
+            if (timed) HIPCHK(c, hipEventRecord(ev[2], st));
         }
-        HIPCHK(c, hipEventRecord(ev[3], md));
+        if (timed) HIPCHK(c, hipEventRecord(ev[3], md));
         if (split) {
             // the subbands are in HBM (k_qmf_sub8 wrote them: for the gain analysis, or for the M/S matrixing)
             MdctSubParams mp;
@@ -916,13 +935,20 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             const int n_waves = S * 2 * fp.frame_runs;
             hipLaunchKernelGGL(k_qmf_mdct8, dim3((unsigned)((n_waves + kFusedWaves - 1) / kFusedWaves)), dim3(64 * kFusedWaves), 0, st, fp, c->d_tables, n_waves);
         }
-        HIPCHK(c, hipEventRecord(ev[4], md));
+        if (timed) HIPCHK(c, hipEventRecord(ev[4], md));
+        HIPCHK(c, hipEventRecord(c->ev_mdct_done[slot], md));
         c->slot_k1_launches[slot] = split ? 2 : 1;
     }
     if (gain) {
         if (n_out == 0) launch_state(st, 1);   // (with frames it followed the QMF kernel)
         launch_state(md, 2);                     // last curves: the light stage's own hand-over
-        HIPCHK(c, hipEventRecord(c->ev_mid_done[par], md));
+        // with frames the MDCT kernel was the last reader of the parity's subbands and gain records (the update above touches the curves and
+        // the band states, which only this stream reads and writes): its event serves, one record less between the kernels
+        if (n_out > 0) c->mid_done_of[par] = c->ev_mdct_done[slot];
+        else {
+            HIPCHK(c, hipEventRecord(c->ev_mid_done[par], md));
+            c->mid_done_of[par] = c->ev_mid_done[par];
+        }
         c->mid_done_valid[par] = true;
     } else {
         launch_state(st, 3);
@@ -933,8 +959,8 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         // (no event hop between the streams in front of them); k_gain_energy_scale on this stream beside the MDCT; TrackLoudness inside k_psy (no k_loudness
         // launch); k_loud_sum in 22 KB blocks that fit a slot one retiring analysis workgroup frees. EXPERIMENTS.md: the step's schedule is one of several
         // stable ones, tools/event_timeline.py shows which.)
-        HIPCHK(c, hipStreamWaitEvent(bk, ev[4], 0));
-        HIPCHK(c, hipEventRecord(ev[5], bk));
+        HIPCHK(c, hipStreamWaitEvent(bk, c->ev_mdct_done[slot], 0));
+        if (timed) HIPCHK(c, hipEventRecord(ev[5], bk));
         BackParams bp;
         bp.specs = d_specs;
         bp.ges = gain ? d_ges : nullptr;
@@ -959,21 +985,24 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
         bp.one_channel = c->cfg.channels == 1 ? 1 : 0;
         hipLaunchKernelGGL(k_loud_sum, dim3((unsigned)((S * n_out * 2 + kLoudCf - 1) / kLoudCf)), dim3(256), (size_t)c->dbg_pad[5], bk, bp, c->d_tables, S * n_out * 2);
         hipLaunchKernelGGL(k_psy, dim3((S * n_out * 2 + kPsyCf - 1) / kPsyCf), dim3(256), (size_t)c->dbg_pad[6], bk, bp, c->d_tables, S * n_out * 2);
-        HIPCHK(c, hipEventRecord(ev[6], bk));
+        if (timed) HIPCHK(c, hipEventRecord(ev[6], bk));
         hipLaunchKernelGGL(k_loudness, dim3(S), dim3(64), 0, bk, bp);
         hipLaunchKernelGGL(k_alloc_pack, dim3(S * n_out * 2), dim3(64), (size_t)c->alloc_lds_pad, bk, bp, c->d_tables);
-        HIPCHK(c, hipEventRecord(ev[7], bk));
+        if (timed) HIPCHK(c, hipEventRecord(ev[7], bk));
         if (!(flags & AT3HIP_OUT_ON_DEVICE))
             HIPCHK(c, hipMemcpyAsync(out_frames, c->d_out, (size_t)S * n_out * c->frame_sz, hipMemcpyDeviceToHost, bk));
-        HIPCHK(c, hipEventRecord(c->ev_back_done[par], bk));
-        c->back_done_valid[par] = true;
+        // one event per call on this stream: the frames are out (at3hip_wait_frames) and the back half is done with the parity's buffers
         HIPCHK(c, hipEventRecord(c->ev_host_out[hq], bk));
+        c->ev_back_done[par] = c->ev_host_out[hq];
+        c->back_done_valid[par] = true;
         host_out_recorded = true;
         c->slot_has_frames[slot] = true;
         c->last_slot = slot;
     }
-    HIPCHK(c, hipEventRecord(c->ev_front_done, st));
-    c->front_done_valid = true;
+    if (c->stream != c->own_stream) {   // (at3hip_destroy waits for the context's own streams themselves)
+        HIPCHK(c, hipEventRecord(c->ev_front_done, st));
+        c->front_done_valid = true;
+    }
     if (staged) {   // (the PCM is read by the first stage and by the carried-state update, both on `st`)
         HIPCHK(c, hipEventRecord(c->ev_pcm_free[par], st));
         c->pcm_free_valid[par] = true;

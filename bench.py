@@ -149,6 +149,9 @@ class DeviceJob:
         if DeviceJob.gain_wgs:
             from atracdenc_amd import binding as B
             self.enc.set_option(B.OPT_GAIN_WGS_PER_CU, DeviceJob.gain_wgs)
+        if DeviceJob.timing_every != 1:
+            from atracdenc_amd import binding as B
+            self.enc.set_option(B.OPT_TIMING_EVERY, DeviceJob.timing_every)
         self.bitrate, self.no_gain = bitrate, no_gain
         self.fsz = self.enc.frame_size
         # synthetic PCM resident in HBM before timing: a priming look-ahead block + two alternating batches that are
@@ -176,6 +179,7 @@ class DeviceJob:
         self.torch.cuda.synchronize(self.dev)
 
     sync_steps = False   # --sync-steps (profiling aid)
+    timing_every = 8     # --timing-every: which steps carry the stage-timing HIP events (AT3HIP_OPT_TIMING_EVERY)
     runs = 0             # --runs (tuning aid: AT3HIP_OPT_RUNS)
     gain_form = 0        # --gain-form (A/B aid: AT3HIP_OPT_GAIN_FORM)
     gain_wgs = 0         # --gain-wgs (tuning aid: AT3HIP_OPT_GAIN_WGS_PER_CU)
@@ -224,23 +228,30 @@ class DeviceJob:
         self.enc.sync()
         self.torch.cuda.synchronize(self.dev)
 
-    def k1_stats(self, n_timed, first_ago):
-        k1_ms, stage_ms = [], {}
-        for ago in range(first_ago, first_ago + n_timed):
+    def k1_stats(self, n_calls, first_ago):
+        """The QMF + MDCT launch times and the stage spans of those of the last n_calls steps that carried timing events."""
+        k1_ms, stage_ms, n = [], {}, 0
+        for ago in range(first_ago, min(first_ago + n_calls, 32)):
             tm = self.enc.timings_ago(ago)
+            if tm["qmf_mdct_launches"] == 0:
+                continue                                      # a step without timing events (AT3HIP_OPT_TIMING_EVERY)
+            n += 1
             k1_ms.append(tm["qmf_ms"] + tm["qmf_mdct_ms"])   # the QMF + MDCT work of one step, one or two kernels
             for k, v in tm.items():
                 if k.endswith("_ms"):
                     stage_ms[k] = stage_ms.get(k, 0.0) + v
-        return k1_ms, {k: v / max(1, n_timed) for k, v in stage_ms.items()}
+        return k1_ms, {k: v / max(1, n) for k, v in stage_ms.items()}
 
     def isolated_k1(self, reps=3):
+        from atracdenc_amd import binding as B
         ms = []
+        self.enc.set_option(B.OPT_TIMING_EVERY, 1)            # these steps are all timed
         for _ in range(reps):
             self.step(False)
             tm = self.enc.timings()
             ms.append(tm["qmf_ms"] + tm["qmf_mdct_ms"])
             self.k1_launches = tm["qmf_mdct_launches"]
+        self.enc.set_option(B.OPT_TIMING_EVERY, DeviceJob.timing_every)
         return float(np.mean(ms))
 
     def checksum(self):
@@ -302,7 +313,7 @@ def kernel_source_sha16():
 
 
 def roofline_of(k1_avg_ms, frames_per_launch):
-    achieved = ALGO_BYTES_PER_FRAME_K1 * frames_per_launch / (k1_avg_ms * 1e-3) / 1e9
+    achieved = ALGO_BYTES_PER_FRAME_K1 * frames_per_launch / (max(k1_avg_ms, 1e-6) * 1e-3) / 1e9
     return round(achieved, 2), round(achieved / HBM_PEAK_GBS, 5)
 
 
@@ -315,7 +326,7 @@ FP32_NO_FMA_PEAK_TF = FP32_VECTOR_PEAK_TF / 2.0
 
 
 def flops_of(k1_ms, frames_per_launch):
-    tf = ALGO_FLOPS_PER_FRAME_K1 * frames_per_launch / (k1_ms * 1e-3) / 1e12
+    tf = ALGO_FLOPS_PER_FRAME_K1 * frames_per_launch / (max(k1_ms, 1e-6) * 1e-3) / 1e12
     return round(tf, 3), round(tf / FP32_NO_FMA_PEAK_TF, 4)
 
 
@@ -331,7 +342,7 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
         dts = [timed_region([job], reg_steps, None) / reg_steps for _ in range(3)]
         dt = float(np.median(dts)) * steps
         iso = job.isolated_k1()
-        k1_ms, stage = job.k1_stats(min(steps, 28), 3)
+        k1_ms, stage = job.k1_stats(min(reg_steps, 29), 3)
         k1 = float(np.mean(k1_ms))
         ach, frac = roofline_of(k1, S * F)
         ach_i, frac_i = roofline_of(iso, S * F)
@@ -502,6 +513,8 @@ def main():
     ap.add_argument("--runs", type=int, default=0, help="TUNING AID: AT3HIP_OPT_RUNS (runs per stream and channel of the QMF / MDCT kernels)")
     ap.add_argument("--gain-form", type=int, default=0, help="A/B AID: AT3HIP_OPT_GAIN_FORM (0 = the two-wavefront workgroups of the upsampler / "
                                                              "AnalyzeGain kernel, 1 = one wavefront per item; same results)")
+    ap.add_argument("--timing-every", type=int, default=8, help="AT3HIP_OPT_TIMING_EVERY: every Nth step carries the stage-timing HIP events the "
+                                                                 "roofline figure is read from (recording them on every step costs the step 3 %%)")
     ap.add_argument("--gain-wgs", type=int, default=0, help="TUNING AID: AT3HIP_OPT_GAIN_WGS_PER_CU")
     ap.add_argument("--sync-steps", action="store_true", help="PROFILING AID: run the timed steps synchronously (no overlap of "
                                                               "consecutive calls) so that rocprofv3 sees every kernel alone; "
@@ -519,6 +532,7 @@ def main():
     import torch
 
     DeviceJob.sync_steps = args.sync_steps
+    DeviceJob.timing_every = max(0, args.timing_every)
     DeviceJob.runs = args.runs
     DeviceJob.gain_form = int(args.gain_form)
     DeviceJob.gain_wgs = args.gain_wgs
@@ -588,12 +602,22 @@ def main():
     # launch hiccup or a clock ramp does not decide the figure; the steps they run are the same steps.
     region_ms = [elapsed / args.steps * 1e3]
     region_steps = args.steps
+    k1_ms, stage_sum = [], {}
+
+    def collect_k1(n_calls):
+        # the timed steps of the region that just ended (the ctx keeps the events of its last 32 calls)
+        ms, stage = j0.k1_stats(min(n_calls, 32), 0)
+        k1_ms.extend(ms)
+        for k, v in stage.items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v * len(ms)
+    collect_k1(args.steps)
     if args.regions > 0 and not args.sync_steps:
         region_steps = max(args.steps, int(np.ceil(args.region_ms / max(region_ms[0], 1e-6))))
         for _ in range(args.regions):
             dt = timed_region(jobs, region_steps, dist)
             dt = at3dist.max_over_ranks(dt, dist, device="cpu")
             region_ms.append(dt / region_steps * 1e3)
+            collect_k1(region_steps)
     # every step device 0's job has run since its LOOK_AHEAD call - warm-up, the one_gpu_same_workload regions of a
     # one-process multi-GPU run, the timed regions - is what the replay has to repeat to land on the same batch parity
     steps_done = j0.calls
@@ -602,7 +626,7 @@ def main():
         sclk_mhz = j0.enc.sclk_mhz()
     except Exception:   # noqa: BLE001 - diagnostic only
         sclk_mhz = None
-    k1_ms, stage_ms = j0.k1_stats(min(region_steps, 28), 0)      # the last region's launches
+    stage_ms = {k: v / max(1, len(k1_ms)) for k, v in stage_sum.items()}   # the timed steps of all the regions
     iso_ms = j0.isolated_k1()                       # 3 synchronous steps after the timed regions
     parity = None
     contexts = []
@@ -740,8 +764,10 @@ def main():
                          "frac": frac, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FRAME_K1 * S * F,
                          "avg_launch_ms": round(k1_avg_ms, 5), "launches_per_step": getattr(j0, "k1_launches", 1),
-                         "timing": "HIP events on the context's stream around the kernel(s); they include the launch gaps that "
-                                   "rocprofv3's kernel durations (profiles/) do not",
+                         "launches_timed": len(k1_ms), "timing_every": DeviceJob.timing_every,
+                         "timing": "HIP events on the context's stream around the kernel(s) of every timing_every-th step of the timed regions "
+                                   "(AT3HIP_OPT_TIMING_EVERY: recorded on every step the events cost the step 3 %); they include the launch gaps "
+                                   "that rocprofv3's kernel durations (profiles/) do not",
                          "limiter": "the vector pipe (FMA-free fp32 arithmetic contract: the FIR's multiplies and adds are two packed instructions "
                                     "each), not HBM - and for the fused kernel running back to back on white noise the board's 1400 W power cap, which holds "
                                     "the shader clock at 2.0 - 2.1 GHz instead of 2.4 (profiles/r06_k1_power_probe.txt, not measured in this run): see "
@@ -763,7 +789,7 @@ def main():
                          "sclk_note": "shader clock under the rate loop of the last timed step: s_memtime cycles / s_memrealtime (100 MHz) ticks over the "
                                       "life of k_alloc_pack's workgroup 0 (AT3HIP_TAP_CLOCK)",
                          "valu_floor_ms": None if valu_floor_ms is None else round(valu_floor_ms, 5),
-                         "valu_frac": None if valu_floor_ms is None else round(valu_floor_ms / iso_ms, 4),
+                         "valu_frac": None if valu_floor_ms is None else round(valu_floor_ms / max(iso_ms, 1e-6), 4),
                          "valu_floor_note": valu_note + "; valu_frac = valu_floor_ms / isolated.avg_launch_ms",
                          "isolated": dict({"avg_launch_ms": round(iso_ms, 5), "achieved": ach_iso, "frac": frac_iso,
                                            "note": "same kernel, same batch, launched alone (3 synchronous steps after the timed region)"},

@@ -223,6 +223,10 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
  *   AT3HIP_OPT_CHAIN             tuning aid for the fused QMF + MDCT kernel (no gain control, discrete stereo): whether the runs of a
  *                                workgroup hand their MDCT overlap on to each other instead of each priming its own from a block of
  *                                PCM: 0 = chosen per call (default), 1 = never, 2 = whenever the cut allows it. Same bytes either way.
+ *   AT3HIP_OPT_TIMING_EVERY      which calls record the at3hip_timings stage events: 1 (default) = every call with frames, N > 1 = every
+ *                                Nth, 0 = none. The events sit between the kernels of the ctx's streams; recording all of them costs a
+ *                                pipelined step of 4096 frames 3 %. A call that was not timed reports all-zero timings with
+ *                                qmf_mdct_launches == 0. Same bytes either way.
  * Values outside the ranges above are rejected with AT3HIP_EINVAL (nothing is stored). */
 #define AT3HIP_OPT_RUNS 1
 #define AT3HIP_OPT_LITERAL_FORMS 2
@@ -232,6 +236,7 @@ int at3hip_set_stream(at3hip_ctx* ctx, void* hip_stream);
 #define AT3HIP_OPT_GAIN_TWO_WAVES AT3HIP_OPT_GAIN_FORM   /* the option's former name (same number; its former value 2 = AT3HIP_GAIN_FORM_ONE_WAVE is still accepted) */
 #define AT3HIP_OPT_GAIN_WGS_PER_CU 5
 #define AT3HIP_OPT_CHAIN 6
+#define AT3HIP_OPT_TIMING_EVERY 7
 #define AT3HIP_GAIN_FORM_TWO_WAVES 0
 #define AT3HIP_GAIN_FORM_ONE_WAVE 1
 int at3hip_set_option(at3hip_ctx* ctx, int32_t option, int32_t value);
@@ -282,10 +287,11 @@ int at3hip_host_tables(void* dst, size_t bytes);
  *   1.3  at3hip_get_counters; AT3HIP_OPT_GAIN_FORM's values renumbered (the former AT3HIP_OPT_GAIN_TWO_WAVES: 0 = one workgroup of two
  *        wavefronts per item, 1 = the one-wavefront form, formerly 2 - the legacy value 2 is still accepted and means ONE_WAVE)
  *   1.4  AT3HIP_OPT_CHAIN, at3hip_device_numa_node
+ *   1.5  AT3HIP_OPT_TIMING_EVERY
  * A host layer compiled against this header checks at3hip_version() >= AT3HIP_VERSION before it relies on them
  * (atracdenc_amd/host/at3hip_host.hpp and the ctypes stub do). */
 #define AT3HIP_VERSION_MAJOR 1
-#define AT3HIP_VERSION_MINOR 4
+#define AT3HIP_VERSION_MINOR 5
 #define AT3HIP_VERSION ((AT3HIP_VERSION_MAJOR << 16) | AT3HIP_VERSION_MINOR)
 uint32_t at3hip_version(void);
 

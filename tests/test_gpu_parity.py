@@ -925,6 +925,37 @@ def test_overflow_counters(hip, oracle, br, channels):
     enc.close()
 
 
+def test_timing_every_samples_calls_and_changes_no_byte(hip):
+    """AT3HIP_OPT_TIMING_EVERY (ABI 1.5): with N = 3 every third call with frames carries stage timings, the others report zeros and
+    qmf_mdct_launches == 0; with 0 none does. The frames are the same bytes as with every call timed (the hand-overs between a call's
+    streams are their own untimed events)."""
+    import torch
+    from atracdenc_amd import binding as B
+    dev = torch.device("cuda", 0)
+    S, nb, calls = 3, 8, 7
+    g = torch.Generator(device="cpu").manual_seed(77)
+    pcm = [((torch.rand((S, nb, 2, 1024), generator=g) - 0.5) * 1.6).to(dev) for _ in range(calls)]
+    outs = {}
+    for every in (1, 3, 0):
+        enc = hip.At3Hip(n_streams=S, max_blocks=nb)
+        enc.set_option(B.OPT_TIMING_EVERY, every)
+        got, timed = [], []
+        for i in range(calls):
+            out = torch.zeros(S * nb * 384, dtype=torch.uint8, device=dev)
+            n = enc.encode_device(pcm[i].data_ptr(), nb, out.data_ptr(), asynchronous=False)
+            got.append(out[: S * n * 384].cpu())
+            if n:
+                tm = enc.timings()
+                timed.append(tm["qmf_mdct_launches"] > 0)
+                assert (tm["total_ms"] > 0) == timed[-1]
+        enc.close()
+        outs[every] = torch.cat(got)
+        if every == 1: assert all(timed)
+        if every == 0: assert not any(timed)
+        if every == 3: assert timed == [i % 3 == 0 for i in range(len(timed))]
+    assert torch.equal(outs[1], outs[3]) and torch.equal(outs[1], outs[0])
+
+
 def test_option_values_are_validated_and_version(hip):
     """at3hip_set_option rejects values outside an option's range and stores nothing; a 16-bit device pointer that
     the conversion kernel cannot read sixteen bytes at a time is refused; the library reports the ABI the binding was written for."""
@@ -934,12 +965,12 @@ def test_option_values_are_validated_and_version(hip):
     assert lib.at3hip_version() == B.AT3HIP_VERSION and B.AT3HIP_VERSION >> 16 == 1
     enc = hip.At3Hip(n_streams=1, max_blocks=4)
     for opt, bad in ((B.OPT_RUNS, -1), (B.OPT_LITERAL_FORMS, 2), (B.OPT_LITERAL_FORMS, -1), (B.OPT_QUANT_TAP, 2), (B.OPT_GAIN_FORM, 3),
-                     (B.OPT_GAIN_FORM, -1), (B.OPT_GAIN_WGS_PER_CU, 17), (B.OPT_GAIN_WGS_PER_CU, 100000), (B.OPT_CHAIN, 3), (B.OPT_CHAIN, -1), (0, 0), (7, 0)):
+                     (B.OPT_GAIN_FORM, -1), (B.OPT_GAIN_WGS_PER_CU, 17), (B.OPT_GAIN_WGS_PER_CU, 100000), (B.OPT_CHAIN, 3), (B.OPT_CHAIN, -1), (B.OPT_TIMING_EVERY, -1), (0, 0), (8, 0)):
         with pytest.raises(hip.At3HipError):
             enc.set_option(opt, bad)
     for opt, good in ((B.OPT_RUNS, 2), (B.OPT_RUNS, 0), (B.OPT_LITERAL_FORMS, 1), (B.OPT_LITERAL_FORMS, 0), (B.OPT_GAIN_FORM, B.GAIN_FORM_ONE_WAVE),
                       (B.OPT_GAIN_FORM, 2), (B.OPT_GAIN_FORM, B.GAIN_FORM_TWO_WAVES), (B.OPT_GAIN_WGS_PER_CU, 6), (B.OPT_GAIN_WGS_PER_CU, 0), (B.OPT_CHAIN, 2), (B.OPT_CHAIN, 1),
-                      (B.OPT_CHAIN, 0)):
+                      (B.OPT_CHAIN, 0), (B.OPT_TIMING_EVERY, 0), (B.OPT_TIMING_EVERY, 8), (B.OPT_TIMING_EVERY, 1)):
         enc.set_option(opt, good)
     assert B.OPT_FLATNESS_LITERAL == B.OPT_LITERAL_FORMS
     dev = torch.device("cuda", 0)
