@@ -242,15 +242,24 @@ class DeviceJob:
                     stage_ms[k] = stage_ms.get(k, 0.0) + v
         return k1_ms, {k: v / max(1, n) for k, v in stage_ms.items()}
 
-    def isolated_k1(self, reps=3):
+    def isolated_k1(self, reps=5):
         from atracdenc_amd import binding as B
         ms = []
         self.enc.set_option(B.OPT_TIMING_EVERY, 1)            # these steps are all timed
+        wall, total = [], []
         for _ in range(reps):
-            self.step(False)
+            self.torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            self.step(False)                                  # a synchronous call: returns when its frames are in d_out
+            wall.append((time.perf_counter() - t0) * 1e3)
             tm = self.enc.timings()
             ms.append(tm["qmf_ms"] + tm["qmf_mdct_ms"])
+            total.append(tm["total_ms"])
             self.k1_launches = tm["qmf_mdct_launches"]
+        # one call on an idle context: what a caller that does not keep the pipeline full waits for
+        self.lone_call = {"host_wall_ms": round(float(np.median(wall)), 4), "device_ms": round(float(np.median(total)), 4),
+                          "note": "one synchronous at3hip_encode of this workload on the idle context (median of %d): wall time around the call on the host, "
+                                  "and first kernel to last kernel on the device" % reps}
         self.enc.set_option(B.OPT_TIMING_EVERY, DeviceJob.timing_every)
         return float(np.mean(ms))
 
@@ -497,8 +506,8 @@ def widened_rows(S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: 64 at N=1, 1024 at N>1)")
     ap.add_argument("--frames", type=int, default=0, help="frames per stream per step (default: 64 at N=1, 128 at N>1)")
     ap.add_argument("--bitrate", type=int, default=LP2)
@@ -627,7 +636,7 @@ def main():
     except Exception:   # noqa: BLE001 - diagnostic only
         sclk_mhz = None
     stage_ms = {k: v / max(1, len(k1_ms)) for k, v in stage_sum.items()}   # the timed steps of all the regions
-    iso_ms = j0.isolated_k1()                       # 3 synchronous steps after the timed regions
+    iso_ms = j0.isolated_k1()                       # 5 synchronous steps after the timed regions
     parity = None
     contexts = []
     if not args.no_parity and not args.sync_steps:
@@ -792,7 +801,7 @@ def main():
                          "valu_frac": None if valu_floor_ms is None else round(valu_floor_ms / max(iso_ms, 1e-6), 4),
                          "valu_floor_note": valu_note + "; valu_frac = valu_floor_ms / isolated.avg_launch_ms",
                          "isolated": dict({"avg_launch_ms": round(iso_ms, 5), "achieved": ach_iso, "frac": frac_iso,
-                                           "note": "same kernel, same batch, launched alone (3 synchronous steps after the timed region)"},
+                                           "note": "same kernel, same batch, launched alone (5 synchronous steps after the timed region)"},
                                           **profile_isolated)},
             "pipeline_traffic": pipe_traffic,
             "pipeline_valu": pipe_valu,
@@ -806,12 +815,13 @@ def main():
                        "ms_per_step_median": round(med_ms, 4), "ms_per_step_min": round(min(region_ms), 4), "ms_per_step_max": round(max(region_ms), 4),
                        "ms_per_step_contract_region": round(region_ms[0], 4),
                        "sclk_mhz_contract_region": None if sclk_contract is None else round(sclk_contract, 1),
-                       "contract_region_note": "every timed region starts with an empty pipeline and ends with a drain (barrier + synchronize on both sides): one call's "
-                                               "latency (~0.8 ms, stage_ms_per_step.total_ms) less one step is paid once per region - ~0.5 ms, i.e. 6 % of a 30-step "
-                                               "region and 1 % of a 165-step one; region 0 also starts --warmup steps (a few milliseconds) after an idle device, while "
-                                               "the part is still stepping its clock up (sclk_mhz_contract_region against roofline.sclk_mhz_observed, taken after the "
-                                               "last region: ~4 %). The later regions (>= 50 ms each) are what a batch service sees",
-                       "value_contract_region": round(n_gpus * S * F / (region_ms[0] * 1e-3), 1)},
+                       "contract_region_note": "every timed region starts with an empty pipeline and ends with a drain (barrier + synchronize on both sides): "
+                                               "about one step's time is paid once per region on top of its steps (30-step regions read 0.258 ms per step where 182-step "
+                                               "ones read 0.249); region 0 also starts --warmup steps after an idle device, while the part is still stepping its clock up "
+                                               "(sclk_mhz_contract_region against roofline.sclk_mhz_observed, taken after the last region) - with the defaults (50 warm-up "
+                                               "steps, 200 timed) neither matters",
+                       "value_contract_region": round(n_gpus * S * F / (region_ms[0] * 1e-3), 1),
+                       "lone_call": getattr(j0, "lone_call", None)},
             "checksum": checksum,
         }
         if parity is not None:
