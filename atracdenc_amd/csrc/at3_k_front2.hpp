@@ -440,33 +440,9 @@ __device__ __forceinline__ void row_gather(Rd2 rd2, int b, float (&X)[4][4])
 // one running-product ramp. `cv` should be read in place (LDS).
 __device__ __forceinline__ void cell_divisors(const Curve& cv, const float* gain_interp, int cell, float (&d)[8])
 {
-    int kind = 0;
-    float lvl = 1.0f, inc = 1.0f;
-    int pos = 0;
-    for (int q = 0; q < cv.n; ++q) {
-        const int lastPos = (int)cv.loc[q] << 3;
-        if (cell >= pos && cell < lastPos) {
-            kind = 1;
-            lvl = gain_level_of(cv.level[q]);
-            break;
-        }
-        if (lastPos > pos) pos = lastPos;
-        if (pos < lastPos + 8) {
-            if (cell >= pos && cell < lastPos + 8) {
-                kind = 2;
-                lvl = gain_level_of(cv.level[q]);
-                inc = gain_interp[((q + 1) < cv.n ? (int)cv.level[q + 1] : 4) - (int)cv.level[q] + 15];
-                break;
-            }
-            pos = lastPos + 8;
-        }
-    }
-    float v = (kind == 0) ? 1.0f : lvl;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        d[k] = v;
-        if (kind == 2) v *= inc;
-    }
+    // the curve as its two 8-byte halves, walked by selects (cell_divisors_packed, at3_k_frontend.hpp)
+    const uint4 w = *reinterpret_cast<const uint4*>(&cv);
+    cell_divisors_packed((uint64_t)w.x | ((uint64_t)w.y << 32), (uint64_t)w.z | ((uint64_t)w.w << 32), gain_interp, cell, d);
 }
 
 __device__ __forceinline__ f2 f2lo(float4 v) { return mk2(v.x, v.y); }

@@ -34,37 +34,39 @@ struct FrontParams {
 // The divisors of the eight samples of cell `cell / 8` under a curve given as its two 8-byte halves (n, level[7] |
 // loc[7], pad): TGainProcessor::Modulate (gain_processor.h:93-112). Level boundaries and the 8-sample ramps are
 // aligned to these cells, so a cell is untouched (1), divided by one level or by one running-product ramp.
+// The point list is walked WITHOUT lane conditions: every lane runs the same (wave-uniformly bounded) trips and keeps what
+// the first matching point gives it by selects - a lane condition costs a wavefront ~50 cycles (EXPERIMENTS.md, round 5), the
+// walk as the reference writes it has three per point plus a divergent loop exit. A cell that no point covers keeps level 1,
+// a cell that is not a ramp keeps the increment 1: v * 1.0f is v, so the running product needs no condition either.
 __device__ __forceinline__ void cell_divisors_packed(uint64_t lo, uint64_t hi, const float* gain_interp, int cell, float (&d)[8])
 {
     const int n = (int)(lo & 0xffu);
-    int kind = 0;
     float lvl = 1.0f, inc = 1.0f;
     int pos = 0;
-    for (int q = 0; q < n; ++q) {
+    bool open = true;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        if (__ballot(q < n) == 0ull) break;   // wave-uniform
         const int level = (int)((lo >> (8 * (q + 1))) & 0xffu);
+        const int next = (q + 1 < 7) ? (int)((lo >> (8 * ((q + 1 < 7 ? q + 1 : 0) + 1))) & 0xffu) : 4;
         const int lastPos = (int)((hi >> (8 * q)) & 0xffu) << 3;
-        if (cell >= pos && cell < lastPos) {
-            kind = 1;
-            lvl = gain_level_of(level);
-            break;
-        }
-        if (lastPos > pos) pos = lastPos;
-        if (pos < lastPos + 8) {
-            if (cell >= pos && cell < lastPos + 8) {
-                kind = 2;
-                lvl = gain_level_of(level);
-                const int next = (q + 1) < n ? (int)((lo >> (8 * (q + 2))) & 0xffu) : 4;
-                inc = gain_interp[next - level + 15];
-                break;
-            }
-            pos = lastPos + 8;
-        }
+        const bool live = open & (q < n);
+        const bool flat = live & (cell >= pos) & (cell < lastPos);
+        const int pos2 = lastPos > pos ? lastPos : pos;
+        const bool has_ramp = pos2 < lastPos + 8;
+        const bool ramp = live & has_ramp & (cell >= pos2) & (cell < lastPos + 8);   // (never both: flat needs cell < lastPos <= pos2)
+        const float step = gain_interp[(((q + 1) < n ? next : 4) - level + 15) & 31];
+        const bool hit = flat | ramp;
+        lvl = hit ? gain_level_of(level) : lvl;
+        inc = ramp ? step : inc;
+        open = open & !hit;
+        pos = has_ramp ? lastPos + 8 : pos2;
     }
-    float v = (kind == 0) ? 1.0f : lvl;
+    float v = lvl;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         d[k] = v;
-        if (kind == 2) v *= inc;
+        v *= inc;
     }
 }
 
@@ -75,6 +77,11 @@ __device__ __forceinline__ void cell_divisors_packed(uint64_t lo, uint64_t hi, c
 // and two over the previous one (its "next overlap" scale, which the reference carries forward as
 // PrevOverlapGainScale). The frame's modulated bands are taken two at a time: all 64 lanes produce the 2 x 5 x 256
 // terms (four samples each), then ten lanes run the ten ordered sums side by side.
+#ifndef GES_SPLIT
+#define GES_SPLIT 1
+#endif
+constexpr int kGesSplit = GES_SPLIT;       // workgroups per frame (1, 2 or 4), each taking 8 / kGesSplit of its bands: the pairs of a workgroup run one after another
+constexpr int kGesBands = 8 / kGesSplit;
 constexpr int kGesRow = 260;   // row stride of the term lists: the ten chain lanes read ten rows at once, in different banks
 __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const Tables* T, int n_frames_total)
 {
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
     __shared__ __attribute__((aligned(16))) Curve s_cv[8][2];
     __shared__ float s_gi[32];
     const int lane = threadIdx.x;
-    const int sf = blockIdx.x;
+    const int sf = blockIdx.x / kGesSplit, part = blockIdx.x % kGesSplit;   // `part`: which kGesBands bands of the frame's eight (channel-major)
     if (sf >= n_frames_total) return;
     const int nfr = p.n_blocks - p.f0;
     const int f = p.f0 + sf % nfr;
@@ -94,16 +101,17 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
     const int b = f - 1;   // the block this frame's new half comes from
     // lanes 0..7: the band's two curves as 16-byte words; their point lists are later walked from LDS
     uint4 w_cur = {0u, 0u, 0u, 0u}, w_prev = {0u, 0u, 0u, 0u};
-    if (lane < 8) {
+    const bool mine = lane >= part * kGesBands && lane < (part + 1) * kGesBands;   // lane = band index c for the curve loads
+    if (mine) {
         w_cur = *reinterpret_cast<const uint4*>(p.curves + ((size_t)s * p.n_blocks + f) * 8 + lane);
         w_prev = *reinterpret_cast<const uint4*>((f - 1 < 0) ? &p.state[(size_t)s * 8 + lane].prev_curve
                                                              : p.curves + ((size_t)s * p.n_blocks + (f - 1)) * 8 + lane);
         *reinterpret_cast<uint4*>(&s_cv[lane][0]) = w_cur;
         *reinterpret_cast<uint4*>(&s_cv[lane][1]) = w_prev;
     }
-    const uint32_t active = (uint32_t)__ballot(lane < 8 && (((w_cur.x | w_prev.x) & 0xffu) != 0u));   // Curve::n is the first byte
+    const uint32_t active = (uint32_t)__ballot(mine && (((w_cur.x | w_prev.x) & 0xffu) != 0u));   // Curve::n is the first byte
     float* out8 = p.ges + ((size_t)s * p.n_blocks + f) * 8;
-    if (lane < 8 && !((active >> lane) & 1u)) out8[lane] = 1.0f;   // no modulation on either side: every ratio is exactly 1
+    if (mine && !((active >> lane) & 1u)) out8[lane] = 1.0f;   // no modulation on either side: every ratio is exactly 1
     if (active == 0u || p.debug == 3) return;
     // (most frames leave above: the tables are fetched only by those that modulate something)
     if (lane < 32) s_gi[lane] = T->gain_interp[lane < 31 ? lane : 30];
@@ -141,21 +149,40 @@ __global__ __launch_bounds__(64) void k_gain_energy_scale(FrontParams p, const T
             }
             const float xc[4] = {l.x, l.y, l.z, l.w}, xp[4] = {lp.x, lp.y, lp.z, lp.w};
             const bool hi_half = lane & 1;
-            float dc4[4], dp4[4];   // the lane's four samples are one half of cell lane / 2: that half's divisors
-            {
-                float dc8[8], dp8[8];
-                const uint4 wc4 = *reinterpret_cast<const uint4*>(&s_cv[c][0]), wp4 = *reinterpret_cast<const uint4*>(&s_cv[c][1]);
-                cell_divisors_packed((uint64_t)wc4.x | ((uint64_t)wc4.y << 32), (uint64_t)wc4.z | ((uint64_t)wc4.w << 32), s_gi, 8 * (lane >> 1), dc8);
-                cell_divisors_packed((uint64_t)wp4.x | ((uint64_t)wp4.y << 32), (uint64_t)wp4.z | ((uint64_t)wp4.w << 32), s_gi, 8 * (lane >> 1), dp8);
-                // (selected with static indices: `d[4 hi_half + k]` is a run-time index and sends the arrays to scratch memory)
-                dc4[0] = hi_half ? dc8[4] : dc8[0]; dc4[1] = hi_half ? dc8[5] : dc8[1]; dc4[2] = hi_half ? dc8[6] : dc8[2]; dc4[3] = hi_half ? dc8[7] : dc8[3];
-                dp4[0] = hi_half ? dp8[4] : dp8[0]; dp4[1] = hi_half ? dp8[5] : dp8[1]; dp4[2] = hi_half ? dp8[6] : dp8[2]; dp4[3] = hi_half ? dp8[7] : dp8[3];
+            // the lane's four samples are one half of cell lane / 2: that half's divisors. A band mostly has ONE of its two curves (a transient's
+            // curve is `cur` for one frame and `prev` for the next): the other side's walk and divisions are skipped wave-uniformly (x / 1.0f is x)
+            float dc4[4] = {1.0f, 1.0f, 1.0f, 1.0f}, dp4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            uint4 wc4 = *reinterpret_cast<const uint4*>(&s_cv[c][0]), wp4 = *reinterpret_cast<const uint4*>(&s_cv[c][1]);
+            // (one band's curves for the whole wavefront: as scalars the point walk's byte fields and bounds cost no vector instructions)
+            wc4.x = __builtin_amdgcn_readfirstlane(wc4.x); wc4.y = __builtin_amdgcn_readfirstlane(wc4.y);
+            wc4.z = __builtin_amdgcn_readfirstlane(wc4.z); wc4.w = __builtin_amdgcn_readfirstlane(wc4.w);
+            wp4.x = __builtin_amdgcn_readfirstlane(wp4.x); wp4.y = __builtin_amdgcn_readfirstlane(wp4.y);
+            wp4.z = __builtin_amdgcn_readfirstlane(wp4.z); wp4.w = __builtin_amdgcn_readfirstlane(wp4.w);
+            const bool mod_c = (wc4.x & 0xffu) != 0u, mod_p = (wp4.x & 0xffu) != 0u;   // wave-uniform
+            // (selected with static indices: `d[4 hi_half + k]` is a run-time index and sends the arrays to scratch memory)
+            if (mod_c) {
+                float d8[8];
+                cell_divisors_packed((uint64_t)wc4.x | ((uint64_t)wc4.y << 32), (uint64_t)wc4.z | ((uint64_t)wc4.w << 32), s_gi, 8 * (lane >> 1), d8);
+                dc4[0] = hi_half ? d8[4] : d8[0]; dc4[1] = hi_half ? d8[5] : d8[1]; dc4[2] = hi_half ? d8[6] : d8[2]; dc4[3] = hi_half ? d8[7] : d8[3];
+            }
+            if (mod_p) {
+                float d8[8];
+                cell_divisors_packed((uint64_t)wp4.x | ((uint64_t)wp4.y << 32), (uint64_t)wp4.z | ((uint64_t)wp4.w << 32), s_gi, 8 * (lane >> 1), d8);
+                dp4[0] = hi_half ? d8[4] : d8[0]; dp4[1] = hi_half ? d8[5] : d8[1]; dp4[2] = hi_half ? d8[6] : d8[2]; dp4[3] = hi_half ? d8[7] : d8[3];
+            }
+            float mc4[4] = {xc[0], xc[1], xc[2], xc[3]}, mp4[4] = {xp[0], xp[1], xp[2], xp[3]};
+            if (mod_c) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mc4[k] = xc[k] / dc4[k];
+            }
+            if (mod_p) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mp4[k] = xp[k] / dp4[k];
             }
             float t[4][4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float mc = xc[k] / dc4[k];
-                const float mp = xp[k] / dp4[k];
+                const float mc = mc4[k], mp = mp4[k];
                 const float pv = wn[k] * mp;                // the overlap this block inherited: EncodeWindow[i] * modulated sample
                 const float cw = xc[k] * wc[k], mw = mc * wc[k], nw = xp[k] * wn[k];   // (mod x winNext of the previous block IS pv: multiplication commutes)
                 t[0][k] = pv * pv;

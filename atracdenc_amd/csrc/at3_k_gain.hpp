@@ -1201,58 +1201,26 @@ __device__ __forceinline__ void early_mismatch_score_pair(const Log2fTab* L2, co
                                                           const CurvePts& cpA, const CurvePts& cpB, float* s_tmpA, uint8_t* s_ptsA,
                                                           float* aB, float* sqB, float* ltB, uint8_t* s_ptsB, int j, float& scoreA, float& scoreB)
 {
-    if (j < 7) {
-        int lvA = 0, lcA = 0, lvB = 0, lcB = 0;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            lvA = (j == i) ? cpA.level[i] : lvA;
-            lcA = (j == i) ? cpA.loc[i] : lcA;
-            lvB = (j == i) ? cpB.level[i] : lvB;
-            lcB = (j == i) ? cpB.loc[i] : lcB;
-        }
-        s_ptsA[j] = (uint8_t)lvA;
-        s_ptsA[8 + j] = (uint8_t)lcA;
-        s_ptsB[j] = (uint8_t)lvB;
-        s_ptsB[8 + j] = (uint8_t)lcB;
-    }
-    wave_sync();
     // BuildSampleDivisors restricted to sub-frame j (samples 8j .. 8j+7): level boundaries and ramps are aligned to these cells, so
     // the eight divisors are all 1, all one level, or one running-product ramp (same values as curve_divisor sample by sample). The
-    // points are walked from LDS: indexing a register-resident list with a run-time index costs a select chain per access.
-    auto cell_div = [&](const uint8_t* s_pts, int n) -> float {
-        float dsum = 0.0f;
-        const int cell = 8 * j;
-        int kind = 0;
-        float lvl = 1.0f, inc = 1.0f;
-        int pos = 0;
-        for (int q = 0; q < n; ++q) {
-            const int lastPos = (int)s_pts[8 + q] << 3;
-            if (cell >= pos && cell < lastPos) {
-                kind = 1;
-                lvl = gain_level_of(s_pts[q]);
-                break;
-            }
-            if (lastPos > pos) pos = lastPos;
-            if (pos < lastPos + 8) {
-                if (cell >= pos && cell < lastPos + 8) {
-                    kind = 2;
-                    lvl = gain_level_of(s_pts[q]);
-                    inc = gain_interp[((q + 1) < n ? (int)s_pts[q + 1] : 4) - (int)s_pts[q] + 15];
-                    break;
-                }
-                pos = lastPos + 8;
-            }
-        }
-        float d = (kind == 0) ? 1.0f : lvl;
+    // point list is packed into two 8-byte words from its registers (static indices) and walked by selects (cell_divisors_packed,
+    // at3_k_frontend.hpp): as a loop with lane conditions over a list in LDS this walk was the slowest part of a scoring wavefront.
+    auto cell_div = [&](const CurvePts& cp) -> float {
+        uint64_t lo = (uint64_t)(uint32_t)cp.n, hi = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            dsum += d;
-            if (kind == 2) d *= inc;
+        for (int i = 0; i < 7; ++i) {
+            lo |= (uint64_t)((uint32_t)cp.level[i] & 0xffu) << (8 * (i + 1));
+            hi |= (uint64_t)((uint32_t)cp.loc[i] & 0xffu) << (8 * i);
         }
+        float d[8];
+        cell_divisors_packed(lo, hi, gain_interp, 8 * j, d);
+        float dsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dsum += d[k];
         return dsum / 8.0f;
     };
-    const float divA = cell_div(s_ptsA, cpA.n), divB = cell_div(s_ptsB, cpB.n);
-    wave_sync();   // the point lists are rewritten by the next call
+    (void)s_ptsA; (void)s_ptsB;
+    const float divA = cell_div(cpA), divB = cell_div(cpB);
     int maxLocA = 0, maxLocB = 0;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {

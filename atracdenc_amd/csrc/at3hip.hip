@@ -902,7 +902,7 @@ int encode_impl(at3hip_ctx* c, const void* pcm_any, bool s16, int32_t n_blocks, 
             hipLaunchKernelGGL(k_gain_tail, dim3((unsigned)((S * n_out * 6 + 7) / 8)), dim3(256), (size_t)c->dbg_pad[4], md, gp, S * n_out * 6);
             hipLaunchKernelGGL(k_gain_scan, dim3(S * 6), dim3(64), (size_t)c->dbg_pad[7], md, gp, S);
             hipLaunchKernelGGL(k_gain_curve, dim3((S * n_out * 6 + 7) / 8), dim3(256), (size_t)c->dbg_pad[2], md, gp, c->d_tables, S);
-            hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out), dim3(64), (size_t)c->dbg_pad[3], md, fp, c->d_tables, S * n_out);
+            hipLaunchKernelGGL(k_gain_energy_scale, dim3(S * n_out * kGesSplit), dim3(64), (size_t)c->dbg_pad[3], md, fp, c->d_tables, S * n_out);
         } else {
             if (split) launch_qmf_sub();   // joint stereo without gain control: the QMF kernel, timed as qmf_ms
             if (timed) HIPCHK(c, hipEventRecord(ev[1], st));
