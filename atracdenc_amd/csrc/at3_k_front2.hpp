@@ -728,16 +728,15 @@ __global__ __launch_bounds__(64 * NW) void k_mdct_sub(MdctSubParams p, const Tab
             wave_sync();
             const bool has_curve = cv.n > 0;
             if (__ballot(has_curve) != 0ull) {   // rare on stationary material, the rule on transients
-                if (has_curve) {
-                    inv_scale = __uint_as_float((uint32_t)(127 - 4 + cv.level[0]) << 23);   // 1 / GainLevel[level[0]], a power of two
+                if (has_curve) inv_scale = __uint_as_float((uint32_t)(127 - 4 + cv.level[0]) << 23);   // 1 / GainLevel[level[0]], a power of two
+                // (all four rows walk - the walk bounds its trips by a ballot, which wants the whole wavefront; a row without a curve gets ones)
 #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2) {
-                        float d[8];
-                        cell_divisors(cv, s_gi, 8 * (2 * L + c2), d);
-                        float4* dst = reinterpret_cast<float4*>(divs + 16 * L + 8 * c2);
-                        dst[0] = make_float4(d[0], d[1], d[2], d[3]);
-                        dst[1] = make_float4(d[4], d[5], d[6], d[7]);
-                    }
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    float d[8];
+                    cell_divisors(cv, s_gi, 8 * (2 * L + c2), d);
+                    float4* dst = reinterpret_cast<float4*>(divs + 16 * L + 8 * c2);
+                    dst[0] = make_float4(d[0], d[1], d[2], d[3]);
+                    dst[1] = make_float4(d[4], d[5], d[6], d[7]);
                 }
                 wave_sync();
                 float D[4][4];
