@@ -347,16 +347,33 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
     }
     if (flat_job) {
         const int b = fb;
-        const float* sp = s_spec[fk];
-        const int start = bfu_start(b), end = bfu_start(b + 1);
         rec0[fk].flat[b] = flat;
-        if (flat < 0.01f) {  // ExtractTonalComponents search, atrac3denc.cpp:606-625
-            // every window of one to five lines, first maximum wins (ascending start, then ascending length); the five
-            // magnitudes a start needs are a shift register fed by one LDS read per start (len >= 16 here)
+        if (flat < 0.01f) s_run_len[fk][b] = 1;   // a candidate of the ExtractTonalComponents search below
+    }
+    __syncthreads();
+
+    // ExtractTonalComponents' search (atrac3denc.cpp:606-625): every window of one to five lines, first maximum wins (ascending start, then
+    // ascending length). One lane per SIXTEEN STARTS of a candidate BFU - 160 jobs for the workgroup's 4 x 21 BFUs, sixteen steps each -, and a
+    // lane per BFU that takes the first of its chunks' maxima (a later chunk wins only with a strictly larger score, as a later start does in
+    // the reference's loop). One lane per BFU it was 64 steps of a 12-lane wavefront for the 64-line BFUs (`tones`: k_psy 35.6 -> 28.4 us;
+    // rotating the long jobs over the workgroup's wavefronts instead changed nothing). The chunks' results use the tonal value lists' storage,
+    // dead until the mapping.
+    float* s_best_score = &s_tv_val[0][0];
+    uint16_t* s_best_start = &s_tv_pos[0][0];
+    uint8_t* s_best_len = &s_tv_bfu[0][0];
+    if (tid < 160) {
+        int k, b, chunk;
+        if (tid < 48) { k = tid / 12; b = 26 + (tid % 12) / 4; chunk = tid % 4; }
+        else if (tid < 128) { k = (tid - 48) / 20; b = 16 + ((tid - 48) % 20) / 2; chunk = (tid - 48) % 2; }
+        else { k = (tid - 128) / 8; b = 8 + (tid - 128) % 8; chunk = 0; }
+        if (k < ncf && s_run_len[k][b]) {
+            const float* sp = s_spec[k];
+            const int end = bfu_start(b + 1), cs = bfu_start(b) + 16 * chunk;
+            // the five magnitudes a start needs are a shift register fed by one LDS read per start (cs + 4 < end: BFUs are whole chunks)
             float bestScore = -1.0f;
-            int bestStart = start, bestLen = 1;
-            float a0 = fabsf(sp[start]), a1 = fabsf(sp[start + 1]), a2 = fabsf(sp[start + 2]), a3 = fabsf(sp[start + 3]), a4 = fabsf(sp[start + 4]);
-            for (int st = start; st < end; ++st) {
+            int bestStart = cs, bestLen = 1;
+            float a0 = fabsf(sp[cs]), a1 = fabsf(sp[cs + 1]), a2 = fabsf(sp[cs + 2]), a3 = fabsf(sp[cs + 3]), a4 = fabsf(sp[cs + 4]);
+            for (int st = cs; st < cs + 16; ++st) {
                 const int ml = 5 < end - st ? 5 : end - st;
                 const float nxt = (st + 5 < end) ? fabsf(sp[st + 5]) : 0.0f;
                 float score = 0.0f;
@@ -372,68 +389,138 @@ __global__ __launch_bounds__(256) AT3_WAVES_PER_EU(8) void k_psy(BackParams p, c
                 if (ml >= 5 && score > bestScore) { bestScore = score; bestStart = st; bestLen = 5; }
                 a0 = a1; a1 = a2; a2 = a3; a3 = a4; a4 = nxt;
             }
+            s_best_score[tid] = bestScore;
+            s_best_start[tid] = (uint16_t)bestStart;
+            s_best_len[tid] = (uint8_t)bestLen;
+        }
+    }
+    __syncthreads();
+    if (tid < 21 * kPsyCf) {
+        const int k = tid / 21, b = 8 + tid % 21;
+        if (k < ncf && s_run_len[k][b]) {
+            const int job0 = b >= 26 ? k * 12 + (b - 26) * 4 : (b >= 16 ? 48 + k * 20 + (b - 16) * 2 : 128 + k * 8 + (b - 8));
+            const int nchunks = b >= 26 ? 4 : (b >= 16 ? 2 : 1);
+            float bestScore = s_best_score[job0];
+            int best = job0;
+            for (int c = 1; c < nchunks; ++c) {
+                const float sc = s_best_score[job0 + c];
+                if (sc > bestScore) { bestScore = sc; best = job0 + c; }
+            }
             if (bestScore > 0.0f) {
-                s_run_start[fk][b] = (uint16_t)bestStart;
-                s_run_len[fk][b] = (uint8_t)bestLen;
-                s_any[fk] = 1;
+                s_run_start[k][b] = s_best_start[best];
+                s_run_len[k][b] = s_best_len[best];
+                s_any[k] = 1;
+            } else {
+                s_run_len[k][b] = 0;
             }
         }
     }
     __syncthreads();
 
-    if (wave == 3 && lane < ncf) {   // one lane per channel-frame: the extraction order is serial
-        const int k0 = lane;
+    static_assert(kPsyCf == 4, "one wavefront of the workgroup per channel-frame");
+    if (wave < ncf) {   // one WAVEFRONT per channel-frame (wave-uniform). The reference's extraction and mapping are serial loops
+        // (atrac3denc.cpp:627-662); as ONE lane per channel-frame they were two thirds of this kernel on tonal material (46 of 63 us on `tones`).
+        // Their result has a closed form: BFU b's run goes to the list at the sum of the earlier runs' lengths; a component starts where a
+        // position does not continue the one before it, and every seven positions after such a start.
+        const int k0 = wave;
         PsyRec* rec = rec0 + k0;
-        int nb = 0;
+        int n_comp = 0;
         if (s_any[k0]) {
             float* sp = s_spec[k0];
             float* specs = specs0 + (size_t)k0 * 1024;
-            int nv = 0;
-            for (int b = 8; b < 29; ++b) {
-                for (int k = 0; k < s_run_len[k0][b]; ++k) {
-                    const int pos = s_run_start[k0][b] + k;
-                    s_tv_pos[k0][nv] = (uint16_t)pos;
-                    s_tv_val[k0][nv] = sp[pos];
-                    s_tv_bfu[k0][nv] = (uint8_t)b;
-                    ++nv;
-                    sp[pos] = 0.0f;
+            // lane l < 21 owns BFU 8 + l: its run's place in the list by an inclusive scan of the run lengths
+            const int b = 8 + (lane < 21 ? lane : 20);
+            const int rl = lane < 21 ? (int)s_run_len[k0][b] : 0;
+            const int rs = (int)s_run_start[k0][b];
+            int incl = rl;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const int t = __builtin_amdgcn_ds_bpermute(4 * (lane >= d ? lane - d : lane), incl);
+                incl += (lane >= d) ? t : 0;
+            }
+            const int off = incl - rl;
+            const int nv = __builtin_amdgcn_readlane(incl, 20);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                if (k < rl) {
+                    const int pos = rs + k;
+                    s_tv_pos[k0][off + k] = (uint16_t)pos;
+                    s_tv_val[k0][off + k] = sp[pos];
+                    s_tv_bfu[k0][off + k] = (uint8_t)b;
+                    sp[pos] = 0.0f;      // (runs of different BFUs never share a line)
                     specs[pos] = 0.0f;
                 }
             }
-            // MapTonalComponents (atrac3denc.cpp:646-662): runs of consecutive positions, at most 7 long
-            for (int i = 0; i < nv;) {
-                const int startPos = i;
-                int curPos;
-                do {
-                    curPos = s_tv_pos[k0][i];
-                    ++i;
-                } while (i < nv && s_tv_pos[k0][i] == curPos + 1 && i - startPos < 7);
-                const int len = i - startPos;
-                if (nb < kMaxTonal) {   // the block is assembled in place (a local copy with run-time indices would live in scratch memory)
-                    TonalBlock* tb = &rec->tonal[nb];
-                    tb->pos = s_tv_pos[k0][startPos];
-                    tb->bfu = s_tv_bfu[k0][startPos];
-                    tb->len = (uint8_t)len;
-                    for (int j = 0; j < 3; ++j) tb->pad[j] = 0;
-                    for (int j = 0; j < 4; ++j) tb->pad2[j] = 0;
-                    for (int j = len; j < 7; ++j) tb->values[j] = 0.0f;
-                    tb->sfi = (uint8_t)scale_block(s_scale, s_tv_val[k0] + startPos, len, tb->values, nullptr);
-                }
-                // TScaler::Scale's diagnostics for this component (atrac_scale.cpp:150-153, 163-167): a block whose largest magnitude
-                // exceeds MAX_SCALE = 1.0 is scaled by ScaleTable[63] = 1.0, so its clipped values are those above 1.0. (The reference
-                // scales every component it maps, also those beyond the 24 a sound unit keeps.)
-                if (p.counters && !(p.one_channel && ((c0 + k0) & 1))) {
+            wave_sync();
+            // MapTonalComponents (atrac3denc.cpp:646-662): runs of consecutive positions, at most 7 long. The list has at most 105 entries:
+            // index i = lane (first half) and 64 + lane (second half)
+            const int i0 = lane, i1 = 64 + lane;
+            const int p0 = i0 < nv ? (int)s_tv_pos[k0][i0] : -1, p0m = (i0 > 0 && i0 - 1 < nv) ? (int)s_tv_pos[k0][i0 - 1] : -3;
+            const int p1 = i1 < nv ? (int)s_tv_pos[k0][i1] : -1, p1m = (i1 - 1 < nv) ? (int)s_tv_pos[k0][i1 - 1] : -3;
+            const unsigned long long B0 = __ballot(i0 < nv && (i0 == 0 || p0 != p0m + 1));   // a position that starts a stretch
+            const unsigned long long B1 = __ballot(i1 < nv && p1 != p1m + 1);
+            const unsigned long long upto = ~0ull >> (63 - lane);        // bits 0 .. lane
+            const unsigned long long above = (lane < 63) ? (~0ull << (lane + 1)) : 0ull;   // bits lane + 1 .. 63
+            const unsigned long long m0 = B0 & upto, m1 = B1 & upto;
+            const int seg0 = 63 - __builtin_clzll(m0 | 1ull);                                       // (bit 0 of B0 is set whenever nv > 0)
+            const int seg1 = m1 ? 64 + 63 - __builtin_clzll(m1) : 63 - __builtin_clzll(B0 | 1ull);
+            const bool st0 = i0 < nv && (i0 - seg0) % 7 == 0, st1 = i1 < nv && (i1 - seg1) % 7 == 0;
+            const unsigned long long S0 = __ballot(st0), S1 = __ballot(st1);                         // the components' first positions
+            n_comp = __builtin_popcountll(S0) + __builtin_popcountll(S1);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (half && S1 == 0ull) break;   // (wave-uniform: most lists have fewer than 64 entries)
+                if (half ? st1 : st0) {
+                    const int startPos = half ? i1 : i0;
+                    const int nb = half ? __builtin_popcountll(S0) + __builtin_popcountll(S1 & upto) - 1 : __builtin_popcountll(S0 & upto) - 1;
+                    const unsigned long long nx = (half ? S1 : S0) & above;
+                    const int next = nx ? (half ? 64 : 0) + __builtin_ctzll(nx) : ((!half && S1) ? 64 + __builtin_ctzll(S1) : nv);
+                    const int len = next - startPos;
+                    // TScaler::Scale on the component (atrac_scale.cpp:141-172; scale_block above) as straight-line code over seven slots - the
+                    // slots behind `len` hold zeros, which change neither the maximum nor the counts -, the block assembled in registers and
+                    // stored as five 8-byte words (it sits at 168 + 40 nb in its PsyRec)
+                    float x[7];
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) {
+                        const float t = s_tv_val[k0][startPos + j];   // (startPos + 6 <= 110: inside the list's 112 slots)
+                        x[j] = j < len ? t : 0.0f;
+                    }
+                    float maxAbs = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) maxAbs = fabsf(x[j]) > maxAbs ? fabsf(x[j]) : maxAbs;
                     int over = 0;
-                    for (int j = 0; j < len; ++j) over += fabsf(s_tv_val[k0][startPos + j]) > 1.0f;
-                    if (over) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) over += fabsf(x[j]) > 1.0f;
+                    if (nb < kMaxTonal) {
+                        if (maxAbs > 1.0f) maxAbs = 1.0f;
+                        const int sfi = scale_index(s_scale, maxAbs);
+                        const float sf = s_scale[sfi];
+                        uint32_t w[7];
+#pragma unroll
+                        for (int j = 0; j < 7; ++j) {
+                            float v = x[j] / sf;
+                            if (fabsf(v) >= 1.0f) v = (v > 0) ? 0.99999f : -0.99999f;
+                            w[j] = j < len ? __float_as_uint(v) : 0u;
+                        }
+                        static_assert(offsetof(PsyRec, tonal) % 8 == 0 && sizeof(TonalBlock) % 8 == 0, "8-byte stores");
+                        uint2* tb = reinterpret_cast<uint2*>(&rec->tonal[nb]);
+                        tb[0] = uint2{(uint32_t)s_tv_pos[k0][startPos] | ((uint32_t)s_tv_bfu[k0][startPos] << 16) | ((uint32_t)len << 24), (uint32_t)sfi};
+                        tb[1] = uint2{w[0], w[1]};
+                        tb[2] = uint2{w[2], w[3]};
+                        tb[3] = uint2{w[4], w[5]};
+                        tb[4] = uint2{w[6], 0u};
+                    }
+                    // TScaler::Scale's diagnostics for this component (atrac_scale.cpp:150-153, 163-167): a block whose largest magnitude
+                    // exceeds MAX_SCALE = 1.0 is scaled by ScaleTable[63] = 1.0, so its clipped values are those above 1.0. (The reference
+                    // scales every component it maps, also those beyond the 24 a sound unit keeps.)
+                    if (over && p.counters && !(p.one_channel && ((c0 + k0) & 1))) {
                         atomicAdd(p.counters, 1ull);
                         atomicAdd(p.counters + 1, (unsigned long long)over);
                     }
                 }
-                ++nb;
             }
         }
-        rec->n_tonal = nb < kMaxTonal ? nb : kMaxTonal;
+        if (lane == 0) rec->n_tonal = n_comp < kMaxTonal ? n_comp : kMaxTonal;
     }
     __syncthreads();
     if (tid < 32 * kPsyCf) (&s_maxbits[0][0])[tid] = 0u;   // (the position list is dead: its storage holds the maxima now)
