@@ -11,6 +11,7 @@ from atracdenc_amd import binding as B
 args = sys.argv[1:]
 kind = args[args.index("--input") + 1] if "--input" in args else "noise"
 br = int(args[args.index("--bitrate") + 1]) if "--bitrate" in args else bench.LP2
+bench.DeviceJob.timing_every = 1   # (every call carries its events here)
 for _ in range(int(args[args.index("--prior") + 1]) if "--prior" in args else 0):   # contexts created, run and closed before the measured one
     j0 = bench.DeviceJob(0, 64, 64, br, False, kind, seed=1)
     j0.warmup(3); j0.run_steps(20); j0.close()
