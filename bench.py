@@ -738,7 +738,7 @@ def main():
                 prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_isolated_rocprof_summary.txt")))[-1]
                 us = {}
                 for ln in open(prof):
-                    m = re.match(r"^(k_qmf_sub8|k_mdct_sub<false>)\s+\d+\s+[\d.]+\s+([\d.]+)\s", ln)
+                    m = re.match(r"^(k_qmf_sub8|k_mdct_sub<false(?:, \d)?>)\s+\d+\s+[\d.]+\s+([\d.]+)\s", ln)
                     if m and m.group(1) not in us:
                         us[m.group(1)] = float(m.group(2))
                 if len(us) == 2:
