@@ -195,7 +195,11 @@ public:
         CheckLibraryVersion();
         Check(at3hip_create(&cfg, &Ctx), nullptr, "at3hip_create");
         FrameSz = at3hip_frame_size(Ctx);
+        // nothing in this layer reads the stage timings: their HIP events between the kernels cost a pipelined step ~3 % (AT3HIP_OPT_TIMING_EVERY)
+        Check(at3hip_set_option(Ctx, AT3HIP_OPT_TIMING_EVERY, 0), Ctx, "at3hip_set_option");
     }
+    // Stage timings (at3hip_get_timings / _ago on Handle()) on every Nth call with frames; 0 (this layer's default) = never.
+    void SetTimingEvery(int n) { Check(at3hip_set_option(Ctx, AT3HIP_OPT_TIMING_EVERY, n), Ctx, "at3hip_set_option"); }
     ~TAtrac3EncoderBatch() { at3hip_destroy(Ctx); }
     TAtrac3EncoderBatch(const TAtrac3EncoderBatch&) = delete;
     TAtrac3EncoderBatch& operator=(const TAtrac3EncoderBatch&) = delete;
