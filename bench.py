@@ -351,8 +351,8 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
         dts = [timed_region([job], reg_steps, None) / reg_steps for _ in range(3)]
         dt = float(np.median(dts)) * steps
         iso = job.isolated_k1()
-        k1_ms, stage = job.k1_stats(min(reg_steps, 29), 3)
-        k1 = float(np.mean(k1_ms))
+        k1_ms, stage = job.k1_stats(min(reg_steps, 27), 5)   # (the five isolated steps are the latest calls)
+        k1 = float(np.mean(k1_ms)) if k1_ms else iso
         ach, frac = roofline_of(k1, S * F)
         ach_i, frac_i = roofline_of(iso, S * F)
         out.update({"value": round(S * F * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 4),
@@ -542,6 +542,8 @@ def main():
 
     DeviceJob.sync_steps = args.sync_steps
     DeviceJob.timing_every = max(0, args.timing_every)
+    if args.sync_steps or (args.regions == 0 and args.steps < 8 * max(1, args.timing_every)):
+        DeviceJob.timing_every = 1   # a run too short to sample (profiling passes): every step carries its events
     DeviceJob.runs = args.runs
     DeviceJob.gain_form = int(args.gain_form)
     DeviceJob.gain_wgs = args.gain_wgs
@@ -663,7 +665,7 @@ def main():
     if rank == 0:
         med_ms = float(np.median(region_ms))
         value = n_gpus * S * F / (med_ms * 1e-3)
-        k1_avg_ms = float(np.mean(k1_ms))
+        k1_avg_ms = float(np.mean(k1_ms)) if k1_ms else iso_ms   # (no timed step in the regions: --timing-every 0)
         achieved, frac = roofline_of(k1_avg_ms, S * F)
         ach_iso, frac_iso = roofline_of(iso_ms, S * F)
         traffic, traffic_note = None, "not measured"
