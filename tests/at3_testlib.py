@@ -260,6 +260,24 @@ def pcm_mix(nblocks, seed=7):
     return _quant16(bed + tone + hit).reshape(nblocks, 1024, 2)
 
 
+def pcm_dense_tonal(nb, seed, amp=0.02):
+    """Every BFU 8..28 tonal: clusters of eight adjacent spectral lines across ten BFU boundaries (the runs of two BFUs are consecutive
+    positions and merge into components of 7 + 3) and single lines elsewhere."""
+    rng = np.random.RandomState(seed)
+    n = nb * 1024
+    t = np.arange(n, dtype=np.float64)
+    x = np.zeros((n, 2))
+    lines = [k for bnd in (80, 96, 128, 176, 192, 256, 320, 384, 512, 576) for k in range(bnd - 4, bnd + 4)]
+    lines += [70, 105, 118, 150, 165, 210, 240, 290, 350, 420, 460, 490, 540, 610, 680, 740, 800, 860]
+    for k in lines:
+        f = (k + 0.5) * 22050.0 / 1024
+        a = amp * rng.uniform(0.6, 1.0)
+        ph = rng.uniform(0, 6.28)
+        x[:, 0] += a * np.sin(2 * np.pi * f * t / 44100 + ph)
+        x[:, 1] += a * np.sin(2 * np.pi * f * t / 44100 + 1.3 * ph)
+    return x.reshape(nb, 1024, 2).astype(np.float32)
+
+
 def pcm_stress(nblocks, seed=3):
     """Corner cases of the arithmetic, one after another in 4-block segments: full-scale noise (scale-factor clamp at
     1.0 and the +-0.99999 clip), full-scale square wave, isolated unit impulses, DC with a tiny dither (denormal-range

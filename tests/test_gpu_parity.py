@@ -259,6 +259,40 @@ def test_flatness_threshold_adversarial(hip, oracle, literal):
         assert np.array_equal(got[i], frames), i
 
 
+@pytest.mark.parametrize("br", [LP2, LP4])
+def test_dense_tonal_material(hip, oracle, br):
+    """ExtractTonalComponents / MapTonalComponents (atrac3denc.cpp:606-662) where the wavefront-parallel form has its corners: all 21 BFUs
+    tonal (105 extracted values: both halves of the position list), runs that continue across BFU boundaries (components of seven
+    positions and the split behind them). Every field of every tonal block, the counts and the frames equal the oracle's."""
+    from atracdenc_amd import binding as B
+    from at3_testlib import pcm_dense_tonal
+    nb = 8
+    pcm = np.stack([pcm_dense_tonal(nb, 7), pcm_dense_tonal(nb, 8, amp=0.3), pcm_dense_tonal(nb, 9, amp=0.002)])
+    S = pcm.shape[0]
+    for ng in (1, 0):
+        enc = hip.At3Hip(n_streams=S, max_blocks=nb, bitrate=br, no_gain=ng)
+        got = enc.encode(pcm)
+        psy = enc.read_tap(B.TAP_PSY, B.At3Hip.PSY_DTYPE, (S, got.shape[1], 2))
+        enc.close()
+        seen_values, seen_len7 = 0, False
+        for i in range(S):
+            frames, tap = oracle.encode(pcm[i], br, ng, 0, taps=True)
+            assert np.array_equal(got[i], frames), (ng, i)
+            assert np.array_equal(psy[i]["n_tonal"], tap["n_tonal"]), (ng, i)
+            for f in range(tap["n_tonal"].shape[0]):
+                for ch in range(2):
+                    n = int(tap["n_tonal"][f, ch])
+                    blk = psy[i, f, ch]["tonal"][:n]
+                    assert np.array_equal(blk["pos"], tap["tonal_pos"][f, ch, :n]), (ng, i, f, ch)
+                    assert np.array_equal(blk["len"], tap["tonal_len"][f, ch, :n]), (ng, i, f, ch)
+                    assert np.array_equal(blk["sfi"], tap["tonal_sfi"][f, ch, :n]), (ng, i, f, ch)
+                    assert np.array_equal(np.ascontiguousarray(blk["values"]).view(np.uint32),
+                                          np.ascontiguousarray(tap["tonal_values"][f, ch, :n, :7]).view(np.uint32)), (ng, i, f, ch)
+                    seen_values = max(seen_values, int(tap["tonal_len"][f, ch, :n].sum()))
+                    seen_len7 = seen_len7 or bool((tap["tonal_len"][f, ch, :n] == 7).any())
+        assert seen_values > 64 and seen_len7      # the material reaches the corners it was made for
+
+
 def test_high_freq_ratio_short_form(hip, oracle):
     """highFreqRatio (transient_spectral_upsampler.cpp:99-118) gates the gain analysis (`< 0.05`, `< 0.3`). k_gain_spec adds the
     two f64 energy sums in lane order and keeps the f32 of the quotient only when an error bound says the reference's 257-term

@@ -56,6 +56,12 @@ def test_atrac3_overflow_counters(harness):
     assert re.search(r"overflow counters [1-9]\d+, [1-9]\d+ ", out), out[-2000:]
 
 
+def test_atrac3_dense_tonal_material(harness):
+    """Every BFU tonal, runs continuing across BFU boundaries (at3_testlib.pcm_dense_tonal): k_psy's wavefront-parallel tonal
+    extraction and mapping with both halves of its position list in use, under the emulator's rendezvous checks."""
+    _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "dense"), 12)
+
+
 def test_atrac3_gain_analysis_one_wavefront_form(harness):
     """AT3HIP_OPT_GAIN_FORM = AT3HIP_GAIN_FORM_ONE_WAVE (k_gain_analysis1, incl. the restated v_permlane32/16_swap, which tools/ubench/permlane_check
     compares with the hardware): the signals with gain curves x LP2 / LP4 x three option sets."""

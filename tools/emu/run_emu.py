@@ -5,8 +5,9 @@ import ctypes, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from at3_testlib import SIGNALS, LP2, LP4, oracle, oracle_diag_counts, pcm_hot, pcm_stress
-SIGNALS = dict(SIGNALS, stress=lambda nb: pcm_stress(nb, seed=7), hot=lambda nb: pcm_hot(nb))   # hot: above full scale (overflow counters)
+from at3_testlib import SIGNALS, LP2, LP4, oracle, oracle_diag_counts, pcm_dense_tonal, pcm_hot, pcm_stress
+SIGNALS = dict(SIGNALS, stress=lambda nb: pcm_stress(nb, seed=7), hot=lambda nb: pcm_hot(nb),
+               dense=lambda nb: pcm_dense_tonal(nb, 7))   # dense: every BFU tonal, runs across BFU boundaries (k_psy's parallel extraction)   # hot: above full scale (overflow counters)
 from atracdenc_amd.binding import At3Hip
 
 EMU = os.path.join(ROOT, "tools", "emu", "libat3hip_emu.so")
