@@ -1328,3 +1328,50 @@ int at3hip_qmf_mdct(at3hip_ctx* c, const float* pcm, int32_t n_blocks, float* sp
 }
 
 }  // extern "C"
+
+#if defined(AT3_EMU_HOST) || defined(AT3HIP_DEBUG_KNOBS)
+// TEST AND PROFILING BUILDS ONLY (the SIMT harness, -DAT3HIP_DEBUG_KNOBS; not in include/at3hip.h): the divisors of all 256 samples under n arbitrary
+// curves (16 bytes each: n, level[7], loc[7], pad - any byte values) from the select walk the pipeline's kernels use (cell_divisors_packed) and from the
+// sample-by-sample restatement of TGainProcessor::Modulate (curve_divisor), side by side: tests/test_kernels_simt_harness.py compares the bit patterns.
+namespace {
+__global__ __launch_bounds__(64) void k_debug_cell_divisors(const Curve* curves, const Tables* T, float* out_packed, float* out_ref, int n)
+{
+    __shared__ float s_gi[32];
+    const int lane = threadIdx.x;
+    if (lane < 32) s_gi[lane] = T->gain_interp[lane < 31 ? lane : 30];
+    __syncthreads();
+    const int item = blockIdx.x * 2 + (lane >> 5), cell = lane & 31;   // two curves per wavefront, a lane per cell of eight samples
+    const int it = item < n ? item : n - 1;
+    const uint4 w = *reinterpret_cast<const uint4*>(curves + it);
+    float d[8];
+    cell_divisors_packed((uint64_t)w.x | ((uint64_t)w.y << 32), (uint64_t)w.z | ((uint64_t)w.w << 32), s_gi, 8 * cell, d);
+    if (item < n) {
+        for (int k = 0; k < 8; ++k) {
+            out_packed[(size_t)item * 256 + 8 * cell + k] = d[k];
+            out_ref[(size_t)item * 256 + 8 * cell + k] = curve_divisor(s_gi, curves[it], 8 * cell + k);
+        }
+    }
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) int at3hip_debug_cell_divisors(at3hip_ctx* c, const void* curves, int32_t n, float* out_packed, float* out_ref)
+{
+    if (!c || !curves || n < 1 || !out_packed || !out_ref) return AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    Curve* d_cv = nullptr;
+    float* d_out = nullptr;
+    const size_t nb = (size_t)n * 256 * sizeof(float);
+    if (hipMalloc((void**)&d_cv, (size_t)n * sizeof(Curve)) != hipSuccess || hipMalloc((void**)&d_out, 2 * nb) != hipSuccess) return AT3HIP_EDEVICE;
+    int rc = AT3HIP_OK;
+    if (hipMemcpy(d_cv, curves, (size_t)n * sizeof(Curve), hipMemcpyHostToDevice) != hipSuccess) rc = AT3HIP_EDEVICE;
+    if (rc == AT3HIP_OK) {
+        hipLaunchKernelGGL(k_debug_cell_divisors, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, c->stream, d_cv, c->d_tables, d_out, d_out + (size_t)n * 256, n);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out_packed, d_out, nb, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out_ref, d_out + (size_t)n * 256, nb, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = AT3HIP_EDEVICE;
+    }
+    (void)hipFree(d_cv);
+    (void)hipFree(d_out);
+    return rc;
+}
+#endif

@@ -62,6 +62,39 @@ def test_atrac3_dense_tonal_material(harness):
     _assert_clean(_run("run_emu.py", "--strict", "--nobuild", "dense"), 12)
 
 
+def test_gain_curve_select_walk(harness):
+    """cell_divisors_packed - the gain curve's point list walked by selects, as k_gain_energy_scale, k_mdct_sub and k_gain_curve's score use it -
+    against curve_divisor, the sample-by-sample restatement of TGainProcessor::Modulate (gain_processor.h:93-112), for 20 000 curves of
+    ARBITRARY bytes per field (0 .. 7 points, levels 0 .. 15, locations 0 .. 31 in any order, repeated, adjacent): all 256 divisors, bit patterns."""
+    import ctypes
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from atracdenc_amd import binding as B
+    lib = ctypes.CDLL(harness)
+    enc = B.At3Hip(n_streams=1, max_blocks=2, lib_path=harness)
+    rng = np.random.RandomState(5)
+    n = 20000
+    cv = np.zeros((n, 16), np.uint8)
+    cv[:, 0] = rng.randint(0, 8, n)
+    cv[:, 1:8] = rng.randint(0, 16, (n, 7))
+    loc = rng.randint(0, 32, (n, 7))
+    srt = rng.rand(n) < 0.6                                  # most as the encoder makes them: ascending
+    loc[srt] = np.sort(loc[srt], axis=1)
+    cv[:, 8:15] = loc
+    cv[: n // 10, 1:8] = rng.randint(0, 256, (n // 10, 7))   # and bytes no encoder writes: the walk masks what it must
+    a = np.zeros((n, 256), np.float32)
+    b = np.zeros((n, 256), np.float32)
+    fn = lib.at3hip_debug_cell_divisors
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    lv = cv[: n // 10, 1:8]
+    lv[lv > 15] &= 15                                         # (levels are four bits in the bitstream and in both walks' tables)
+    assert fn(enc.ctx, cv.ctypes.data, n, a.ctypes.data, b.ctypes.data) == 0
+    enc.close()
+    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32))
+    assert bad.size == 0, (bad[:5].tolist(), cv[bad[0, 0]].tolist())
+    assert (a != 1.0).any(axis=1).sum() > n // 2
+
+
 def test_atrac3_gain_analysis_one_wavefront_form(harness):
     """AT3HIP_OPT_GAIN_FORM = AT3HIP_GAIN_FORM_ONE_WAVE (k_gain_analysis1, incl. the restated v_permlane32/16_swap, which tools/ubench/permlane_check
     compares with the hardware): the signals with gain curves x LP2 / LP4 x three option sets."""
