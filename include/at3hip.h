@@ -59,7 +59,9 @@ typedef struct at3hip_config {
 
 /* Per-call device timings in milliseconds (HIP events on the ctx's streams), filled by the last
  * at3hip_encode / at3hip_qmf_mdct call. total_ms spans the first front-half kernel to the last back-half kernel of ONE
- * call (its latency); with AT3HIP_ASYNC consecutive calls overlap, so throughput is not 1 / total_ms. */
+ * call (its latency); with AT3HIP_ASYNC consecutive calls overlap, so throughput is not 1 / total_ms.
+ * The events sit between the call's kernels and are not free (AT3HIP_OPT_TIMING_EVERY): a call that was not timed reports zeros and
+ * qmf_mdct_launches == 0. */
 typedef struct at3hip_timings {
     float total_ms;
     float qmf_ms;        /* QMF tree as its own kernel (subbands to HBM: gain control and joint stereo); ~0 when fused */
@@ -186,7 +188,7 @@ int at3hip_sync(at3hip_ctx* ctx);
 int at3hip_read_tap(at3hip_ctx* ctx, int32_t kind, void* dst, size_t bytes);
 
 /* Timings of the at3hip_encode call `ago` calls back (0 = the most recent one, at most 31); waits for queued work.
- * Zeroed for calls that produced no frames (the LOOK_AHEAD call). */
+ * Zeroed for calls that produced no frames (the LOOK_AHEAD call) and for calls AT3HIP_OPT_TIMING_EVERY left untimed. */
 int at3hip_get_timings_ago(at3hip_ctx* ctx, int32_t ago, at3hip_timings* out);
 
 /* Order this ctx's work after a caller-provided hipStream_t (NULL = the ctx's own stream): the first stage of every call
