@@ -46,7 +46,7 @@ SYMBOLS = ["at3hip_encode_s16", "at3hip_create", "at3hip_destroy", "at3hip_frame
            "at3hip_host_free", "at3hip_wait_input", "at3hip_wait_frames", "at3hip_get_counters", "at3hip_device_numa_node"]
 # include/at1hip.h
 AT1_SYMBOLS = ["at1hip_create", "at1hip_destroy", "at1hip_last_error", "at1hip_encode", "at1hip_reset", "at1hip_get_timings",
-               "at1hip_read_tap", "at1hip_host_tables"]
+               "at1hip_read_tap", "at1hip_host_tables", "at1hip_sync"]
 # include/at3phip.h
 AT3P_SYMBOLS = ["at3phip_create", "at3phip_destroy", "at3phip_last_error", "at3phip_reset", "at3phip_pqf_analyse", "at3phip_mdct",
                 "at3phip_pqf_mdct", "at3phip_get_timings", "at3phip_host_tables", "at3phip_write_frames", "at3phip_encode_frames",
@@ -139,6 +139,7 @@ def load_library(path=None):
     lib.at1hip_last_error.restype = ctypes.c_char_p
     lib.at1hip_encode.argtypes = [vp, vp, i32, vp, ctypes.c_uint32]
     lib.at1hip_reset.argtypes = [vp]
+    lib.at1hip_sync.argtypes = [vp]
     lib.at1hip_get_timings.argtypes = [vp, ctypes.POINTER(At1Timings)]
     lib.at1hip_read_tap.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.at1hip_host_tables.argtypes = [vp, ctypes.c_size_t]
@@ -432,9 +433,12 @@ class At1Hip:
         self._check(self.lib.at1hip_encode(self.ctx, _vp(pcm), nb, _vp(out), 0), "at1hip_encode")
         return out
 
-    def encode_device(self, pcm_ptr, n_blocks, out_ptr):
+    def encode_device(self, pcm_ptr, n_blocks, out_ptr, asynchronous=False):
         self._check(self.lib.at1hip_encode(self.ctx, ctypes.c_void_p(pcm_ptr), n_blocks, ctypes.c_void_p(out_ptr),
-                                           AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE), "at1hip_encode")
+                                           AT3HIP_PCM_ON_DEVICE | AT3HIP_OUT_ON_DEVICE | (AT3HIP_ASYNC if asynchronous else 0)), "at1hip_encode")
+
+    def sync(self):
+        self._check(self.lib.at1hip_sync(self.ctx), "at1hip_sync")
 
     def read_tap(self, kind, dtype, shape):
         out = np.zeros(shape, dtype=dtype)

@@ -20,6 +20,7 @@ struct at1hip_ctx {
     int debug_stop = 0;           // AT1HIP_DEBUG_STOP, honoured by -DAT3HIP_DEBUG_KNOBS builds only
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {};
+    bool tm_pending = false;      // a call's stage events have not been read yet (AT3HIP_ASYNC)
     Tables* d_tables = nullptr;
     float* d_pcm_in = nullptr;    // staging for host PCM [S][max_blocks][512][nch]
     float* d_hist = nullptr;      // [S][512][nch] last PCM block of the previous call
@@ -235,13 +236,27 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     HIPCHK(c, hipEventRecord(c->ev[3], st));
     if (!(flags & AT3HIP_OUT_ON_DEVICE))
         HIPCHK(c, hipMemcpyAsync(out_frames, c->d_out, S * F * C * kFrame, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
     c->blocks_fed += n_blocks;
     c->last_blocks = n_blocks;
-    (void)hipEventElapsedTime(&c->tm.front_ms, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&c->tm.scan_ms, c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&c->tm.pack_ms, c->ev[2], c->ev[3]);
-    (void)hipEventElapsedTime(&c->tm.total_ms, c->ev[0], c->ev[3]);
+    c->tm_pending = true;
+    // AT3HIP_ASYNC: the call is queued (one stream: consecutive calls follow each other on the device without the host in between);
+    // at1hip_sync waits and reads the last call's timings
+    return (flags & AT3HIP_ASYNC) ? AT3HIP_OK : at1hip_sync(c);
+}
+
+int at1hip_sync(at1hip_ctx* c)
+{
+    if (!c) return AT3HIP_EINVAL;
+    at3host::DeviceGuard guard(c->device);
+    HIPCHK(c, guard.error());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->tm_pending) {
+        c->tm_pending = false;
+        (void)hipEventElapsedTime(&c->tm.front_ms, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&c->tm.scan_ms, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&c->tm.pack_ms, c->ev[2], c->ev[3]);
+        (void)hipEventElapsedTime(&c->tm.total_ms, c->ev[0], c->ev[3]);
+    }
     return AT3HIP_OK;
 }
 

@@ -55,9 +55,14 @@ const char* at1hip_last_error(const at1hip_ctx* ctx);
  *   pcm        [n_streams][n_blocks][512][channels] float32, interleaved, +-1.0 (pcmengin.h:173-184)
  *   out_frames [n_streams][n_blocks][channels][212] bytes: the buffers handed to ICompressedOutput::WriteFrame, in the
  *              reference's order (channel 0 then channel 1 of each block, atrac1denc.cpp:249-251)
- * flags: AT3HIP_PCM_ON_DEVICE / AT3HIP_OUT_ON_DEVICE as for at3hip_encode. Stream state (filter histories, the high
- * band's delay line, MDCT overlap, detector energies, loudness) is carried between calls. */
+ * flags: AT3HIP_PCM_ON_DEVICE / AT3HIP_OUT_ON_DEVICE as for at3hip_encode; AT3HIP_ASYNC only queues the call (buffers must stay
+ * valid until at1hip_sync; host buffers then have to be page-locked for the copies to be asynchronous): consecutive calls follow
+ * each other on the device without the host in between. Stream state (filter histories, the high band's delay line, MDCT
+ * overlap, detector energies, loudness) is carried between calls. */
 int at1hip_encode(at1hip_ctx* ctx, const float* pcm, int32_t n_blocks, uint8_t* out_frames, uint32_t flags);
+
+/* Waits for everything queued on the ctx; the timings are then those of the last call. */
+int at1hip_sync(at1hip_ctx* ctx);
 
 /* Back to start-of-stream state for every stream (a fresh TAtrac1Encoder). */
 int at1hip_reset(at1hip_ctx* ctx);

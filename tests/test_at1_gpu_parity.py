@@ -89,6 +89,25 @@ def test_reset_and_device_pointers(oracle):
     enc.close()
 
 
+def test_queued_calls(oracle):
+    """AT3HIP_ASYNC + at1hip_sync: four calls of eight blocks queued back to back on device-resident buffers give the bytes of one
+    synchronous call of 32 blocks (carried state across queued calls), and the timings after the wait are the last call's."""
+    import torch
+    blocks = np.stack([at1_blocks(pcm_mix(16, seed=s)) for s in (4, 5)])
+    exp = np.stack([at1_oracle_encode(b, "auto") for b in blocks])
+    enc = _enc(n_streams=2, max_blocks=32)
+    pieces = [torch.from_numpy(np.ascontiguousarray(blocks[:, 8 * i: 8 * i + 8])).cuda() for i in range(4)]
+    outs = [torch.zeros((2, 8, 2, 212), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    for p, o in zip(pieces, outs):
+        enc.encode_device(p.data_ptr(), 8, o.data_ptr(), asynchronous=True)
+    enc.sync()
+    got = np.concatenate([o.cpu().numpy() for o in outs], axis=1)
+    assert np.array_equal(got, exp)
+    tm = enc.timings()
+    assert tm["total_ms"] > 0 and tm["front_ms"] > 0
+    enc.close()
+
+
 def test_wide_batch(oracle):
     """96 streams x 64 blocks (the batch shape of BASELINE configs[1], in ATRAC1 sound units): every stream equals the
     oracle's encode of that stream alone - no cross-stream leakage, grid-size independent results."""
