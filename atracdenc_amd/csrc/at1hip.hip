@@ -172,6 +172,7 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     HIPCHK(c, guard.error());
     const size_t S = c->cfg.n_streams, C = c->cfg.channels, F = (size_t)n_blocks;
     hipStream_t st = c->stream;
+    const bool timed = !(flags & AT3HIP_ASYNC);   // a queued call carries no stage-timing events (not free between the kernels): its timings read zero
     const float* d_pcm = pcm;
     if (!(flags & AT3HIP_PCM_ON_DEVICE)) {
         HIPCHK(c, hipMemcpyAsync(c->d_pcm_in, pcm, S * F * 512 * C * sizeof(float), hipMemcpyHostToDevice, st));
@@ -179,7 +180,7 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     }
     uint8_t* d_out = (flags & AT3HIP_OUT_ON_DEVICE) ? out_frames : c->d_out;
 
-    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[0], st));
     FrontParams fp;
     fp.T = c->d_tables;
     fp.pcm = d_pcm;
@@ -207,7 +208,7 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_at1_state, dim3((unsigned)((S * 512 * C + 255) / 256)), dim3(256), 0, st, d_pcm, c->d_hist, n_blocks, (int)C,
                        (int)S);
-    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[1], st));
 
     ScanParams sp;
     sp.mask = c->d_mask;
@@ -218,7 +219,7 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     sp.n_frames = n_blocks;
     sp.nch = (int)C;
     hipLaunchKernelGGL(k_at1_loud_scan, dim3((unsigned)S), dim3(64), 0, st, sp);
-    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[2], st));
 
     PackParams pp;
     pp.T = c->d_tables;
@@ -233,12 +234,13 @@ int at1hip_encode(at1hip_ctx* c, const float* pcm, int32_t n_blocks, uint8_t* ou
     pp.bfu_idx_const = c->cfg.bfu_idx_const;
     hipLaunchKernelGGL(k_at1_alloc_pack, dim3((unsigned)((S * F * C + 3) / 4)), dim3(256), 0, st, pp);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev[3], st));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[3], st));
     if (!(flags & AT3HIP_OUT_ON_DEVICE))
         HIPCHK(c, hipMemcpyAsync(out_frames, c->d_out, S * F * C * kFrame, hipMemcpyDeviceToHost, st));
     c->blocks_fed += n_blocks;
     c->last_blocks = n_blocks;
-    c->tm_pending = true;
+    c->tm_pending = timed;
+    if (!timed) memset(&c->tm, 0, sizeof(c->tm));
     // AT3HIP_ASYNC: the call is queued (one stream: consecutive calls follow each other on the device without the host in between);
     // at1hip_sync waits and reads the last call's timings
     return (flags & AT3HIP_ASYNC) ? AT3HIP_OK : at1hip_sync(c);

@@ -363,24 +363,28 @@ int at3phip_encode_frames(at3phip_ctx* c, const float* pcm, int32_t n_frames, ui
     hipStream_t ws = c->write_stream;
     // the writer of the call before the previous one must be done with this parity's spectra
     if (c->write_done_valid[par]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_write_done[par], 0));
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    // the stage timings are events between the kernels and not free (the ATRAC3 path measured ~1.5 us of the dependent chain per record):
+    // a call that is only queued carries none - its timings read zero -, a synchronous one carries all five
+    const bool timed = !(flags & AT3HIP_ASYNC);
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     int rc = launch_pqf(c, d_pcm, n_frames, c->d_bands);
     if (rc != AT3HIP_OK) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     rc = launch_mdct(c, c->d_bands, n_frames, nullptr, d_specs, AT3PHIP_RESIDUAL_SCALE);   // sine windows: EncodeFrame's default Win
     if (rc != AT3HIP_OK) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     HIPCHK(c, hipEventRecord(c->ev_specs[par], c->stream));
     HIPCHK(c, hipStreamWaitEvent(ws, c->ev_specs[par], 0));
-    HIPCHK(c, hipEventRecord(c->ev[4], ws));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[4], ws));
     rc = launch_write(c, d_specs, n_frames, nullptr, d_frames, ws);
     if (rc != AT3HIP_OK) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[3], ws));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev[3], ws));
     if (!(flags & AT3HIP_OUT_ON_DEVICE)) HIPCHK(c, hipMemcpyAsync(frames, c->d_frames, items * kFrameBytes, hipMemcpyDeviceToHost, ws));
     HIPCHK(c, hipEventRecord(c->ev_write_done[par], ws));
     c->write_done_valid[par] = true;
     c->enc_calls++;
-    c->ev_from_encode = true;
+    c->ev_from_encode = timed;
+    if (!timed) c->pqf_ms = c->mdct_ms = c->write_ms = 0.0f;
     if (flags & AT3HIP_ASYNC) return AT3HIP_OK;   // at3phip_sync is the completion point
     return at3phip_sync(c);
 }

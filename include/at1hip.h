@@ -61,7 +61,8 @@ const char* at1hip_last_error(const at1hip_ctx* ctx);
  * overlap, detector energies, loudness) is carried between calls. */
 int at1hip_encode(at1hip_ctx* ctx, const float* pcm, int32_t n_blocks, uint8_t* out_frames, uint32_t flags);
 
-/* Waits for everything queued on the ctx; the timings are then those of the last call. */
+/* Waits for everything queued on the ctx. (A queued call records no stage-timing events - they are not free between the kernels -: the
+ * timings then read zero; a synchronous call is timed.) */
 int at1hip_sync(at1hip_ctx* ctx);
 
 /* Back to start-of-stream state for every stream (a fresh TAtrac1Encoder). */

@@ -77,7 +77,9 @@ int at3phip_write_frames(at3phip_ctx* ctx, const float* specs, int32_t n_frames,
 int at3phip_encode_frames(at3phip_ctx* ctx, const float* pcm, int32_t n_frames, uint8_t* frames, uint32_t flags);
 /* With AT3HIP_ASYNC in `flags` at3phip_encode_frames only queues the call (pcm must stay valid, frames must not be read)
  * and the frame writer of one call runs beside the filter bank and transform of the next (its own stream, spectra
- * double-buffered); at3phip_sync waits for everything queued. Without the flag the call waits itself. */
+ * double-buffered); at3phip_sync waits for everything queued. Without the flag the call waits itself. A queued call records no
+ * stage-timing events (they sit between the kernels and cost the chain): the timing getters then read zero; a synchronous call
+ * is timed as before. */
 int at3phip_sync(at3phip_ctx* ctx);
 
 /* Device milliseconds the frame writer took in the last at3phip_write_frames / at3phip_encode_frames call. */

@@ -91,7 +91,7 @@ def test_reset_and_device_pointers(oracle):
 
 def test_queued_calls(oracle):
     """AT3HIP_ASYNC + at1hip_sync: four calls of eight blocks queued back to back on device-resident buffers give the bytes of one
-    synchronous call of 32 blocks (carried state across queued calls), and the timings after the wait are the last call's."""
+    synchronous call of 32 blocks (carried state across queued calls), queued calls carry no timing events, a synchronous call does."""
     import torch
     blocks = np.stack([at1_blocks(pcm_mix(16, seed=s)) for s in (4, 5)])
     exp = np.stack([at1_oracle_encode(b, "auto") for b in blocks])
@@ -103,8 +103,12 @@ def test_queued_calls(oracle):
     enc.sync()
     got = np.concatenate([o.cpu().numpy() for o in outs], axis=1)
     assert np.array_equal(got, exp)
+    assert enc.timings()["total_ms"] == 0          # queued calls carry no timing events
+    enc.reset()
+    o = torch.zeros((2, 32, 2, 212), dtype=torch.uint8, device="cuda")
+    enc.encode_device(torch.from_numpy(blocks).cuda().data_ptr(), 32, o.data_ptr())
     tm = enc.timings()
-    assert tm["total_ms"] > 0 and tm["front_ms"] > 0
+    assert tm["total_ms"] > 0 and tm["front_ms"] > 0 and np.array_equal(o.cpu().numpy(), exp)
     enc.close()
 
 
