@@ -118,7 +118,9 @@ int at1hip_create(const at1hip_config* cfg, at1hip_ctx** out)
     if (!host_tables) return bail(AT3HIP_ENOMEM);
     build_tables(host_tables);
     rc = dev_alloc(c, &c->d_tables, 1);
-    if (rc == AT3HIP_OK && hipMemcpy(c->d_tables, host_tables, sizeof(Tables), hipMemcpyHostToDevice) != hipSuccess) rc = AT3HIP_EDEVICE;
+    if (rc == AT3HIP_OK && (hipMemcpy(c->d_tables, host_tables, sizeof(Tables), hipMemcpyHostToDevice) != hipSuccess ||
+                            hipDeviceSynchronize() != hipSuccess))   // (pageable source: the transfer may still be running when the copy returns, at3hip_create)
+        rc = AT3HIP_EDEVICE;
     delete host_tables;
     if (rc != AT3HIP_OK) return bail(rc);
 

@@ -457,7 +457,12 @@ int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out)
     build_tables(host_tables);
     rc = dev_alloc(c, &c->d_tables, 1);
     if (rc == AT3HIP_OK) {
+        // From pageable memory a blocking copy may return once the data is STAGED: the transfer itself then still runs on the null stream, which the
+        // context's non-blocking streams do not wait for. Seen with eight processes on one device: the first call of a fresh process summed its
+        // loudness with a curve that had not arrived yet (TrackLoudness state in the millions, silent frames until the stream was reset) - the
+        // device is drained here, once, before anything can read the tables.
         hipError_t e = hipMemcpy(c->d_tables, host_tables, sizeof(Tables), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) rc = AT3HIP_EDEVICE;
     }
     delete host_tables;
@@ -1076,7 +1081,10 @@ int at3hip_get_counters(at3hip_ctx* c, at3hip_counters* out, int32_t reset)
     HIPCHK(c, hipMemcpy(v, c->d_counters, sizeof(v), hipMemcpyDeviceToHost));
     out->scale_overflow = v[0];
     out->clipped_values = v[1];
-    if (reset) HIPCHK(c, hipMemset(c->d_counters, 0, sizeof(v)));
+    if (reset) {
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(v), c->back_stream));   // (the stream whose kernels add to them)
+        HIPCHK(c, hipStreamSynchronize(c->back_stream));
+    }
     return AT3HIP_OK;
 }
 

@@ -172,7 +172,9 @@ int at3phip_create(const at3phip_config* cfg, at3phip_ctx** out)
     if (!host_tables) return bail(AT3HIP_ENOMEM);
     build_tables(host_tables);
     rc = dev_alloc(c, &c->d_tables, 1);
-    if (rc == AT3HIP_OK && hipMemcpy(c->d_tables, host_tables, sizeof(Tables), hipMemcpyHostToDevice) != hipSuccess) rc = AT3HIP_EDEVICE;
+    if (rc == AT3HIP_OK && (hipMemcpy(c->d_tables, host_tables, sizeof(Tables), hipMemcpyHostToDevice) != hipSuccess ||
+                            hipDeviceSynchronize() != hipSuccess))   // (pageable source: the transfer may still be running when the copy returns, at3hip_create)
+        rc = AT3HIP_EDEVICE;
     delete host_tables;
     if (rc != AT3HIP_OK) return bail(rc);
     const size_t S = cfg->n_streams, F = cfg->max_frames, C = cfg->channels;
@@ -195,7 +197,7 @@ int at3phip_create(const at3phip_config* cfg, at3phip_ctx** out)
         if (!wt) return bail(AT3HIP_ENOMEM);
         build_write_tables(wt);
         rc = dev_alloc(c, &c->d_wtables, 1);
-        if (rc == AT3HIP_OK && hipMemcpy(c->d_wtables, wt, sizeof(WriteTables), hipMemcpyHostToDevice) != hipSuccess) rc = AT3HIP_EDEVICE;
+        if (rc == AT3HIP_OK && (hipMemcpy(c->d_wtables, wt, sizeof(WriteTables), hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) rc = AT3HIP_EDEVICE;
         delete wt;
         if (rc != AT3HIP_OK) return bail(rc);
     }

@@ -270,6 +270,16 @@ class DeviceJob:
         self.enc.close()
 
 
+def _dbg_loud(job, tag):
+    """BENCH_DEBUG_TAPS: the tracked loudness after a phase of the run (the eight-rank failure hunt)."""
+    if not os.environ.get("BENCH_DEBUG_TAPS"):
+        return
+    from atracdenc_amd import binding as B
+    lo = job.enc.read_tap(B.TAP_LOUDNESS, np.float32, (job.S, job.F))
+    if not (lo.max() < 1.0):
+        sys.stderr.write("LOUDBAD rank %s after %s (calls %d): max %g min %g\n" % (os.environ.get("RANK", "0"), tag, job.calls, float(lo.max()), float(lo.min())))
+
+
 def timed_region(jobs, steps, dist):
     """Barrier + synchronize on both sides; returns wall seconds for `steps` steps on every job (max over devices)."""
     import torch
@@ -598,8 +608,10 @@ def main():
         one_gpu_ref = {"value": round(S * F * args.steps / dt1, 1), "unit": "frames/s", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
                        "note": "device 0 alone on the same per-GPU shard, measured in this run before the N-GPU timed region"}
 
+    _dbg_loud(jobs[0], "warm-up")
     # The contract's timed region: EXACTLY --steps steps between barrier + synchronize pairs, max over ranks.
     elapsed = timed_region(jobs, args.steps, dist)
+    _dbg_loud(jobs[0], "contract region")
     elapsed = at3dist.max_over_ranks(elapsed, dist, device="cpu")
     j0 = jobs[0]
     try:
@@ -625,6 +637,7 @@ def main():
             dt = timed_region(jobs, region_steps, dist)
             dt = at3dist.max_over_ranks(dt, dist, device="cpu")
             region_ms.append(dt / region_steps * 1e3)
+            _dbg_loud(jobs[0], "region")
             collect_k1(region_steps)
     # every step device 0's job has run since its LOOK_AHEAD call - warm-up, the one_gpu_same_workload regions of a
     # one-process multi-GPU run, the timed regions - is what the replay has to repeat to land on the same batch parity
@@ -636,6 +649,7 @@ def main():
         sclk_mhz = None
     stage_ms = {k: v / max(1, len(k1_ms)) for k, v in stage_sum.items()}   # the timed steps of all the regions
     iso_ms = j0.isolated_k1()                       # 5 synchronous steps after the timed regions
+    _dbg_loud(j0, "isolated steps")
     parity = None
     contexts = []
     if not args.no_parity and not args.sync_steps:
@@ -646,7 +660,36 @@ def main():
             rep = {"rank": rank, "device": j.device, "seed": 1 + rank * 64 + i, "steps": j.calls, "checksum": j.checksum()}
             same = None
             if j.calls * S * F <= 64 * 1024 * 1024:
-                same = (j.replay(j.calls) == rep["checksum"])
+                n_calls = j.calls
+                timed_out = j.d_out.clone()
+                dbg_taps = None
+                if os.environ.get("BENCH_DEBUG_TAPS"):
+                    from atracdenc_amd import binding as B
+                    nbk = j.F + 1
+                    sp = j.enc.read_tap(B.TAP_SPECTRA, np.float32, (j.S, j.F, 2, 1024))
+                    ge = j.enc.read_tap(B.TAP_ENERGY_SCALE, np.float32, (j.S, nbk, 2, 4))
+                    lo = j.enc.read_tap(B.TAP_LOUDNESS, np.float32, (j.S, j.F))
+                    ps = j.enc.read_tap(B.TAP_PSY, B.At3Hip.PSY_DTYPE, (j.S, j.F, 2))
+                    dbg_taps = {"spec_absmax": float(np.abs(sp).max()), "spec_nonzero": int((sp != 0).sum()), "ges_min": float(np.nanmin(ge)), "ges_max": float(np.nanmax(ge)),
+                                "ges_nan": int(np.isnan(ge).sum()), "loud_min": float(np.nanmin(lo)), "loud_max": float(np.nanmax(lo)), "loud_nan": int(np.isnan(lo).sum()),
+                                "loud_ch_max": float(np.nanmax(ps["loud_ch"])), "energy_max": float(np.nanmax(ps["energy"])), "sfi_max": int(ps["sfi"].max())}
+                    cv = j.enc.read_tap(B.TAP_CURVES, np.uint8, (j.S, nbk, 2, 4, 16))
+                    dbg_taps["curve_points_total"] = int(cv[..., 0].sum()); dbg_taps["ges_not_one"] = int((ge[:, 1:] != 1.0).sum())
+                    dbg_taps["loud_first_stream"] = [float(x) for x in lo[0, :3]]
+                    if os.environ.get("BENCH_DEBUG_TAPS") == "2":
+                        sys.stderr.write("taps rank %d: %r\n" % (rank, dbg_taps))
+                again = j.replay(n_calls)
+                same = (again == rep["checksum"])
+                if not same:   # which of the two runs is the odd one out: the sequence a third time, and where the frames differ
+                    diff = (timed_out != j.d_out).any(dim=2)                     # [S, F]
+                    third = j.replay(n_calls)
+                    rep["replay_diagnostic"] = {"steps": n_calls, "timed": rep["checksum"], "replay": again, "replay_again": third,
+                                                "frames_differing": int(diff.sum().item()), "streams_differing": int(diff.any(dim=1).sum().item()),
+                                                "first": diff.nonzero()[:6].tolist(), "timed_nonzero_bytes": int((timed_out != 0).sum().item()),
+                                                "replay_nonzero_bytes": int((j.d_out != 0).sum().item()),
+                                                "taps_of_the_timed_run": dbg_taps,
+                                                "timed_frame0_head": timed_out[diff.nonzero()[0][0], diff.nonzero()[0][1], :24].tolist() if diff.any() else None}
+                    sys.stderr.write("replay mismatch on rank %d: %r\n" % (rank, rep["replay_diagnostic"]))
             try:
                 chk = j.parity_sample(n_check=4 if n_gpus == 1 else 2)
                 chk["timed_sequence_replayed_identically"] = same
