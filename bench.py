@@ -161,6 +161,10 @@ class DeviceJob:
         self.d_batches = [pcm[:, 1 + i * F: 1 + (i + 1) * F].contiguous() for i in range(2)]
         del pcm
         self.d_out = torch.zeros((S, F, self.fsz), dtype=torch.uint8, device=self.dev)
+        # The library reads and writes these buffers on ITS streams, which do not wait for torch's: everything torch has queued for them (the
+        # synthesis, the copies above, the zero fill) must be done before the first call. Without this wait a fresh process on a crowded device
+        # - eight ranks on one GPU - now and then encoded its first call from PCM that was not there yet.
+        torch.cuda.synchronize(self.dev)
         self.calls = 0
         self.enc.encode_device(self.d_prime.data_ptr(), 1, self.d_out.data_ptr())     # LOOK_AHEAD call, emits nothing
 
@@ -206,6 +210,7 @@ class DeviceJob:
         self.calls = 0
         self.enc.encode_device(self.d_prime.data_ptr(), 1, self.d_out.data_ptr())
         outs = [torch.zeros_like(self.d_out) for _ in range(2)]
+        torch.cuda.synchronize(self.dev)   # (torch's zero fills before the library's streams write the same buffers)
         for i in range(2):
             self.enc.encode_device(self.d_batches[i].data_ptr(), self.F, outs[i].data_ptr(), asynchronous=not DeviceJob.sync_steps)
         self.enc.sync()
@@ -479,6 +484,7 @@ def widened_rows(S):
 
         e1 = atracdenc_amd.At1Hip(n_streams=S, max_blocks=128)
         o1 = torch.zeros((S, 128, 2, 212), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()   # (the libraries' streams do not wait for torch's)
         for _ in range(2):
             e1.encode_device(pcm.data_ptr(), 128, o1.data_ptr())
         t0 = time.perf_counter()
@@ -492,6 +498,7 @@ def widened_rows(S):
         e1.close()
         ep = atracdenc_amd.At3pHip(n_streams=S, max_frames=32)
         op = torch.zeros((S, 32, 2048), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         for _ in range(2):
             ep.encode_frames_device(pcm.data_ptr(), 32, op.data_ptr())
         t0 = time.perf_counter()

@@ -74,6 +74,12 @@ typedef struct at3hip_timings {
     int32_t qmf_mdct_launches; /* kernels the QMF + MDCT work was spread over: 1 (fused) or 2 */
 } at3hip_timings;
 
+/* DEVICE BUFFERS AND STREAMS. With AT3HIP_PCM_ON_DEVICE / AT3HIP_OUT_ON_DEVICE the library reads and writes the caller's buffers on the
+ * context's own streams, which are non-blocking: they wait for no other stream, the null stream included. Whatever produces the PCM (or
+ * clears the output) on a stream of the caller's must be complete before the call - or the caller hands that stream over with
+ * at3hip_set_stream, and the first stage of every call is ordered behind it. (Found the hard way: a benchmark that queued its PCM
+ * synthesis with another library and called at3hip_encode at once encoded, on a crowded device, samples that were not there yet.) */
+
 /* Replaces: TAtrac3Encoder::TAtrac3Encoder(TCompressedOutputPtr&&, TAtrac3EncoderSettings&&)
  * (atrac3denc.cpp:93-103) for n_streams encoders at once.
  * A context creates three prioritised HIP streams and a copy stream; the runtime maps a process's streams onto FOUR hardware queues per device

@@ -81,6 +81,7 @@ def test_reset_and_device_pointers(oracle):
     enc = _enc(n_streams=3, max_blocks=32)
     d_pcm = torch.from_numpy(blocks).cuda()
     d_out = torch.zeros((3, 32, 2, 212), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()   # (the library's streams do not wait for torch's: its copies and fills first)
     for _ in range(2):
         enc.encode_device(d_pcm.data_ptr(), 32, d_out.data_ptr())
         torch.cuda.synchronize()
@@ -98,6 +99,7 @@ def test_queued_calls(oracle):
     enc = _enc(n_streams=2, max_blocks=32)
     pieces = [torch.from_numpy(np.ascontiguousarray(blocks[:, 8 * i: 8 * i + 8])).cuda() for i in range(4)]
     outs = [torch.zeros((2, 8, 2, 212), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()   # (the library's streams do not wait for torch's: its copies and fills first)
     for p, o in zip(pieces, outs):
         enc.encode_device(p.data_ptr(), 8, o.data_ptr(), asynchronous=True)
     enc.sync()
@@ -106,6 +108,7 @@ def test_queued_calls(oracle):
     assert enc.timings()["total_ms"] == 0          # queued calls carry no timing events
     enc.reset()
     o = torch.zeros((2, 32, 2, 212), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()   # (the library's streams do not wait for torch's: its copies and fills first)
     enc.encode_device(torch.from_numpy(blocks).cuda().data_ptr(), 32, o.data_ptr())
     tm = enc.timings()
     assert tm["total_ms"] > 0 and tm["front_ms"] > 0 and np.array_equal(o.cpu().numpy(), exp)

@@ -4,7 +4,10 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/.."); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + "/../tests")
 import numpy as np, torch, bench
 from atracdenc_amd import binding as B
-job = bench.DeviceJob(0, 64, 16, bench.LP2, False, "noise", seed=1 + os.getpid() % 7)
+if "RANK" in os.environ:   # under torch.distributed.run: the bench's own start (gloo group, a barrier in front of the job)
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo"); dist.barrier()
+job = bench.DeviceJob(0, 64, 16, bench.LP2, False, "noise", seed=1 + int(os.environ.get("RANK", os.getpid() % 7)) * 64)
 import time
 def barrier(q=0.2):   # the ranks of the bench meet in a gloo barrier before every region: here all processes start on the same tick of the wall clock
     t = (int(time.time() / q) + 1) * q
