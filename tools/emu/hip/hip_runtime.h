@@ -84,6 +84,7 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
