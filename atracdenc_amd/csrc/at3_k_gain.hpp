@@ -1243,41 +1243,43 @@ __device__ __forceinline__ void early_mismatch_score_pair(const Log2fTab* L2, co
     const float dA = aA_next - aA, dB = aB_next - avB;
     const float w = 0.5f * (in_j + in_next);
     const float ltermA = dA * dA * w, ltermB = dB * dB * w;
+    // The reference's sums stop at the evaluated sub-frames (fit: sf < eval, leak and weight: sf + 1 < eval). The terms behind that point are
+    // stored as +0.0f instead and every list is summed to its end: x + 0.0f is x for every x a sum that started at +0.0f can hold (never
+    // -0.0f; NaN and inf stay what they are), and six conditions per sub-frame - 192 per scoring wavefront - become plain adds. B's weights
+    // get a list of their own for it (the first 32 floats of the item's scratch: the a-list, dead by now).
     float* st = s_tmpA + 32;   // A: [3][32] behind the first 32 floats of the item's scratch
-    st[j] = sqA;
-    st[32 + j] = ltermA;
-    st[64 + j] = w;
-    sqB[j] = sqvB;
-    ltB[j] = ltermB;
+    st[j] = j < evalA ? sqA : 0.0f;
+    st[32 + j] = j + 1 < evalA ? ltermA : 0.0f;
+    st[64 + j] = j + 1 < evalA ? w : 0.0f;
+    sqB[j] = j < evalB ? sqvB : 0.0f;
+    ltB[j] = j + 1 < evalB ? ltermB : 0.0f;
+    s_tmpA[j] = j + 1 < evalB ? w : 0.0f;
     wave_sync();
     float fitA = 0.0f, leakA = 0.0f, wsumA = 0.0f, fitB = 0.0f, leakB = 0.0f, wsumB = 0.0f;
     {
         const float4* a4 = reinterpret_cast<const float4*>(st);
         const float4* s4 = reinterpret_cast<const float4*>(sqB);
         const float4* l4 = reinterpret_cast<const float4*>(ltB);
-        // (sixteen terms of each of the five lists per step, the next step's requested ahead by the compiler's schedule: holding all
-        // forty 16-byte words at once cost the kernel a wavefront per SIMD)
+        const float4* w4 = reinterpret_cast<const float4*>(s_tmpA);
+        // (sixteen terms of each of the six lists per step, the next step's requested ahead by the compiler's schedule: holding all
+        // forty-eight 16-byte words at once cost the kernel a wavefront per SIMD)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float4 va = a4[q], vl = a4[8 + q], vw = a4[16 + q], vb = s4[q], vm = l4[q];
+            const float4 va = a4[q], vl = a4[8 + q], vw = a4[16 + q], vb = s4[q], vm = l4[q], vx = w4[q];
             const float v[4] = {va.x, va.y, va.z, va.w};
             const float lt[4] = {vl.x, vl.y, vl.z, vl.w};
             const float ww[4] = {vw.x, vw.y, vw.z, vw.w};
             const float vB[4] = {vb.x, vb.y, vb.z, vb.w};
             const float lB[4] = {vm.x, vm.y, vm.z, vm.w};
+            const float wB[4] = {vx.x, vx.y, vx.z, vx.w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int sf = 4 * q + t;
-                if (sf < evalA) fitA += v[t];
-                if (sf + 1 < evalA) {
-                    leakA += lt[t];
-                    wsumA += ww[t];
-                }
-                if (sf < evalB) fitB += vB[t];
-                if (sf + 1 < evalB) {
-                    leakB += lB[t];
-                    wsumB += ww[t];
-                }
+                fitA += v[t];
+                leakA += lt[t];
+                wsumA += ww[t];
+                fitB += vB[t];
+                leakB += lB[t];
+                wsumB += wB[t];
             }
         }
     }
