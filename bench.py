@@ -354,10 +354,19 @@ def flops_of(k1_ms, frames_per_launch):
     return round(tf, 3), round(tf / FP32_NO_FMA_PEAK_TF, 4)
 
 
-def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
-    """One of SURVEY 8(d)'s other workloads on device 0, after the headline: whole-pipeline rate + K1 launch time."""
+def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False, prior=0):
+    """One of SURVEY 8(d)'s other workloads on device 0, after the headline: whole-pipeline rate + K1 launch time.
+    prior > 0: that many contexts of the same workload are created, run and closed first (later contexts of a process)."""
     out = {"workload": name}
     try:
+        for k in range(prior):
+            j0 = DeviceJob(0, S, F, bitrate, no_gain, kind, seed=11)
+            j0.warmup(warmup)
+            n0 = max(steps, 150)
+            dt0 = float(np.median([timed_region([j0], n0, None) / n0 for _ in range(3)]))
+            if k == 0:
+                out["first_context_value"] = round(S * F / dt0, 1)
+            j0.close()
         job = DeviceJob(0, S, F, bitrate, no_gain, kind, seed=11)
         job.warmup(warmup)
         # like the headline: the median of several regions of at least ~50 ms each (one 10 ms region read 3 - 5 % low)
@@ -378,6 +387,9 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
                     "k1_kernels": "k_qmf_mdct8 (fused QMF + MDCT, one launch)" if getattr(job, "k1_launches", 2) == 1 else "k_qmf_sub8 + k_mdct_sub (two launches)",
                     "gain_control": not no_gain,
                     "stage_ms_per_step": {k: round(v, 4) for k, v in sorted(stage.items())}})
+        if prior:
+            out["contexts_before_this_one"] = prior
+            out["vs_first_context"] = round(out["value"] / out["first_context_value"], 4)
         job.close()
         del job
         import torch
@@ -387,21 +399,20 @@ def side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
     return out
 
 
-def side_workload_fresh(name, S, F, bitrate, kind, steps, warmup, no_gain=False):
-    """side_workload in a process of its own, as the headline has. Why: the FIRST context a process creates runs `tones` at 16.2 M frames/s,
-    any later one of the same process at 12.2 - 14.9 M (same kernels, same isolated kernel times; where the buffers lie and the number of
-    hardware queues do not matter; white noise does not show it) - so figures taken from the second .. seventh context of the bench
-    process said more about their position in the list than about the workload. Falls back to the in-process
-    measurement, and says so, if the child fails."""
+def side_workload_fresh(name, S, F, bitrate, kind, steps, warmup, no_gain=False, prior=0):
+    """side_workload in a process of its own, as the headline has: every figure of the line is a first context's. (Rounds 5 and 6 believed later contexts
+    of a process ran `tones` 10 - 25 % slower; that was this file handing tensors over before torch had filled them - DeviceJob.__init__ waits now, and the
+    "third context" entry of `other_workloads` reads what the first does. The fresh processes stay: they cost nothing and keep the entries independent.)
+    Falls back to the in-process measurement, and says so, if the child fails."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-side-workload", json.dumps([name, S, F, bitrate, kind, steps, warmup, bool(no_gain)])],
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-side-workload", json.dumps([name, S, F, bitrate, kind, steps, warmup, bool(no_gain), int(prior)])],
                            capture_output=True, text=True, timeout=600)
         out = json.loads(r.stdout.strip().splitlines()[-1])
         out["fresh_process"] = True
         return out
     except Exception as ex:   # noqa: BLE001
-        out = side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=no_gain)
+        out = side_workload(name, S, F, bitrate, kind, steps, warmup, no_gain=no_gain, prior=prior)
         out["fresh_process"] = False
         out["fresh_process_error"] = repr(ex)
         return out
@@ -548,8 +559,8 @@ def main():
                     "(fresh) process and print its record (what `other_workloads` calls for each entry)")
     args = ap.parse_args()
     if args.one_side_workload:
-        name, S, F, br, kind, steps, warmup, no_gain = json.loads(args.one_side_workload)
-        print(json.dumps(side_workload(name, S, F, br, kind, steps, warmup, no_gain=bool(no_gain))))
+        name, S, F, br, kind, steps, warmup, no_gain, prior = (json.loads(args.one_side_workload) + [0])[:9]
+        print(json.dumps(side_workload(name, S, F, br, kind, steps, warmup, no_gain=bool(no_gain), prior=int(prior))))
         return
 
     import torch
@@ -894,6 +905,7 @@ def main():
                 line["other_workloads"] = [
                     side_workload_fresh("configs[1] shape, 'burst' input (gain-control path busy)", 64, 64, LP2, "burst", 30, 3),
                     side_workload_fresh("configs[1] shape, 'tones' input (tonal extraction busy)", 64, 64, LP2, "tones", 30, 3),
+                    side_workload_fresh("configs[1] shape, 'tones', as the THIRD context of its process (DESIGN section 7: open)", 64, 64, LP2, "tones", 30, 3, prior=2),
                     side_workload_fresh("configs[3]: LP4 66 kbps joint stereo, configs[1] shape, 'noise'", 64, 64, LP4, "noise", 30, 3),
                     side_workload_fresh("shard_1024x128: per-GPU shard of configs[2] (1024 streams x 128 frames) on one GPU, 'noise'", 1024, 128, LP2, "noise", 10, 2),
                     side_workload_fresh("configs[1] shape, 'noise', --nogaincontrol: the FUSED QMF + MDCT kernel k_qmf_mdct8 (north_star's kernel)", 64, 64, LP2, "noise", 30, 3, no_gain=True),

@@ -85,7 +85,7 @@ typedef struct at3hip_timings {
  * A context creates three prioritised HIP streams and a copy stream; the runtime maps a process's streams onto FOUR hardware queues per device
  * by default (GPU_MAX_HW_QUEUES), and streams that share one serialise. Create the contexts at start-up, before the process creates other
  * prioritised streams, and keep them (at3hip_reset starts new audio streams on a context): measured, a first context created behind eight other
- * streams runs at half speed, and later jobs of a process can run tonal material ~10 % slower than its first. */
+ * streams runs at half speed. */
 int at3hip_create(const at3hip_config* cfg, at3hip_ctx** out);
 void at3hip_destroy(at3hip_ctx* ctx);
 
