@@ -1,5 +1,6 @@
 # fresh single processes of the loudness detector beside a process that keeps every CU's LDS full of 1e30 (then of 0.5)
 for V in 1e30 0.5; do
+[ -x tools/ubench/lds_noise ] || hipcc --offload-arch=gfx950 -O2 -o tools/ubench/lds_noise tools/ubench/lds_noise.hip 2>/dev/null
 tools/ubench/lds_noise 60 $V > /dev/null &
 NP=$!
 sleep 1
